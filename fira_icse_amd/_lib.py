@@ -1,0 +1,118 @@
+"""ctypes binding of libfira_hip.so (the C ABI of include/fira_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing the import fails, and every call
+raises ``FiraError`` with the library's own message when it returns non-zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfira_hip.so")
+
+
+class FiraError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [("sou_len", C.c_int32), ("sub_len", C.c_int32), ("ast_len", C.c_int32), ("tar_len", C.c_int32),
+                ("d_model", C.c_int32), ("n_head", C.c_int32), ("n_layer", C.c_int32), ("vocab", C.c_int32),
+                ("ast_vocab", C.c_int32), ("d_ff", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("nnz", C.c_int32), ("sou", C.c_void_p), ("tar", C.c_void_p), ("mark", C.c_void_p),
+                ("ast_change", C.c_void_p), ("tar_label", C.c_void_p), ("sub_token", C.c_void_p),
+                ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("head_rows", C.c_void_p),
+                ("n_head_rows", C.c_int32)]
+
+
+class TrainOpts(C.Structure):
+    _fields_ = [("dropout", C.c_float), ("gcn_dropout", C.c_float), ("seed", C.c_uint64), ("compact_head", C.c_int32)]
+
+
+_P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
+_U64, _U32 = C.c_uint64, C.c_uint32
+_DP, _BP, _OP = C.POINTER(Dims), C.POINTER(Batch), C.POINTER(TrainOpts)
+
+# name -> (restype, argtypes); every symbol declared in include/fira_hip.h
+SIGNATURES = {
+    "fira_last_error": (C.c_char_p, []),
+    "fira_abi_version": (_I, []),
+    "fira_param_count": (_I, [_DP]),
+    "fira_param_info": (_I, [_DP, _I, C.c_char_p, C.POINTER(_L), C.POINTER(_L), C.POINTER(C.c_int32), C.POINTER(_L)]),
+    "fira_param_total": (_L, [_DP]),
+    "fira_workspace_bytes": (_Z, [_DP, _I, _I]),
+    "fira_decode_workspace_bytes": (_Z, [_DP, _I, _I]),
+    "fira_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
+    "fira_csr_spmm_f32": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I]),
+    "fira_embed_gather_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I]),
+    "fira_embed_gather_bwd": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I]),
+    "fira_combination_fwd": (_I, [_P, _I, _P, _P, _P, _P, _F, _U64, _U32]),
+    "fira_combination_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
+    "fira_add_layernorm_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
+    "fira_add_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
+    "fira_colsum_f32": (_I, [_P, _I, _I, _P, _I, _P]),
+    "fira_attention_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I]),
+    "fira_attention_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I,
+                                _P, _I, _P, _I, _P, _I]),
+    "fira_copy_score_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "fira_copy_score_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fira_head_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "fira_adam_step": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
+    "fira_inv_count": (_I, [_P, _P, _P]),
+    "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P]),
+    "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P]),
+    "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
+    "fira_decode_step": (_I, [_P, _DP, _P, _P, _Z, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "fira_decode_memory": (_P, [_DP, _P, _I, _I]),
+    "fira_decode_mem_valid": (_P, [_DP, _P, _I, _I]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "fira_icse_amd: %s is missing. Build it with `python -m fira_icse_amd.build` (needs hipcc, "
+            "gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fira_abi_version() != 1:
+        raise ImportError("libfira_hip.so ABI version mismatch")
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().fira_last_error()
+        raise FiraError("%s failed: %s" % (what or "libfira_hip call", msg.decode() if msg else "unknown error"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_dims(cfg) -> Dims:
+    return Dims(cfg.sou_len, cfg.sub_token_len, cfg.ast_change_len, cfg.tar_len, cfg.embedding_dim, cfg.num_head,
+                cfg.num_layers, cfg.vocab_size, cfg.ast_change_vocab_size, 4 * cfg.embedding_dim)

@@ -1,0 +1,411 @@
+// Multi-head attention core for the decoder (reference gnn_transformer.py:137-158): per (commit, head)
+//   O = softmax( masked_fill(Q K^T / sqrt(32), mask == 0, -1e9) ) V          head width 32, Tq <= 32.
+// Sequence geometry is tiny and fixed (Tq = 30; Tk = 30 self / 370 cross), so one workgroup handles one
+// (b, h): NW wavefronts split the key tiles (32 keys each), everything stays in registers and the only
+// LDS traffic is the cross-wave combine of the row statistics and of the 32x32 output tile.
+//
+// The matrix products run on v_mfma_f32_32x32x2_f32 (exact fp32).  Two operand tricks keep it shuffle-free:
+//  * the reduction index order of an MFMA chain is free, so operand fragments are fetched as 16 contiguous
+//    floats per lane:   X[row = lane&31][ (lane>>5)*16 + s ],  s = MFMA step 0..15   (4 x 16-byte loads);
+//  * scores are produced TRANSPOSED (S^T = K Q^T: rows = keys in the accumulator registers, column = query
+//    in the lane), so the soft-max row reduction is in-lane, and accumulator register s of S^T is exactly
+//    the A-operand fragment of step s for P·V when the V rows are fetched in the accumulator's row order
+//    key(s, lane>>5) = (s&3) + 8*(s>>2) + 4*(lane>>5).
+// The backward also needs the non-transposed tile (for dK = dS^T Q and dV = P^T dO); it is recomputed by
+// swapping the two operand fragments of the same MFMA chain, never by a transpose.
+#include "engine.h"
+
+namespace fira {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// fragment X[row][col0 + kh*16 + s], s = 0..15; zero when !valid
+__device__ __forceinline__ void load_frag(float (&f)[16], const float* __restrict__ base, bool valid) {
+    if (valid) {
+        const float4* p = reinterpret_cast<const float4*>(base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = p[i];
+            f[4 * i + 0] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) f[i] = 0.f;
+    }
+}
+
+constexpr float SQRT_DH = 5.656854249492381f;
+constexpr int MAX_TK = 384;
+
+// masked, scaled score.  beyond Tk: -inf (not part of the soft-max at all); masked key: -1e9 as the reference.
+__device__ __forceinline__ float mask_score(float raw, int key, int query, int Tk, const int* kv, int causal, int q_pos0,
+                                            bool& masked) {
+    if (key >= Tk) { masked = true; return -INFINITY; }
+    masked = (kv[key] == 0) || (causal && key > query + q_pos0);
+    return masked ? -1e9f : raw / SQRT_DH;
+}
+
+template <int NW, int TPW>
+__global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, int Tk, const float* __restrict__ Q,
+                                                                int ldq, const float* __restrict__ K, int ldk,
+                                                                const float* __restrict__ V, int ldv,
+                                                                const int32_t* __restrict__ key_valid, int causal,
+                                                                int q_pos0, float* __restrict__ O, int ldo, int kb,
+                                                                int kvb, int qpk) {
+    // kb: K/V rows per batch entry, kvb: key_valid entries per batch entry, qpk: consecutive query batches
+    // that share one K/V batch entry (beam rows of one commit share the encoder memory)
+    __shared__ int sm_kv[MAX_TK];
+    __shared__ float sm_red[NW][32];
+    __shared__ float sm_o[NW > 1 ? NW * 1024 : 1];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bk = b / qpk;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int NT = (Tk + 31) / 32;
+    for (int i = t; i < Tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)bk * kvb + i];
+    __syncthreads();
+    K += (size_t)bk * kb * ldk;           // this batch entry's key/value rows
+    V += (size_t)bk * kb * ldv;
+
+    float bq[16];
+    load_frag(bq, Q + ((size_t)b * Tq + l31) * ldq + h * FIRA_DH + kh * 16, l31 < Tq);
+
+    f32x16 st[TPW];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
+        if (kt < NT) {
+            float ak[16];
+            const int key = kt * 32 + l31;
+            load_frag(ak, K + (size_t)key * ldk + h * FIRA_DH + kh * 16, key < Tk);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[s], bq[s], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool masked;
+                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, Tk, sm_kv, causal, q_pos0, masked);
+                st[i][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (NW > 1) {
+        if (kh == 0) sm_red[wave][l31] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sm_red[w][l31]);
+        __syncthreads();
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(st[i][r] - mx);       // exp(-inf) = 0 for keys beyond Tk / tiles not owned
+            st[i][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (NW > 1) {
+        if (kh == 0) sm_red[wave][l31] = sum;
+        __syncthreads();
+        sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += sm_red[w][l31];
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+        if (kt < NT) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int key = kt * 32 + acc_row(s, kh);
+                const float v = key < Tk ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
+                o = MFMA32(st[i][s] / sum, v, o);
+            }
+        }
+    }
+    // o[r]: query = acc_row(r, kh), d = l31
+    if (NW > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm_o[wave * 1024 + r * 64 + lane] = o[r];
+        __syncthreads();
+        for (int idx = t; idx < 1024; idx += NW * 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sm_o[w * 1024 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int q = acc_row(r, ln >> 5);
+            if (q < Tq) O[((size_t)b * Tq + q) * ldo + h * FIRA_DH + (ln & 31)] = v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = acc_row(r, kh);
+            if (q < Tq) O[((size_t)b * Tq + q) * ldo + h * FIRA_DH + l31] = o[r];
+        }
+    }
+}
+
+template <int NW, int TPW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
+    int H, int Tq, int Tk, const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
+    const float* __restrict__ V, int ldv, const int32_t* __restrict__ key_valid, int causal, int q_pos0,
+    const float* __restrict__ O, int ldo, const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq,
+    float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv) {
+    __shared__ int sm_kv[MAX_TK];
+    __shared__ float sm_red[NW][32];
+    __shared__ float sm_m[32], sm_sum[32], sm_delta[32];
+    __shared__ float sm_o[NW > 1 ? NW * 1024 : 1];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int NT = (Tk + 31) / 32;
+    for (int i = t; i < Tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)b * Tk + i];
+    __syncthreads();
+
+    // operand fragments indexed by "row = lane&31": queries
+    float bq[16], bdo[16];
+    load_frag(bq, Q + ((size_t)b * Tq + l31) * ldq + h * FIRA_DH + kh * 16, l31 < Tq);
+    load_frag(bdo, dO + ((size_t)b * Tq + l31) * lddo + h * FIRA_DH + kh * 16, l31 < Tq);
+    float delta;
+    {
+        float bo[16];
+        load_frag(bo, O + ((size_t)b * Tq + l31) * ldo + h * FIRA_DH + kh * 16, l31 < Tq);
+        float d = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) d = fmaf(bdo[s], bo[s], d);
+        delta = d + __shfl_xor(d, 32, 64);           // rowsum(dO * O) = rowsum(P * dP)
+    }
+
+    // ---- statistics (identical to the forward) -------------------------------------------------
+    f32x16 st[TPW];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
+        if (kt < NT) {
+            float ak[16];
+            const int key = kt * 32 + l31;
+            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[s], bq[s], acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool masked;
+                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, Tk, sm_kv, causal, q_pos0, masked);
+                st[i][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (NW > 1) {
+        if (kh == 0) sm_red[wave][l31] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mx = fmaxf(mx, sm_red[w][l31]);
+        __syncthreads();
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(st[i][r] - mx);
+            st[i][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (NW > 1) {
+        if (kh == 0) sm_red[wave][l31] = sum;
+        __syncthreads();
+        sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += sm_red[w][l31];
+    }
+    if (wave == 0 && kh == 0) {
+        sm_m[l31] = mx;
+        sm_sum[l31] = sum;
+        sm_delta[l31] = delta;
+    }
+    __syncthreads();
+
+    // ---- phase T (transposed tiles: register row = key, lane column = query): dQ -------------------
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+        if (kt < NT) {
+            float av[16];
+            const int key = kt * 32 + l31;
+            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk);
+            f32x16 dpt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dpt = MFMA32(av[s], bdo[s], dpt);       // dP^T = V dO^T
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kr = kt * 32 + acc_row(s, kh);
+                const bool dead = kr >= Tk || sm_kv[kr < Tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
+                const float p = st[i][s] / sum;
+                const float ds = dead ? 0.f : p * (dpt[s] - delta) / SQRT_DH;
+                const float kv = kr < Tk ? K[((size_t)b * Tk + kr) * ldk + h * FIRA_DH + l31] : 0.f;
+                dq = MFMA32(ds, kv, dq);                                        // dQ += dS K
+            }
+        }
+    }
+    if (NW > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm_o[wave * 1024 + r * 64 + lane] = dq[r];
+        __syncthreads();
+        for (int idx = t; idx < 1024; idx += NW * 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sm_o[w * 1024 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int q = acc_row(r, ln >> 5);
+            if (q < Tq) dQ[((size_t)b * Tq + q) * lddq + h * FIRA_DH + (ln & 31)] = v;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = acc_row(r, kh);
+            if (q < Tq) dQ[((size_t)b * Tq + q) * lddq + h * FIRA_DH + l31] = dq[r];
+        }
+    }
+
+    // ---- phase N (register row = query, lane column = key): dK, dV ---------------------------------
+    float qrow[16], dorow[16];              // B operands: X[query = acc_row(s,kh)][d = l31]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int q = acc_row(s, kh);
+        qrow[s] = q < Tq ? Q[((size_t)b * Tq + q) * ldq + h * FIRA_DH + l31] : 0.f;
+        dorow[s] = q < Tq ? dO[((size_t)b * Tq + q) * lddo + h * FIRA_DH + l31] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+        if (kt < NT) {
+            float ak[16], av[16];
+            const int key = kt * 32 + l31;
+            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk);
+            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk);
+            f32x16 sN, dpN;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                sN = MFMA32(bq[s], ak[s], sN);        // S   = Q K^T
+                dpN = MFMA32(bdo[s], av[s], dpN);     // dP  = dO V^T
+            }
+            f32x16 dk, dv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int q = acc_row(s, kh);
+                bool masked;
+                const float x = mask_score(sN[s], key, q, Tk, sm_kv, causal, q_pos0, masked);
+                const float p = expf(x - sm_m[q]) / sm_sum[q];
+                const float ds = masked ? 0.f : p * (dpN[s] - sm_delta[q]) / SQRT_DH;
+                dk = MFMA32(ds, qrow[s], dk);         // dK += dS^T Q
+                dv = MFMA32(p, dorow[s], dv);         // dV += P^T dO
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kr = kt * 32 + acc_row(r, kh);
+                if (kr < Tk) {
+                    dK[((size_t)b * Tk + kr) * lddk + h * FIRA_DH + l31] = dk[r];
+                    dV[((size_t)b * Tk + kr) * lddv + h * FIRA_DH + l31] = dv[r];
+                }
+            }
+        }
+    }
+}
+
+static int check_geometry(const char* who, int Tq, int Tk, int ldq, int ldk, int ldv, const void* Q, const void* K,
+                          const void* V) {
+    FIRA_REQUIRE(Tq >= 1 && Tq <= 32, "%s: Tq=%d must be in 1..32", who, Tq);
+    FIRA_REQUIRE(Tk >= 1 && Tk <= MAX_TK, "%s: Tk=%d must be in 1..%d", who, Tk, MAX_TK);
+    FIRA_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 &&
+                     (uintptr_t)V % 16 == 0,
+                 "%s: Q/K/V rows must be 16-byte aligned", who);
+    return 0;
+}
+
+int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                     const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
+                     int kb, int kvb, int qpk) {
+    if (B <= 0) return 0;
+    if (int e = check_geometry("attention_fwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
+    FIRA_REQUIRE(kb >= Tk && kvb >= Tk && qpk >= 1, "attention_fwd: bad batch strides");
+    if (Tk <= 32)
+        hipLaunchKernelGGL((attention_fwd_kernel<1, 1>), dim3(B * H), dim3(64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, ldv,
+                           key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk);
+    else
+        hipLaunchKernelGGL((attention_fwd_kernel<4, 3>), dim3(B * H), dim3(256), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V,
+                           ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk);
+    FIRA_CHECK_LAUNCH("attention_fwd");
+    return 0;
+}
+int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo) {
+    return attention_fwd_ex(s, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O, ldo, Tk, Tk, 1);
+}
+
+int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
+                  const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv) {
+    if (B <= 0) return 0;
+    if (int e = check_geometry("attention_bwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
+    FIRA_REQUIRE(ldo % 4 == 0 && lddo % 4 == 0 && (uintptr_t)O % 16 == 0 && (uintptr_t)dO % 16 == 0,
+                 "attention_bwd: O/dO rows must be 16-byte aligned");
+    if (Tk <= 32)
+        hipLaunchKernelGGL((attention_bwd_kernel<1, 1>), dim3(B * H), dim3(64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, ldv,
+                           key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv);
+    else
+        hipLaunchKernelGGL((attention_bwd_kernel<4, 3>), dim3(B * H), dim3(256), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V,
+                           ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv);
+    FIRA_CHECK_LAUNCH("attention_bwd");
+    return 0;
+}
+
+}  // namespace fira
+
+extern "C" {
+int fira_attention_fwd(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                       const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo) {
+    return fira::attention_fwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
+                               ldo);
+}
+int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                       const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O,
+                       int ldo, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                       int lddv) {
+    return fira::attention_bwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
+                               ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv);
+}
+}

@@ -1,0 +1,402 @@
+// Dual-copy output head of the reference (Model.py:15-20, 54-86):
+//   copy score   s[b,t,j] = w . tanh(Ws mem[b,j] + Wt dec[b,t]) + c      (additive attention)
+//   gate         g[b,t]   = softmax(Wp dec[b,t] + bp)                    (2-way)
+//   p            = [ g0 * softmax(out_fc(dec)) ; g1 * softmax(mask(s, -1e9)) ]
+//   loss         = -log(clamp(p[label], 1e-10, 1)),  label = tar_label shifted left, 0 = ignore
+// The reference materialises a [B,30,370,256] tanh tensor (11.4 MB per commit, twice for backward; 44 % of
+// its CPU step) and the [B,30,25020] probability tensor five times.  Here the tanh tile lives
+// in registers (forward and re-computed in backward) and the loss kernel turns the logits into their
+// gradient in place, one pass after the soft-max statistics.
+#include "engine.h"
+
+namespace fira {
+
+constexpr int T_MAX = 32;
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (S chunks of 32 rows, B); 4 waves; one wave per memory row j, lanes hold 4 of the 256 dims.
+__global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const float* __restrict__ src,
+                                                             const float* __restrict__ tgt,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ score, int qpk) {
+    __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
+    const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
+    src += (size_t)(b / qpk) * S * FIRA_D - (size_t)b * S * FIRA_D;     // qpk target batches share one memory
+    for (int i = t0; i < T * (FIRA_D / 4); i += 256)
+        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
+    __syncthreads();
+    const float4 w4 = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float c = bias[0];
+    const int j_end = min(S, (int)(blockIdx.x + 1) * 32);
+    for (int j = blockIdx.x * 32 + wave; j < j_end; j += 4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
+        for (int t = 0; t < T; ++t) {
+            const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
+            float a = w4.x * tanhf(s4.x + x.x);
+            a = fmaf(w4.y, tanhf(s4.y + x.y), a);
+            a = fmaf(w4.z, tanhf(s4.z + x.z), a);
+            a = fmaf(w4.w, tanhf(s4.w + x.w), a);
+            a = wave_sum(a);
+            if (lane == 0) score[((size_t)b * T + t) * S + j] = a + c;
+        }
+    }
+}
+
+// backward (tanh re-computed): dsrc[b,j,:] = sum_t g*w*(1-th^2)   (owned by one wave: plain store)
+//                              dtgt[b,t,:] += sum_j (same)        (registers -> LDS -> global atomics)
+//                              dw += sum g*th ; dbias += sum g
+__global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const float* __restrict__ src,
+                                                             const float* __restrict__ tgt,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ dscore,
+                                                             float* __restrict__ dsrc, float* __restrict__ dtgt,
+                                                             float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
+    __shared__ float sm_dt[T_MAX * FIRA_D];
+    __shared__ float sm_dw[FIRA_D + 1];
+    const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
+    for (int i = t0; i < T * (FIRA_D / 4); i += 256)
+        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
+    for (int i = t0; i < T_MAX * FIRA_D; i += 256) sm_dt[i] = 0.f;
+    for (int i = t0; i < FIRA_D + 1; i += 256) sm_dw[i] = 0.f;
+    __syncthreads();
+    const float4 w4 = *reinterpret_cast<const float4*>(w + lane * 4);
+    float dt[T_MAX][4];
+#pragma unroll
+    for (int t = 0; t < T_MAX; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dt[t][e] = 0.f;
+    float dwa[4] = {0.f, 0.f, 0.f, 0.f};
+    float dba = 0.f;
+    const int j_end = min(S, (int)(blockIdx.x + 1) * 32);
+    for (int j = blockIdx.x * 32 + wave; j < j_end; j += 4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
+        float ds[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < T_MAX; ++t) {
+            if (t < T) {
+                const float g = dscore[((size_t)b * T + t) * S + j];
+                const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
+                const float th[4] = {tanhf(s4.x + x.x), tanhf(s4.y + x.y), tanhf(s4.z + x.z), tanhf(s4.w + x.w)};
+                const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = g * wv[e] * (1.f - th[e] * th[e]);
+                    ds[e] += u;
+                    dt[t][e] += u;
+                    dwa[e] = fmaf(g, th[e], dwa[e]);
+                }
+                dba += g;
+            }
+        }
+        *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+    }
+#pragma unroll
+    for (int t = 0; t < T_MAX; ++t)
+        if (t < T) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[t * FIRA_D + lane * 4 + e], dt[t][e]);
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
+    if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
+    __syncthreads();
+    for (int i = t0; i < T * FIRA_D; i += 256) unsafeAtomicAdd(&dtgt[(size_t)b * T * FIRA_D + i], sm_dt[i]);
+    for (int i = t0; i < FIRA_D; i += 256) unsafeAtomicAdd(&dw[i], sm_dw[i]);
+    if (t0 == 0) unsafeAtomicAdd(dbias, sm_dw[FIRA_D]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide reductions for the loss kernel (256 threads)
+__device__ __forceinline__ float block_max(float v, float* sm) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// arg-max with first-occurrence tie-break (torch.argmax semantics)
+__device__ __forceinline__ void block_argmax(float& v, int& idx, float* smv, int* smi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { smv[threadIdx.x >> 6] = v; smi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    v = smv[0]; idx = smi[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (smv[k] > v || (smv[k] == v && smi[k] < idx)) { v = smv[k]; idx = smi[k]; }
+}
+
+// one workgroup per (b,t) row.
+__global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, const int32_t* __restrict__ compact_row,
+                                                        float* __restrict__ logits, int ldl,
+                                                        float* __restrict__ score,
+                                                        const int32_t* __restrict__ mem_valid,
+                                                        float* __restrict__ gate_logits,
+                                                        const int32_t* __restrict__ tar_label,
+                                                        float* __restrict__ loss_sum, int32_t* __restrict__ n_tok,
+                                                        int32_t* __restrict__ argmax_out, int want_grad) {
+    __shared__ float smf[4];
+    __shared__ int smi[4];
+    const int bt = blockIdx.x, b = bt / T, t = bt - b * T, tid = threadIdx.x;
+    const int crow = compact_row ? compact_row[bt] : bt;
+    const int y = (t + 1 < T) ? tar_label[b * T + t + 1] : 0;        // label = cat(tar_label, 0)[:, 1:]
+    float* lrow = crow >= 0 ? logits + (size_t)crow * ldl : nullptr;
+    float* srow = score + (size_t)bt * S;
+    const int32_t* mv = mem_valid + (size_t)b * S;
+
+    // gate = softmax(z0, z1)
+    const float z0 = gate_logits[2 * bt], z1 = gate_logits[2 * bt + 1];
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+
+    // copy soft-max statistics over the S memory slots (-1e9 where masked)
+    float cmax = -INFINITY;
+    int cidx = 0x7fffffff;
+    for (int j = tid; j < S; j += 256) {
+        const float x = mv[j] ? srow[j] : -1e9f;
+        if (x > cmax) { cmax = x; cidx = j; }
+    }
+    block_argmax(cmax, cidx, smf, smi);
+    float csum = 0.f;
+    for (int j = tid; j < S; j += 256) csum += expf((mv[j] ? srow[j] : -1e9f) - cmax);
+    csum = block_sum(csum, smf);
+
+    // generator soft-max statistics over the V logits
+    float gmax = -INFINITY, gsum = 1.f;
+    int gidx = 0x7fffffff;
+    if (lrow) {
+        for (int j = tid; j < V; j += 256) {
+            const float x = lrow[j];
+            if (x > gmax) { gmax = x; gidx = j; }
+        }
+        block_argmax(gmax, gidx, smf, smi);
+        gsum = 0.f;
+        for (int j = tid; j < V; j += 256) gsum += expf(lrow[j] - gmax);
+        gsum = block_sum(gsum, smf);
+    }
+
+    if (argmax_out) {
+        // teacher-forced argmax over [g0*p_gen ; g1*p_copy] (Model.py:85-86); first index wins ties
+        const float pg = lrow ? g0 * (1.0f / gsum) : -1.f;
+        const float pc = g1 * (1.0f / csum);
+        if (tid == 0) argmax_out[bt] = (pg >= pc) ? gidx : V + cidx;
+    }
+
+    // loss of this row
+    bool live = false, is_copy = false;
+    float p = 1.f;
+    if (y != 0) {
+        if (y < V) {
+            if (lrow) { p = g0 * (expf(lrow[y] - gmax) / gsum); live = true; }
+        } else if (y - V < S) {
+            is_copy = true;
+            p = g1 * (expf((mv[y - V] ? srow[y - V] : -1e9f) - cmax) / csum);
+            live = true;
+        }
+    }
+    const bool pass = live && p >= 1e-10f && p <= 1.0f;     // clamp(min=1e-10,max=1) blocks the gradient outside
+    if (live && tid == 0 && loss_sum) {
+        const float pc = fminf(fmaxf(p, 1e-10f), 1.0f);
+        unsafeAtomicAdd(loss_sum, -logf(pc));
+        atomicAdd(n_tok, 1);
+    }
+    if (!want_grad) return;
+    __syncthreads();      // every thread has read lrow[y] / srow[y-V] before they are overwritten
+
+    // d loss / d gate logits:  g_k - [k == chosen branch]
+    if (tid == 0) {
+        gate_logits[2 * bt] = pass ? g0 - (is_copy ? 0.f : 1.f) : 0.f;
+        gate_logits[2 * bt + 1] = pass ? g1 - (is_copy ? 1.f : 0.f) : 0.f;
+    }
+    // d loss / d copy scores (masked slots receive none: masked_fill)
+    const bool copy_grad = pass && is_copy;
+    for (int j = tid; j < S; j += 256) {
+        float d = 0.f;
+        if (copy_grad && mv[j]) d = expf(srow[j] - cmax) / csum - (j == y - V ? 1.f : 0.f);
+        srow[j] = d;
+    }
+    // d loss / d logits, in place
+    if (lrow) {
+        const bool gen_grad = pass && !is_copy;
+        for (int j = tid; j < V; j += 256) {
+            float d = 0.f;
+            if (gen_grad) d = expf(lrow[j] - gmax) / gsum - (j == y ? 1.f : 0.f);
+            lrow[j] = d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults, run_model.py:396), one fused pass over the flat parameter buffer.
+__global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float lr,
+                                                   float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ scale_ptr) {
+    const float scale = scale_ptr ? *scale_ptr : 1.0f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * scale;
+        const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;        // mul_(beta2).addcmul_(g, g, 1-beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+// inv_scale[0] = 1 / max(n_tok, 1): the token-count normaliser of run_model.py:105 without a host sync
+__global__ void inv_count_kernel(const int32_t* __restrict__ n_tok, float* __restrict__ out) {
+    const int n = *n_tok;
+    *out = 1.0f / (float)(n > 0 ? n : 1);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Decode-time output distribution (run_model.py:257-265): dist[r,:] = [g0*softmax(logits) ; g1*softmax(mask(score))]
+// for one position per row, plus the arg-max entry (greedy fast path).  One workgroup per row.
+__global__ __launch_bounds__(256) void decode_dist_kernel(int V, int S, const float* __restrict__ logits, int ldl,
+                                                          const float* __restrict__ score,
+                                                          const int32_t* __restrict__ mem_valid, int qpk,
+                                                          const float* __restrict__ gate_logits,
+                                                          float* __restrict__ dist, int32_t* __restrict__ best_id,
+                                                          float* __restrict__ best_p) {
+    __shared__ float smf[4];
+    __shared__ int smi[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* lrow = logits + (size_t)r * ldl;
+    const float* srow = score + (size_t)r * S;
+    const int32_t* mv = mem_valid + (size_t)(r / qpk) * S;
+    const float z0 = gate_logits[2 * r], z1 = gate_logits[2 * r + 1];
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+    float cmax = -INFINITY, gmax = -INFINITY;
+    int cidx = 0x7fffffff, gidx = 0x7fffffff;
+    for (int j = tid; j < S; j += 256) {
+        const float x = mv[j] ? srow[j] : -1e9f;
+        if (x > cmax) { cmax = x; cidx = j; }
+    }
+    block_argmax(cmax, cidx, smf, smi);
+    float csum = 0.f;
+    for (int j = tid; j < S; j += 256) csum += expf((mv[j] ? srow[j] : -1e9f) - cmax);
+    csum = block_sum(csum, smf);
+    for (int j = tid; j < V; j += 256) {
+        const float x = lrow[j];
+        if (x > gmax) { gmax = x; gidx = j; }
+    }
+    block_argmax(gmax, gidx, smf, smi);
+    float gsum = 0.f;
+    for (int j = tid; j < V; j += 256) gsum += expf(lrow[j] - gmax);
+    gsum = block_sum(gsum, smf);
+    if (dist) {
+        float* drow = dist + (size_t)r * (V + S);
+        for (int j = tid; j < V; j += 256) drow[j] = g0 * (expf(lrow[j] - gmax) / gsum);
+        for (int j = tid; j < S; j += 256) drow[V + j] = g1 * (expf((mv[j] ? srow[j] : -1e9f) - cmax) / csum);
+    }
+    if (tid == 0 && best_id) {
+        const float pg = g0 * (1.0f / gsum), pc = g1 * (1.0f / csum);
+        best_id[r] = pg >= pc ? gidx : V + cidx;
+        if (best_p) best_p[r] = pg >= pc ? pg : pc;
+    }
+}
+int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
+                const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
+                float* best_p) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(decode_dist_kernel, dim3(R), dim3(256), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
+                       gate_logits, dist, best_id, best_p);
+    FIRA_CHECK_LAUNCH("decode_dist");
+    return 0;
+}
+
+int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                      const float* bias, float* score, int qpk) {
+    if (B <= 0) return 0;
+    FIRA_REQUIRE(T <= T_MAX && qpk >= 1, "copy_score_fwd: T=%d > %d", T, T_MAX);
+    hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
+                       qpk);
+    FIRA_CHECK_LAUNCH("copy_score_fwd");
+    return 0;
+}
+int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                   const float* bias, float* score) {
+    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1);
+}
+int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                   const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
+    if (B <= 0) return 0;
+    FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
+    hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
+                       dtgt, dw, dbias);
+    FIRA_CHECK_LAUNCH("copy_score_bwd");
+    return 0;
+}
+int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
+              float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,
+              int32_t* n_tok, int32_t* argmax_out, int want_grad) {
+    if (BT <= 0) return 0;
+    hipLaunchKernelGGL(head_loss_kernel, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
+                       mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
+    FIRA_CHECK_LAUNCH("head_loss");
+    return 0;
+}
+int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+              float beta2, float eps, int step, const float* scale_ptr) {
+    if (n <= 0) return 0;
+    FIRA_REQUIRE(step >= 1, "adam_step: step must start at 1");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, n, p, g, m, v, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), scale_ptr);
+    FIRA_CHECK_LAUNCH("adam_step");
+    return 0;
+}
+int inv_count(hipStream_t s, const int32_t* n_tok, float* out) {
+    hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(1), 0, s, n_tok, out);
+    FIRA_CHECK_LAUNCH("inv_count");
+    return 0;
+}
+
+}  // namespace fira
+
+extern "C" {
+int fira_copy_score_fwd(void* stream, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                        const float* bias, float* score) {
+    return fira::copy_score_fwd((hipStream_t)stream, B, T, S, src, tgt, w, bias, score);
+}
+int fira_copy_score_bwd(void* stream, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                        const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
+    return fira::copy_score_bwd((hipStream_t)stream, B, T, S, src, tgt, w, dscore, dsrc, dtgt, dw, dbias);
+}
+int fira_head_loss(void* stream, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
+                   float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label,
+                   float* loss_sum, int32_t* n_tok, int32_t* argmax_out, int want_grad) {
+    return fira::head_loss((hipStream_t)stream, BT, T, V, S, compact_row, logits, ldl, score, mem_valid, gate_logits,
+                           tar_label, loss_sum, n_tok, argmax_out, want_grad);
+}
+int fira_inv_count(void* stream, const int32_t* n_tok, float* out) {
+    return fira::inv_count((hipStream_t)stream, n_tok, out);
+}
+int fira_adam_step(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                   float beta2, float eps, int step, const float* inv_scale_ntok) {
+    return fira::adam_step((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, step, inv_scale_ntok);
+}
+}

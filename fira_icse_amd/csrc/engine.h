@@ -1,0 +1,98 @@
+// Internal interfaces between the translation units of libfira_hip (not part of the C ABI).
+#pragma once
+#include "common.h"
+#include <string>
+#include <vector>
+
+namespace fira {
+
+// ---- op launchers (defined next to their kernels) ---------------------------------------------------
+int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             float* C, int ldc, const float* bias, int flags, int splitk);
+int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+             int ldx, float* Y, int ldy, int graph_rows, int variant);
+int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
+                     int out_bstride, int out_off);
+int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
+                     int out_bstride, int out_off, int padding_idx);
+int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark, float* out,
+                    float dropout, uint64_t seed, uint32_t site);
+int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
+                    const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site);
+// seg_*: output row r is stored at row (r / seg_len) * seg_stride + seg_off + r % seg_len (seg_len <= 0: identity)
+int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
+                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, int seg_len, int seg_stride,
+                      int seg_off);
+int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
+                      float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
+                      uint32_t site);
+int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out);
+// compact[r,:] (op)= strided[(r/seg_len)*seg_stride + seg_off + r%seg_len, :]   and the inverse
+int rows_gather_seg(hipStream_t s, int M, float* compact, const float* strided, int seg_len, int seg_stride, int seg_off);
+int rows_scatter_seg(hipStream_t s, int M, const float* compact, float* strided, int seg_len, int seg_stride,
+                     int seg_off);
+// compact[r,:] = src[rows[r],:] ;  dst[rows[r],:] += compact[r,:]
+int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows);
+int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows);
+int relu_bwd(hipStream_t s, int64_t n, float* dh, const float* h);
+int make_masks(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
+               int32_t* mem_valid, int32_t* tar_valid);
+int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar);
+int invert_rows(hipStream_t s, int BT, int R, const int32_t* rows, int32_t* compact_row);
+int iota_rows(hipStream_t s, int n, int32_t* out);
+// beam re-ordering of the decoder self-attention cache: dst[r, 0:len) = src[parent[r], 0:len) for nl layers of K and V,
+// plus the key-valid history; then hist_dst[r, step] = tokens[r] != 0
+int permute_cache(hipStream_t s, int nl, int BR, int T, int len, const int32_t* parent, const float* ksrc,
+                  const float* vsrc, float* kdst, float* vdst, const int32_t* hist_src, int32_t* hist_dst);
+int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist);
+
+int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo);
+int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                     const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
+                     int kb, int kvb, int qpk);
+int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
+                  const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
+int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                   const float* bias, float* score);
+int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                      const float* bias, float* score, int qpk);
+int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
+                const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
+                float* best_p);
+int inv_count(hipStream_t s, const int32_t* n_tok, float* out);
+int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                   const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias);
+int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
+              float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,
+              int32_t* n_tok, int32_t* argmax_out, int want_grad);
+int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+              float beta2, float eps, int step, const float* scale_ptr);
+
+// ---- parameter layout ---------------------------------------------------------------------------------
+struct ParamInfo {
+    std::string name;
+    int64_t offset = -1, numel = 0;
+    int ndim = 0;
+    int64_t shape[2] = {0, 0};
+};
+
+struct EncLayer {
+    int64_t wqk, bqk, w2, b2, wo, bo, ln1g, ln1b, fc1w, fc1b, fc2w, fc2b, ln2g, ln2b;
+};
+struct DecLayer {
+    int64_t wqkv, bqkv, wo_s, bo_s, lns_g, lns_b, wq_c, bq_c, wkv_c, bkv_c, wo_c, bo_c, lnc_g, lnc_b, w1, b1, w2, b2,
+        lnf_g, lnf_b;
+};
+struct Layout {
+    fira_dims d;
+    std::vector<ParamInfo> infos;     // reference state_dict order
+    int64_t total = 0;                // floats
+    int64_t emb, ast_emb, mark_emb, w2_all, b2_all, dec_emb, wkv_all, bkv_all, wout, bout, ws, wt, wres, bres, wp, bp;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+};
+const Layout* get_layout(const fira_dims* d);     // cached per geometry; nullptr + error on bad dims
+
+}  // namespace fira

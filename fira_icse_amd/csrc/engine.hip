@@ -1,0 +1,534 @@
+// Model-level entry points: chain the hand-written kernels into TransModel.forward / backward
+// (reference Model.py:38-86, gnn_transformer.py:45-62,108-122) and the decode step of run_model.py:225-274.
+// One host call enqueues the whole step on the caller's stream; nothing here synchronises or allocates.
+//
+// HBM layout of a training workspace (all fp32 unless noted; NB = B*650 node rows, CB = B*210 code rows,
+// MB = B*370 memory rows, TB = B*30 target rows):
+//   node buffers  X[l] [NB,256], l = 0..6   layer inputs; X[l] code rows are updated in place by the Combination
+//   per enc layer Xc [CB,256] (code rows before the update), qk [CB,512], c [CB,256], s1 [CB,256] + stats,
+//                 Z [NB,256], s2 [NB,256] + stats
+//   decoder       kv_all [MB, 6*512], per layer qkv [TB,768], ao, s_a, x_a, qc, ao2, s_c, x_c, h [TB,1024], s_f, x_f
+//   head          mem [MB,256], src [MB,256], tgt [TB,256], score [TB,370], gate [TB,2], dec_c [R,256], logits [R, ldl]
+//   backward      gradient temporaries of the same shapes (ping-pong node buffers, dkv_all, ...)
+#include "engine.h"
+
+namespace fira {
+
+struct Arena {
+    char* base;
+    size_t used = 0;
+    explicit Arena(void* b) : base((char*)b) {}
+    template <typename T>
+    T* get(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) / 256 * 256;
+        T* p = base ? (T*)(base + used) : nullptr;
+        used += bytes;
+        return p;
+    }
+    float* f(size_t n) { return get<float>(n); }
+};
+
+struct EncSave {
+    float *Xc, *qk, *c, *s1, *st1, *Z, *s2, *st2;
+};
+struct DecSave {
+    float *qkv, *ao, *s_a, *st_a, *x_a, *qc, *ao2, *s_c, *st_c, *x_c, *h, *s_f, *st_f, *x_f;
+};
+
+struct Plan {
+    int B, NB, CB, MB, TB, N, L, S, A, T, V, ldl, nl, F;
+    float *pos_code, *pos_tar;
+    int32_t *mem_valid, *tar_valid, *compact_row, *iota;
+    std::vector<float*> X;          // nl + 1 node buffers
+    std::vector<EncSave> enc;
+    std::vector<DecSave> dec;
+    float *vtab_all, *H, *mem, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
+    float *inv_ntok;
+    // backward temporaries (training only)
+    float *dXa, *dXb, *dNB1, *dNB2, *dCB_a, *dCB_b, *dCB_c, *dqk, *dvtab_all;
+    float *dmem, *dsrc, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_b, *dT_c, *dqkv, *dh;
+
+    size_t build(void* ws, const fira_dims& d, int B_, bool training) {
+        Arena a(ws);
+        B = B_; L = d.sou_len; S = d.sub_len; A = d.ast_len; T = d.tar_len; V = d.vocab; nl = d.n_layer; F = d.d_ff;
+        N = L + S + A;
+        NB = B * N; CB = B * L; MB = B * (L + S); TB = B * T;
+        ldl = (V + 63) / 64 * 64;
+        const size_t D = FIRA_D;
+        pos_code = a.f((size_t)L * D);
+        pos_tar = a.f((size_t)T * D);
+        mem_valid = a.get<int32_t>((size_t)MB);
+        tar_valid = a.get<int32_t>((size_t)TB);
+        compact_row = a.get<int32_t>((size_t)TB);
+        iota = a.get<int32_t>((size_t)TB);
+        inv_ntok = a.f(64);
+        X.resize(nl + 1);
+        for (int l = 0; l <= nl; ++l) X[l] = a.f((size_t)NB * D);
+        enc.resize(nl);
+        for (int l = 0; l < nl; ++l) {
+            EncSave& e = enc[l];
+            e.Xc = a.f((size_t)CB * D); e.qk = a.f((size_t)CB * 2 * D); e.c = a.f((size_t)CB * D);
+            e.s1 = a.f((size_t)CB * D); e.st1 = a.f((size_t)CB * 2);
+            e.Z = a.f((size_t)NB * D); e.s2 = a.f((size_t)NB * D); e.st2 = a.f((size_t)NB * 2);
+        }
+        vtab_all = a.f((size_t)4 * nl * D);
+        H = a.f((size_t)NB * D);
+        mem = a.f((size_t)MB * D);
+        x0 = a.f((size_t)TB * D);
+        kv_all = a.f((size_t)MB * nl * 2 * D);
+        dec.resize(nl);
+        for (int l = 0; l < nl; ++l) {
+            DecSave& e = dec[l];
+            e.qkv = a.f((size_t)TB * 3 * D); e.ao = a.f((size_t)TB * D); e.s_a = a.f((size_t)TB * D);
+            e.st_a = a.f((size_t)TB * 2); e.x_a = a.f((size_t)TB * D); e.qc = a.f((size_t)TB * D);
+            e.ao2 = a.f((size_t)TB * D); e.s_c = a.f((size_t)TB * D); e.st_c = a.f((size_t)TB * 2);
+            e.x_c = a.f((size_t)TB * D); e.h = a.f((size_t)TB * F); e.s_f = a.f((size_t)TB * D);
+            e.st_f = a.f((size_t)TB * 2); e.x_f = a.f((size_t)TB * D);
+        }
+        src = a.f((size_t)MB * D); tgt = a.f((size_t)TB * D);
+        score = a.f((size_t)TB * (L + S)); gate = a.f((size_t)TB * 2);
+        dec_c = a.f((size_t)TB * D); logits = a.f((size_t)TB * ldl);
+        if (training) {
+            dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB1 = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
+            dCB_a = a.f((size_t)CB * D); dCB_b = a.f((size_t)CB * D); dCB_c = a.f((size_t)CB * D);
+            dqk = a.f((size_t)CB * 2 * D); dvtab_all = a.f((size_t)4 * nl * D);
+            dmem = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dtgt = a.f((size_t)TB * D);
+            dkv_all = a.f((size_t)MB * nl * 2 * D);
+            ddec = a.f((size_t)TB * D); ddec_c = a.f((size_t)TB * D);
+            dT_a = a.f((size_t)TB * D); dT_b = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
+            dqkv = a.f((size_t)TB * 3 * D); dh = a.f((size_t)TB * F);
+        }
+        return a.used;
+    }
+};
+
+#define TRY(x)                 \
+    do {                       \
+        if (int e__ = (x)) return e__; \
+    } while (0)
+
+static int zero(hipStream_t s, void* p, size_t bytes) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, s);
+    if (e != hipSuccess) return set_err("hipMemsetAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// Y = X W^T + b
+static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int ldx, const float* W, const float* b,
+                         float* Y, int ldy, int flags = 0) {
+    return gemm_f32(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 1);
+}
+// dX (+)= dY W          (W stored [N,K]; reduce over N)
+static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* W, float* dX,
+                               int lddx, bool accum) {
+    return gemm_f32(s, 0, 0, M, K, N, dY, lddy, W, K, dX, lddx, nullptr, accum ? FIRA_GEMM_ACCUM : 0, 1);
+}
+// dW += dY^T X ; db += colsum(dY)      (reduce over the M rows: split-K over rows keeps the chip busy)
+static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx,
+                               float* dW, float* db) {
+    const int tiles = cdiv(N, 64) * cdiv(K, 64);
+    int splitk = 1;
+    if (tiles < 512) splitk = std::min(std::max(1, 768 / tiles), std::max(1, M / 128));
+    TRY(gemm_f32(s, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, splitk));
+    if (db) TRY(colsum(s, M, N, dY, lddy, db));
+    return 0;
+}
+
+enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
+static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
+
+struct Ctx {
+    hipStream_t s;
+    const Layout* L;
+    const fira_batch* bt;
+    const float* P;
+    float* G;
+    Plan* pl;
+    float p_drop, p_gcn;
+    uint64_t seed;
+};
+
+// ------------------------------------------------------------------------------------------ encoder forward
+static int encoder_forward(Ctx& c) {
+    Plan& p = *c.pl;
+    const Layout& L = *c.L;
+    hipStream_t s = c.s;
+    const int D = FIRA_D;
+    TRY(fill_pos_tables(s, p.L, p.pos_code, p.T, p.pos_tar));
+    TRY(make_masks(s, p.B, p.L, p.S, p.T, c.bt->sou, c.bt->sub_token, c.bt->tar, p.mem_valid, c.bt->tar ? p.tar_valid : nullptr));
+    // node features straight into the [B, 650, 256] buffer (gnn_transformer.py:46-52,58)
+    TRY(embed_gather_fwd(s, p.B, p.L, c.bt->sou, c.P + L.emb, p.pos_code, p.X[0], p.N, 0));
+    TRY(embed_gather_fwd(s, p.B, p.S, c.bt->sub_token, c.P + L.emb, nullptr, p.X[0], p.N, p.L));
+    TRY(embed_gather_fwd(s, p.B, p.A, c.bt->ast_change, c.P + L.ast_emb, nullptr, p.X[0], p.N, p.L + p.S));
+    // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
+    TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
+    for (int l = 0; l < p.nl; ++l) {
+        const EncLayer& w = L.enc[l];
+        EncSave& e = p.enc[l];
+        float* X = p.X[l];
+        // Combination (gnn_transformer.py:192-205): code rows only
+        TRY(rows_gather_seg(s, p.CB, e.Xc, X, p.L, p.N, 0));
+        TRY(linear(s, p.CB, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
+        TRY(combination_fwd(s, p.CB, e.qk, p.vtab_all + l * D, p.nl * D, c.bt->mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
+        TRY(linear(s, p.CB, D, D, e.c, D, c.P + w.wo, c.P + w.bo, e.s1, D));
+        TRY(add_layernorm_fwd(s, p.CB, e.s1, e.Xc, c.P + w.ln1g, c.P + w.ln1b, X, e.st1, c.p_drop, c.seed,
+                              site(l, SITE_COMB_OUT), p.L, p.N, 0));
+        // GCN (gnn_transformer.py:74-86): fc1 -> A_hat . -> fc2 -> +residual -> LN
+        TRY(linear(s, p.NB, D, D, X, D, c.P + w.fc1w, c.P + w.fc1b, p.H, D));
+        TRY(csr_spmm(s, p.NB, c.bt->rowptr, c.bt->col, c.bt->val, p.H, D, e.Z, D, p.N, 1));
+        TRY(linear(s, p.NB, D, D, e.Z, D, c.P + w.fc2w, c.P + w.fc2b, e.s2, D));
+        TRY(add_layernorm_fwd(s, p.NB, e.s2, X, c.P + w.ln2g, c.P + w.ln2b, p.X[l + 1], e.st2, c.p_gcn, c.seed,
+                              site(l, SITE_GCN), 0, 0, 0));
+    }
+    // memory = [code ; sub-token] rows (Model.py:48)
+    TRY(rows_gather_seg(s, p.MB, p.mem, p.X[p.nl], p.L + p.S, p.N, 0));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ decoder forward
+static int decoder_forward(Ctx& c) {
+    Plan& p = *c.pl;
+    const Layout& L = *c.L;
+    hipStream_t s = c.s;
+    const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
+    TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
+    TRY(linear(s, p.MB, KV, D, p.mem, D, c.P + L.wkv_all, c.P + L.bkv_all, p.kv_all, KV));
+    const float* x = p.x0;
+    for (int l = 0; l < p.nl; ++l) {
+        const DecLayer& w = L.dec[l];
+        DecSave& e = p.dec[l];
+        TRY(linear(s, p.TB, 3 * D, D, x, D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 3 * D));
+        TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D));
+        TRY(linear(s, p.TB, D, D, e.ao, D, c.P + w.wo_s, c.P + w.bo_s, e.s_a, D));
+        TRY(add_layernorm_fwd(s, p.TB, e.s_a, x, c.P + w.lns_g, c.P + w.lns_b, e.x_a, e.st_a, c.p_drop, c.seed, site(l, SITE_SELF), 0, 0, 0));
+        TRY(linear(s, p.TB, D, D, e.x_a, D, c.P + w.wq_c, c.P + w.bq_c, e.qc, D));
+        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D));
+        TRY(linear(s, p.TB, D, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.s_c, D));
+        TRY(add_layernorm_fwd(s, p.TB, e.s_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.x_c, e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS), 0, 0, 0));
+        TRY(linear(s, p.TB, p.F, D, e.x_c, D, c.P + w.w1, c.P + w.b1, e.h, p.F, FIRA_GEMM_RELU));
+        TRY(linear(s, p.TB, D, p.F, e.h, p.F, c.P + w.w2, c.P + w.b2, e.s_f, D));
+        TRY(add_layernorm_fwd(s, p.TB, e.s_f, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.x_f, e.st_f, c.p_drop, c.seed, site(l, SITE_FFN), 0, 0, 0));
+        x = e.x_f;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ head forward (+ loss)
+// The vocabulary GEMM runs on the R rows listed in `rows` (bt indices); the copy / gate branch is dense.
+static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int32_t* n_tok, int32_t* argmax_out,
+                        int want_grad) {
+    Plan& p = *c.pl;
+    const Layout& L = *c.L;
+    hipStream_t s = c.s;
+    const int D = FIRA_D, Sm = p.L + p.S;
+    const float* dec = p.dec[p.nl - 1].x_f;
+    TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));
+    TRY(invert_rows(s, p.TB, R, rows, p.compact_row));
+    TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
+    TRY(gemm_f32(s, 0, 1, p.MB, D, D, p.mem, D, c.P + L.ws, D, p.src, D, nullptr, 0, 1));
+    TRY(gemm_f32(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 1));
+    TRY(copy_score_fwd(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score));
+    TRY(linear(s, p.TB, 2, D, dec, D, c.P + L.wp, c.P + L.bp, p.gate, 2));
+    if (loss_sum) TRY(zero(s, loss_sum, sizeof(float)));
+    if (n_tok) TRY(zero(s, n_tok, sizeof(int32_t)));
+    TRY(head_loss(s, p.TB, p.T, p.V, Sm, p.compact_row, p.logits, p.ldl, p.score, p.mem_valid, p.gate,
+                  c.bt->tar_label, loss_sum, n_tok, argmax_out, want_grad));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ backward
+static int backward(Ctx& c, int R, const int32_t* rows) {
+    Plan& p = *c.pl;
+    const Layout& L = *c.L;
+    hipStream_t s = c.s;
+    const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
+    const float* dec = p.dec[p.nl - 1].x_f;
+    float* G = c.G;
+    const bool drop = c.p_drop > 0.f, gdrop = c.p_gcn > 0.f;
+
+    // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
+    TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
+    TRY(linear_wgrad(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
+    TRY(zero(s, p.dtgt, (size_t)p.TB * D * sizeof(float)));
+    TRY(copy_score_bwd(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres));
+    TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
+    TRY(linear_wgrad(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
+    TRY(linear_dgrad(s, p.MB, D, D, p.dsrc, D, c.P + L.ws, p.dmem, D, false));
+    TRY(linear_wgrad(s, p.MB, D, D, p.dsrc, D, p.mem, D, G + L.ws, nullptr));
+    if (R > 0) {
+        TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
+        TRY(zero(s, p.ddec_c, (size_t)R * D * sizeof(float)));
+        // ddec_rows = dlogits W_out : [R, V] x [V, 256], split over the vocabulary axis
+        const int tiles = cdiv(R, 64) * cdiv(D, 64);
+        const int splitk = std::max(1, std::min(64, 512 / std::max(1, tiles)));
+        TRY(gemm_f32(s, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, splitk));
+        TRY(rows_scatter_add_idx(s, R, p.ddec_c, p.ddec, rows));
+    }
+
+    // ---- decoder layers, last to first ------------------------------------------------------------------
+    const float* dy = p.ddec;
+    for (int l = p.nl - 1; l >= 0; --l) {
+        const DecLayer& w = L.dec[l];
+        DecSave& e = p.dec[l];
+        const float* x_in = l == 0 ? p.x0 : p.dec[l - 1].x_f;
+        // FeedForward (gnn_transformer.py:170-174)
+        TRY(add_layernorm_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, drop ? p.dT_b : nullptr, G + w.lnf_g,
+                              G + w.lnf_b, c.p_drop, c.seed, site(l, SITE_FFN)));
+        const float* dY = drop ? p.dT_b : p.dT_a;
+        TRY(linear_wgrad(s, p.TB, D, p.F, dY, D, e.h, p.F, G + w.w2, G + w.b2));
+        TRY(linear_dgrad(s, p.TB, D, p.F, dY, D, c.P + w.w2, p.dh, p.F, false));
+        TRY(relu_bwd(s, (int64_t)p.TB * p.F, p.dh, e.h));
+        TRY(linear_wgrad(s, p.TB, p.F, D, p.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
+        TRY(linear_dgrad(s, p.TB, p.F, D, p.dh, p.F, c.P + w.w1, p.dT_a, D, true));          // dT_a = d x_c
+        // cross attention
+        TRY(add_layernorm_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, drop ? p.dT_b : nullptr,
+                              G + w.lnc_g, G + w.lnc_b, c.p_drop, c.seed, site(l, SITE_CROSS)));
+        dY = drop ? p.dT_b : p.dT_c;
+        TRY(linear_wgrad(s, p.TB, D, D, dY, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
+        TRY(linear_dgrad(s, p.TB, D, D, dY, D, c.P + w.wo_c, p.dT_a, D, false));              // dT_a = d ao2
+        TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
+                          p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, p.dT_b, D, p.dkv_all + l * 2 * D, KV,
+                          p.dkv_all + l * 2 * D + D, KV));                                      // dT_b = d qc
+        TRY(linear_wgrad(s, p.TB, D, D, p.dT_b, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
+        TRY(linear_dgrad(s, p.TB, D, D, p.dT_b, D, c.P + w.wq_c, p.dT_c, D, true));           // dT_c = d x_a
+        // self attention
+        TRY(add_layernorm_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, drop ? p.dT_b : nullptr,
+                              G + w.lns_g, G + w.lns_b, c.p_drop, c.seed, site(l, SITE_SELF)));
+        dY = drop ? p.dT_b : p.dT_a;
+        TRY(linear_wgrad(s, p.TB, D, D, dY, D, e.ao, D, G + w.wo_s, G + w.bo_s));
+        TRY(linear_dgrad(s, p.TB, D, D, dY, D, c.P + w.wo_s, p.dT_c, D, false));              // dT_c = d ao
+        TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
+                          e.ao, D, p.dT_c, D, p.dqkv, 3 * D, p.dqkv + D, 3 * D, p.dqkv + 2 * D, 3 * D));
+        TRY(linear_wgrad(s, p.TB, 3 * D, D, p.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
+        TRY(linear_dgrad(s, p.TB, 3 * D, D, p.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
+        dy = p.dT_a;
+    }
+    // decoder embedding (no padding_idx: gnn_transformer.py:92-93)
+    TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, -1));
+    // cross-attention K|V projections of all layers
+    TRY(linear_dgrad(s, p.MB, KV, D, p.dkv_all, KV, c.P + L.wkv_all, p.dmem, D, true));
+    TRY(linear_wgrad(s, p.MB, KV, D, p.dkv_all, KV, p.mem, D, G + L.wkv_all, G + L.bkv_all));
+
+    // ---- encoder layers, last to first ------------------------------------------------------------------
+    float* dXn = p.dXa;
+    float* other = p.dXb;
+    TRY(zero(s, dXn, (size_t)p.NB * D * sizeof(float)));          // AST/edit rows of the last layer feed nothing
+    TRY(rows_scatter_seg(s, p.MB, p.dmem, dXn, Sm, p.N, 0));
+    TRY(zero(s, p.dvtab_all, (size_t)4 * p.nl * D * sizeof(float)));
+    for (int l = p.nl - 1; l >= 0; --l) {
+        const EncLayer& w = L.enc[l];
+        EncSave& e = p.enc[l];
+        const float* Xg = p.X[l];                                  // GCN input (code rows already updated)
+        TRY(add_layernorm_bwd(s, p.NB, dXn, e.s2, e.st2, c.P + w.ln2g, other, gdrop ? p.dNB1 : nullptr, G + w.ln2g,
+                              G + w.ln2b, c.p_gcn, c.seed, site(l, SITE_GCN)));
+        const float* dY = gdrop ? p.dNB1 : other;
+        TRY(linear_wgrad(s, p.NB, D, D, dY, D, e.Z, D, G + w.fc2w, G + w.fc2b));
+        TRY(linear_dgrad(s, p.NB, D, D, dY, D, c.P + w.fc2w, p.dNB2, D, false));               // dZ
+        TRY(csr_spmm(s, p.NB, c.bt->rowptr, c.bt->col, c.bt->val, p.dNB2, D, p.dNB1, D, p.N, 1));   // dH = A_hat dZ
+        TRY(linear_wgrad(s, p.NB, D, D, p.dNB1, D, Xg, D, G + w.fc1w, G + w.fc1b));
+        TRY(linear_dgrad(s, p.NB, D, D, p.dNB1, D, c.P + w.fc1w, other, D, true));             // other = dG
+        // Combination on the code rows
+        TRY(rows_gather_seg(s, p.CB, p.dCB_a, other, p.L, p.N, 0));
+        TRY(add_layernorm_bwd(s, p.CB, p.dCB_a, e.s1, e.st1, c.P + w.ln1g, p.dCB_b, drop ? p.dCB_c : nullptr,
+                              G + w.ln1g, G + w.ln1b, c.p_drop, c.seed, site(l, SITE_COMB_OUT)));
+        const float* dYc = drop ? p.dCB_c : p.dCB_b;
+        TRY(linear_wgrad(s, p.CB, D, D, dYc, D, e.c, D, G + w.wo, G + w.bo));
+        TRY(linear_dgrad(s, p.CB, D, D, dYc, D, c.P + w.wo, p.dCB_a, D, false));               // d c
+        TRY(combination_bwd(s, p.CB, e.qk, p.vtab_all + l * D, p.nl * D, c.bt->mark, p.dCB_a, p.dqk,
+                            p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE)));
+        TRY(linear_wgrad(s, p.CB, 2 * D, D, p.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
+        TRY(linear_dgrad(s, p.CB, 2 * D, D, p.dqk, 2 * D, c.P + w.wqk, p.dCB_b, D, true));     // dCB_b = d Xc
+        TRY(rows_scatter_seg(s, p.CB, p.dCB_b, other, p.L, p.N, 0));                           // other = dX[l]
+        float* tmp = dXn; dXn = other; other = tmp;
+    }
+    // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39)
+    TRY(embed_gather_bwd(s, p.B, p.L, c.bt->sou, G + L.emb, dXn, p.N, 0, 0));
+    TRY(embed_gather_bwd(s, p.B, p.S, c.bt->sub_token, G + L.emb, dXn, p.N, p.L, 0));
+    TRY(embed_gather_bwd(s, p.B, p.A, c.bt->ast_change, G + L.ast_emb, dXn, p.N, p.L + p.S, 0));
+    // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
+    TRY(gemm_f32(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
+                 FIRA_GEMM_ACCUM, 1));
+    TRY(colsum(s, 4, p.nl * D, p.dvtab_all, p.nl * D, G + L.b2_all));
+    TRY(linear_dgrad(s, 4, p.nl * D, D, p.dvtab_all, p.nl * D, c.P + L.w2_all, G + L.mark_emb, D, true));
+    TRY(zero(s, G + L.mark_emb, (size_t)D * sizeof(float)));       // padding_idx row 0 never gets a gradient
+    return 0;
+}
+
+static int check_batch(const fira_batch* b) {
+    FIRA_REQUIRE(b && b->B > 0, "empty batch");
+    FIRA_REQUIRE(b->sou && b->mark && b->ast_change && b->sub_token && b->rowptr && b->col && b->val,
+                 "batch has null encoder inputs");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ decode state
+struct DecodePlan {
+    Plan enc;
+    int BR;
+    float *kc[2], *vc[2];
+    int32_t* hist[2];
+    float *x, *q, *ao, *s, *xa, *qc, *xc, *h, *tgt, *score, *gate, *logits;
+    size_t build(void* ws, const fira_dims& d, int B, int n_beam) {
+        size_t used = enc.build(ws, d, B, false);
+        Arena a(ws ? (char*)ws + used : nullptr);
+        BR = B * n_beam;
+        const size_t D = FIRA_D, T = d.tar_len, cache = (size_t)d.n_layer * BR * T * D;
+        for (int i = 0; i < 2; ++i) {
+            kc[i] = a.f(cache); vc[i] = a.f(cache);
+            hist[i] = a.get<int32_t>((size_t)BR * T);
+        }
+        x = a.f(BR * D); q = a.f(BR * D); ao = a.f(BR * D); s = a.f(BR * D); xa = a.f(BR * D); qc = a.f(BR * D);
+        xc = a.f(BR * D); h = a.f((size_t)BR * d.d_ff); tgt = a.f(BR * D);
+        score = a.f((size_t)BR * (d.sou_len + d.sub_len)); gate = a.f((size_t)BR * 2);
+        logits = a.f((size_t)BR * enc.ldl);
+        return used + a.used;
+    }
+};
+
+}  // namespace fira
+
+using namespace fira;
+
+extern "C" {
+
+size_t fira_workspace_bytes(const fira_dims* d, int B, int mode) {
+    if (!get_layout(d) || B <= 0) return 0;
+    Plan p;
+    return p.build(nullptr, *d, B, mode == 1);
+}
+size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam) {
+    if (!get_layout(d) || B <= 0 || n_beam <= 0) return 0;
+    DecodePlan dp;
+    return dp.build(nullptr, *d, B, n_beam);
+}
+
+int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                       void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                       int32_t* n_tok) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    TRY(check_batch(batch));
+    FIRA_REQUIRE(batch->tar && batch->tar_label, "training batch needs tar and tar_label");
+    FIRA_REQUIRE(params && grads && workspace && loss_sum && n_tok, "null pointer argument");
+    Plan p;
+    const size_t need = p.build(workspace, *d, batch->B, true);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    Ctx c{(hipStream_t)stream, L, batch, params, grads, &p, opts ? opts->dropout : 0.f, opts ? opts->gcn_dropout : 0.f,
+          opts ? opts->seed : 0};
+    FIRA_REQUIRE(c.p_drop >= 0.f && c.p_drop < 1.f && c.p_gcn >= 0.f && c.p_gcn < 1.f, "dropout must be in [0,1)");
+    TRY(encoder_forward(c));
+    TRY(decoder_forward(c));
+    int R = p.TB;
+    const int32_t* rows = p.iota;
+    if (opts && opts->compact_head && batch->head_rows) {
+        R = batch->n_head_rows;
+        rows = batch->head_rows;
+        FIRA_REQUIRE(R >= 0 && R <= p.TB, "bad n_head_rows %d", R);
+    } else {
+        TRY(iota_rows(c.s, p.TB, p.iota));
+    }
+    TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
+    TRY(backward(c, R, rows));
+    return 0;
+}
+
+int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,
+                     size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    TRY(check_batch(batch));
+    FIRA_REQUIRE(batch->tar && batch->tar_label && params && workspace && ids_out, "null pointer argument");
+    Plan p;
+    const size_t need = p.build(workspace, *d, batch->B, false);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
+    TRY(encoder_forward(c));
+    TRY(decoder_forward(c));
+    TRY(iota_rows(c.s, p.TB, p.iota));
+    TRY(head_forward(c, p.TB, p.iota, loss_sum, n_tok, ids_out, 0));
+    return 0;
+}
+
+int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,
+                      size_t workspace_bytes, int n_beam) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    TRY(check_batch(batch));
+    FIRA_REQUIRE(params && workspace && n_beam >= 1, "bad argument");
+    DecodePlan dp;
+    const size_t need = dp.build(workspace, *d, batch->B, n_beam);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    Plan& p = dp.enc;
+    fira_batch b2 = *batch;
+    b2.tar = nullptr;
+    Ctx c{(hipStream_t)stream, L, &b2, params, nullptr, &p, 0.f, 0.f, 0};
+    TRY(encoder_forward(c));
+    const int D = FIRA_D, KV = p.nl * 2 * D;
+    TRY(linear(c.s, p.MB, KV, D, p.mem, D, params + L->wkv_all, params + L->bkv_all, p.kv_all, KV));
+    TRY(gemm_f32(c.s, 0, 1, p.MB, D, D, p.mem, D, params + L->ws, D, p.src, D, nullptr, 0, 1));
+    return 0;
+}
+
+int fira_decode_step(void* stream, const fira_dims* d, const float* params, void* workspace, size_t workspace_bytes,
+                     int B, int n_beam, int step, const int32_t* tokens, const int32_t* parent, float* dist,
+                     int32_t* best_id, float* best_p) {
+    const Layout* Lp = get_layout(d);
+    if (!Lp) return 1;
+    const Layout& L = *Lp;
+    FIRA_REQUIRE(params && workspace && tokens && B > 0 && n_beam >= 1, "bad argument");
+    FIRA_REQUIRE(step >= 0 && step < d->tar_len, "step %d out of range", step);
+    DecodePlan dp;
+    const size_t need = dp.build(workspace, *d, B, n_beam);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    Plan& p = dp.enc;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = FIRA_D, H = d->n_head, T = p.T, KV = p.nl * 2 * D, Sm = p.L + p.S, BR = dp.BR;
+    const int cur = n_beam > 1 ? (step & 1) : 0, prev = n_beam > 1 ? ((step + 1) & 1) : 0;
+    if (n_beam > 1 && step > 0)
+        TRY(permute_cache(s, p.nl, BR, T, step, parent, dp.kc[prev], dp.vc[prev], dp.kc[cur], dp.vc[cur], dp.hist[prev],
+                          dp.hist[cur]));
+    TRY(mark_history(s, BR, T, step, tokens, dp.hist[cur]));
+    // token embedding + position `step` (gnn_transformer.py:110-113)
+    TRY(embed_gather_fwd(s, BR, 1, tokens, params + L.dec_emb, p.pos_tar + (size_t)step * D, dp.x, 1, 0));
+    const size_t lay = (size_t)BR * T * D;
+    for (int l = 0; l < p.nl; ++l) {
+        const DecLayer& w = L.dec[l];
+        float* kc = dp.kc[cur] + l * lay;
+        float* vc = dp.vc[cur] + l * lay;
+        TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.q, D));
+        TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)D * D, params + w.bqkv + D, kc + (size_t)step * D, T * D));
+        TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
+        TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
+        TRY(linear(s, BR, D, D, dp.ao, D, params + w.wo_s, params + w.bo_s, dp.s, D));
+        TRY(add_layernorm_fwd(s, BR, dp.s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, nullptr, 0.f, 0, 0, 0, 0, 0));
+        TRY(linear(s, BR, D, D, dp.xa, D, params + w.wq_c, params + w.bq_c, dp.qc, D));
+        TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
+                             p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
+        TRY(linear(s, BR, D, D, dp.ao, D, params + w.wo_c, params + w.bo_c, dp.s, D));
+        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, nullptr, 0.f, 0, 0, 0, 0, 0));
+        TRY(linear(s, BR, p.F, D, dp.xc, D, params + w.w1, params + w.b1, dp.h, p.F, FIRA_GEMM_RELU));
+        TRY(linear(s, BR, D, p.F, dp.h, p.F, params + w.w2, params + w.b2, dp.s, D));
+        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, nullptr, 0.f, 0, 0, 0, 0, 0));
+    }
+    TRY(linear(s, BR, p.V, D, dp.x, D, params + L.wout, params + L.bout, dp.logits, p.ldl));
+    TRY(gemm_f32(s, 0, 1, BR, D, D, dp.x, D, params + L.wt, D, dp.tgt, D, nullptr, 0, 1));
+    TRY(copy_score_fwd_ex(s, BR, 1, Sm, p.src, dp.tgt, params + L.wres, params + L.bres, dp.score, n_beam));
+    TRY(linear(s, BR, 2, D, dp.x, D, params + L.wp, params + L.bp, dp.gate, 2));
+    TRY(decode_dist(s, BR, p.V, Sm, dp.logits, p.ldl, dp.score, p.mem_valid, n_beam, dp.gate, dist, best_id, best_p));
+    return 0;
+}
+
+const float* fira_decode_memory(const fira_dims* d, void* workspace, int B, int n_beam) {
+    if (!get_layout(d) || !workspace) return nullptr;
+    DecodePlan dp;
+    dp.build(workspace, *d, B, n_beam);
+    return dp.enc.mem;
+}
+const int32_t* fira_decode_mem_valid(const fira_dims* d, void* workspace, int B, int n_beam) {
+    if (!get_layout(d) || !workspace) return nullptr;
+    DecodePlan dp;
+    dp.build(workspace, *d, B, n_beam);
+    return dp.enc.mem_valid;
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain).
+//
+// Replaces every nn.Linear forward/backward of the reference (addmm/mm rows of SURVEY.md §2.3):
+//   forward   Y[M,N]  = X[M,K] · W[N,K]^T + b      transA=0, transB=1
+//   dgrad     dX[M,K] = dY[M,N] · W[N,K]            transA=0, transB=0
+//   wgrad     dW[N,K] += dY[M,N]^T · X[M,K]         transA=1, transB=0  (split-K + fp32 atomics)
+//
+// Structure: 256 threads = 4 waves in 2x2; block tile BMxBN (128x128 or 64x64), BK = 32;
+// operands are staged global -> registers -> LDS in k-major order ([k][m], [k][n]) so that the MFMA
+// operand fetch (lane l needs X[m0 + (l&31)][k + (l>>5)]) is one conflict-free ds_read_b32 for both
+// storage orders; the register stage of tile t+1 is issued before the MFMAs of tile t (one barrier per
+// K tile, two LDS buffers).  LDS row pitch 129 makes the transposing scalar writes of the k-contiguous
+// path conflict-free (4*129 = 4 mod 32); the m-contiguous path writes 16-byte rows at pitch 132.
+#include "common.h"
+
+namespace fira {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+template <int ROWS, bool CONTIG_K>
+struct TileLoader {
+    // ROWS = BM or BN (extent along the non-reduction axis)
+    static constexpr int NV = ROWS / 32;            // float4 per thread per tile
+    static constexpr int LD = CONTIG_K ? ROWS + 1 : ROWS + 4;
+
+    // source element (r, k): CONTIG_K ? src[r*ld + k] : src[k*ld + r]
+    __device__ __forceinline__ static void load(float4 (&v)[NV], const float* __restrict__ src, int ld,
+                                                int r0, int r_end, int k0, int k_end, bool vec_ok, int t) {
+        if constexpr (CONTIG_K) {
+            const int kq = (t & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = r0 + (t >> 3) + 32 * i;
+                const int k = k0 + kq;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < r_end) {
+                    const float* p = src + (size_t)r * ld + k;
+                    if (vec_ok && k + 3 < k_end) {
+                        x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (k + 0 < k_end) x.x = p[0];
+                        if (k + 1 < k_end) x.y = p[1];
+                        if (k + 2 < k_end) x.z = p[2];
+                        if (k + 3 < k_end) x.w = p[3];
+                    }
+                }
+                v[i] = x;
+            }
+        } else {
+            constexpr int CPR = ROWS / 4;           // float4 columns per k-row (32 or 16)
+            constexpr int KSTEP = 256 / CPR;        // k-rows covered per pass (8 or 16)
+            const int c = (t % CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = k0 + (t / CPR) + KSTEP * i;
+                const int r = r0 + c;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < k_end) {
+                    const float* p = src + (size_t)k * ld + r;
+                    if (vec_ok && r + 3 < r_end) {
+                        x = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (r + 0 < r_end) x.x = p[0];
+                        if (r + 1 < r_end) x.y = p[1];
+                        if (r + 2 < r_end) x.z = p[2];
+                        if (r + 3 < r_end) x.w = p[3];
+                    }
+                }
+                v[i] = x;
+            }
+        }
+    }
+
+    __device__ __forceinline__ static void store(const float4 (&v)[NV], float* __restrict__ lds, int t) {
+        if constexpr (CONTIG_K) {
+            const int kq = (t & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = (t >> 3) + 32 * i;
+                lds[(kq + 0) * LD + r] = v[i].x;
+                lds[(kq + 1) * LD + r] = v[i].y;
+                lds[(kq + 2) * LD + r] = v[i].z;
+                lds[(kq + 3) * LD + r] = v[i].w;
+            }
+        } else {
+            constexpr int CPR = ROWS / 4;
+            constexpr int KSTEP = 256 / CPR;
+            const int c = (t % CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int k = (t / CPR) + KSTEP * i;
+                *reinterpret_cast<float4*>(&lds[k * LD + c]) = v[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                       const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                       int ldc, const float* __restrict__ bias, int flags,
+                                                       int k_chunk, int vecA, int vecB) {
+    using LA = TileLoader<BM, !TA>;       // A stored [M,K] (k contiguous) unless TA
+    using LB = TileLoader<BN, TB>;        // B stored [N,K] (k contiguous) when TB
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float smA[2][BK * LA::LD];
+    __shared__ __attribute__((aligned(16))) float smB[2][BK * LB::LD];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * k_chunk;
+    const int kend = min(K, kbeg + k_chunk);
+    const int ntile = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[LA::NV], rb[LB::NV];
+    if (ntile > 0) {
+        LA::load(ra, A, lda, m0, M, kbeg, kend, vecA != 0, t);
+        LB::load(rb, B, ldb, n0, N, kbeg, kend, vecB != 0, t);
+        LA::store(ra, smA[0], t);
+        LB::store(rb, smB[0], t);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = 0; it < ntile; ++it) {
+        const bool more = it + 1 < ntile;
+        if (more) {
+            const int k0 = kbeg + (it + 1) * BK;
+            LA::load(ra, A, lda, m0, M, k0, kend, vecA != 0, t);
+            LB::load(rb, B, ldb, n0, N, k0, kend, vecB != 0, t);
+        }
+        const float* sa = smA[cur] + kh * LA::LD + wm * WM + l31;
+        const float* sb = smB[cur] + kh * LB::LD + wn * WN + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = sa[2 * kk * LA::LD + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = sb[2 * kk * LB::LD + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            LA::store(ra, smA[cur ^ 1], t);
+            LB::store(rb, smB[cur ^ 1], t);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool relu = flags & FIRA_GEMM_RELU;
+    const bool accum = flags & FIRA_GEMM_ACCUM;
+    const bool atomic = gridDim.z > 1;
+    const bool add_bias = bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        if (col >= N) continue;
+        const float bv = add_bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row >= M) continue;
+                float v = acc[i][j][r] + bv;
+                float* p = C + (size_t)row * ldc + col;
+                if (atomic) {
+                    unsafeAtomicAdd(p, v);
+                } else {
+                    if (accum) v += *p;
+                    if (relu) v = fmaxf(v, 0.f);
+                    *p = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                  float* C, int ldc, const float* bias, int flags, int splitk) {
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk);
+    int k_chunk = cdiv(cdiv(K, splitk), BK) * BK;
+    const int vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+    const int vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+#define FIRA_GEMM_GO(TA, TB)                                                                                     \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
+                       bias, flags, k_chunk, vecA, vecB)
+    if (!tA && tB) FIRA_GEMM_GO(false, true);
+    else if (!tA && !tB) FIRA_GEMM_GO(false, false);
+    else if (tA && !tB) FIRA_GEMM_GO(true, false);
+    else FIRA_GEMM_GO(true, true);
+#undef FIRA_GEMM_GO
+    FIRA_CHECK_LAUNCH("gemm_f32");
+    return 0;
+}
+
+int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+             float* C, int ldc, const float* bias, int flags, int splitk) {
+    if (M <= 0 || N <= 0) return 0;
+    FIRA_REQUIRE(K > 0 && splitk >= 1, "gemm_f32: bad K=%d splitk=%d", K, splitk);
+    FIRA_REQUIRE(!(splitk > 1 && (flags & FIRA_GEMM_RELU)), "gemm_f32: relu cannot be combined with split-K");
+    FIRA_REQUIRE(!(splitk > 1 && !(flags & FIRA_GEMM_ACCUM)), "gemm_f32: split-K needs accumulate semantics");
+    // big tiles only when they still fill the chip (256 CUs); the decoder-side GEMMs are small
+    const long big_blocks = (long)cdiv(M, 128) * cdiv(N, 128) * splitk;
+    if (big_blocks >= 192) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
+    return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
+}
+
+}  // namespace fira
+
+extern "C" int fira_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                             const float* B, int ldb, float* C, int ldc, const float* bias, int flags, int splitk) {
+    return fira::gemm_f32((hipStream_t)stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
+}

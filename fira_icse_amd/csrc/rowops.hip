@@ -1,0 +1,536 @@
+// Row-wise (256-wide) memory-bound kernels: embedding gather/scatter, the element-wise
+// Combination gate, fused dropout + residual + LayerNorm, bias-gradient column sums.
+// One wavefront owns one 256-float row as float4 per lane (a 1 KiB coalesced access);
+// row statistics are wave reductions (no LDS, no atomics on the forward path).
+#include "engine.h"
+
+namespace fira {
+
+// ------------------------------------------------------------------------------------------------
+// Embedding gathers of Encoder.forward / Decoder.forward (reference gnn_transformer.py:46-52,110-113),
+// written straight into the [B, N, 256] node buffer (replaces the torch.cat of gnn_transformer.py:58).
+__global__ __launch_bounds__(256) void embed_gather_fwd_kernel(int rows, int L, const int32_t* __restrict__ idx,
+                                                               const float* __restrict__ table,
+                                                               const float* __restrict__ pos, float* __restrict__ out,
+                                                               int out_bstride, int out_off) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int b = r / L, i = r - b * L;
+    const int id = idx[r];
+    float4 v = *reinterpret_cast<const float4*>(table + (size_t)id * FIRA_D + lane * 4);
+    if (pos) {
+        const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)i * FIRA_D + lane * 4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    *reinterpret_cast<float4*>(out + ((size_t)b * out_bstride + out_off + i) * FIRA_D + lane * 4) = v;
+}
+
+// backward of the gather: dtable[idx] += dout[row] (embedding_dense_backward of SURVEY.md §2.3);
+// rows whose id is the padding index get no gradient (nn.Embedding(padding_idx=0)).
+__global__ __launch_bounds__(256) void embed_gather_bwd_kernel(int rows, int L, const int32_t* __restrict__ idx,
+                                                               float* __restrict__ dtable,
+                                                               const float* __restrict__ dout, int out_bstride,
+                                                               int out_off, int padding_idx) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int b = r / L, i = r - b * L;
+    const int id = idx[r];
+    if (id == padding_idx) return;
+    const float4 g = *reinterpret_cast<const float4*>(dout + ((size_t)b * out_bstride + out_off + i) * FIRA_D + lane * 4);
+    float* p = dtable + (size_t)id * FIRA_D + lane * 4;
+    unsafeAtomicAdd(p + 0, g.x);
+    unsafeAtomicAdd(p + 1, g.y);
+    unsafeAtomicAdd(p + 2, g.z);
+    unsafeAtomicAdd(p + 3, g.w);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CombinationLayer (reference combination_layer.py:7-17): per element
+//   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
+// The head split/transposes of gnn_transformer.py:197-202 cancel.
+__device__ __forceinline__ void gate_elem(float q, float k, float v, float& g0, float& g1) {
+    const float s = 5.656854249492381f;          // sqrt(32)
+    const float a = q * k / s, b = q * v / s;
+    const float m = fmaxf(a, b);
+    const float ea = expf(a - m), eb = expf(b - m);
+    const float den = ea + eb;
+    g0 = ea / den;
+    g1 = eb / den;
+}
+
+__global__ __launch_bounds__(256) void combination_fwd_kernel(int M, const float* __restrict__ qk,
+                                                              const float* __restrict__ vtab, int ldv,
+                                                              const int32_t* __restrict__ mark,
+                                                              float* __restrict__ out, float p, float inv_keep,
+                                                              uint64_t seed, uint32_t site) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const float4 q4 = *reinterpret_cast<const float4*>(qk + (size_t)r * 2 * FIRA_D + lane * 4);
+    const float4 k4 = *reinterpret_cast<const float4*>(qk + (size_t)r * 2 * FIRA_D + FIRA_D + lane * 4);
+    const float4 v4 = *reinterpret_cast<const float4*>(vtab + (size_t)mark[r] * ldv + lane * 4);
+    const float q[4] = {q4.x, q4.y, q4.z, q4.w}, k[4] = {k4.x, k4.y, k4.z, k4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float c[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float g0, g1;
+        gate_elem(q[e], k[e], v[e], g0, g1);
+        c[e] = g0 * k[e] + g1 * v[e];
+        if (p > 0.f) c[e] *= dropout_scale(seed, site, (uint32_t)r * FIRA_D + lane * 4 + e, p, inv_keep);
+    }
+    *reinterpret_cast<float4*>(out + (size_t)r * FIRA_D + lane * 4) = make_float4(c[0], c[1], c[2], c[3]);
+}
+
+// backward: dq, dk per element; dv is reduced over all rows sharing a mark value into dvtab[4,256]
+// (block-level LDS reduction, then one atomic per (mark, column) per block).
+__global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float* __restrict__ qk,
+                                                              const float* __restrict__ vtab, int ldv,
+                                                              const int32_t* __restrict__ mark,
+                                                              const float* __restrict__ dout,
+                                                              float* __restrict__ dqk, float* __restrict__ dvtab,
+                                                              int lddv, float p, float inv_keep, uint64_t seed,
+                                                              uint32_t site, int rows_per_block) {
+    __shared__ float red[4 * FIRA_D];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < 4 * FIRA_D; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float dv_acc[4][4];                // [mark value][element]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv_acc[a][e] = 0.f;
+    const float s = 5.656854249492381f;
+    const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
+    for (int r = r_beg + wave; r < r_end; r += 4) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qk + (size_t)r * 2 * FIRA_D + lane * 4);
+        const float4 k4 = *reinterpret_cast<const float4*>(qk + (size_t)r * 2 * FIRA_D + FIRA_D + lane * 4);
+        const int mk = mark[r];
+        const float4 v4 = *reinterpret_cast<const float4*>(vtab + (size_t)mk * ldv + lane * 4);
+        const float4 d4 = *reinterpret_cast<const float4*>(dout + (size_t)r * FIRA_D + lane * 4);
+        const float q[4] = {q4.x, q4.y, q4.z, q4.w}, k[4] = {k4.x, k4.y, k4.z, k4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float dc[4] = {d4.x, d4.y, d4.z, d4.w};
+        float dq[4], dk[4], dv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p > 0.f) dc[e] *= dropout_scale(seed, site, (uint32_t)r * FIRA_D + lane * 4 + e, p, inv_keep);
+            float g0, g1;
+            gate_elem(q[e], k[e], v[e], g0, g1);
+            const float dg0 = dc[e] * k[e], dg1 = dc[e] * v[e];
+            const float dot = g0 * dg0 + g1 * dg1;
+            const float da = g0 * (dg0 - dot), db = g1 * (dg1 - dot);
+            dq[e] = (da * k[e] + db * v[e]) / s;
+            dk[e] = dc[e] * g0 + da * q[e] / s;
+            dv[e] = dc[e] * g1 + db * q[e] / s;
+        }
+        *reinterpret_cast<float4*>(dqk + (size_t)r * 2 * FIRA_D + lane * 4) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        *reinterpret_cast<float4*>(dqk + (size_t)r * 2 * FIRA_D + FIRA_D + lane * 4) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (mk == a) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv_acc[a][e] += dv[e];
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&red[a * FIRA_D + lane * 4 + e], dv_acc[a][e]);
+    __syncthreads();
+    for (int i = t; i < 4 * FIRA_D; i += 256) {
+        const float x = red[i];
+        if (x != 0.f) unsafeAtomicAdd(&dvtab[(size_t)(i / FIRA_D) * lddv + (i % FIRA_D)], x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = LayerNorm(dropout(x) + res) (eps = 1e-5, biased variance): the post-LN residual of every block
+// (reference gnn_transformer.py:86,161,174,205).  x is overwritten with the pre-norm sum.
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __restrict__ x,
+                                                                const float* __restrict__ res,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ y, float* __restrict__ stats,
+                                                                float p, float inv_keep, uint64_t seed,
+                                                                uint32_t site, int seg_len, int seg_stride,
+                                                                int seg_off) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const size_t o = (size_t)r * FIRA_D + lane * 4;
+    const size_t oy = seg_len > 0 ? ((size_t)(r / seg_len) * seg_stride + seg_off + r % seg_len) * FIRA_D + lane * 4 : o;
+    float4 a = *reinterpret_cast<const float4*>(x + o);
+    if (p > 0.f) {
+        const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
+        a.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
+        a.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
+        a.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
+        a.w *= dropout_scale(seed, site, e0 + 3, p, inv_keep);
+    }
+    if (res) {
+        const float4 b = *reinterpret_cast<const float4*>(res + o);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float mean = wave_sum(a.x + a.y + a.z + a.w) * (1.0f / FIRA_D);
+    const float dx = a.x - mean, dy = a.y - mean, dz = a.z - mean, dw = a.w - mean;
+    const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / FIRA_D);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + lane * 4);
+    *reinterpret_cast<float4*>(x + o) = a;
+    *reinterpret_cast<float4*>(y + oy) =
+        make_float4(dx * rstd * g.x + bt.x, dy * rstd * g.y + bt.y, dz * rstd * g.z + bt.z, dw * rstd * g.w + bt.w);
+    if (stats && lane == 0) {
+        stats[2 * r] = mean;
+        stats[2 * r + 1] = rstd;
+    }
+}
+
+// backward of the block above.  ds = gradient wrt the pre-norm sum (also the residual-branch gradient);
+// dx_drop (optional) = ds * keep-mask / (1-p): the gradient wrt the un-dropped GEMM output.
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const float* __restrict__ dy,
+                                                                const float* __restrict__ sum,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma,
+                                                                float* __restrict__ ds, float* __restrict__ dx_drop,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float p, float inv_keep, uint64_t seed, uint32_t site,
+                                                                int rows_per_block) {
+    __shared__ float red[2 * FIRA_D];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < 2 * FIRA_D; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
+    for (int r = r_beg + wave; r < r_end; r += 4) {
+        const size_t o = (size_t)r * FIRA_D + lane * 4;
+        const float4 d = *reinterpret_cast<const float4*>(dy + o);
+        const float4 sv = *reinterpret_cast<const float4*>(sum + o);
+        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+        const float xh0 = (sv.x - mean) * rstd, xh1 = (sv.y - mean) * rstd, xh2 = (sv.z - mean) * rstd,
+                    xh3 = (sv.w - mean) * rstd;
+        dg.x += d.x * xh0; dg.y += d.y * xh1; dg.z += d.z * xh2; dg.w += d.w * xh3;
+        db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
+        const float h0 = d.x * g.x, h1 = d.y * g.y, h2 = d.z * g.z, h3 = d.w * g.w;
+        const float m1 = wave_sum(h0 + h1 + h2 + h3) * (1.0f / FIRA_D);
+        const float m2 = wave_sum(h0 * xh0 + h1 * xh1 + h2 * xh2 + h3 * xh3) * (1.0f / FIRA_D);
+        float4 o4 = make_float4(rstd * (h0 - m1 - xh0 * m2), rstd * (h1 - m1 - xh1 * m2), rstd * (h2 - m1 - xh2 * m2),
+                                rstd * (h3 - m1 - xh3 * m2));
+        *reinterpret_cast<float4*>(ds + o) = o4;
+        if (dx_drop) {
+            if (p > 0.f) {
+                const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
+                o4.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
+                o4.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
+                o4.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
+                o4.w *= dropout_scale(seed, site, e0 + 3, p, inv_keep);
+            }
+            *reinterpret_cast<float4*>(dx_drop + o) = o4;
+        }
+    }
+    atomicAdd(&red[lane * 4 + 0], dg.x); atomicAdd(&red[lane * 4 + 1], dg.y);
+    atomicAdd(&red[lane * 4 + 2], dg.z); atomicAdd(&red[lane * 4 + 3], dg.w);
+    atomicAdd(&red[FIRA_D + lane * 4 + 0], db.x); atomicAdd(&red[FIRA_D + lane * 4 + 1], db.y);
+    atomicAdd(&red[FIRA_D + lane * 4 + 2], db.z); atomicAdd(&red[FIRA_D + lane * 4 + 3], db.w);
+    __syncthreads();
+    for (int i = t; i < FIRA_D; i += 256) {
+        unsafeAtomicAdd(&dgamma[i], red[i]);
+        unsafeAtomicAdd(&dbeta[i], red[FIRA_D + i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[n] += sum_m X[m,n]: bias gradients.  Block = 256 threads over 64 columns x 4 row-phases.
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ X, int ldx,
+                                                     float* __restrict__ out, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    const int r_beg = blockIdx.y * rows_per_block, r_end = min(M, r_beg + rows_per_block);
+    float acc = 0.f;
+    if (c < N)
+        for (int r = r_beg + ph; r < r_end; r += 4) acc += X[(size_t)r * ldx + c];
+    red[ph][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ph == 0 && c < N) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        unsafeAtomicAdd(&out[c], v);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// row movers: segment-strided <-> compact (code rows of the [B,650,256] node buffer, memory rows), and
+// index lists (rows of the head that carry a label).
+template <int MODE>   // 0: compact = strided ; 1: strided = compact
+__global__ __launch_bounds__(256) void rows_seg_kernel(int M, float* __restrict__ compact, float* __restrict__ strided,
+                                                       int seg_len, int seg_stride, int seg_off) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const size_t oc = (size_t)r * FIRA_D + lane * 4;
+    const size_t os = ((size_t)(r / seg_len) * seg_stride + seg_off + r % seg_len) * FIRA_D + lane * 4;
+    if (MODE == 0) *reinterpret_cast<float4*>(compact + oc) = *reinterpret_cast<const float4*>(strided + os);
+    else *reinterpret_cast<float4*>(strided + os) = *reinterpret_cast<const float4*>(compact + oc);
+}
+template <int MODE>   // 0: compact[r] = src[rows[r]] ; 1: dst[rows[r]] += compact[r]
+__global__ __launch_bounds__(256) void rows_idx_kernel(int R, float* __restrict__ compact, float* __restrict__ full,
+                                                       const int32_t* __restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t oc = (size_t)r * FIRA_D + lane * 4;
+    const size_t of = (size_t)rows[r] * FIRA_D + lane * 4;
+    if (MODE == 0) {
+        *reinterpret_cast<float4*>(compact + oc) = *reinterpret_cast<const float4*>(full + of);
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(compact + oc);
+        float4 b = *reinterpret_cast<const float4*>(full + of);       // rows[] has no duplicates: plain RMW
+        b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+        *reinterpret_cast<float4*>(full + of) = b;
+    }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t n4, float4* __restrict__ dh, const float4* __restrict__ h) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 d = dh[i];
+    const float4 a = h[i];
+    d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
+    dh[i] = d;
+}
+// mem_valid[b, 0:L] = sou != 0, mem_valid[b, L:L+S] = sub != 0 (Model.py:42-50); tar_valid = tar != 0
+__global__ void make_masks_kernel(int B, int L, int S, int T, const int32_t* __restrict__ sou,
+                                  const int32_t* __restrict__ sub, const int32_t* __restrict__ tar,
+                                  int32_t* __restrict__ mem_valid, int32_t* __restrict__ tar_valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int W = L + S;
+    if (i < B * W) {
+        const int b = i / W, j = i - b * W;
+        mem_valid[i] = (j < L ? sou[b * L + j] : sub[b * S + (j - L)]) != 0;
+    }
+    if (tar && i < B * T) tar_valid[i] = tar[i] != 0;
+}
+// sinusoidal tables (gnn_transformer.py:10-19): evaluated in fp64 like the reference's python floats, stored fp32
+__global__ void pos_table_kernel(int L, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L * FIRA_D) return;
+    const int pos = i / FIRA_D, c = i % FIRA_D, j = c >> 1;
+    const double a = (double)pos / pow(10000.0, (double)(2 * j) / (double)FIRA_D);
+    out[i] = (float)((c & 1) ? cos(a) : sin(a));
+}
+__global__ void invert_rows_kernel(int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < R) compact_row[rows[r]] = r;
+}
+
+// ---------------------------------------------------------------- host launchers
+int rows_gather_seg(hipStream_t s, int M, float* compact, const float* strided, int seg_len, int seg_stride, int seg_off) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(rows_seg_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, s, M, compact, const_cast<float*>(strided),
+                       seg_len, seg_stride, seg_off);
+    FIRA_CHECK_LAUNCH("rows_gather_seg");
+    return 0;
+}
+int rows_scatter_seg(hipStream_t s, int M, const float* compact, float* strided, int seg_len, int seg_stride,
+                     int seg_off) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(rows_seg_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, s, M, const_cast<float*>(compact), strided,
+                       seg_len, seg_stride, seg_off);
+    FIRA_CHECK_LAUNCH("rows_scatter_seg");
+    return 0;
+}
+int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(rows_idx_kernel<0>, dim3(cdiv(R, 4)), dim3(256), 0, s, R, compact, const_cast<float*>(src), rows);
+    FIRA_CHECK_LAUNCH("rows_gather_idx");
+    return 0;
+}
+int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows) {
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(rows_idx_kernel<1>, dim3(cdiv(R, 4)), dim3(256), 0, s, R, const_cast<float*>(compact), dst, rows);
+    FIRA_CHECK_LAUNCH("rows_scatter_add_idx");
+    return 0;
+}
+int relu_bwd(hipStream_t s, int64_t n, float* dh, const float* h) {
+    if (n <= 0) return 0;
+    FIRA_REQUIRE(n % 4 == 0, "relu_bwd: n must be a multiple of 4");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, n / 4,
+                       reinterpret_cast<float4*>(dh), reinterpret_cast<const float4*>(h));
+    FIRA_CHECK_LAUNCH("relu_bwd");
+    return 0;
+}
+int make_masks(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
+               int32_t* mem_valid, int32_t* tar_valid) {
+    const int n = B * (L + S) > B * T ? B * (L + S) : B * T;
+    hipLaunchKernelGGL(make_masks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid,
+                       tar_valid);
+    FIRA_CHECK_LAUNCH("make_masks");
+    return 0;
+}
+int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar) {
+    hipLaunchKernelGGL(pos_table_kernel, dim3(cdiv(L * FIRA_D, 256)), dim3(256), 0, s, L, pos_code);
+    hipLaunchKernelGGL(pos_table_kernel, dim3(cdiv(T * FIRA_D, 256)), dim3(256), 0, s, T, pos_tar);
+    FIRA_CHECK_LAUNCH("fill_pos_tables");
+    return 0;
+}
+int invert_rows(hipStream_t s, int BT, int R, const int32_t* rows, int32_t* compact_row) {
+    hipError_t e = hipMemsetAsync(compact_row, 0xFF, (size_t)BT * sizeof(int32_t), s);
+    if (e != hipSuccess) return set_err("invert_rows: %s", hipGetErrorString(e));
+    if (R > 0) hipLaunchKernelGGL(invert_rows_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, R, rows, compact_row);
+    FIRA_CHECK_LAUNCH("invert_rows");
+    return 0;
+}
+int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
+                     int out_bstride, int out_off) {
+    const int rows = B * L;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(embed_gather_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, L, idx, table, pos, out,
+                       out_bstride, out_off);
+    FIRA_CHECK_LAUNCH("embed_gather_fwd");
+    return 0;
+}
+int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
+                     int out_bstride, int out_off, int padding_idx) {
+    const int rows = B * L;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(embed_gather_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, L, idx, dtable, dout,
+                       out_bstride, out_off, padding_idx);
+    FIRA_CHECK_LAUNCH("embed_gather_bwd");
+    return 0;
+}
+int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark, float* out,
+                    float dropout, uint64_t seed, uint32_t site) {
+    if (M <= 0) return 0;
+    const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
+    hipLaunchKernelGGL(combination_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, qk, vtab, ldv, mark, out, dropout,
+                       inv_keep, seed, site);
+    FIRA_CHECK_LAUNCH("combination_fwd");
+    return 0;
+}
+int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
+                    const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site) {
+    if (M <= 0) return 0;
+    const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
+    const int rpb = 32;
+    hipLaunchKernelGGL(combination_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, qk, vtab, ldv, mark, dout, dqk,
+                       dvtab, lddv, dropout, inv_keep, seed, site, rpb);
+    FIRA_CHECK_LAUNCH("combination_bwd");
+    return 0;
+}
+int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
+                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, int seg_len, int seg_stride,
+                      int seg_off) {
+    if (M <= 0) return 0;
+    const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, x, res, gamma, beta, y, stats,
+                       dropout, inv_keep, seed, site, seg_len, seg_stride, seg_off);
+    FIRA_CHECK_LAUNCH("add_layernorm_fwd");
+    return 0;
+}
+int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
+                      float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
+                      uint32_t site) {
+    if (M <= 0) return 0;
+    const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
+    const int rpb = 32;
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
+                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb);
+    FIRA_CHECK_LAUNCH("add_layernorm_bwd");
+    return 0;
+}
+int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out) {
+    if (M <= 0 || N <= 0) return 0;
+    const int rpb = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, s, M, N, X, ldx, out, rpb);
+    FIRA_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+__global__ void iota_kernel(int n, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+int iota_rows(hipStream_t s, int n, int32_t* out) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, out);
+    FIRA_CHECK_LAUNCH("iota_rows");
+    return 0;
+}
+// grid (len, BR, 2*nl): one wave-row copy per block of 64 threads
+__global__ __launch_bounds__(64) void permute_cache_kernel(int BR, int T, const int32_t* __restrict__ parent,
+                                                           const float* __restrict__ ksrc, const float* __restrict__ vsrc,
+                                                           float* __restrict__ kdst, float* __restrict__ vdst, int nl) {
+    const int pos = blockIdx.x, r = blockIdx.y, which = blockIdx.z, lane = threadIdx.x;
+    const int l = which >> 1;
+    const float* src = (which & 1) ? vsrc : ksrc;
+    float* dst = (which & 1) ? vdst : kdst;
+    const int pr = parent ? parent[r] : r;
+    const size_t lay = (size_t)l * BR * T * FIRA_D;
+    *reinterpret_cast<float4*>(dst + lay + ((size_t)r * T + pos) * FIRA_D + lane * 4) =
+        *reinterpret_cast<const float4*>(src + lay + ((size_t)pr * T + pos) * FIRA_D + lane * 4);
+}
+__global__ void permute_hist_kernel(int BR, int T, int len, const int32_t* __restrict__ parent,
+                                    const int32_t* __restrict__ src, int32_t* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BR * len) return;
+    const int r = i / len, pos = i - r * len;
+    dst[r * T + pos] = src[(parent ? parent[r] : r) * T + pos];
+}
+int permute_cache(hipStream_t s, int nl, int BR, int T, int len, const int32_t* parent, const float* ksrc,
+                  const float* vsrc, float* kdst, float* vdst, const int32_t* hist_src, int32_t* hist_dst) {
+    if (len <= 0 || BR <= 0) return 0;
+    hipLaunchKernelGGL(permute_cache_kernel, dim3(len, BR, 2 * nl), dim3(64), 0, s, BR, T, parent, ksrc, vsrc, kdst,
+                       vdst, nl);
+    hipLaunchKernelGGL(permute_hist_kernel, dim3(cdiv(BR * len, 256)), dim3(256), 0, s, BR, T, len, parent, hist_src,
+                       hist_dst);
+    FIRA_CHECK_LAUNCH("permute_cache");
+    return 0;
+}
+__global__ void mark_history_kernel(int BR, int T, int step, const int32_t* __restrict__ tokens, int32_t* __restrict__ hist) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < BR) hist[r * T + step] = tokens[r] != 0;
+}
+int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist) {
+    hipLaunchKernelGGL(mark_history_kernel, dim3(cdiv(BR, 256)), dim3(256), 0, s, BR, T, step, tokens, hist);
+    FIRA_CHECK_LAUNCH("mark_history");
+    return 0;
+}
+
+}  // namespace fira
+
+extern "C" {
+int fira_embed_gather_fwd(void* stream, int B, int L, const int32_t* idx, const float* table, const float* pos,
+                          float* out, int out_bstride, int out_off) {
+    return fira::embed_gather_fwd((hipStream_t)stream, B, L, idx, table, pos, out, out_bstride, out_off);
+}
+int fira_embed_gather_bwd(void* stream, int B, int L, const int32_t* idx, float* dtable, const float* dout,
+                          int out_bstride, int out_off, int padding_idx) {
+    return fira::embed_gather_bwd((hipStream_t)stream, B, L, idx, dtable, dout, out_bstride, out_off, padding_idx);
+}
+int fira_combination_fwd(void* stream, int M, const float* qk, const float* vtab, const int32_t* mark, float* out,
+                         float dropout, uint64_t seed, uint32_t stream_id) {
+    return fira::combination_fwd((hipStream_t)stream, M, qk, vtab, FIRA_D, mark, out, dropout, seed, stream_id);
+}
+int fira_combination_bwd(void* stream, int M, const float* qk, const float* vtab, const int32_t* mark,
+                         const float* dout, float* dqk, float* dvtab, float dropout, uint64_t seed,
+                         uint32_t stream_id) {
+    return fira::combination_bwd((hipStream_t)stream, M, qk, vtab, FIRA_D, mark, dout, dqk, dvtab, FIRA_D, dropout, seed,
+                                 stream_id);
+}
+int fira_add_layernorm_fwd(void* stream, int M, float* x, const float* res, const float* gamma, const float* beta,
+                           float* y, float* stats, float dropout, uint64_t seed, uint32_t stream_id) {
+    return fira::add_layernorm_fwd((hipStream_t)stream, M, x, res, gamma, beta, y, stats, dropout, seed, stream_id, 0, 0,
+                                   0);
+}
+int fira_add_layernorm_bwd(void* stream, int M, const float* dy, const float* sum, const float* stats,
+                           const float* gamma, float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout,
+                           uint64_t seed, uint32_t stream_id) {
+    return fira::add_layernorm_bwd((hipStream_t)stream, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout,
+                                   seed, stream_id);
+}
+int fira_colsum_f32(void* stream, int M, int N, const float* X, int ldx, float* out) {
+    return fira::colsum((hipStream_t)stream, M, N, X, ldx, out);
+}
+}

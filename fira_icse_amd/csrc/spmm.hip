@@ -1,0 +1,145 @@
+// CSR SpMM for the GCN aggregation  Z = A_hat · H  (reference gnn_transformer.py:80 does a dense
+// torch.bmm over a [B,650,650] float64->float32 adjacency that is ~0.5 % dense).
+//
+// Data layout: one block-diagonal CSR over all B graphs of the batch (rowptr int32[B*N+1], col int32
+// global node id, val fp32); features row-major [B*N, 256] fp32.  A_hat is symmetric, so the backward
+// dH = A_hat^T · dZ is the same kernel.
+//
+// variant 1 (default, realistic graphs, ~4 nnz/row): one wavefront per output row; the 64 lanes hold the
+//   256-wide row as float4 (one coalesced 1 KiB load per neighbour row); col/val of the row are fetched
+//   64 at a time with one coalesced load and broadcast lane-to-lane (readlane), neighbour loads are
+//   issued 4 deep before the FMAs.  No atomics: the reduction over neighbours is a per-lane register sum.
+//   Neighbour re-reads (each H row is used ~4x) hit L2: a graph's H is 665 KB.
+// variant 2 (dense stress graphs, SURVEY.md config 5, ~130 nnz/row): one workgroup per (graph, 64-column
+//   slab); the slab of H (rows x 64 floats) is staged once into LDS with coalesced float4 loads and every
+//   neighbour gather is an LDS read (ds_read_b128: 16 lanes cover one 64-float row, so a wave gathers 4
+//   neighbours per instruction); partial sums of the 4 lane-groups are combined with wave shuffles.
+#include "common.h"
+
+namespace fira {
+
+__global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float* __restrict__ X, int ldx,
+                                                           float* __restrict__ Y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += 64) {
+        const int n = min(64, end - base);
+        int c = 0;
+        float v = 0.f;
+        if (lane < n) {
+            c = col[base + lane];
+            v = val[base + lane];
+        }
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+            const int c0 = __shfl(c, j, 64), c1 = __shfl(c, j + 1, 64), c2 = __shfl(c, j + 2, 64),
+                      c3 = __shfl(c, j + 3, 64);
+            const float4 x0 = *reinterpret_cast<const float4*>(X + (size_t)c0 * ldx + lane * 4);
+            const float4 x1 = *reinterpret_cast<const float4*>(X + (size_t)c1 * ldx + lane * 4);
+            const float4 x2 = *reinterpret_cast<const float4*>(X + (size_t)c2 * ldx + lane * 4);
+            const float4 x3 = *reinterpret_cast<const float4*>(X + (size_t)c3 * ldx + lane * 4);
+            const float v0 = __shfl(v, j, 64), v1 = __shfl(v, j + 1, 64), v2 = __shfl(v, j + 2, 64),
+                        v3 = __shfl(v, j + 3, 64);
+            acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y); acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
+            acc.x = fmaf(v1, x1.x, acc.x); acc.y = fmaf(v1, x1.y, acc.y); acc.z = fmaf(v1, x1.z, acc.z); acc.w = fmaf(v1, x1.w, acc.w);
+            acc.x = fmaf(v2, x2.x, acc.x); acc.y = fmaf(v2, x2.y, acc.y); acc.z = fmaf(v2, x2.z, acc.z); acc.w = fmaf(v2, x2.w, acc.w);
+            acc.x = fmaf(v3, x3.x, acc.x); acc.y = fmaf(v3, x3.y, acc.y); acc.z = fmaf(v3, x3.z, acc.z); acc.w = fmaf(v3, x3.w, acc.w);
+        }
+        for (; j < n; ++j) {
+            const int c0 = __shfl(c, j, 64);
+            const float v0 = __shfl(v, j, 64);
+            const float4 x0 = *reinterpret_cast<const float4*>(X + (size_t)c0 * ldx + lane * 4);
+            acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y); acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
+        }
+    }
+    *reinterpret_cast<float4*>(Y + (size_t)row * ldy + lane * 4) = acc;
+}
+
+// LDS-staged variant: grid (4 column slabs, n_graphs); block 512 threads = 8 waves.
+// Slab: graph_rows x 64 floats (<= 640 rows -> 160 KiB; config 5: 512 rows = 128 KiB).
+constexpr int SLAB = 64;
+__global__ __launch_bounds__(512) void spmm_lds_kernel(int graph_rows, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val,
+                                                       const float* __restrict__ X, int ldx,
+                                                       float* __restrict__ Y, int ldy) {
+    extern __shared__ __attribute__((aligned(16))) float slab[];   // [graph_rows][64]
+    const int g = blockIdx.y, c0 = blockIdx.x * SLAB;
+    const int row0 = g * graph_rows;
+    const int t = threadIdx.x;
+    // stage: each row of the slab is 64 floats = 16 float4; 512 threads cover 32 rows per pass
+    for (int r = t >> 4; r < graph_rows; r += 32) {
+        const float4 x = *reinterpret_cast<const float4*>(X + (size_t)(row0 + r) * ldx + c0 + (t & 15) * 4);
+        *reinterpret_cast<float4*>(&slab[r * SLAB + (t & 15) * 4]) = x;
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    const int sub = lane >> 4;          // which of 4 neighbours this lane-group gathers
+    const int q = (lane & 15) * 4;      // float4 column inside the slab
+    for (int r = wave; r < graph_rows; r += 8) {
+        const int beg = rowptr[row0 + r], end = rowptr[row0 + r + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = beg; base < end; base += 64) {
+            const int n = min(64, end - base);
+            int c = 0;
+            float v = 0.f;
+            if (lane < n) {
+                c = col[base + lane] - row0;     // local row inside the graph
+                v = val[base + lane];
+            }
+            for (int j = 0; j < n; j += 4) {
+                const int jj = j + sub;
+                const int cj = __shfl(c, jj & 63, 64);
+                const float vj = (jj < n) ? __shfl(v, jj & 63, 64) : 0.f;
+                const float4 x = *reinterpret_cast<const float4*>(&slab[cj * SLAB + q]);
+                acc.x = fmaf(vj, x.x, acc.x); acc.y = fmaf(vj, x.y, acc.y);
+                acc.z = fmaf(vj, x.z, acc.z); acc.w = fmaf(vj, x.w, acc.w);
+            }
+        }
+        // combine the 4 lane-groups (lanes l, l^16, l^32, l^48 hold the same columns)
+        acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+        acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
+        acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+        acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+        if (sub == 0) *reinterpret_cast<float4*>(Y + (size_t)(row0 + r) * ldy + c0 + q) = acc;
+    }
+}
+
+int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+             int ldx, float* Y, int ldy, int graph_rows, int variant) {
+    if (n_rows <= 0) return 0;
+    FIRA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0),
+                 "csr_spmm: feature rows must be 16-byte aligned");
+    if (variant == 0) variant = 1;
+    if (variant == 2) {
+        FIRA_REQUIRE(graph_rows > 0 && n_rows % graph_rows == 0 && graph_rows * SLAB * 4 <= 160 * 1024,
+                     "csr_spmm: LDS variant needs rows-per-graph (%d) dividing n_rows and <= 640", graph_rows);
+        const size_t lds = (size_t)graph_rows * SLAB * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)spmm_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(spmm_lds_kernel, dim3(FIRA_D / SLAB, n_rows / graph_rows), dim3(512), lds, s, graph_rows,
+                           rowptr, col, val, X, ldx, Y, ldy);
+    } else {
+        hipLaunchKernelGGL(spmm_rowwave_kernel, dim3(cdiv(n_rows, 4)), dim3(256), 0, s, n_rows, rowptr, col, val, X,
+                           ldx, Y, ldy);
+    }
+    FIRA_CHECK_LAUNCH("csr_spmm");
+    return 0;
+}
+
+}  // namespace fira
+
+extern "C" int fira_csr_spmm_f32(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col,
+                                 const float* val, const float* X, int ldx, float* Y, int ldy, int graph_rows,
+                                 int variant) {
+    return fira::csr_spmm((hipStream_t)stream, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant);
+}

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's ``Model.TransModel`` (reference Model.py:22-86) on the HIP engine.
+
+Drop-in surface kept: ``TransModel(args)``, ``forward(sou, tar, attr, mark, ast_change, edge,
+tar_label, sub_token, stage)`` with the reference's return values, ``parameters()``, ``state_dict()`` /
+``load_state_dict()`` with the reference's 338 keys and shapes, ``train()`` / ``eval()``.  All arithmetic happens in
+``libfira_hip.so`` (hand-written gfx950 kernels behind the C ABI of ``include/fira_hip.h``); PyTorch only owns the
+device memory, the stream and (in the drop-in ``forward``) the autograd hook.  There is no CPU path.
+
+Parameters live in ONE flat fp32 device buffer (layout defined by the library, ``fira_param_info``); the named
+tensors of the state dict are views into it.  ``parameters()`` therefore yields a single flat ``nn.Parameter``: Adam
+is element-wise, so ``torch.optim.Adam(model.parameters(), lr)`` updates exactly what the reference's optimizer
+updates (dead tensors keep a zero gradient and never move).  The native training loop (``fira_icse_amd.train``) skips
+autograd entirely and calls the fused Adam kernel on the same buffer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import FiraConfig
+from .data import HostBatch
+
+
+def config_from_args(args) -> FiraConfig:
+    """Accept the reference's DotDict-style ``args`` (run_model.py:30-46) or a FiraConfig."""
+    if isinstance(args, FiraConfig):
+        return args
+    cfg = FiraConfig()
+    for k in ("sou_len", "tar_len", "att_len", "ast_change_len", "sub_token_len", "lr", "dropout_rate", "num_head",
+              "embedding_dim", "batch_size", "test_batch_size", "epoches", "beam_size", "vocab_size",
+              "ast_change_vocab_size"):
+        try:
+            setattr(cfg, k, args[k])
+        except (KeyError, TypeError, AttributeError):
+            pass
+    return cfg
+
+
+def reference_init_state_dict(cfg: FiraConfig) -> "OrderedDict[str, torch.Tensor]":
+    """Freshly initialised weights, bit-identical to ``TransModel(args)`` of the reference under the same torch seed.
+
+    The reference relies on PyTorch's default initialisers; building the same leaf modules in the same order
+    (gnn_transformer.py:21-43, 88-106, 124-136, 163-169, 176-190; Model.py:7-14, 24-36) consumes the global RNG
+    identically.  (Checked against the reference in tests/test_model_host.py.)
+    """
+    D, V = cfg.embedding_dim, cfg.vocab_size
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def put(prefix, mod):
+        for n, p in mod.named_parameters():
+            sd[prefix + "." + n] = p.detach()
+
+    def combination(prefix):
+        for j in range(3):
+            put("%s.linear_layers.%d" % (prefix, j), nn.Linear(D, D))
+        put(prefix + ".output_linear", nn.Linear(D, D))
+        put(prefix + ".layernorm", nn.LayerNorm(D))
+
+    def attention(prefix):
+        for n in ("fc_q", "fc_k", "fc_v", "fc_o"):
+            put(prefix + "." + n, nn.Linear(D, D))
+        put(prefix + ".layernorm", nn.LayerNorm(D))
+
+    put("encoder.embedding", nn.Embedding(V, D, padding_idx=0))
+    put("encoder.ast_change_embedding", nn.Embedding(cfg.ast_change_vocab_size, D, padding_idx=0))
+    put("encoder.mark_embedding", nn.Embedding(4, D, padding_idx=0))
+    put("encoder.lstm", nn.LSTM(input_size=D, hidden_size=D, num_layers=3, batch_first=True))
+    for lst in (1, 2):
+        for i in range(cfg.num_layers):
+            combination("encoder.combination_list%d.%d" % (lst, i))
+    for i in range(cfg.num_layers):
+        put("encoder.gcn_list.%d.fc1" % i, nn.Linear(D, D))
+        put("encoder.gcn_list.%d.fc2" % i, nn.Linear(D, D))
+        put("encoder.gcn_list.%d.layernorm" % i, nn.LayerNorm(D))
+    put("decoder.embedding", nn.Embedding(V, D))
+    for i in range(cfg.num_layers):
+        attention("decoder.attention_list.%d" % i)
+    for i in range(cfg.num_layers):
+        attention("decoder.cross_attention_list.%d" % i)
+    for i in range(cfg.num_layers):
+        put("decoder.feed_forward_list.%d.fc1" % i, nn.Linear(D, 4 * D))
+        put("decoder.feed_forward_list.%d.fc2" % i, nn.Linear(4 * D, D))
+        put("decoder.feed_forward_list.%d.layernorm" % i, nn.LayerNorm(D))
+    put("out_fc", nn.Linear(D, V))
+    put("gate_fc", nn.Linear(D, 1))
+    put("copy_net.LinearSource", nn.Linear(D, D, bias=False))
+    put("copy_net.LinearTarget", nn.Linear(D, D, bias=False))
+    put("copy_net.LinearRes", nn.Linear(D, 1))
+    put("copy_net.LinearProb", nn.Linear(D, 2))
+    return sd
+
+
+class ParamLayout:
+    """name -> (offset, shape) inside the flat buffer, as defined by the library."""
+
+    def __init__(self, cfg: FiraConfig):
+        lib = _lib.lib()
+        self.dims = _lib.make_dims(cfg)
+        n = lib.fira_param_count(C.byref(self.dims))
+        if n < 0:
+            _lib.check(1, "fira_param_count")
+        self.total = int(lib.fira_param_total(C.byref(self.dims)))
+        self.entries: "OrderedDict[str, tuple]" = OrderedDict()
+        name = C.create_string_buffer(128)
+        off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int32()
+        shape = (C.c_int64 * 2)()
+        for i in range(n):
+            _lib.check(lib.fira_param_info(C.byref(self.dims), i, name, C.byref(off), C.byref(numel), C.byref(ndim),
+                                           shape), "fira_param_info")
+            shp = tuple(int(shape[k]) for k in range(ndim.value))
+            self.entries[name.value.decode()] = (int(off.value), shp)
+
+    def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        out = OrderedDict()
+        for k, (off, shp) in self.entries.items():
+            n = int(np.prod(shp))
+            out[k] = flat[off:off + n].view(shp)
+        return out
+
+
+class DeviceBatch:
+    """One collated batch resident in HBM: int32 id arrays + block-diagonal CSR adjacency (+ head row list)."""
+
+    def __init__(self, hb: HostBatch, cfg: FiraConfig, device="cuda"):
+        self.cfg = cfg
+        self.B = len(hb)
+        V = cfg.vocab_size
+        if hb.tar_label is not None and hb.tar_label.size and int(hb.tar_label.max()) >= cfg.out_len:
+            # the reference's nll_loss would raise "Target out of bounds" here (SURVEY.md §8a note N3)
+            raise ValueError("copy label %d outside the %d-way output" % (int(hb.tar_label.max()), cfg.out_len))
+
+        def dev(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device, non_blocking=True)
+
+        self.sou = dev(hb.sou, np.int32)
+        self.tar = dev(hb.tar, np.int32) if hb.tar is not None else None
+        self.mark = dev(hb.mark, np.int32)
+        self.ast_change = dev(hb.ast_change, np.int32)
+        self.tar_label = dev(hb.tar_label, np.int32) if hb.tar_label is not None else None
+        self.sub_token = dev(hb.sub_token, np.int32)
+        self.rowptr = dev(hb.rowptr, np.int32)
+        self.col = dev(hb.col, np.int32)
+        self.val = dev(hb.val, np.float32)
+        self.nnz = int(hb.col.shape[0])
+        self.head_rows = None
+        self.n_head_rows = 0
+        if hb.tar_label is not None:
+            shifted = np.concatenate([hb.tar_label[:, 1:], np.zeros((self.B, 1), hb.tar_label.dtype)], axis=1)
+            rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0].astype(np.int32)
+            self.n_head_rows = int(rows.shape[0])
+            self.head_rows = dev(rows if rows.size else np.zeros(1, np.int32), np.int32)
+        self.struct = _lib.Batch(
+            self.B, self.nnz, self.sou.data_ptr(), self.tar.data_ptr() if self.tar is not None else None,
+            self.mark.data_ptr(), self.ast_change.data_ptr(),
+            self.tar_label.data_ptr() if self.tar_label is not None else None, self.sub_token.data_ptr(),
+            self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(),
+            self.head_rows.data_ptr() if self.head_rows is not None else None, self.n_head_rows)
+
+
+class _FusedStep(torch.autograd.Function):
+    """Autograd hook for the drop-in ``forward(..., 'train')``: the engine computes d(loss_sum)/d(params) together
+    with the loss; ``backward`` only scales it by the incoming gradient (1 / n_tok in the reference driver)."""
+
+    @staticmethod
+    def forward(ctx, flat, model, dbatch):
+        loss_sum, n_tok = model.train_fwd_bwd(dbatch, zero_grad=True)
+        ctx.model = model
+        return loss_sum.clone(), n_tok.to(torch.int64)
+
+    @staticmethod
+    def backward(ctx, g_loss, g_ntok):
+        return ctx.model.gbuf * g_loss, None, None
+
+
+class TransModel(nn.Module):
+    def __init__(self, args, device="cuda", init: bool = True):
+        super().__init__()
+        self.cfg = config_from_args(args)
+        self.layout = ParamLayout(self.cfg)
+        self.dims = self.layout.dims
+        if not torch.cuda.is_available():
+            raise RuntimeError("fira_icse_amd.TransModel needs a ROCm GPU (no CPU path); use device='cuda'")
+        self.device_ = torch.device(device)
+        flat = torch.zeros(self.layout.total, dtype=torch.float32, device=self.device_)
+        self.flat = nn.Parameter(flat)
+        self.gbuf = torch.zeros_like(flat)                     # d loss_sum / d params (engine output)
+        self._views = self.layout.views(self.flat.data)
+        self._gviews = self.layout.views(self.gbuf)
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=self.device_)
+        self.n_tok = torch.zeros(1, dtype=torch.int32, device=self.device_)
+        self.dropout_seed = 0
+        self.compact_head = True
+        if init:
+            self.load_state_dict(reference_init_state_dict(self.cfg))
+
+    # ------------------------------------------------------------------ checkpoint surface
+    def state_dict(self, *a, **k):
+        return OrderedDict((n, v.detach().clone()) for n, v in self._views.items())
+
+    def load_state_dict(self, sd, strict: bool = True):
+        missing = [k for k in self._views if k not in sd]
+        unexpected = [k for k in sd if k not in self._views]
+        if strict and (missing or unexpected):
+            raise RuntimeError("load_state_dict: missing keys %s, unexpected keys %s" % (missing[:5], unexpected[:5]))
+        with torch.no_grad():
+            for k, v in self._views.items():
+                if k in sd:
+                    if tuple(sd[k].shape) != tuple(v.shape):
+                        raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), tuple(v.shape)))
+                    v.copy_(sd[k].to(torch.float32))
+        return self
+
+    def named_views(self):
+        return self._views
+
+    def grad_views(self):
+        return self._gviews
+
+    # ------------------------------------------------------------------ engine calls
+    def workspace(self, B: int, mode: int) -> torch.Tensor:
+        key = (B, mode)
+        if key not in self._ws:
+            lib = _lib.lib()
+            n = lib.fira_workspace_bytes(C.byref(self.dims), B, mode)
+            if n == 0:
+                _lib.check(1, "fira_workspace_bytes")
+            self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device_)
+        return self._ws[key]
+
+    def train_fwd_bwd(self, db: DeviceBatch, zero_grad: bool = True, dropout: Optional[float] = None,
+                      gcn_dropout: Optional[float] = None):
+        """loss_sum, n_tok (device scalars) and d(loss_sum)/d(params) into ``self.gbuf`` (reference
+        run_model.py:104-108 minus the optimizer).  Dropout follows ``self.training`` unless given."""
+        lib = _lib.lib()
+        if zero_grad:
+            self.gbuf.zero_()
+        p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
+        pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
+        self.dropout_seed += 1
+        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0)
+        ws = self.workspace(db.B, 1)
+        _lib.check(lib.fira_train_fwd_bwd(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
+                                          _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
+                                          C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok)),
+                   "fira_train_fwd_bwd")
+        return self.loss_sum, self.n_tok
+
+    def forward_dev(self, db: DeviceBatch) -> torch.Tensor:
+        """Teacher-forced argmax ids [B, tar_len] (reference Model.py:85-86)."""
+        lib = _lib.lib()
+        ids = torch.empty((db.B, self.cfg.tar_len), dtype=torch.int32, device=self.device_)
+        ws = self._ws.get((db.B, 1))          # share the training arena when it exists
+        if ws is None:
+            ws = self.workspace(db.B, 0)
+        _lib.check(lib.fira_forward_dev(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
+                                        _lib.ptr(self.flat.data), _lib.ptr(ws), ws.numel(), _lib.ptr(ids),
+                                        _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok)), "fira_forward_dev")
+        return ids
+
+    # ------------------------------------------------------------------ the reference's call signature
+    def make_batch(self, sou, tar, mark, ast_change, edge, tar_label, sub_token) -> DeviceBatch:
+        """Build a DeviceBatch from the reference's tensors; ``edge`` may be the dense [B,N,N] adjacency
+        (converted to CSR here: the slow compatibility path) or a HostBatch carrying the CSR already."""
+        if isinstance(edge, HostBatch):
+            return DeviceBatch(edge, self.cfg, self.device_)
+        N = self.cfg.graph_len
+        e = edge.detach().to("cpu")
+        B = e.shape[0]
+        nz = (e != 0)
+        rows_b, rows_i, cols = nz.nonzero(as_tuple=True)
+        counts = torch.bincount(rows_b * N + rows_i, minlength=B * N)
+        rowptr = torch.zeros(B * N + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        hb = HostBatch(sou.cpu().numpy(), tar.cpu().numpy(), mark.cpu().numpy(), ast_change.cpu().numpy(),
+                       tar_label.cpu().numpy(), sub_token.cpu().numpy(), rowptr.numpy().astype(np.int32),
+                       (rows_b * N + cols).numpy().astype(np.int32), e[nz].to(torch.float32).numpy())
+        return DeviceBatch(hb, self.cfg, self.device_)
+
+    def forward(self, sou, tar, attr, mark, ast_change, edge, tar_label, sub_token, stage="train"):
+        """Reference signature (Model.py:38). ``attr`` is accepted and ignored, as in the reference."""
+        db = edge if isinstance(edge, DeviceBatch) else self.make_batch(sou, tar, mark, ast_change, edge, tar_label,
+                                                                        sub_token)
+        if stage == "train":
+            loss_sum, n_tok = _FusedStep.apply(self.flat, self, db)
+            return loss_sum.reshape(()), n_tok.reshape(())
+        return self.forward_dev(db).to(torch.int64)

@@ -1,0 +1,181 @@
+"""Thin tensor-level wrappers over the op-level C ABI (one reference op each; see include/fira_hip.h).
+
+They take/return ``torch`` CUDA tensors, launch on the current stream and never fall back to PyTorch maths.
+Used by the piecewise drop-in surface (``model.encoder`` / ``decoder`` / ``out_fc`` / ``copy_net``) and by the
+per-kernel parity tests.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, cur_stream, ptr
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expected a contiguous fp32 CUDA tensor"
+    return t
+
+
+def _i32(t):
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous(), "expected a contiguous int32 CUDA tensor"
+    return t
+
+
+def gemm(A, B, *, transA=False, transB=True, bias=None, relu=False, out=None, accumulate=False, splitk=1):
+    """C = op(A) op(B) (+bias)(relu).  transB=True: B is an nn.Linear weight [N,K]."""
+    for t in (A, B):
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    assert (B.shape[1] if transB else B.shape[0]) == K
+    if out is None:
+        out = torch.zeros((M, N), dtype=torch.float32, device=A.device) if accumulate else \
+            torch.empty((M, N), dtype=torch.float32, device=A.device)
+    flags = (1 if relu else 0) | (2 if accumulate else 0)
+    check(_lib.lib().fira_gemm_f32(cur_stream(), int(transA), int(transB), M, N, K, ptr(A), A.stride(0), ptr(B),
+                                   B.stride(0), ptr(out), out.stride(0), ptr(bias), flags, splitk), "fira_gemm_f32")
+    return out
+
+
+def csr_spmm(rowptr, col, val, X, graph_rows=0, variant=0):
+    X = _f32(X)
+    Y = torch.empty_like(X)
+    check(_lib.lib().fira_csr_spmm_f32(cur_stream(), X.shape[0], ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)),
+                                       ptr(X), X.stride(0), ptr(Y), Y.stride(0), graph_rows, variant),
+          "fira_csr_spmm_f32")
+    return Y
+
+
+def embed_gather(idx, table, pos=None, out=None, out_bstride=None, out_off=0):
+    B, L = idx.shape
+    if out is None:
+        out = torch.empty((B, L, 256), dtype=torch.float32, device=table.device)
+        out_bstride = L
+    check(_lib.lib().fira_embed_gather_fwd(cur_stream(), B, L, ptr(_i32(idx)), ptr(_f32(table)), ptr(pos), ptr(out),
+                                           out_bstride, out_off), "fira_embed_gather_fwd")
+    return out
+
+
+def embed_scatter_add(idx, dtable, dout, out_bstride, out_off, padding_idx):
+    B, L = idx.shape
+    check(_lib.lib().fira_embed_gather_bwd(cur_stream(), B, L, ptr(_i32(idx)), ptr(_f32(dtable)), ptr(_f32(dout)),
+                                           out_bstride, out_off, padding_idx), "fira_embed_gather_bwd")
+    return dtable
+
+
+def combination_fwd(qk, vtab, mark, dropout=0.0, seed=0, site=0):
+    M = qk.shape[0]
+    out = torch.empty((M, 256), dtype=torch.float32, device=qk.device)
+    check(_lib.lib().fira_combination_fwd(cur_stream(), M, ptr(_f32(qk)), ptr(_f32(vtab)), ptr(_i32(mark)), ptr(out),
+                                          dropout, seed, site), "fira_combination_fwd")
+    return out
+
+
+def combination_bwd(qk, vtab, mark, dout, dropout=0.0, seed=0, site=0):
+    M = qk.shape[0]
+    dqk = torch.empty_like(qk)
+    dvtab = torch.zeros_like(vtab)
+    check(_lib.lib().fira_combination_bwd(cur_stream(), M, ptr(_f32(qk)), ptr(_f32(vtab)), ptr(_i32(mark)),
+                                          ptr(_f32(dout)), ptr(dqk), ptr(dvtab), dropout, seed, site),
+          "fira_combination_bwd")
+    return dqk, dvtab
+
+
+def add_layernorm_fwd(x, res, gamma, beta, dropout=0.0, seed=0, site=0):
+    """Returns (y, pre-norm sum, stats[M,2]); ``x`` is consumed (overwritten with the sum)."""
+    M = x.shape[0]
+    y = torch.empty_like(x)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_add_layernorm_fwd(cur_stream(), M, ptr(_f32(x)), ptr(res), ptr(_f32(gamma)), ptr(_f32(beta)),
+                                            ptr(y), ptr(stats), dropout, seed, site), "fira_add_layernorm_fwd")
+    return y, x, stats
+
+
+def add_layernorm_bwd(dy, s, stats, gamma, dropout=0.0, seed=0, site=0, want_dx_drop=False):
+    M = dy.shape[0]
+    ds = torch.empty_like(dy)
+    dxd = torch.empty_like(dy) if want_dx_drop else None
+    dg = torch.zeros(256, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(256, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().fira_add_layernorm_bwd(cur_stream(), M, ptr(_f32(dy)), ptr(_f32(s)), ptr(_f32(stats)),
+                                            ptr(_f32(gamma)), ptr(ds), ptr(dxd), ptr(dg), ptr(db), dropout, seed, site),
+          "fira_add_layernorm_bwd")
+    return ds, dxd, dg, db
+
+
+def colsum(X):
+    out = torch.zeros(X.shape[1], dtype=torch.float32, device=X.device)
+    check(_lib.lib().fira_colsum_f32(cur_stream(), X.shape[0], X.shape[1], ptr(_f32(X)), X.stride(0), ptr(out)),
+          "fira_colsum_f32")
+    return out
+
+
+def attention_fwd(q, k, v, key_valid, causal=False, q_pos0=0, heads=8):
+    """q [B,Tq,256], k/v [B,Tk,256] (any row stride), key_valid int32 [B,Tk] -> o [B,Tq,256]."""
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    o = torch.empty((B, Tq, 256), dtype=torch.float32, device=q.device)
+    check(_lib.lib().fira_attention_fwd(cur_stream(), B, heads, Tq, Tk, ptr(q), q.stride(1), ptr(k), k.stride(1),
+                                        ptr(v), v.stride(1), ptr(_i32(key_valid)), int(causal), q_pos0, ptr(o), 256),
+          "fira_attention_fwd")
+    return o
+
+
+def attention_bwd(q, k, v, key_valid, o, do, causal=False, q_pos0=0, heads=8):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    dq = torch.empty((B, Tq, 256), dtype=torch.float32, device=q.device)
+    dk = torch.empty((B, Tk, 256), dtype=torch.float32, device=q.device)
+    dv = torch.empty((B, Tk, 256), dtype=torch.float32, device=q.device)
+    check(_lib.lib().fira_attention_bwd(cur_stream(), B, heads, Tq, Tk, ptr(q), q.stride(1), ptr(k), k.stride(1),
+                                        ptr(v), v.stride(1), ptr(_i32(key_valid)), int(causal), q_pos0, ptr(_f32(o)),
+                                        256, ptr(_f32(do)), 256, ptr(dq), 256, ptr(dk), 256, ptr(dv), 256),
+          "fira_attention_bwd")
+    return dq, dk, dv
+
+
+def copy_score_fwd(src, tgt, w, bias):
+    B, S, _ = src.shape
+    T = tgt.shape[1]
+    score = torch.empty((B, T, S), dtype=torch.float32, device=src.device)
+    check(_lib.lib().fira_copy_score_fwd(cur_stream(), B, T, S, ptr(_f32(src)), ptr(_f32(tgt)), ptr(_f32(w)),
+                                         ptr(_f32(bias)), ptr(score)), "fira_copy_score_fwd")
+    return score
+
+
+def copy_score_bwd(src, tgt, w, dscore):
+    B, S, _ = src.shape
+    T = tgt.shape[1]
+    dsrc = torch.empty_like(src)
+    dtgt = torch.zeros_like(tgt)
+    dw = torch.zeros(256, dtype=torch.float32, device=src.device)
+    db = torch.zeros(1, dtype=torch.float32, device=src.device)
+    check(_lib.lib().fira_copy_score_bwd(cur_stream(), B, T, S, ptr(_f32(src)), ptr(_f32(tgt)), ptr(_f32(w)),
+                                         ptr(_f32(dscore)), ptr(dsrc), ptr(dtgt), ptr(dw), ptr(db)),
+          "fira_copy_score_bwd")
+    return dsrc, dtgt, dw, db
+
+
+def head_loss(logits, score, mem_valid, gate_logits, tar_label, V, compact_row=None, want_grad=True, argmax=False):
+    """In place: logits/score/gate_logits become their gradients when want_grad.  Returns (loss_sum, n_tok, ids)."""
+    B, T = tar_label.shape
+    S = score.shape[-1]
+    loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    ntok = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    ids = torch.empty((B, T), dtype=torch.int32, device=logits.device) if argmax else None
+    check(_lib.lib().fira_head_loss(cur_stream(), B * T, T, V, S, ptr(compact_row), ptr(_f32(logits)),
+                                    logits.stride(0), ptr(_f32(score)), ptr(_i32(mem_valid)), ptr(_f32(gate_logits)),
+                                    ptr(_i32(tar_label)), ptr(loss), ptr(ntok), ptr(ids), int(want_grad)),
+          "fira_head_loss")
+    return loss, ntok, ids
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, inv_scale=None):
+    check(_lib.lib().fira_adam_step(cur_stream(), p.numel(), ptr(_f32(p)), ptr(_f32(g)), ptr(_f32(m)), ptr(_f32(v)),
+                                    lr, beta1, beta2, eps, step, ptr(inv_scale)), "fira_adam_step")
+
+
+def inv_count(n_tok, out):
+    check(_lib.lib().fira_inv_count(cur_stream(), ptr(_i32(n_tok)), ptr(_f32(out))), "fira_inv_count")
+    return out

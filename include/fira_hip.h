@@ -1,0 +1,204 @@
+/*
+ * fira_hip.h — C ABI of libfira_hip.so: the MI355X (gfx950) compute path of the FIRA
+ * commit-message model (GNN encoder + Transformer decoder with dual copy head).
+ *
+ * The reference (DJjjjhao/FIRA-ICSE) has no FFI: its hot path is a chain of stock PyTorch ops
+ * (SURVEY.md §2.2).  Each entry point below replaces the reference lines cited next to it; a
+ * binding (ctypes / cgo / JNI) only needs this header.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *   - nothing allocates: scratch comes from the caller (fira_workspace_bytes);
+ *   - work is enqueued on the hipStream_t passed as `void* stream` (NULL = default stream),
+ *     nothing synchronises; distinct streams may be driven from distinct threads;
+ *   - return 0 on success, non-zero on error (message: fira_last_error(), thread-local);
+ *   - activations are row-major [rows, 256] fp32; nn.Linear weights are [out, in] row-major
+ *     exactly as in the reference's state_dict; ids are int32.
+ */
+#ifndef FIRA_HIP_H
+#define FIRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIRA_ABI_VERSION 1
+
+/* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
+typedef struct fira_dims {
+    int32_t sou_len;         /* 210 code-token nodes                                   */
+    int32_t sub_len;         /* 160 sub-token nodes                                    */
+    int32_t ast_len;         /* 280 AST + edit-operation nodes                         */
+    int32_t tar_len;         /* 30 message positions                                   */
+    int32_t d_model;         /* 256 (kernels are specialised for 256)                  */
+    int32_t n_head;          /* 8   (head width 32)                                    */
+    int32_t n_layer;         /* 6                                                      */
+    int32_t vocab;           /* 24650                                                  */
+    int32_t ast_vocab;       /* 71                                                     */
+    int32_t d_ff;            /* 1024                                                   */
+} fira_dims;
+
+/* ---- one collated batch of commits (replaces the 8-tensor batch of Dataset.py:336-343) ---- */
+typedef struct fira_batch {
+    int32_t B;               /* commits in the batch                                   */
+    int32_t nnz;             /* entries of the block-diagonal adjacency                */
+    const int32_t* sou;      /* [B, sou_len]  code-token ids                           */
+    const int32_t* tar;      /* [B, tar_len]  decoder input ids                        */
+    const int32_t* mark;     /* [B, sou_len]  0 pad,1 deleted,2 context,3 added        */
+    const int32_t* ast_change; /* [B, ast_len]                                         */
+    const int32_t* tar_label;/* [B, tar_len]  labels incl. copy ids (>= vocab)         */
+    const int32_t* sub_token;/* [B, sub_len]                                           */
+    const int32_t* rowptr;   /* [B*N + 1] CSR row offsets, N = sou+sub+ast             */
+    const int32_t* col;      /* [nnz] GLOBAL node ids (b*N + local)                    */
+    const float*   val;      /* [nnz] D^-1/2 (A+I) D^-1/2 entries (fp32 of Dataset.py:291) */
+    const int32_t* head_rows;/* [n_head_rows] optional: flat (b*tar_len+t) indices of the target rows whose shifted
+                                label is a vocabulary id (0 < label < vocab), ascending, no duplicates; only these
+                                rows need the vocabulary GEMM in training.  NULL = all rows.           */
+    int32_t n_head_rows;
+} fira_batch;
+
+typedef struct fira_train_opts {
+    float    dropout;        /* 0.1 in the reference (Attention/FFN/Combination); 0 = off */
+    float    gcn_dropout;    /* 0.2 (gnn_transformer.py:43)                             */
+    uint64_t seed;           /* dropout stream seed; masks are re-derived in backward   */
+    int32_t  compact_head;   /* 1 = run the vocabulary head only on rows whose label != 0 (results identical) */
+} fira_train_opts;
+
+const char* fira_last_error(void);
+int         fira_abi_version(void);
+
+/* ---- parameter layout: one flat fp32 buffer holding the 338 state-dict tensors ------------
+ * (SURVEY.md §8b "Checkpoint").  Index order == reference state_dict order.                  */
+int    fira_param_count(const fira_dims* d);
+/* name_buf >= 128 bytes; shape has up to 2 entries (ndim returned). offset/numel in floats.  */
+int    fira_param_info(const fira_dims* d, int index, char* name_buf, int64_t* offset, int64_t* numel,
+                       int32_t* ndim, int64_t shape[2]);
+int64_t fira_param_total(const fira_dims* d);            /* floats in the flat buffer        */
+
+/* bytes of caller-provided scratch for a batch of B commits. mode: 0 = forward only, 1 = training */
+size_t fira_workspace_bytes(const fira_dims* d, int B, int mode);
+/* scratch for fira_decode_begin / fira_decode_step with n_beam hypotheses per commit */
+size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam);
+
+/* =========================== op level (one reference op each) ============================== */
+
+/* C[M,N] (+)= op(A)·op(B) (+ bias[n]) (relu).  Replaces every nn.Linear / its backward
+ * (addmm/mm calls listed in SURVEY.md §2.3).  transA=0: A stored [M,K] (lda); transA=1: A stored
+ * [K,M].  transB=1: B stored [N,K] (the nn.Linear weight layout); transB=0: B stored [K,N].
+ * flags: bit0 relu, bit1 accumulate into C (C += ...), splitk >= 1 partitions K over grid.z
+ * (partials combined with fp32 atomics; requires accumulate semantics, C pre-initialised).     */
+#define FIRA_GEMM_RELU 1
+#define FIRA_GEMM_ACCUM 2
+int fira_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
+                  const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  const float* bias, int flags, int splitk);
+
+/* Y[r,:] = sum_j val[j] * X[col[j],:]  over CSR row r (d = 256).  The GCN aggregation
+ * torch.bmm(edge.float(), x) (gnn_transformer.py:80); its backward is the same call because
+ * the normalised adjacency is symmetric.  variant: 0 auto, 1 wave-per-row gather, 2 LDS-staged
+ * (needs graph_rows > 0: rows per graph, cols local to the graph's row block).                  */
+int fira_csr_spmm_f32(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val,
+                      const float* X, int ldx, float* Y, int ldy, int graph_rows, int variant);
+
+/* out[(b*out_bstride + out_off + i), :] = table[idx[b*L + i], :] (+ pos[i,:])  — the embedding
+ * gathers of gnn_transformer.py:46-52,110-113 written straight into the node buffer.           */
+int fira_embed_gather_fwd(void* stream, int B, int L, const int32_t* idx, const float* table,
+                          const float* pos, float* out, int out_bstride, int out_off);
+/* dtable[idx,:] += dout[row,:]  (rows with idx == padding_idx skipped; padding_idx < 0: none) */
+int fira_embed_gather_bwd(void* stream, int B, int L, const int32_t* idx, float* dtable,
+                          const float* dout, int out_bstride, int out_off, int padding_idx);
+
+/* CombinationLayer (combination_layer.py:7-17): c = softmax2(q*k/s, q*v/s) . (k, v), s = sqrt(32),
+ * v = vtab[mark[row]] (vtab = linear_layers[2] applied to the 4-row mark table).  qk: [M,512] = [q|k]. */
+int fira_combination_fwd(void* stream, int M, const float* qk, const float* vtab, const int32_t* mark,
+                         float* out, float dropout, uint64_t seed, uint32_t stream_id);
+int fira_combination_bwd(void* stream, int M, const float* qk, const float* vtab, const int32_t* mark,
+                         const float* dout, float* dqk, float* dvtab /* [4,256] += */,
+                         float dropout, uint64_t seed, uint32_t stream_id);
+
+/* y = LayerNorm(dropout(x) + res) * gamma + beta  (eps 1e-5), rows of 256.  x is overwritten with the
+ * pre-norm sum (kept for backward); stats[row] = {mean, rstd}.  Post-LN residual blocks of
+ * gnn_transformer.py:86,161,174,205.                                                            */
+int fira_add_layernorm_fwd(void* stream, int M, float* x, const float* res, const float* gamma,
+                           const float* beta, float* y, float* stats, float dropout, uint64_t seed,
+                           uint32_t stream_id);
+/* ds = dLN/d(sum); dgamma/dbeta += ...;  if dx_drop != NULL: dx_drop = ds * mask/(1-p)           */
+int fira_add_layernorm_bwd(void* stream, int M, const float* dy, const float* sum, const float* stats,
+                           const float* gamma, float* ds, float* dx_drop, float* dgamma, float* dbeta,
+                           float dropout, uint64_t seed, uint32_t stream_id);
+
+/* colsum[n] += sum_m X[m,n]  (bias gradients) */
+int fira_colsum_f32(void* stream, int M, int N, const float* X, int ldx, float* out);
+
+/* Multi-head attention core of gnn_transformer.py:137-158 (head width 32): per (b, head)
+ * O = softmax(mask(Q K^T / sqrt(32), -1e9)) V.  Q rows [B*Tq, ldq], K/V rows [B*Tk, ldk/ldv]; head h at
+ * columns h*32.. ; key_valid [B,Tk] (0 = masked); causal != 0 adds key <= query + q_pos0.        */
+int fira_attention_fwd(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq,
+                       const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
+                       int causal, int q_pos0, float* O, int ldo);
+int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq,
+                       const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
+                       int causal, int q_pos0, const float* O, int ldo, const float* dO, int lddo,
+                       float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
+
+/* CopyNet score (Model.py:15-18): score[b,t,s] = w . tanh(src[b,s,:] + tgt[b,t,:]) + bias, never
+ * materialising the [B,T,S,256] tensor.  bwd re-computes tanh.                                   */
+int fira_copy_score_fwd(void* stream, int B, int T, int S, const float* src, const float* tgt,
+                        const float* w, const float* bias, float* score);
+int fira_copy_score_bwd(void* stream, int B, int T, int S, const float* src, const float* tgt,
+                        const float* w, const float* dscore, float* dsrc /* = */, float* dtgt /* += */,
+                        float* dw /* += */, float* dbias /* += */);
+
+/* Output head + loss (Model.py:54-86), one workgroup per target row bt = b*T + t (BT rows):
+ * p = [g0*softmax(logits) ; g1*softmax(mask(score,-1e9))], loss = -log(clamp(p[label],1e-10,1)),
+ * label = tar_label shifted left (Model.py:71-77).  compact_row[bt] = row of `logits` holding (b,t), or -1
+ * when that row was not computed (NULL = identity).  loss_sum / n_tok are device scalars (+=).  With
+ * want_grad the three inputs are overwritten in place by dlogits / dscore / dgate_logits.  With
+ * argmax_out != NULL the teacher-forced argmax id of every row is written ('dev' stage, Model.py:85-86). */
+int fira_head_loss(void* stream, int BT, int T, int V, int S, const int32_t* compact_row,
+                   float* logits, int ldl, float* score /* [BT,S] */, const int32_t* mem_valid /* [B,S] */,
+                   float* gate_logits /* [BT,2] */, const int32_t* tar_label /* [B,T] */,
+                   float* loss_sum, int32_t* n_tok, int32_t* argmax_out, int want_grad);
+
+/* Adam (run_model.py:396 torch.optim.Adam defaults) over a flat buffer.  grad_scale (device scalar,
+ * may be NULL) multiplies g first: 1/n_tok of run_model.py:105 without a host sync.              */
+int fira_adam_step(void* stream, int64_t n, float* p, const float* g, float* m, float* v,
+                   float lr, float beta1, float beta2, float eps, int step, const float* inv_scale_ntok);
+/* out[0] = 1 / max(n_tok[0], 1) on the device */
+int fira_inv_count(void* stream, const int32_t* n_tok, float* out);
+
+/* =========================== model level (one call per step) =============================== */
+
+/* forward + backward of TransModel.forward(..., 'train') (Model.py:38-84, run_model.py:104-108):
+ * grads (flat, same layout as params) += d(loss_sum)/dparams; loss_sum / n_tok are device scalars
+ * that are overwritten.  grads must be zeroed by the caller when a fresh gradient is wanted.       */
+int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
+                       float* grads, void* workspace, size_t workspace_bytes, const fira_train_opts* opts,
+                       float* loss_sum, int32_t* n_tok);
+
+/* TransModel.forward(..., 'dev') (Model.py:85-86): teacher-forced argmax ids [B, tar_len].         */
+int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
+                     void* workspace, size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok);
+
+/* Encoder once per batch (run_model.py:202-207) + everything of the decode loop that does not depend
+ * on the generated prefix: memory [B,S,256], mem_valid [B,S], cross-attention K/V of all layers,
+ * LinearSource(memory).  State lives in the caller's workspace.                                     */
+int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
+                      void* workspace, size_t workspace_bytes, int n_beam);
+/* One decode step for every (commit, beam) row with KV cache: consumes tokens[B*n_beam] (ids at position
+ * `step`), produces dist [B*n_beam, vocab+S] = the reference's `output[:, step, :]` (run_model.py:256-267)
+ * if dist != NULL, and/or greedy argmax ids + their probability.  parent[B*n_beam] (may be NULL) re-orders
+ * the self-attention cache rows after a beam re-ranking.                                            */
+int fira_decode_step(void* stream, const fira_dims* d, const float* params, void* workspace,
+                     size_t workspace_bytes, int B, int n_beam, int step, const int32_t* tokens,
+                     const int32_t* parent, float* dist, int32_t* best_id, float* best_p);
+
+/* read-only views into a decode workspace (device pointers), for tests and the Python driver */
+const float*   fira_decode_memory(const fira_dims* d, void* workspace, int B, int n_beam);
+const int32_t* fira_decode_mem_valid(const fira_dims* d, void* workspace, int B, int n_beam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIRA_HIP_H */

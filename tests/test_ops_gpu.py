@@ -1,0 +1,313 @@
+"""Per-kernel parity: every HIP op (through the C ABI) against a plain PyTorch fp32/fp64 reference of the same op.
+
+Tolerances are stated per test: fp32 kernels with a different summation order than the reference agree to a few
+1e-6 relative (SURVEY.md §8c measured 2.5e-7 between fp32 and fp64 of the reference itself).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import util  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(960, 256, 256), (20800, 256, 256), (130, 70, 50), (4, 1536, 256), (64, 24650, 256),
+                                   (333, 256, 24650), (960, 1024, 256), (960, 2, 256)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(M, N, K, layout):
+    from fira_icse_amd import ops
+    if M * N * K > 3e9:
+        pytest.skip("too large")
+    tA, tB = {"nt": (False, True), "nn": (False, False), "tn": (True, False)}[layout]
+    A = randn(*((K, M) if tA else (M, K)), seed=1)
+    B = randn(*((N, K) if tB else (K, N)), seed=2)       # asymmetric operands: a swapped tile cannot pass
+    bias = randn(N, seed=3)
+    ref = ((A.t() if tA else A).double() @ (B.t() if tB else B).double()) + bias.double()
+    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias)
+    assert rel_err(out, ref) < 2e-6
+    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, relu=True)
+    assert rel_err(out, ref.clamp_min(0)) < 2e-6
+
+
+def test_gemm_accumulate_and_splitk():
+    from fira_icse_amd import ops
+    M, N, K = 256, 256, 20800                      # the weight-gradient shape of a GCN layer at batch 32
+    A, B = randn(K, M, seed=4), randn(K, N, seed=5)
+    C0 = randn(M, N, seed=6)
+    ref = C0.double() + A.t().double() @ B.double()
+    for sk in (1, 8, 37):
+        C = C0.clone()
+        ops.gemm(A, B, transA=True, transB=False, out=C, accumulate=True, splitk=sk)
+        assert rel_err(C, ref) < 2e-6, sk
+
+
+def test_gemm_strided_output_and_padded_ld():
+    from fira_icse_amd import ops
+    # decode writes K/V rows into the cache with a row stride of T*256; logits rows are padded to 24704
+    X, W = randn(64, 256, seed=7), randn(256, 256, seed=8)
+    cache = torch.zeros(64, 30, 256, device=DEV)
+    ops.gemm(X, W, out=cache[:, 5, :])
+    assert rel_err(cache[:, 5, :], X.double() @ W.double().t()) < 2e-6
+    assert float(cache[:, 4, :].abs().max()) == 0 and float(cache[:, 6, :].abs().max()) == 0
+    dl = torch.zeros(100, 24704, device=DEV)
+    dl[:, :24650] = randn(100, 24650, seed=9)
+    Wo = randn(24650, 256, seed=10)
+    out = ops.gemm(dl[:, :24650], Wo, transB=False)
+    assert rel_err(out, dl[:, :24650].double() @ Wo.double()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ SpMM
+def random_graph_batch(B, N, nnz_per_graph, seed):
+    rng = np.random.default_rng(seed)
+    rowptr, col, val = [0], [], []
+    dense = np.zeros((B, N, N), dtype=np.float32)
+    for b in range(B):
+        pairs = set((i, i) for i in range(N))
+        while len(pairs) < nnz_per_graph:
+            i, j = rng.integers(0, N, 2)
+            pairs.add((int(i), int(j))); pairs.add((int(j), int(i)))
+        pairs = sorted(pairs)
+        for r in range(N):
+            cs = [c for (rr, c) in pairs if rr == r]
+            for c in cs:
+                v = np.float32(rng.uniform(0.05, 1.0))
+                dense[b, r, c] = v
+                col.append(b * N + c); val.append(v)
+            rowptr.append(len(col))
+    t = lambda a, dt: torch.tensor(np.array(a, dtype=dt), device=DEV)
+    return t(rowptr, np.int32), t(col, np.int32), t(val, np.float32), torch.tensor(dense, device=DEV)
+
+
+@pytest.mark.parametrize("variant,N,nnz", [(1, 650, 2500), (1, 97, 4000), (2, 512, 9000), (2, 640, 3000)])
+def test_csr_spmm_vs_dense_bmm(variant, N, nnz):
+    from fira_icse_amd import ops
+    B = 3
+    rowptr, col, val, dense = random_graph_batch(B, N, nnz, seed=N)
+    X = randn(B * N, 256, seed=11)
+    ref = torch.bmm(dense.double(), X.view(B, N, 256).double()).view(B * N, 256)
+    Y = ops.csr_spmm(rowptr, col, val, X, graph_rows=N, variant=variant)
+    assert rel_err(Y, ref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ row ops
+def test_embed_gather_and_scatter():
+    from fira_icse_amd import ops
+    B, L, V = 5, 210, 1000
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, V, (B, L), generator=g).to(torch.int32).to(DEV)
+    idx[:, -20:] = 0
+    table, pos = randn(V, 256, seed=1), randn(L, 256, seed=2)
+    node = torch.zeros(B, 650, 256, device=DEV)
+    ops.embed_gather(idx, table, pos, out=node, out_bstride=650, out_off=0)
+    assert torch.equal(node[:, :L], table[idx.long()] + pos)
+    assert float(node[:, L:].abs().max()) == 0
+    dout = randn(B, 650, 256, seed=3)
+    dtab = torch.zeros_like(table)
+    ops.embed_scatter_add(idx, dtab, dout, 650, 0, padding_idx=0)
+    ref = torch.zeros_like(table).double().index_add_(0, idx.long().view(-1), dout[:, :L].reshape(-1, 256).double())
+    ref[0] = 0
+    assert rel_err(dtab, ref) < 1e-6 and float(dtab[0].abs().max()) == 0
+
+
+def test_combination_gate_fwd_bwd():
+    from fira_icse_amd import ops
+    M = 6720 + 3
+    qk = randn(M, 512, seed=1).requires_grad_(True)
+    vtab = randn(4, 256, seed=2).requires_grad_(True)
+    mark = (torch.arange(M) % 4).to(torch.int32).to(DEV)
+    q, k = qk[:, :256], qk[:, 256:]
+    v = vtab[mark.long()]
+    s = math.sqrt(32)
+    w = torch.softmax(torch.stack([q * k / s, q * v / s], -1), -1)
+    ref = (w * torch.stack([k, v], -1)).sum(-1)
+    out = ops.combination_fwd(qk.detach(), vtab.detach(), mark)
+    assert rel_err(out, ref) < 1e-6
+    dout = randn(M, 256, seed=3)
+    ref.backward(dout)
+    dqk, dvtab = ops.combination_bwd(qk.detach(), vtab.detach(), mark, dout)
+    assert rel_err(dqk, qk.grad) < 2e-6
+    assert rel_err(dvtab, vtab.grad) < 1e-5
+
+
+def test_add_layernorm_fwd_bwd_and_dropout_mask():
+    from fira_icse_amd import ops
+    M = 1237
+    x, res = randn(M, 256, seed=1).requires_grad_(True), randn(M, 256, seed=2).requires_grad_(True)
+    gamma, beta = (1 + 0.1 * randn(256, seed=3)).requires_grad_(True), randn(256, seed=4).requires_grad_(True)
+    ref = F.layer_norm(x + res, (256,), gamma, beta, 1e-5)
+    y, s, stats = ops.add_layernorm_fwd(x.detach().clone(), res.detach(), gamma.detach(), beta.detach())
+    assert rel_err(y, ref) < 1e-6
+    assert rel_err(s, x + res) < 1e-7
+    dy = randn(M, 256, seed=5)
+    ref.backward(dy)
+    ds, _, dg, db = ops.add_layernorm_bwd(dy, s, stats, gamma.detach())
+    assert rel_err(ds, x.grad) < 5e-6 and rel_err(ds, res.grad) < 5e-6
+    assert rel_err(dg, gamma.grad) < 1e-5 and rel_err(db, beta.grad) < 1e-5
+    # dropout: y = LN(x*mask/(1-p) (+ res)); the same counter-based mask is re-derived by the backward
+    p = 0.2
+    x0 = randn(M, 256, seed=6)
+    y, s, stats = ops.add_layernorm_fwd(x0.clone(), None, gamma.detach(), beta.detach(), p, seed=77, site=5)
+    kept = s != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+    assert rel_err(s[kept], x0[kept] / (1 - p)) < 1e-6
+    ds, dxd, _, _ = ops.add_layernorm_bwd(dy, s, stats, gamma.detach(), p, seed=77, site=5, want_dx_drop=True)
+    assert torch.equal(dxd != 0, kept & (ds != 0))
+    assert rel_err(dxd[kept], ds[kept] / (1 - p)) < 1e-6
+    y2, _, _ = ops.add_layernorm_fwd(x0.clone(), None, gamma.detach(), beta.detach(), p, seed=78, site=5)
+    assert not torch.equal(y, y2)                     # a different seed draws a different mask
+
+
+def test_colsum():
+    from fira_icse_amd import ops
+    X = randn(20800, 300, seed=1)
+    assert rel_err(ops.colsum(X[:, :256].contiguous()), X[:, :256].double().sum(0)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def torch_attention(q, k, v, key_valid, causal, q_pos0=0):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    qh, kh, vh = (t.view(B, -1, 8, 32).transpose(1, 2) for t in (q, k, v))
+    w = qh @ kh.transpose(-1, -2) / math.sqrt(32)
+    mask = key_valid[:, None, None, :].bool()
+    if causal:
+        tri = (torch.arange(Tk, device=q.device)[None, :] <= torch.arange(Tq, device=q.device)[:, None] + q_pos0)
+        mask = mask & tri[None, None]
+    w = torch.softmax(w.masked_fill(~mask, -1e9), -1)
+    return (w @ vh).transpose(1, 2).reshape(B, Tq, 256)
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(30, 30, True), (30, 370, False), (1, 17, False), (1, 370, False), (7, 33, False)])
+def test_attention_fwd_bwd(Tq, Tk, causal):
+    from fira_icse_amd import ops
+    B = 5
+    q = randn(B, Tq, 256, seed=1).double().requires_grad_(True)
+    k = randn(B, Tk, 256, seed=2).double().requires_grad_(True)
+    v = randn(B, Tk, 256, seed=3).double().requires_grad_(True)      # asymmetric V: catches transposed tiles
+    g = torch.Generator().manual_seed(4)
+    key_valid = (torch.rand(B, Tk, generator=g) > 0.3).to(torch.int32).to(DEV)
+    key_valid[:, 0] = 1
+    ref = torch_attention(q, k, v, key_valid, causal)
+    o = ops.attention_fwd(q.detach().float(), k.detach().float(), v.detach().float(), key_valid, causal)
+    assert rel_err(o, ref) < 2e-6
+    do = randn(B, Tq, 256, seed=5)
+    ref.backward(do.double())
+    dq, dk, dv = ops.attention_bwd(q.detach().float(), k.detach().float(), v.detach().float(), key_valid, o, do, causal)
+    assert rel_err(dq, q.grad) < 5e-6
+    assert rel_err(dk, k.grad) < 5e-6
+    assert rel_err(dv, v.grad) < 5e-6
+
+
+def test_attention_strided_qkv_buffer():
+    """Q|K|V read straight out of the fused [rows, 768] projection buffer (row stride 768)."""
+    from fira_icse_amd import ops
+    B, T = 4, 30
+    qkv = randn(B, T, 768, seed=1)
+    kv = torch.ones(B, T, dtype=torch.int32, device=DEV)
+    o = ops.attention_fwd(qkv[:, :, :256], qkv[:, :, 256:512], qkv[:, :, 512:], kv, causal=True)
+    ref = torch_attention(qkv[:, :, :256].double(), qkv[:, :, 256:512].double(), qkv[:, :, 512:].double(), kv, True)
+    assert rel_err(o, ref) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ copy head / loss
+def test_copy_score_fwd_bwd():
+    from fira_icse_amd import ops
+    B, T, S = 3, 30, 370
+    src = randn(B, S, 256, seed=1).double().requires_grad_(True)
+    tgt = randn(B, T, 256, seed=2).double().requires_grad_(True)
+    w = randn(256, seed=3, scale=0.1).double().requires_grad_(True)
+    b = randn(1, seed=4).double().requires_grad_(True)
+    ref = (torch.tanh(src[:, None] + tgt[:, :, None]) * w).sum(-1) + b
+    sc = ops.copy_score_fwd(src.detach().float(), tgt.detach().float(), w.detach().float(), b.detach().float())
+    assert rel_err(sc, ref) < 2e-6
+    ds = randn(B, T, S, seed=5)
+    ref.backward(ds.double())
+    dsrc, dtgt, dw, db = ops.copy_score_bwd(src.detach().float(), tgt.detach().float(), w.detach().float(), ds)
+    assert rel_err(dsrc, src.grad) < 5e-6 and rel_err(dtgt, tgt.grad) < 5e-6
+    assert rel_err(dw, w.grad) < 1e-5 and rel_err(db, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_head_loss_fwd_bwd(compact):
+    from fira_icse_amd import ops
+    B, T, V, S = 4, 30, 24650, 370
+    g = torch.Generator().manual_seed(0)
+    logits = randn(B * T, V, seed=1, scale=2.0).double().requires_grad_(True)
+    score = randn(B * T, S, seed=2, scale=2.0).double().requires_grad_(True)
+    gate = randn(B * T, 2, seed=3).double().requires_grad_(True)
+    mem_valid = (torch.rand(B, S, generator=g) > 0.4).to(torch.int32).to(DEV)
+    mem_valid[:, :3] = 1
+    lab = torch.zeros(B, T, dtype=torch.int64)
+    lab[:, 0] = 2
+    for b in range(B):
+        n = 5 + 3 * b
+        lab[b, 1:n] = torch.randint(4, V, (n - 1,), generator=g)
+        valid = mem_valid[b].cpu().nonzero().view(-1)
+        lab[b, 2] = V + int(valid[1])                 # a copy label
+        lab[b, 4] = V + int((mem_valid[b] == 0).cpu().nonzero().view(-1)[0])   # copy label on a masked slot
+        lab[b, n] = 1
+    lab = lab.to(DEV)
+    # reference (Model.py:54-82)
+    p_gen = torch.softmax(logits, -1).view(B, T, V)
+    p_copy = torch.softmax(score.view(B, T, S).masked_fill(mem_valid[:, None, :] == 0, -1e9), -1)
+    gt = torch.softmax(gate, -1).view(B, T, 2)
+    p = torch.cat([gt[..., :1] * p_gen, gt[..., 1:] * p_copy], -1)
+    logp = torch.log(p.clamp(min=1e-10, max=1))
+    label = torch.cat([lab[:, 1:], torch.zeros_like(lab[:, :1])], 1)
+    nll = F.nll_loss(logp.view(-1, V + S), label.view(-1), reduction="none").masked_fill(label.view(-1) == 0, 0)
+    nll.sum().backward()
+    ids_ref = logp.argmax(-1)
+
+    lg = torch.zeros(B * T, 24704, device=DEV)
+    lg[:, :V] = logits.detach().float()
+    sc, gl = score.detach().float().clone(), gate.detach().float().clone()
+    compact_row = None
+    rows = torch.arange(B * T, device=DEV)
+    if compact:
+        rows = ((label.view(-1) > 0) & (label.view(-1) < V)).nonzero().view(-1)
+        lg = lg[rows].contiguous()
+        compact_row = torch.full((B * T,), -1, dtype=torch.int32, device=DEV)
+        compact_row[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=DEV)
+    else:
+        _, _, ids = ops.head_loss(lg.clone(), sc.clone(), mem_valid, gl.clone(), lab.to(torch.int32), V,
+                                  want_grad=False, argmax=True)
+        assert torch.equal(ids.long(), ids_ref)
+    loss, ntok, _ = ops.head_loss(lg, sc, mem_valid, gl, lab.to(torch.int32), V, compact_row=compact_row)
+    assert int(ntok) == int((label != 0).sum())
+    assert abs(float(loss) - float(nll.sum())) / float(nll.sum()) < 2e-6
+    assert rel_err(lg[:, :V], logits.grad[rows]) < 5e-6
+    assert rel_err(sc, score.grad) < 5e-6
+    assert rel_err(gl, gate.grad) < 5e-6
+
+
+def test_adam_matches_torch():
+    from fira_icse_amd import ops
+    n = 100003
+    p0, grads = randn(n, seed=1), [randn(n, seed=10 + i, scale=0.01) for i in range(4)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ntok = torch.tensor([8], dtype=torch.int32, device=DEV)
+    inv = ops.inv_count(ntok, torch.zeros(1, device=DEV))
+    for i, gr in enumerate(grads):
+        ref.grad = gr / 8
+        opt.step()
+        ops.adam_step(p, gr, m, v, 1e-4, i + 1, inv_scale=inv)
+        assert float((p - ref.data).abs().max()) < 2e-7

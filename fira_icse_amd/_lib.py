@@ -63,7 +63,10 @@ SIGNATURES = {
     "fira_head_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
     "fira_adam_step": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "fira_inv_count": (_I, [_P, _P, _P]),
-    "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P]),
+    "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
+    "fira_prof_enable": (None, [_I]),
+    "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
+    "fira_param_groups": (_I, [_DP, C.POINTER(_L), C.POINTER(_L)]),
     "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P]),
     "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
     "fira_decode_step": (_I, [_P, _DP, _P, _P, _Z, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -359,6 +359,7 @@ static int check_geometry(const char* who, int Tq, int Tk, int ldq, int ldk, int
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
                      int kb, int kvb, int qpk) {
+    ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_fwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(kb >= Tk && kvb >= Tk && qpk >= 1, "attention_fwd: bad batch strides");
@@ -379,6 +380,7 @@ int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, i
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv) {
+    ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_bwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(ldo % 4 == 0 && lddo % 4 == 0 && (uintptr_t)O % 16 == 0 && (uintptr_t)dO % 16 == 0,

@@ -26,6 +26,21 @@ int set_err(const char* fmt, ...);
         if (!(cond)) return fira::set_err(__VA_ARGS__);                           \
     } while (0)
 
+// ---------------------------------------------------------------- per-kernel-class event profiling
+// Off by default (one relaxed bool test per launch).  When enabled (fira_prof_enable), every launcher brackets
+// its kernel with two hipEvents on the launch stream; fira_prof_report synchronises and aggregates the elapsed
+// time and the algorithmic work (FLOP for GEMM/attention, bytes for the memory-bound classes) per class.
+enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_NCLASS };
+bool prof_on();
+void prof_begin(hipStream_t s, int cls, double work);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(hipStream_t s_, int cls, double work) : s(s_), on(prof_on()) { if (on) prof_begin(s, cls, work); }
+    ~ProfScope() { if (on) prof_end(s); }
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void decode_dist_kernel(int V, int S, const fl
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
                 float* best_p) {
+    ProfScope prof(s, PROF_HEAD, 0.0);
     if (R <= 0) return 0;
     hipLaunchKernelGGL(decode_dist_kernel, dim3(R), dim3(256), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
                        gate_logits, dist, best_id, best_p);
@@ -328,6 +329,7 @@ int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl
 
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* bias, float* score, int qpk) {
+    ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX && qpk >= 1, "copy_score_fwd: T=%d > %d", T, T_MAX);
     hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
@@ -341,6 +343,7 @@ int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const f
 }
 int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
+    ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
     hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
@@ -351,6 +354,7 @@ int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const f
 int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
               float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,
               int32_t* n_tok, int32_t* argmax_out, int want_grad) {
+    ProfScope prof(s, PROF_HEAD, 0.0);
     if (BT <= 0) return 0;
     hipLaunchKernelGGL(head_loss_kernel, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
                        mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
@@ -359,6 +363,7 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
 }
 int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
               float beta2, float eps, int step, const float* scale_ptr) {
+    ProfScope prof(s, PROF_ADAM, 0.0);
     if (n <= 0) return 0;
     FIRA_REQUIRE(step >= 1, "adam_step: step must start at 1");
     const double bc1 = 1.0 - pow((double)beta1, step);

@@ -89,6 +89,7 @@ struct Layout {
     fira_dims d;
     std::vector<ParamInfo> infos;     // reference state_dict order
     int64_t total = 0;                // floats
+    int64_t split = 0, live = 0;      // [0,split) decoder+head, [split,live) encoder, [live,total) dead tensors
     int64_t emb, ast_emb, mark_emb, w2_all, b2_all, dec_emb, wkv_all, bkv_all, wout, bout, ws, wt, wres, bres, wp, bp;
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;

@@ -237,7 +237,7 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
 }
 
 // ------------------------------------------------------------------------------------------ backward
-static int backward(Ctx& c, int R, const int32_t* rows) {
+static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
     hipStream_t s = c.s;
@@ -308,6 +308,10 @@ static int backward(Ctx& c, int R, const int32_t* rows) {
     // cross-attention K|V projections of all layers
     TRY(linear_dgrad(s, p.MB, KV, D, p.dkv_all, KV, c.P + L.wkv_all, p.dmem, D, true));
     TRY(linear_wgrad(s, p.MB, KV, D, p.dkv_all, KV, p.mem, D, G + L.wkv_all, G + L.bkv_all));
+    if (mid_event) {                         // gradients of [0, split) are final from here on
+        hipError_t e = hipEventRecord(mid_event, s);
+        if (e != hipSuccess) return set_err("hipEventRecord: %s", hipGetErrorString(e));
+    }
 
     // ---- encoder layers, last to first ------------------------------------------------------------------
     float* dXn = p.dXa;
@@ -404,7 +408,7 @@ size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam) {
 
 int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
                        void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
-                       int32_t* n_tok) {
+                       int32_t* n_tok, void* mid_event) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
     TRY(check_batch(batch));
@@ -428,7 +432,7 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
         TRY(iota_rows(c.s, p.TB, p.iota));
     }
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
-    TRY(backward(c, R, rows));
+    TRY(backward(c, R, rows, (hipEvent_t)mid_event));
     return 0;
 }
 

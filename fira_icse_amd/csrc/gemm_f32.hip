@@ -221,6 +221,7 @@ int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A,
     FIRA_REQUIRE(!(splitk > 1 && (flags & FIRA_GEMM_RELU)), "gemm_f32: relu cannot be combined with split-K");
     FIRA_REQUIRE(!(splitk > 1 && !(flags & FIRA_GEMM_ACCUM)), "gemm_f32: split-K needs accumulate semantics");
     // big tiles only when they still fill the chip (256 CUs); the decoder-side GEMMs are small
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
     const long big_blocks = (long)cdiv(M, 128) * cdiv(N, 128) * splitk;
     if (big_blocks >= 192) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
     return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);

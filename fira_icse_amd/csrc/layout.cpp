@@ -23,6 +23,37 @@ int set_err(const char* fmt, ...) {
     return 1;
 }
 
+// ---------------------------------------------------------------- event profiler
+namespace {
+struct ProfRec { int cls; double work; hipEvent_t a, b; };
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+};
+ProfState& PS() { static ProfState s; return s; }
+}  // namespace
+bool prof_on() { return PS().on; }
+void prof_begin(hipStream_t s, int cls, double work) {
+    ProfState& p = PS();
+    std::lock_guard<std::mutex> g(p.mu);
+    ProfRec r{cls, work, p.get(), p.get()};
+    hipEventRecord(r.a, s);
+    p.recs.push_back(r);
+}
+void prof_end(hipStream_t s) {
+    ProfState& p = PS();
+    std::lock_guard<std::mutex> g(p.mu);
+    if (!p.recs.empty()) hipEventRecord(p.recs.back().b, s);
+}
+
 namespace {
 
 struct Builder {
@@ -111,44 +142,14 @@ Layout* build(const fira_dims& d) {
     b.linear("copy_net.LinearProb", 2, D);
 
     // ---- placement (offsets) -------------------------------------------------------------------------
-    L->emb = b.place("encoder.embedding.weight");
+    // Group A first: everything whose gradient is complete once the decoder backward has finished (head, decoder
+    // layers, decoder embedding, cross K|V projections) -- the data-parallel all-reduce of this slice overlaps the
+    // encoder backward.  Group B (encoder) follows; `split` is the boundary.
+    L->enc.resize(d.n_layer);
+    L->dec.resize(d.n_layer);
     L->dec_emb = b.place("decoder.embedding.weight");
     L->wout = b.place("out_fc.weight");
     L->bout = b.place("out_fc.bias");
-    L->ast_emb = b.place("encoder.ast_change_embedding.weight");
-    L->mark_emb = b.place("encoder.mark_embedding.weight");
-    L->enc.resize(d.n_layer);
-    L->dec.resize(d.n_layer);
-    // value projections of the six live Combination layers, contiguous: one [6*256, 256] GEMM on the 4-row mark table
-    for (int i = 0; i < d.n_layer; ++i) {
-        int64_t o = b.place(S("encoder.combination_list2.%d.linear_layers.2.weight", i));
-        if (i == 0) L->w2_all = o;
-        L->enc[i].w2 = o;
-    }
-    for (int i = 0; i < d.n_layer; ++i) {
-        int64_t o = b.place(S("encoder.combination_list2.%d.linear_layers.2.bias", i));
-        if (i == 0) L->b2_all = o;
-        L->enc[i].b2 = o;
-    }
-    for (int i = 0; i < d.n_layer; ++i) {
-        EncLayer& e = L->enc[i];
-        std::string pre = S("encoder.combination_list2.%d", i);
-        e.wqk = b.place(pre + ".linear_layers.0.weight");
-        b.place(pre + ".linear_layers.1.weight");
-        e.bqk = b.place(pre + ".linear_layers.0.bias");
-        b.place(pre + ".linear_layers.1.bias");
-        e.wo = b.place(pre + ".output_linear.weight");
-        e.bo = b.place(pre + ".output_linear.bias");
-        e.ln1g = b.place(pre + ".layernorm.weight");
-        e.ln1b = b.place(pre + ".layernorm.bias");
-        pre = S("encoder.gcn_list.%d", i);
-        e.fc1w = b.place(pre + ".fc1.weight");
-        e.fc1b = b.place(pre + ".fc1.bias");
-        e.fc2w = b.place(pre + ".fc2.weight");
-        e.fc2b = b.place(pre + ".fc2.bias");
-        e.ln2g = b.place(pre + ".layernorm.weight");
-        e.ln2b = b.place(pre + ".layernorm.bias");
-    }
     // cross-attention K|V projections of all layers, contiguous: one [6*512, 256] GEMM over the memory rows
     for (int i = 0; i < d.n_layer; ++i) {
         std::string pre = S("decoder.cross_attention_list.%d", i);
@@ -198,6 +199,42 @@ Layout* build(const fira_dims& d) {
     L->bres = b.place("copy_net.LinearRes.bias");
     L->wp = b.place("copy_net.LinearProb.weight");
     L->bp = b.place("copy_net.LinearProb.bias");
+    L->split = L->total;
+    // ---- group B: encoder ----
+    L->emb = b.place("encoder.embedding.weight");
+    L->ast_emb = b.place("encoder.ast_change_embedding.weight");
+    L->mark_emb = b.place("encoder.mark_embedding.weight");
+    // value projections of the six live Combination layers, contiguous: one [6*256, 256] GEMM on the 4-row mark table
+    for (int i = 0; i < d.n_layer; ++i) {
+        int64_t o = b.place(S("encoder.combination_list2.%d.linear_layers.2.weight", i));
+        if (i == 0) L->w2_all = o;
+        L->enc[i].w2 = o;
+    }
+    for (int i = 0; i < d.n_layer; ++i) {
+        int64_t o = b.place(S("encoder.combination_list2.%d.linear_layers.2.bias", i));
+        if (i == 0) L->b2_all = o;
+        L->enc[i].b2 = o;
+    }
+    for (int i = 0; i < d.n_layer; ++i) {
+        EncLayer& e = L->enc[i];
+        std::string pre = S("encoder.combination_list2.%d", i);
+        e.wqk = b.place(pre + ".linear_layers.0.weight");
+        b.place(pre + ".linear_layers.1.weight");
+        e.bqk = b.place(pre + ".linear_layers.0.bias");
+        b.place(pre + ".linear_layers.1.bias");
+        e.wo = b.place(pre + ".output_linear.weight");
+        e.bo = b.place(pre + ".output_linear.bias");
+        e.ln1g = b.place(pre + ".layernorm.weight");
+        e.ln1b = b.place(pre + ".layernorm.bias");
+        pre = S("encoder.gcn_list.%d", i);
+        e.fc1w = b.place(pre + ".fc1.weight");
+        e.fc1b = b.place(pre + ".fc1.bias");
+        e.fc2w = b.place(pre + ".fc2.weight");
+        e.fc2b = b.place(pre + ".fc2.bias");
+        e.ln2g = b.place(pre + ".layernorm.weight");
+        e.ln2b = b.place(pre + ".layernorm.bias");
+    }
+    L->live = L->total;
     // dead tensors last (never touched by a kernel; their gradient stays zero, Adam leaves them unchanged)
     for (auto& p : L->infos)
         if (p.offset < 0) b.place(p.name);
@@ -250,8 +287,35 @@ int fira_param_info(const fira_dims* d, int index, char* name_buf, int64_t* offs
     if (shape) { shape[0] = p.shape[0]; shape[1] = p.shape[1]; }
     return 0;
 }
+void fira_prof_enable(int on) {
+    fira::ProfState& p = fira::PS();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.on = on != 0;
+}
+int fira_prof_report(int n_class, double* ms, double* work, int64_t* count) {
+    fira::ProfState& p = fira::PS();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (int i = 0; i < n_class; ++i) { ms[i] = 0; work[i] = 0; count[i] = 0; }
+    for (auto& r : p.recs) {
+        hipEventSynchronize(r.b);
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.a, r.b);
+        if (r.cls < n_class) { ms[r.cls] += t; work[r.cls] += r.work; count[r.cls] += 1; }
+        p.pool.push_back(r.a);
+        p.pool.push_back(r.b);
+    }
+    p.recs.clear();
+    return 0;
+}
 int64_t fira_param_total(const fira_dims* d) {
     const fira::Layout* L = fira::get_layout(d);
     return L ? L->total : -1;
+}
+int fira_param_groups(const fira_dims* d, int64_t* split, int64_t* live) {
+    const fira::Layout* L = fira::get_layout(d);
+    if (!L) return 1;
+    if (split) *split = L->split;
+    if (live) *live = L->live;
+    return 0;
 }
 }

@@ -327,6 +327,7 @@ __global__ void invert_rows_kernel(int R, const int32_t* __restrict__ rows, int3
 
 // ---------------------------------------------------------------- host launchers
 int rows_gather_seg(hipStream_t s, int M, float* compact, const float* strided, int seg_len, int seg_stride, int seg_off) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     hipLaunchKernelGGL(rows_seg_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, s, M, compact, const_cast<float*>(strided),
                        seg_len, seg_stride, seg_off);
@@ -335,6 +336,7 @@ int rows_gather_seg(hipStream_t s, int M, float* compact, const float* strided, 
 }
 int rows_scatter_seg(hipStream_t s, int M, const float* compact, float* strided, int seg_len, int seg_stride,
                      int seg_off) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     hipLaunchKernelGGL(rows_seg_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, s, M, const_cast<float*>(compact), strided,
                        seg_len, seg_stride, seg_off);
@@ -384,6 +386,7 @@ int invert_rows(hipStream_t s, int BT, int R, const int32_t* rows, int32_t* comp
 }
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
                      int out_bstride, int out_off) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     const int rows = B * L;
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(embed_gather_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, L, idx, table, pos, out,
@@ -393,6 +396,7 @@ int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const floa
 }
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
                      int out_bstride, int out_off, int padding_idx) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     const int rows = B * L;
     if (rows <= 0) return 0;
     hipLaunchKernelGGL(embed_gather_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, L, idx, dtable, dout,
@@ -402,6 +406,7 @@ int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dta
 }
 int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark, float* out,
                     float dropout, uint64_t seed, uint32_t site) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     hipLaunchKernelGGL(combination_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, qk, vtab, ldv, mark, out, dropout,
@@ -411,6 +416,7 @@ int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, in
 }
 int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
                     const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     const int rpb = 32;
@@ -422,6 +428,7 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, int seg_len, int seg_stride,
                       int seg_off) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, x, res, gamma, beta, y, stats,
@@ -432,6 +439,7 @@ int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const fl
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
                       uint32_t site) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     const int rpb = 32;
@@ -441,6 +449,7 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
     return 0;
 }
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0 || N <= 0) return 0;
     const int rpb = 256;
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, s, M, N, X, ldx, out, rpb);

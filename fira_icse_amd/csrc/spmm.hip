@@ -10,10 +10,10 @@
 //   64 at a time with one coalesced load and broadcast lane-to-lane (readlane), neighbour loads are
 //   issued 4 deep before the FMAs.  No atomics: the reduction over neighbours is a per-lane register sum.
 //   Neighbour re-reads (each H row is used ~4x) hit L2: a graph's H is 665 KB.
-// variant 2 (dense stress graphs, SURVEY.md config 5, ~130 nnz/row): one workgroup per (graph, 64-column
+// variant 2 (dense stress graphs, SURVEY.md config 5, ~120 nnz/row): one workgroup per (graph, 64-column
 //   slab); the slab of H (rows x 64 floats) is staged once into LDS with coalesced float4 loads and every
-//   neighbour gather is an LDS read (ds_read_b128: 16 lanes cover one 64-float row, so a wave gathers 4
-//   neighbours per instruction); partial sums of the 4 lane-groups are combined with wave shuffles.
+//   neighbour gather is an LDS read (ds_read_b128: a 16-lane group covers one 64-float row and owns one
+//   output row, so a wave aggregates 4 rows at once with register sums only).
 #include "common.h"
 
 namespace fira {
@@ -63,6 +63,10 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
 
 // LDS-staged variant: grid (4 column slabs, n_graphs); block 512 threads = 8 waves.
 // Slab: graph_rows x 64 floats (<= 640 rows -> 160 KiB; config 5: 512 rows = 128 KiB).
+// Each 16-lane group of a wave owns ONE output row (16 lanes x float4 = the 64 slab columns), so a wave
+// aggregates 4 rows at once with no cross-lane traffic at all: a group's lanes fetch the same (col, val)
+// (one broadcast dword load, served by L1) and their own float4 of the neighbour row from LDS; four
+// neighbours are fetched per step so that 8 index loads and 4 ds_read_b128 are in flight per lane.
 constexpr int SLAB = 64;
 __global__ __launch_bounds__(512) void spmm_lds_kernel(int graph_rows, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ col,
@@ -80,34 +84,33 @@ __global__ __launch_bounds__(512) void spmm_lds_kernel(int graph_rows, const int
     }
     __syncthreads();
     const int lane = t & 63, wave = t >> 6;
-    const int sub = lane >> 4;          // which of 4 neighbours this lane-group gathers
+    const int sub = lane >> 4;          // which of the wave's 4 rows this lane-group owns
     const int q = (lane & 15) * 4;      // float4 column inside the slab
-    for (int r = wave; r < graph_rows; r += 8) {
-        const int beg = rowptr[row0 + r], end = rowptr[row0 + r + 1];
+    for (int r4 = wave * 4; r4 < graph_rows; r4 += 32) {
+        const int r = r4 + sub;
+        const bool live = r < graph_rows;
+        const int beg = live ? rowptr[row0 + r] : 0;
+        const int end = live ? rowptr[row0 + r + 1] : 0;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int base = beg; base < end; base += 64) {
-            const int n = min(64, end - base);
-            int c = 0;
-            float v = 0.f;
-            if (lane < n) {
-                c = col[base + lane] - row0;     // local row inside the graph
-                v = val[base + lane];
+        for (int j = beg; j < end; j += 4) {
+            int c[4];
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = j + u < end;
+                c[u] = ok ? col[j + u] - row0 : 0;
+                v[u] = ok ? val[j + u] : 0.f;
             }
-            for (int j = 0; j < n; j += 4) {
-                const int jj = j + sub;
-                const int cj = __shfl(c, jj & 63, 64);
-                const float vj = (jj < n) ? __shfl(v, jj & 63, 64) : 0.f;
-                const float4 x = *reinterpret_cast<const float4*>(&slab[cj * SLAB + q]);
-                acc.x = fmaf(vj, x.x, acc.x); acc.y = fmaf(vj, x.y, acc.y);
-                acc.z = fmaf(vj, x.z, acc.z); acc.w = fmaf(vj, x.w, acc.w);
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(&slab[c[u] * SLAB + q]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(v[u], x[u].x, acc.x); acc.y = fmaf(v[u], x[u].y, acc.y);
+                acc.z = fmaf(v[u], x[u].z, acc.z); acc.w = fmaf(v[u], x[u].w, acc.w);
             }
         }
-        // combine the 4 lane-groups (lanes l, l^16, l^32, l^48 hold the same columns)
-        acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
-        acc.z += __shfl_xor(acc.z, 16, 64); acc.w += __shfl_xor(acc.w, 16, 64);
-        acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
-        acc.z += __shfl_xor(acc.z, 32, 64); acc.w += __shfl_xor(acc.w, 32, 64);
-        if (sub == 0) *reinterpret_cast<float4*>(Y + (size_t)(row0 + r) * ldy + c0 + q) = acc;
+        if (live) *reinterpret_cast<float4*>(Y + (size_t)(row0 + r) * ldy + c0 + q) = acc;
     }
 }
 
@@ -117,6 +120,9 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
     FIRA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0),
                  "csr_spmm: feature rows must be 16-byte aligned");
     if (variant == 0) variant = 1;
+    // algorithmic bytes: rowptr + (col,val) + features in + features out.  nnz is not known on the
+    // host here: the caller's nnz is folded in by fira_prof users through the count (bench.py adds 8*nnz itself).
+    ProfScope prof(s, PROF_SPMM, 4.0 * (n_rows + 1) + 2.0 * n_rows * FIRA_D * 4.0);
     if (variant == 2) {
         FIRA_REQUIRE(graph_rows > 0 && n_rows % graph_rows == 0 && graph_rows * SLAB * 4 <= 160 * 1024,
                      "csr_spmm: LDS variant needs rows-per-graph (%d) dividing n_rows and <= 640", graph_rows);

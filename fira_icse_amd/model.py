@@ -106,6 +106,9 @@ class ParamLayout:
         if n < 0:
             _lib.check(1, "fira_param_count")
         self.total = int(lib.fira_param_total(C.byref(self.dims)))
+        split, live = C.c_int64(), C.c_int64()
+        _lib.check(lib.fira_param_groups(C.byref(self.dims), C.byref(split), C.byref(live)), "fira_param_groups")
+        self.split, self.live = int(split.value), int(live.value)
         self.entries: "OrderedDict[str, tuple]" = OrderedDict()
         name = C.create_string_buffer(128)
         off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int32()
@@ -235,7 +238,7 @@ class TransModel(nn.Module):
         return self._ws[key]
 
     def train_fwd_bwd(self, db: DeviceBatch, zero_grad: bool = True, dropout: Optional[float] = None,
-                      gcn_dropout: Optional[float] = None):
+                      gcn_dropout: Optional[float] = None, mid_event=None):
         """loss_sum, n_tok (device scalars) and d(loss_sum)/d(params) into ``self.gbuf`` (reference
         run_model.py:104-108 minus the optimizer).  Dropout follows ``self.training`` unless given."""
         lib = _lib.lib()
@@ -248,7 +251,8 @@ class TransModel(nn.Module):
         ws = self.workspace(db.B, 1)
         _lib.check(lib.fira_train_fwd_bwd(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                           _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
-                                          C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok)),
+                                          C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok),
+                                          C.c_void_p(mid_event.cuda_event) if mid_event is not None else None),
                    "fira_train_fwd_bwd")
         return self.loss_sum, self.n_tok
 

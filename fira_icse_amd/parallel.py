@@ -1,0 +1,91 @@
+"""Data parallelism by commit over RCCL/xGMI: one process per GPU, ``torch.distributed``.
+
+The reference's only multi-GPU mode is single-process ``nn.DataParallel`` (run_model.py:392-394): per step it scatters
+the batch, broadcasts 124 MB of weights, and reduces 111 MB of gradients onto GPU 0, where Adam runs alone.  Here every
+rank keeps its own replica and optimizer state; per step there is ONE all-reduce (sum) of the flat gradient buffer, in
+two buckets so that the head+decoder slice overlaps the encoder backward, plus one 2-element all-reduce of
+(loss_sum, n_tok); gradients are scaled by 1/n_tok_global inside the fused Adam kernel, which is exactly the
+normalisation of run_model.py:105 for the global batch.  No parameter broadcast after step 0.
+
+Backend-agnostic (works with ``gloo`` on CPU tensors, which is how the N>1 logic is tested without GPUs).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's environment; initialises the default process group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" IS RCCL on ROCm
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous chunk of a global batch for this rank: ``DataParallel.scatter``'s chunking (ceil(n/world) per
+    replica, the last ones may be short or empty), so an N-rank step sees the same commits per replica as the
+    reference's N-GPU DataParallel step."""
+    per = -(-n // world)
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def shard_indices(idx: Sequence[int], rank: int, world: int) -> List[int]:
+    lo, hi = shard_range(len(idx), rank, world)
+    return list(idx[lo:hi])
+
+
+class GradReducer:
+    """All-reduce of the flat gradient buffer in two readiness buckets + the (loss_sum, n_tok) pair."""
+
+    def __init__(self, split: int, live: int, group=None):
+        self.split, self.live, self.group = split, live, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending = None
+        self._side = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def start_early_bucket(self, gbuf: torch.Tensor, mid_event=None):
+        """Launch the all-reduce of [0, split) as soon as ``mid_event`` fires (decoder backward done)."""
+        if self.world == 1:
+            return
+        if self._side is not None and mid_event is not None:
+            self._side.wait_event(mid_event)
+            with torch.cuda.stream(self._side):
+                self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, gbuf: torch.Tensor, stats: torch.Tensor):
+        """Reduce the encoder bucket and the 2-element stats (fp32: loss_sum, n_tok); wait for the early bucket."""
+        if self.world == 1:
+            return
+        if self._pending is None:
+            self.start_early_bucket(gbuf, None)
+        dist.all_reduce(gbuf[self.split:self.live], op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        self._pending.wait()
+        self._pending = None
+
+
+def gather_lines(lines: List[str], group=None) -> List[str]:
+    """Ordered gather of per-rank output lines onto every rank (decode shards are contiguous ranges of the test set, so
+    concatenating in rank order keeps ``all_index['test']`` order)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return lines
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, lines, group=group)
+    return [l for part in out for l in part]

@@ -1,0 +1,60 @@
+"""Native training step (reference run_model.py:101-112) on the HIP engine: no autograd, no per-tensor optimizer.
+
+    fwd+bwd (one C call, whole step enqueued on the stream)  ->  [RCCL all-reduce]  ->  fused Adam over the flat buffer
+
+The 1/n_tok normaliser stays on the device (no ``loss.item()`` sync per step; the reference syncs every step at
+run_model.py:112); ``last_loss()`` reads it back only when asked.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .model import DeviceBatch, TransModel
+from .parallel import GradReducer
+
+
+class Trainer:
+    def __init__(self, model: TransModel, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
+                 distributed: bool = False):
+        self.model = model
+        self.lr = model.cfg.lr if lr is None else lr
+        self.betas, self.eps = betas, eps
+        self.m = torch.zeros_like(model.gbuf)
+        self.v = torch.zeros_like(model.gbuf)
+        self.t = 0
+        self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
+        self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
+        self.reducer = GradReducer(model.layout.split, model.layout.live) if distributed else None
+        self.mid_event = torch.cuda.Event() if distributed else None
+
+    def step(self, db: DeviceBatch):
+        """One optimisation step on this rank's shard of the global batch."""
+        m = self.model
+        loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
+        if self.reducer is not None and self.reducer.world > 1:
+            self.reducer.start_early_bucket(m.gbuf, self.mid_event)
+            self.stats[0:1].copy_(loss_sum)
+            self.stats[1:2].copy_(n_tok)                       # int32 -> fp32 (exact below 2^24 tokens)
+            self.reducer.finish(m.gbuf, self.stats)
+            torch.reciprocal(self.stats[1:2].clamp_min(1.0), out=self.inv)
+        else:
+            self.stats[0:1].copy_(loss_sum)
+            self.stats[1:2].copy_(n_tok)
+            ops.inv_count(n_tok, self.inv)
+        self.t += 1
+        ops.adam_step(m.flat.data, m.gbuf, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps,
+                      inv_scale=self.inv)
+
+    def last_loss(self) -> float:
+        """Mean token loss of the last (global) batch; synchronises."""
+        s = self.stats.tolist()
+        return s[0] / max(s[1], 1.0)
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "t": self.t}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])

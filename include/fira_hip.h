@@ -75,11 +75,21 @@ int    fira_param_count(const fira_dims* d);
 int    fira_param_info(const fira_dims* d, int index, char* name_buf, int64_t* offset, int64_t* numel,
                        int32_t* ndim, int64_t shape[2]);
 int64_t fira_param_total(const fira_dims* d);            /* floats in the flat buffer        */
+/* Gradient readiness groups of the flat buffer: [0, split) = output head + decoder (complete when the `mid` event of
+ * fira_train_fwd_bwd fires), [split, live) = encoder, [live, total) = tensors no kernel touches. */
+int    fira_param_groups(const fira_dims* d, int64_t* split, int64_t* live);
 
 /* bytes of caller-provided scratch for a batch of B commits. mode: 0 = forward only, 1 = training */
 size_t fira_workspace_bytes(const fira_dims* d, int B, int mode);
 /* scratch for fira_decode_begin / fira_decode_step with n_beam hypotheses per commit */
 size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam);
+
+/* Per-kernel-class HIP-event profiling (bench.py's roofline leg).  Classes: 0 GEMM (work = FLOP), 1 CSR SpMM
+ * (work = algorithmic bytes), 2 attention, 3 row ops, 4 copy score, 5 head/loss, 6 Adam.  report() synchronises,
+ * returns per class the summed event time [ms], summed work and launch count since the last report, and resets. */
+#define FIRA_PROF_NCLASS 7
+void fira_prof_enable(int on);
+int  fira_prof_report(int n_class, double* ms, double* work, int64_t* count);
 
 /* =========================== op level (one reference op each) ============================== */
 
@@ -175,7 +185,9 @@ int fira_inv_count(void* stream, const int32_t* n_tok, float* out);
  * that are overwritten.  grads must be zeroed by the caller when a fresh gradient is wanted.       */
 int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
                        float* grads, void* workspace, size_t workspace_bytes, const fira_train_opts* opts,
-                       float* loss_sum, int32_t* n_tok);
+                       float* loss_sum, int32_t* n_tok, void* mid_event);
+/* mid_event: optional hipEvent_t recorded on `stream` once the gradients of group [0, split) are final (after the
+ * decoder backward, before the encoder backward), so that their RCCL all-reduce can overlap the rest.           */
 
 /* TransModel.forward(..., 'dev') (Model.py:85-86): teacher-forced argmax ids [B, tar_len].         */
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,

@@ -1,0 +1,93 @@
+"""Decode parity: KV-cached greedy / beam search of the HIP engine against (a) the reference's own output lines
+(tests/golden/decode_ref.json, produced by run_model.test on the peaked weights) and (b) the CPU oracle's search."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from fira_icse_amd import data, text
+from fira_icse_amd.config import FiraConfig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict
+    from fira_icse_amd.decode import Searcher
+    cfg = FiraConfig()
+    raw = util.load_golden_raw()
+    store = data.process_raw(cfg, raw)
+    idx = data.split_index(*util.GOLDEN_SPLIT, seed=0)
+    ids = idx["test"][:util.GOLDEN_B]
+    hb = store.batch(ids)
+    torch.manual_seed(0)
+    sd = util.peaked_state_dict(reference_init_state_dict(cfg), seed=2)
+    model = TransModel(cfg, init=False)
+    model.load_state_dict(sd)
+    model.eval()
+    return cfg, raw, ids, hb, sd, model, DeviceBatch(hb, cfg), Searcher(model)
+
+
+def lines_of(hyps, raw, ids):
+    r_vocab = {v: k for k, v in raw["word_vocab"].items()}
+    return [text.detokenize(h, r_vocab, raw["variable"][i]) for h, i in zip(hyps, ids)]
+
+
+def test_greedy_matches_reference_output_lines(setup):
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    gold = json.load(open(os.path.join(util.GOLDEN, "decode_ref.json")))["beam1"]
+    out, length, prob = search.greedy(db)
+    assert lines_of(search.best(out, length, prob), raw, ids) == gold
+    out2, length2, prob2 = search.beam(db, 1)                       # the general path at beam 1 is the same search
+    assert lines_of(search.best(out2, length2, prob2), raw, ids) == gold
+
+
+def test_beam3_matches_reference_output_lines(setup):
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    gold = json.load(open(os.path.join(util.GOLDEN, "decode_ref.json")))["beam3"]
+    gen, length, prob = search.beam(db, 3)
+    assert lines_of(search.best(gen, length, prob), raw, ids) == gold
+
+
+def test_beam3_all_hypotheses_and_probabilities_vs_oracle(setup):
+    from oracle import fira_oracle as O
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    tb = util.to_torch_batch(hb, cfg)
+    hyp, prob = O.beam_decode(sd, cfg, tb["sou"], tb["mark"], tb["ast_change"], tb["edge"], tb["sub_token"], 3)
+    gen, length, p = search.beam(db, 3)
+    gen, length, p = gen.cpu(), length.cpu(), p.cpu()
+    for i in range(len(hyp)):
+        for j in range(3):
+            assert gen[i, j, :length[i, j]].tolist() == hyp[i][j], (i, j)
+            assert abs(float(p[i, j]) - prob[i][j]) <= 2e-4 * abs(prob[i][j]) + 1e-30, (i, j)
+
+
+def test_step_distribution_equals_full_recompute(setup):
+    """KV-cached step == the reference's full 30-position recompute at that position (run_model.py:256-267)."""
+    import ctypes as C
+    from fira_icse_amd import _lib
+    from oracle import fira_oracle as O
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    tb = util.to_torch_batch(hb, cfg)
+    B, T, W = db.B, cfg.tar_len, cfg.out_len
+    prefix = torch.tensor(np.ascontiguousarray(hb.tar[:, :6]))          # teacher tokens as a fixed prefix
+    with torch.no_grad():
+        memory, mem_mask = O.encode_memory(sd, cfg, tb["sou"], tb["mark"], tb["ast_change"], tb["edge"], tb["sub_token"])
+        full = torch.zeros(B, T, dtype=torch.int64)
+        full[:, :6] = prefix
+        dec = O.decoder(sd, cfg, full, memory, mem_mask, full != 0)
+        ref = O.output_distribution(sd, memory, mem_mask, dec)
+    ws = search._begin(db, 1)
+    dist = torch.empty((B, W), dtype=torch.float32, device="cuda")
+    for step in range(6):
+        search._step(ws, B, 1, step, prefix[:, step].to(torch.int32).cuda().contiguous(), None, dist, None, None)
+        got = dist.cpu()
+        err = float((got - ref[:, step]).abs().max() / ref[:, step].abs().max())
+        assert err < 2e-4, (step, err)
+        assert torch.equal(got.argmax(-1), ref[:, step].argmax(-1))
+    mem = _lib.lib().fira_decode_memory(C.byref(model.dims), _lib.ptr(ws), B, 1)
+    assert mem

@@ -40,10 +40,11 @@ def test_gemm_layouts(M, N, K, layout):
     B = randn(*((N, K) if tB else (K, N)), seed=2)       # asymmetric operands: a swapped tile cannot pass
     bias = randn(N, seed=3)
     ref = ((A.t() if tA else A).double() @ (B.t() if tB else B).double()) + bias.double()
+    tol = 2e-6 if K <= 4096 else 6e-6             # a k-ordered fp32 chain: error grows ~ sqrt(K) * 2^-24
     out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias)
-    assert rel_err(out, ref) < 2e-6
+    assert rel_err(out, ref) < tol
     out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, relu=True)
-    assert rel_err(out, ref.clamp_min(0)) < 2e-6
+    assert rel_err(out, ref.clamp_min(0)) < tol
 
 
 def test_gemm_accumulate_and_splitk():
@@ -55,7 +56,7 @@ def test_gemm_accumulate_and_splitk():
     for sk in (1, 8, 37):
         C = C0.clone()
         ops.gemm(A, B, transA=True, transB=False, out=C, accumulate=True, splitk=sk)
-        assert rel_err(C, ref) < 2e-6, sk
+        assert rel_err(C, ref) < 6e-6, sk
 
 
 def test_gemm_strided_output_and_padded_ld():
@@ -70,7 +71,7 @@ def test_gemm_strided_output_and_padded_ld():
     dl[:, :24650] = randn(100, 24650, seed=9)
     Wo = randn(24650, 256, seed=10)
     out = ops.gemm(dl[:, :24650], Wo, transB=False)
-    assert rel_err(out, dl[:, :24650].double() @ Wo.double()) < 2e-6
+    assert rel_err(out, dl[:, :24650].double() @ Wo.double()) < 6e-6
 
 
 # ------------------------------------------------------------------------------------------------ SpMM

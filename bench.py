@@ -52,7 +52,8 @@ def cpu_baseline(cfg, store, seconds_budget=25.0):
     """Reference-equivalent CPU path (oracle port): train steps at batch 4 on this host's cores."""
     from oracle import fira_oracle as O
     from fira_icse_amd.model import reference_init_state_dict
-    threads = os.cpu_count() or 1
+    # more threads than ~32 only add contention on these small-matrix ops (measured: 256 threads are >100x slower)
+    threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     P = {k: v.clone().requires_grad_(True) for k, v in reference_init_state_dict(cfg).items()}
@@ -70,7 +71,7 @@ def cpu_baseline(cfg, store, seconds_budget=25.0):
         (ls / nt).backward()
         opt.step()
         times.append(time.time() - t0)
-        if time.time() - t_all > seconds_budget and len(times) >= 3:
+        if time.time() - t_all > seconds_budget and len(times) >= 2:
             break
     med = float(np.median(times[1:])) if len(times) > 1 else times[0]
     return {"value": 4.0 / med, "unit": "commits/s", "cores": threads, "kind": "port",

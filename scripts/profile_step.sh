@@ -1,0 +1,9 @@
+#!/bin/bash
+# rocprofv3 kernel trace of the training step (run on the GPU box via gpurun); summaries land in gpurun_out/prof_*
+set -x
+cd /tmp && export TMPDIR=/tmp
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$1
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT -o step -- python $REPO/bench.py --steps 10 --warmup 2 --no-decode --no-cpu-baseline > $OUT/bench.log 2>&1
+ls -R $OUT | head -30

@@ -1,0 +1,37 @@
+"""Summarise a rocprofv3 rocpd (sqlite) kernel trace into a per-kernel table (markdown).
+
+    python scripts/rocpd_stats.py gpurun_out/prof_x/step_results.db [steps] > profiles/<name>.md
+"""
+import collections
+import re
+import sqlite3
+import sys
+
+
+def main():
+    db = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = cur.execute("select s.kernel_name, d.start, d.end, s.arch_vgpr_count, s.accum_vgpr_count, s.group_segment_size "
+                       "from %s d join %s s on d.kernel_id = s.id" % (disp, sym)).fetchall()
+    agg = collections.OrderedDict()
+    for name, st, en, vg, ag, lds in rows:
+        short = re.sub(r"\(.*", "", name).replace(".kd", "")
+        a = agg.setdefault(short, [0, 0.0, 1e30, 0.0, vg, ag, lds])
+        d = (en - st) / 1e3
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    tot = sum(v[1] for v in agg.values())
+    print("| kernel | calls | calls/step | total us/step | %% | avg us | min us | max us | VGPR | AGPR | LDS B |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("| `%s` | %d | %.1f | %.1f | %.2f | %.1f | %.1f | %.1f | %s | %s | %s |" %
+              (k[:120], v[0], v[0] / steps, v[1] / steps, 100 * v[1] / tot, v[1] / v[0], v[2], v[3], v[4], v[5], v[6]))
+    print("\ntotal kernel time: %.1f us over %d dispatches (%.1f us/step over %d steps)" % (tot, len(rows), tot / steps, steps))
+
+
+if __name__ == "__main__":
+    main()

@@ -131,12 +131,14 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         if (kt < NT) {
+            float vv[16];                       // all 16 row loads in flight before the MFMA chain
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int key = kt * 32 + acc_row(s, kh);
-                const float v = key < Tk ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
-                o = MFMA32(st[i][s] / sum, v, o);
+                vv[s] = key < Tk ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
             }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] / sum, vv[s], o);
         }
     }
     // o[r]: query = acc_row(r, kh), d = l31
@@ -266,14 +268,19 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) dpt = MFMA32(av[s], bdo[s], dpt);       // dP^T = V dO^T
+            float kvv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kr = kt * 32 + acc_row(s, kh);
+                kvv[s] = kr < Tk ? K[((size_t)b * Tk + kr) * ldk + h * FIRA_DH + l31] : 0.f;
+            }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
                 const bool dead = kr >= Tk || sm_kv[kr < Tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
                 const float p = st[i][s] / sum;
                 const float ds = dead ? 0.f : p * (dpt[s] - delta) / SQRT_DH;
-                const float kv = kr < Tk ? K[((size_t)b * Tk + kr) * ldk + h * FIRA_DH + l31] : 0.f;
-                dq = MFMA32(ds, kv, dq);                                        // dQ += dS K
+                dq = MFMA32(ds, kvv[s], dq);                                    // dQ += dS K
             }
         }
     }

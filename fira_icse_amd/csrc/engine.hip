@@ -116,22 +116,17 @@ static int zero(hipStream_t s, void* p, size_t bytes) {
 // Y = X W^T + b
 static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int ldx, const float* W, const float* b,
                          float* Y, int ldy, int flags = 0) {
-    return gemm_f32(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 1);
+    return gemm_f32_ex(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 0, nullptr);
 }
 // dX (+)= dY W          (W stored [N,K]; reduce over N)
 static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* W, float* dX,
                                int lddx, bool accum) {
-    return gemm_f32(s, 0, 0, M, K, N, dY, lddy, W, K, dX, lddx, nullptr, accum ? FIRA_GEMM_ACCUM : 0, 1);
+    return gemm_f32_ex(s, 0, 0, M, K, N, dY, lddy, W, K, dX, lddx, nullptr, accum ? FIRA_GEMM_ACCUM : 0, 0, nullptr);
 }
 // dW += dY^T X ; db += colsum(dY)      (reduce over the M rows: split-K over rows keeps the chip busy)
 static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx,
                                float* dW, float* db) {
-    const int tiles = cdiv(N, 64) * cdiv(K, 64);
-    int splitk = 1;
-    if (tiles < 512) splitk = std::min(std::max(1, 768 / tiles), std::max(1, M / 128));
-    TRY(gemm_f32(s, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, splitk));
-    if (db) TRY(colsum(s, M, N, dY, lddy, db));
-    return 0;
+    return gemm_f32_ex(s, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
 }
 
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
@@ -259,9 +254,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
         TRY(zero(s, p.ddec_c, (size_t)R * D * sizeof(float)));
         // ddec_rows = dlogits W_out : [R, V] x [V, 256], split over the vocabulary axis
-        const int tiles = cdiv(R, 64) * cdiv(D, 64);
-        const int splitk = std::max(1, std::min(64, 512 / std::max(1, tiles)));
-        TRY(gemm_f32(s, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, splitk));
+        TRY(gemm_f32_ex(s, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
+                        nullptr));
         TRY(rows_scatter_add_idx(s, R, p.ddec_c, p.ddec, rows));
     }
 
@@ -350,9 +344,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(embed_gather_bwd(s, p.B, p.S, c.bt->sub_token, G + L.emb, dXn, p.N, p.L, 0));
     TRY(embed_gather_bwd(s, p.B, p.A, c.bt->ast_change, G + L.ast_emb, dXn, p.N, p.L + p.S, 0));
     // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
-    TRY(gemm_f32(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
-                 FIRA_GEMM_ACCUM, 1));
-    TRY(colsum(s, 4, p.nl * D, p.dvtab_all, p.nl * D, G + L.b2_all));
+    TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
+                    FIRA_GEMM_ACCUM, 1, G + L.b2_all));
     TRY(linear_dgrad(s, 4, p.nl * D, D, p.dvtab_all, p.nl * D, c.P + L.w2_all, G + L.mark_emb, D, true));
     TRY(zero(s, G + L.mark_emb, (size_t)D * sizeof(float)));       // padding_idx row 0 never gets a gradient
     return 0;

@@ -11,7 +11,7 @@
 // storage orders; the register stage of tile t+1 is issued before the MFMAs of tile t (one barrier per
 // K tile, two LDS buffers).  LDS row pitch 129 makes the transposing scalar writes of the k-contiguous
 // path conflict-free (4*129 = 4 mod 32); the m-contiguous path writes 16-byte rows at pitch 132.
-#include "common.h"
+#include "engine.h"
 
 namespace fira {
 
@@ -101,7 +101,7 @@ template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                        const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                        int ldc, const float* __restrict__ bias, int flags,
-                                                       int k_chunk, int vecA, int vecB) {
+                                                       int k_chunk, int vecA, int vecB, float* __restrict__ colsum) {
     using LA = TileLoader<BM, !TA>;       // A stored [M,K] (k contiguous) unless TA
     using LB = TileLoader<BN, TB>;        // B stored [N,K] (k contiguous) when TB
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -125,10 +125,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // fused bias gradient (wgrad layout only): colsum[m] += sum_k A[k][m] over this block's K range, taken from the
+    // A-tile registers on their way to LDS (thread t always carries the same 4 columns of the tile)
+    const bool do_cs = TA && colsum != nullptr && blockIdx.x == 0;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto cs_add = [&](const float4 (&v)[LA::NV]) {
+#pragma unroll
+        for (int i = 0; i < LA::NV; ++i) { cs.x += v[i].x; cs.y += v[i].y; cs.z += v[i].z; cs.w += v[i].w; }
+    };
+
     float4 ra[LA::NV], rb[LB::NV];
     if (ntile > 0) {
         LA::load(ra, A, lda, m0, M, kbeg, kend, vecA != 0, t);
         LB::load(rb, B, ldb, n0, N, kbeg, kend, vecB != 0, t);
+        if (do_cs) cs_add(ra);
         LA::store(ra, smA[0], t);
         LB::store(rb, smB[0], t);
     }
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
             const int k0 = kbeg + (it + 1) * BK;
             LA::load(ra, A, lda, m0, M, k0, kend, vecA != 0, t);
             LB::load(rb, B, ldb, n0, N, k0, kend, vecB != 0, t);
+            if (do_cs) cs_add(ra);
         }
         const float* sa = smA[cur] + kh * LA::LD + wm * WM + l31;
         const float* sb = smB[cur] + kh * LB::LD + wn * WN + l31;
@@ -163,6 +174,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
         }
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (do_cs) {                                   // block-level combine of the column sums, then one atomic per column
+        float* red = smA[0];                       // all tile reads are done (barrier at the end of the last iteration)
+        for (int i = t; i < BM; i += 256) red[i] = 0.f;
+        __syncthreads();
+        const int c = (t % (BM / 4)) * 4;
+        atomicAdd(&red[c + 0], cs.x); atomicAdd(&red[c + 1], cs.y); atomicAdd(&red[c + 2], cs.z); atomicAdd(&red[c + 3], cs.w);
+        __syncthreads();
+        for (int i = t; i < BM; i += 256)
+            if (m0 + i < M) unsafeAtomicAdd(&colsum[m0 + i], red[i]);
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -197,14 +219,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 
 template <int BM, int BN>
 static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                  float* C, int ldc, const float* bias, int flags, int splitk) {
+                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum) {
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk);
     int k_chunk = cdiv(cdiv(K, splitk), BK) * BK;
     const int vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     const int vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
 #define FIRA_GEMM_GO(TA, TB)                                                                                     \
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
-                       bias, flags, k_chunk, vecA, vecB)
+                       bias, flags, k_chunk, vecA, vecB, colsum)
     if (!tA && tB) FIRA_GEMM_GO(false, true);
     else if (!tA && !tB) FIRA_GEMM_GO(false, false);
     else if (tA && !tB) FIRA_GEMM_GO(true, false);
@@ -214,22 +236,43 @@ static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const floa
     return 0;
 }
 
+// splitk == 0: choose.  The fp32 MFMA rate makes a 128x128 tile MFMA-bound (32 FLOP per staged byte) while a 64x64
+// tile is bound by the per-CU load path, so the big tile is used whenever it yields enough workgroups; with
+// accumulate semantics K is split until ~2 workgroups per CU exist (co-resident blocks hide each other's staging).
+int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                float* C, int ldc, const float* bias, int flags, int splitk, float* colsum) {
+    if (M <= 0 || N <= 0) return 0;
+    FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_f32: bad K=%d splitk=%d", K, splitk);
+    FIRA_REQUIRE(!(colsum && !tA), "gemm_f32: fused column sums need the transA layout");
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU);
+    bool big;
+    if (splitk == 0) {
+        big = t128 >= 64;
+        splitk = 1;
+        if (can_split) {
+            const long tiles = big ? t128 : t64;
+            const int want = big ? 512 : 768;
+            if (tiles < want) splitk = (int)std::min<long>(cdiv(want, (int)tiles), std::max(1, K / 128));
+        }
+    } else {
+        big = t128 * splitk >= 192;
+    }
+    FIRA_REQUIRE(!(splitk > 1 && !can_split), "gemm_f32: split-K needs accumulate semantics and no relu");
+    if (big) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
+    return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
+}
+
 int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
              float* C, int ldc, const float* bias, int flags, int splitk) {
-    if (M <= 0 || N <= 0) return 0;
-    FIRA_REQUIRE(K > 0 && splitk >= 1, "gemm_f32: bad K=%d splitk=%d", K, splitk);
-    FIRA_REQUIRE(!(splitk > 1 && (flags & FIRA_GEMM_RELU)), "gemm_f32: relu cannot be combined with split-K");
-    FIRA_REQUIRE(!(splitk > 1 && !(flags & FIRA_GEMM_ACCUM)), "gemm_f32: split-K needs accumulate semantics");
-    // big tiles only when they still fill the chip (256 CUs); the decoder-side GEMMs are small
-    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
-    const long big_blocks = (long)cdiv(M, 128) * cdiv(N, 128) * splitk;
-    if (big_blocks >= 192) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
-    return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
+    return gemm_f32_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, nullptr);
 }
 
 }  // namespace fira
 
 extern "C" int fira_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
                              const float* B, int ldb, float* C, int ldc, const float* bias, int flags, int splitk) {
+    FIRA_REQUIRE(splitk >= 1, "fira_gemm_f32: splitk must be >= 1");
     return fira::gemm_f32((hipStream_t)stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
 }

@@ -3,6 +3,7 @@
 // One wavefront owns one 256-float row as float4 per lane (a 1 KiB coalesced access);
 // row statistics are wave reductions (no LDS, no atomics on the forward path).
 #include "engine.h"
+#include <algorithm>
 
 namespace fira {
 
@@ -442,7 +443,8 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
-    const int rpb = 32;
+    // ~500 workgroups: enough to fill the chip, few enough that the dgamma/dbeta atomics do not serialise
+    const int rpb = std::max(8, std::min(128, cdiv(cdiv(M, 512), 4) * 4));
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
                        dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");

@@ -249,12 +249,15 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU);
     bool big;
     if (splitk == 0) {
-        big = t128 >= 64;
         splitk = 1;
         if (can_split) {
-            const long tiles = big ? t128 : t64;
-            const int want = big ? 512 : 768;
-            if (tiles < want) splitk = (int)std::min<long>(cdiv(want, (int)tiles), std::max(1, K / 128));
+            const int max_split = std::max(1, K / 128);
+            const int sk128 = (int)std::min<long>(cdiv(512, (int)t128), max_split);
+            big = t128 * sk128 >= 128;
+            splitk = big ? sk128 : (int)std::min<long>(cdiv(768, (int)t64), max_split);
+            if (splitk < 1) splitk = 1;
+        } else {
+            big = t128 >= 64;
         }
     } else {
         big = t128 * splitk >= 192;

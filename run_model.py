@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Drop-in for the reference driver: ``python run_model.py train`` / ``python run_model.py test``
+(reference run_model.py:417-425), running on the MI355X engine.
+
+Kept from the reference: the positional ``train|test`` stage, every path relative to the working directory
+(``DataSet/*.json``, ``VOCAB_UPPER_CASE``, ``all_index``, ``best_model.pt`` = ``torch.save(state_dict)`` with the
+reference's 338 keys, ``OUTPUT/train_process``, ``OUTPUT/dev_output``, ``OUTPUT/output_fira``), the hyper-parameters of
+its ``args`` dict as defaults, seed 0, the order in which the global RNGs are consumed (split shuffle, weight
+initialisation, per-epoch DataLoader permutation), dev-BLEU checkpoint selection from epoch 15 every 10 batches, and
+beam search with the reference's scoring quirks at test time.
+
+New (all optional): overrides for what the reference hard-codes (``--batch-size``, ``--splits``, ``--epochs``,
+``--beam``, ...), and multi-GPU through one process per GPU (``torchrun --nproc-per-node N run_model.py train``):
+commits of the global batch are sharded over ranks and gradients all-reduced over RCCL, instead of the reference's
+single-process ``nn.DataParallel``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+from fira_icse_amd import data, metrics, text                      # noqa: E402
+from fira_icse_amd.config import EOS, FiraConfig                  # noqa: E402
+from fira_icse_amd.parallel import gather_lines, init_from_env, shard_indices   # noqa: E402
+
+
+def seed_everything(seed=0):
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("stage", choices=["train", "test"])
+    ap.add_argument("--root", default=".", help="directory holding DataSet/, VOCAB_UPPER_CASE, all_index (default: cwd)")
+    ap.add_argument("--splits", default=None, help="train,valid,test sizes (reference hard-codes 75000,8000,7661)")
+    ap.add_argument("--batch-size", type=int, default=None, help="GLOBAL train batch (reference: 170 x n_gpu)")
+    ap.add_argument("--test-batch-size", type=int, default=20)
+    ap.add_argument("--epochs", type=int, default=150)
+    ap.add_argument("--beam", type=int, default=3)
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--dev-from-epoch", type=int, default=15)
+    ap.add_argument("--dev-every", type=int, default=10)
+    ap.add_argument("--max-steps", type=int, default=0, help="stop after this many optimisation steps (0 = no limit)")
+    ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--save-optimizer", action="store_true", help="also write fira_train_state.pt (Adam moments, step)")
+    ap.add_argument("--resume", action="store_true", help="start from best_model.pt (+ fira_train_state.pt if present)")
+    return ap.parse_args(argv)
+
+
+class Run:
+    def __init__(self, a):
+        self.a = a
+        self.rank, self.world, self.local = init_from_env()
+        torch.cuda.set_device(self.local)
+        self.root = a.root
+        with open(os.path.join(self.root, "DataSet", "word_vocab.json")) as f:
+            self.vocab = json.load(f)
+        with open(os.path.join(self.root, "DataSet", "ast_change_vocab.json")) as f:
+            ast_vocab = json.load(f)
+        self.r_vocab = {v: k for k, v in self.vocab.items()}
+        with open(os.path.join(self.root, "DataSet", "variable.json")) as f:
+            self.var_maps = json.load(f)
+        bs = a.batch_size if a.batch_size else 170 * self.world
+        self.cfg = FiraConfig(lr=a.lr, batch_size=bs, test_batch_size=a.test_batch_size, epoches=a.epochs,
+                              beam_size=a.beam, vocab_size=len(self.vocab), ast_change_vocab_size=len(ast_vocab))
+        splits = tuple(int(x) for x in a.splits.split(",")) if a.splits else None
+        # rank 0 builds the caches; the others wait and read them
+        if self.rank == 0:
+            self.sets = {n: data.TransDataset(self.cfg, n, root=self.root, splits=splits, seed=a.seed)
+                         for n in ("train", "valid", "test")}
+        if self.world > 1:
+            torch.distributed.barrier()
+        if self.rank != 0:
+            self.sets = {n: data.TransDataset(self.cfg, n, root=self.root, splits=splits, seed=a.seed)
+                         for n in ("train", "valid", "test")}
+        with open(os.path.join(self.root, "all_index")) as f:
+            self.all_index = json.load(f)
+        os.makedirs(os.path.join(self.root, "OUTPUT"), exist_ok=True)
+
+    def out(self, name):
+        return os.path.join(self.root, "OUTPUT", name)
+
+    def device_batch(self, store, idx):
+        from fira_icse_amd.model import DeviceBatch
+        return DeviceBatch(store.batch(idx), self.cfg, self.model.device_)
+
+    # ------------------------------------------------------------------------------ dev (run_model.py:118-184)
+    @torch.no_grad()
+    def dev(self, epoch):
+        cfg, store = self.cfg, self.sets["valid"].store
+        valid_index = self.all_index["valid"]
+        self.model.eval()
+        mine = shard_indices(list(range(len(store))), self.rank, self.world)
+        lines, total = [], 0.0
+        bs = max(1, cfg.batch_size // self.world)
+        for lo in range(0, len(mine), bs):
+            idx = mine[lo:lo + bs]
+            ids = self.model.forward_dev(self.device_batch(store, idx)).cpu().tolist()
+            for k, i in enumerate(idx):
+                sen = text.dev_sentence(ids[k], store.sou[i], store.sub_token[i], cfg.vocab_size, cfg.sou_len, EOS)
+                s = " ".join(self.r_vocab[t] for t in sen).replace("<pad>", "").replace("<unkm>", "\U0001F605").strip()
+                hyp = s.split()
+                ref_ids = store.tar[i].tolist()
+                ref = [self.r_vocab[t] for t in ref_ids[1:ref_ids.index(EOS)]]
+                b = metrics.sentence_bleu_method2([ref], hyp)
+                total += b
+                back = {v: k2 for k2, v in self.var_maps[valid_index[i]].items()}
+                lines.append(" ".join(back.get(t, t) for t in hyp) + "," + str(b))
+        if self.world > 1:
+            t = torch.tensor([total], dtype=torch.float64, device=self.model.device_)
+            torch.distributed.all_reduce(t)
+            total = float(t.item())
+            lines = gather_lines(lines)
+        self.model.train()
+        return total / max(1, len(store)), "\n".join(lines) + "\n"
+
+    # ------------------------------------------------------------------------------ train (run_model.py:83-117,382-399)
+    def train(self):
+        from fira_icse_amd.model import TransModel
+        from fira_icse_amd.train import Trainer
+        a, cfg = self.a, self.cfg
+        store = self.sets["train"].store
+        self.model = TransModel(cfg, device="cuda:%d" % self.local)       # consumes the torch RNG like the reference
+        if a.resume and os.path.exists(os.path.join(self.root, "best_model.pt")):
+            self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
+        trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1)
+        state_path = os.path.join(self.root, "fira_train_state.pt")
+        if a.resume and os.path.exists(state_path):
+            trainer.load_state_dict(torch.load(state_path, map_location=self.model.device_))
+        self.model.train(not a.no_dropout)
+        best_bleu, steps = -1.0, 0
+        n_batches = -(-len(store) // cfg.batch_size)
+        for epoch in range(cfg.epoches):
+            total_data, t0 = 0, time.time()
+            for idx_b, gidx in enumerate(data.iterate_batches(len(store), cfg.batch_size, shuffle=True)):
+                if epoch >= a.dev_from_epoch and idx_b % a.dev_every == 0:
+                    cur_bleu, output_str = self.dev(epoch)
+                    if self.rank == 0:
+                        with open(self.out("train_process"), "a") as f:
+                            f.write("epoch: {} batch: {} dev bleu: {} is better: {}\n".format(
+                                epoch, idx_b, cur_bleu, cur_bleu > best_bleu))
+                    if cur_bleu > best_bleu:
+                        best_bleu = cur_bleu
+                        if self.rank == 0:
+                            torch.save(self.model.state_dict(), os.path.join(self.root, "best_model.pt"))
+                            if a.save_optimizer:
+                                torch.save(trainer.state_dict(), state_path)
+                            with open(self.out("dev_output"), "w") as f:
+                                f.write(output_str)
+                    self.model.train(not a.no_dropout)
+                mine = shard_indices(gidx, self.rank, self.world)      # DataParallel.scatter's contiguous chunks
+                if mine:
+                    trainer.step(self.device_batch(store, mine))
+                total_data += len(gidx)
+                steps += 1
+                if idx_b % 10 == 0 and self.rank == 0:
+                    print("epoch: %d batch: %d/%d  data: %d/%d loss: %.4f  (%.1f commits/s)" % (
+                        epoch, idx_b, n_batches, total_data, len(store), trainer.last_loss(),
+                        total_data / max(time.time() - t0, 1e-9)), flush=True)
+                if a.max_steps and steps >= a.max_steps:
+                    break
+            if a.max_steps and steps >= a.max_steps:
+                break
+        if best_bleu < 0 and self.rank == 0:            # never reached a dev point (short runs): keep the last weights
+            torch.save(self.model.state_dict(), os.path.join(self.root, "best_model.pt"))
+        return best_bleu
+
+    # ------------------------------------------------------------------------------ test (run_model.py:187-380,401-415)
+    @torch.no_grad()
+    def test(self):
+        from fira_icse_amd.model import TransModel
+        from fira_icse_amd.decode import Searcher
+        cfg, store = self.cfg, self.sets["test"].store
+        test_index = self.all_index["test"]
+        self.model = TransModel(cfg, device="cuda:%d" % self.local, init=False)
+        self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
+        self.model.eval()
+        search = Searcher(self.model)
+        mine = shard_indices(list(range(len(store))), self.rank, self.world)
+        lines, n_tok, t0 = [], 0, time.time()
+        for lo in range(0, len(mine), cfg.test_batch_size):
+            idx = mine[lo:lo + cfg.test_batch_size]
+            db = self.device_batch(store, idx)
+            if cfg.beam_size == 1:
+                hyps = search.best(*search.greedy(db))
+            else:
+                hyps = search.best(*search.beam(db, cfg.beam_size))
+            for h, i in zip(hyps, idx):
+                lines.append(text.detokenize(h, self.r_vocab, self.var_maps[test_index[i]]))
+                n_tok += max(len(h) - 1, 0)
+            if self.rank == 0:
+                print("data: %d/%d  (%.1f tokens/s)" % (lo + len(idx), len(mine), n_tok / max(time.time() - t0, 1e-9)),
+                      flush=True)
+        lines = gather_lines(lines)
+        if self.rank == 0:
+            with open(self.out("output_fira"), "w") as f:
+                f.write("".join(l + "\n" for l in lines))
+        return lines
+
+
+def main(argv=None):
+    a = parse_args(sys.argv[1:] if argv is None else argv)
+    seed_everything(a.seed)
+    run = Run(a)
+    if a.stage == "train":
+        run.train()
+    else:
+        run.test()
+    if run.world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""Data-parallel logic on CPU with the gloo backend (world_size 2): sharding == DataParallel.scatter chunking, and the
+2-rank reduced gradient with the GLOBAL token normaliser == the single-process gradient of the same global batch
+(SURVEY.md §8d config 3 equivalence check).  The gradient producer here is the CPU oracle (tests only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import util
+from fira_icse_amd import data
+from fira_icse_amd.config import FiraConfig
+from fira_icse_amd.parallel import GradReducer, gather_lines, shard_indices, shard_range
+
+
+def test_shard_range_is_dataparallel_scatter_chunking():
+    for n in (1, 5, 8, 170, 680, 31):
+        for world in (1, 2, 3, 4, 8):
+            chunks = [c.tolist() for c in torch.arange(n).chunk(world)]
+            chunks += [[]] * (world - len(chunks))
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert list(range(lo, hi)) == chunks[r], (n, world, r)
+            assert sum((shard_indices(list(range(n)), r, world) for r in range(world)), []) == list(range(n))
+
+
+def _flat_grad(P, layout):
+    flat = torch.zeros(layout.total)
+    views = layout.views(flat)
+    for k, p in P.items():
+        if p.grad is not None:
+            views[k].copy_(p.grad)
+    return flat
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, util.REPO)
+    torch.set_num_threads(4)
+    from oracle import fira_oracle as O
+    from fira_icse_amd.model import ParamLayout, reference_init_state_dict
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = FiraConfig()
+    store = data.process_raw(cfg, util.load_golden_raw())
+    idx = data.split_index(*util.GOLDEN_SPLIT, seed=0)["train"][:4]
+    torch.manual_seed(0)
+    sd = reference_init_state_dict(cfg)
+    layout = ParamLayout(cfg)
+
+    def grads_of(ids):
+        tb = util.to_torch_batch(store.batch(ids), cfg)
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ls, nt = O.forward(P, cfg, tb["sou"], tb["tar"], tb["mark"], tb["ast_change"], tb["edge"], tb["tar_label"],
+                           tb["sub_token"], "train")
+        ls.backward()                                   # gradient of loss_SUM, like the engine produces
+        return _flat_grad(P, layout), float(ls.detach()), int(nt)
+
+    mine = shard_indices(idx, rank, world)
+    g, ls, nt = grads_of(mine)
+    red = GradReducer(layout.split, layout.live)
+    stats = torch.tensor([ls, float(nt)])
+    red.start_early_bucket(g, None)
+    red.finish(g, stats)
+    lines = gather_lines(["r%d-%d" % (rank, i) for i in mine])
+    if rank == 0:
+        gf, lsf, ntf = grads_of(idx)
+        torch.save(dict(g=g / stats[1], gf=gf / ntf, stats=stats, full=(lsf, ntf), lines=lines, idx=idx), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_single_rank(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 29600 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert int(r["stats"][1]) == r["full"][1]                                   # global token count
+    assert abs(float(r["stats"][0]) - r["full"][0]) <= 1e-5 * r["full"][0]      # global loss sum
+    err = float((r["g"] - r["gf"]).double().norm() / r["gf"].double().norm())
+    assert err < 1e-5, err
+    assert r["lines"] == ["r0-%d" % i for i in r["idx"][:2]] + ["r1-%d" % i for i in r["idx"][2:]]   # ordered gather

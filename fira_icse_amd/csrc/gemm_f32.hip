@@ -73,6 +73,23 @@ struct TileLoader {
         }
     }
 
+    // interior tile (every row and k in range, 16-byte aligned rows): straight-line loads, no exec-mask branches, so
+    // all NV 16-byte loads of a thread are in flight together
+    __device__ __forceinline__ static void load_fast(float4 (&v)[NV], const float* __restrict__ src, int ld, int r0,
+                                                     int k0, int t) {
+        if constexpr (CONTIG_K) {
+            const float* p = src + (size_t)(r0 + (t >> 3)) * ld + k0 + (t & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(p + (size_t)32 * i * ld);
+        } else {
+            constexpr int CPR = ROWS / 4;
+            constexpr int KSTEP = 256 / CPR;
+            const float* p = src + (size_t)(k0 + t / CPR) * ld + r0 + (t % CPR) * 4;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(p + (size_t)KSTEP * i * ld);
+        }
+    }
+
     __device__ __forceinline__ static void store(const float4 (&v)[NV], float* __restrict__ lds, int t) {
         if constexpr (CONTIG_K) {
             const int kq = (t & 7) * 4;
@@ -135,9 +152,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     };
 
     float4 ra[LA::NV], rb[LB::NV];
+    const bool a_in = vecA && m0 + BM <= M, b_in = vecB && n0 + BN <= N;       // block-uniform
+    auto fetch = [&](int k0) {
+        if (a_in && k0 + BK <= kend) LA::load_fast(ra, A, lda, m0, k0, t);
+        else LA::load(ra, A, lda, m0, M, k0, kend, vecA != 0, t);
+        if (b_in && k0 + BK <= kend) LB::load_fast(rb, B, ldb, n0, k0, t);
+        else LB::load(rb, B, ldb, n0, N, k0, kend, vecB != 0, t);
+    };
     if (ntile > 0) {
-        LA::load(ra, A, lda, m0, M, kbeg, kend, vecA != 0, t);
-        LB::load(rb, B, ldb, n0, N, kbeg, kend, vecB != 0, t);
+        fetch(kbeg);
         if (do_cs) cs_add(ra);
         LA::store(ra, smA[0], t);
         LB::store(rb, smB[0], t);
@@ -148,25 +171,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     for (int it = 0; it < ntile; ++it) {
         const bool more = it + 1 < ntile;
         if (more) {
-            const int k0 = kbeg + (it + 1) * BK;
-            LA::load(ra, A, lda, m0, M, k0, kend, vecA != 0, t);
-            LB::load(rb, B, ldb, n0, N, k0, kend, vecB != 0, t);
+            fetch(kbeg + (it + 1) * BK);
             if (do_cs) cs_add(ra);
         }
         const float* sa = smA[cur] + kh * LA::LD + wm * WM + l31;
         const float* sb = smB[cur] + kh * LB::LD + wn * WN + l31;
+        // operand fragments of k-pair kk+1 are read from LDS before the MFMAs of k-pair kk are issued
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = sa[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = sb[j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
+            const int c = kk & 1, n = c ^ 1;
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = sa[2 * kk * LA::LD + i * 32];
+                for (int i = 0; i < TM; ++i) a[n][i] = sa[2 * (kk + 1) * LA::LD + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = sb[2 * kk * LB::LD + j * 32];
+                for (int j = 0; j < TN; ++j) b[n][j] = sb[2 * (kk + 1) * LB::LD + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            // pin the order "LDS reads of the next k-pair, then this k-pair's MFMAs": the reads then complete under
+            // the 64-cycle MFMAs instead of stalling the next group (the compiler otherwise sinks them below)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
         if (more) {
             LA::store(ra, smA[cur ^ 1], t);

@@ -278,6 +278,10 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_f32: bad K=%d splitk=%d", K, splitk);
     FIRA_REQUIRE(!(colsum && !tA), "gemm_f32: fused column sums need the transA layout");
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
+    if (splitk <= 1 && !colsum && (flags & 4) == 0) {          // short-K forward / dgrad shapes: LDS-free kernel
+        int rc;
+        if (gemm_direct_try(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, &rc)) return rc;
+    }
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU);
     bool big;

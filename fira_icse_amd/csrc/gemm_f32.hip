@@ -12,6 +12,7 @@
 // K tile, two LDS buffers).  LDS row pitch 129 makes the transposing scalar writes of the k-contiguous
 // path conflict-free (4*129 = 4 mod 32); the m-contiguous path writes 16-byte rows at pitch 132.
 #include "engine.h"
+#include <cmath>
 
 namespace fira {
 
@@ -269,38 +270,46 @@ static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const floa
     return 0;
 }
 
-// splitk == 0: choose.  The fp32 MFMA rate makes a 128x128 tile MFMA-bound (32 FLOP per staged byte) while a 64x64
-// tile is bound by the per-CU load path, so the big tile is used whenever it yields enough workgroups; with
-// accumulate semantics K is split until ~2 workgroups per CU exist (co-resident blocks hide each other's staging).
+// Tile / split choice.  A workgroup's cost is its MFMA time plus a fixed prologue/epilogue (first-tile load latency,
+// C stores); the launch costs ceil(workgroups / 256 CUs) such rounds -- co-resident workgroups share the CU's matrix
+// pipes, so residency does not shorten a round.  With fp32 MFMA (614 GFLOP/s per CU) the quantisation of M into
+// tiles is the dominant loss on the K = 256 shapes (e.g. M = 20800, N = 256: 326 tiles of 128x128 = 2 rounds for
+// 1.27 rounds of work), so the tile is picked by that cost model instead of "largest that fits".
+struct TileChoice { int tile; int splitk; double cost; };
+static TileChoice choose(int M, int N, int K, bool can_split) {
+    static const int BMs[3] = {128, 64, 64}, BNs[3] = {128, 128, 64};
+    static const double eff[3] = {0.80, 0.72, 0.55};       // fraction of the CU's MFMA peak a tile sustains
+    TileChoice best{0, 1, 1e30};
+    for (int t = 0; t < 3; ++t) {
+        const long tiles = (long)cdiv(M, BMs[t]) * cdiv(N, BNs[t]);
+        const int max_split = can_split ? std::max(1, K / 128) : 1;
+        for (int sk = 1; sk <= max_split; sk = (sk < 4 ? sk + 1 : sk * 2)) {
+            const double kk = (double)cdiv(cdiv(K, sk), BK) * BK;
+            const double t_wg = 2.0 * BMs[t] * BNs[t] * kk / (614e9 * eff[t]) + 3.0e-6 + (sk > 1 ? 1.0e-6 : 0.0);
+            const double cost = std::ceil((double)(tiles * sk) / 256.0) * t_wg;
+            if (cost < best.cost * 0.97) best = TileChoice{t, sk, cost};
+        }
+    }
+    return best;
+}
+
 int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, int flags, int splitk, float* colsum) {
     if (M <= 0 || N <= 0) return 0;
     FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_f32: bad K=%d splitk=%d", K, splitk);
     FIRA_REQUIRE(!(colsum && !tA), "gemm_f32: fused column sums need the transA layout");
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
-    if (splitk <= 1 && !colsum && (flags & 4) == 0) {          // short-K forward / dgrad shapes: LDS-free kernel
-        int rc;
-        if (gemm_direct_try(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, &rc)) return rc;
-    }
-    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU);
-    bool big;
-    if (splitk == 0) {
-        splitk = 1;
-        if (can_split) {
-            const int max_split = std::max(1, K / 128);
-            const int sk128 = (int)std::min<long>(cdiv(512, (int)t128), max_split);
-            big = t128 * sk128 >= 128;
-            splitk = big ? sk128 : (int)std::min<long>(cdiv(768, (int)t64), max_split);
-            if (splitk < 1) splitk = 1;
-        } else {
-            big = t128 >= 64;
-        }
-    } else {
-        big = t128 * splitk >= 192;
+    int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic
+    if (splitk == 0 || tile < 0) {
+        const TileChoice c = choose(M, N, K, can_split && splitk == 0);
+        if (tile < 0) tile = c.tile;
+        if (splitk == 0) splitk = c.splitk;
     }
     FIRA_REQUIRE(!(splitk > 1 && !can_split), "gemm_f32: split-K needs accumulate semantics and no relu");
-    if (big) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
+    flags &= 3;
+    if (tile == 0) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
+    if (tile == 1) return launch<64, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
     return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
 }
 

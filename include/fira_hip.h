@@ -100,7 +100,8 @@ int  fira_prof_report(int n_class, double* ms, double* work, int64_t* count);
  * (partials combined with fp32 atomics; requires accumulate semantics, C pre-initialised).     */
 #define FIRA_GEMM_RELU 1
 #define FIRA_GEMM_ACCUM 2
-#define FIRA_GEMM_FORCE_LDS 4   /* testing: always use the LDS-tiled kernel */
+/* bits 4-5 (testing / tuning): force a tile: 0 auto, 1 128x128, 2 64x128, 3 64x64 */
+#define FIRA_GEMM_TILE_SHIFT 4
 int fira_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, int flags, int splitk);

@@ -24,10 +24,12 @@ def main():
         B = torch.randn((N, K) if tB else (K, N), device="cuda")
         C = torch.zeros(M, N, device="cuda")
         res = {}
-        if not acc and not tA:
-            t = timeit(lambda: ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=C, force_lds=True))
-            res["lds"] = "%.1fus %.1fTF" % (t * 1e6, 2.0 * M * N * K / t / 1e12)
-        for sk in ([1] if not acc else [1, 16, 64, 128]):
+        for tile in (1, 2, 3):
+            if acc:
+                continue
+            t = timeit(lambda: ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=C, tile=tile))
+            res["tile%d" % tile] = "%.1fus %.1fTF" % (t * 1e6, 2.0 * M * N * K / t / 1e12)
+        for sk in ([1] if not acc else [16, 64, 128]):
             if sk > max(1, K // 64):
                 continue
             t = timeit(lambda: ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=C, accumulate=bool(acc), splitk=sk))

@@ -30,25 +30,25 @@ def randn(*shape, seed=0, scale=1.0):
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(960, 256, 256), (20800, 256, 256), (130, 70, 50), (4, 1536, 256), (64, 24650, 256),
                                    (333, 256, 24650), (960, 1024, 256), (960, 2, 256)])
-@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "nt-lds", "nn-lds"])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "nt-t1", "nn-t2", "tn-t3", "nt-t3", "tn-t2"])
 def test_gemm_layouts(M, N, K, layout):
     from fira_icse_amd import ops
     if M * N * K > 3e9:
         pytest.skip("too large")
-    lds = layout.endswith("-lds")              # short-K NT/NN shapes normally take the LDS-free kernel: cover both
+    lds = int(layout[-1]) if "-t" in layout else 0     # force each tile shape (1 128x128, 2 64x128, 3 64x64)
     tA, tB = {"nt": (False, True), "nn": (False, False), "tn": (True, False)}[layout[:2]]
     A = randn(*((K, M) if tA else (M, K)), seed=1)
     B = randn(*((N, K) if tB else (K, N)), seed=2)       # asymmetric operands: a swapped tile cannot pass
     bias = randn(N, seed=3)
     ref = ((A.t() if tA else A).double() @ (B.t() if tB else B).double()) + bias.double()
     tol = 2e-6 if K <= 4096 else 6e-6             # a k-ordered fp32 chain: error grows ~ sqrt(K) * 2^-24
-    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, force_lds=lds)
+    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, tile=lds)
     assert rel_err(out, ref) < tol
-    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, relu=True, force_lds=lds)
+    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, relu=True, tile=lds)
     assert rel_err(out, ref.clamp_min(0)) < tol
     if not tA:
         C0 = randn(M, N, seed=9)
-        out = ops.gemm(A, B, transA=tA, transB=tB, out=C0.clone(), accumulate=True, force_lds=lds)
+        out = ops.gemm(A, B, transA=tA, transB=tB, out=C0.clone(), accumulate=True, tile=lds)
         assert rel_err(out, ref - bias.double() + C0.double()) < tol
 
 

@@ -25,7 +25,9 @@ class Dims(C.Structure):
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int32), ("nnz", C.c_int32), ("sou", C.c_void_p), ("tar", C.c_void_p), ("mark", C.c_void_p),
                 ("ast_change", C.c_void_p), ("tar_label", C.c_void_p), ("sub_token", C.c_void_p),
-                ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("head_rows", C.c_void_p),
+                ("n_nodes", C.c_int32), ("node_rows", C.c_void_p), ("rowptr", C.c_void_p), ("col", C.c_void_p),
+                ("val", C.c_void_p), ("n_code", C.c_int32), ("code_rows", C.c_void_p), ("code_mark", C.c_void_p),
+                ("n_mem", C.c_int32), ("mem_rows", C.c_void_p), ("mem_dst", C.c_void_p), ("head_rows", C.c_void_p),
                 ("n_head_rows", C.c_int32)]
 
 

@@ -41,6 +41,8 @@ __device__ __forceinline__ void load_frag(float (&f)[16], const float* __restric
 constexpr float SQRT_DH = 5.656854249492381f;
 constexpr int MAX_TK = 384;
 
+// Rows of masked keys are never read (their K/V fragments are zero-filled): their score is -1e9 whatever K holds and
+// their soft-max weight is exactly 0, so callers may leave those rows uninitialised.
 // masked, scaled score.  beyond Tk: -inf (not part of the soft-max at all); masked key: -1e9 as the reference.
 __device__ __forceinline__ float mask_score(float raw, int key, int query, int Tk, const int* kv, int causal, int q_pos0,
                                             bool& masked) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
         if (kt < NT) {
             float ak[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + (size_t)key * ldk + h * FIRA_DH + kh * 16, key < Tk);
+            load_frag(ak, K + (size_t)key * ldk + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int key = kt * 32 + acc_row(s, kh);
-                vv[s] = key < Tk ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
+                vv[s] = (key < Tk && sm_kv[key < Tk ? key : 0] != 0) ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] / sum, vv[s], o);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         if (kt < NT) {
             float ak[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk);
+            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         if (kt < NT) {
             float av[16];
             const int key = kt * 32 + l31;
-            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk);
+            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
             f32x16 dpt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
-                kvv[s] = kr < Tk ? K[((size_t)b * Tk + kr) * ldk + h * FIRA_DH + l31] : 0.f;
+                kvv[s] = (kr < Tk && sm_kv[kr < Tk ? kr : 0] != 0) ? K[((size_t)b * Tk + kr) * ldk + h * FIRA_DH + l31] : 0.f;
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         if (kt < NT) {
             float ak[16], av[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk);
-            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk);
+            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
+            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
             f32x16 sN, dpN;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }

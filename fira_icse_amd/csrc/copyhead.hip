@@ -26,10 +26,12 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
                                                              const float* __restrict__ tgt,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
-                                                             float* __restrict__ score, int qpk) {
+                                                             float* __restrict__ score, int qpk,
+                                                             const int32_t* __restrict__ mem_valid) {
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
     src += (size_t)(b / qpk) * S * FIRA_D - (size_t)b * S * FIRA_D;     // qpk target batches share one memory
+    const int32_t* mv = mem_valid ? mem_valid + (size_t)(b / qpk) * S : nullptr;
     for (int i = t0; i < T * (FIRA_D / 4); i += 256)
         reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
     __syncthreads();
@@ -37,6 +39,10 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
     const float c = bias[0];
     const int j_end = min(S, (int)(blockIdx.x + 1) * 32);
     for (int j = blockIdx.x * 32 + wave; j < j_end; j += 4) {
+        if (mv && mv[j] == 0) {                       // masked slot: its score is replaced by -1e9 downstream
+            if (lane < T) score[((size_t)b * T + lane) * S + j] = 0.f;
+            continue;
+        }
         const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
         for (int t = 0; t < T; ++t) {
             const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
@@ -58,7 +64,8 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ dscore,
                                                              float* __restrict__ dsrc, float* __restrict__ dtgt,
-                                                             float* __restrict__ dw, float* __restrict__ dbias) {
+                                                             float* __restrict__ dw, float* __restrict__ dbias,
+                                                             const int32_t* __restrict__ mem_valid) {
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     __shared__ float sm_dt[T_MAX * FIRA_D];
     __shared__ float sm_dw[FIRA_D + 1];
@@ -78,6 +85,10 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
     float dba = 0.f;
     const int j_end = min(S, (int)(blockIdx.x + 1) * 32);
     for (int j = blockIdx.x * 32 + wave; j < j_end; j += 4) {
+        if (mem_valid && mem_valid[(size_t)b * S + j] == 0) {     // masked slot: no gradient flows through masked_fill
+            *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
         float ds[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -335,28 +346,32 @@ int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl
 }
 
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                      const float* bias, float* score, int qpk) {
+                      const float* bias, float* score, int qpk, const int32_t* mem_valid) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX && qpk >= 1, "copy_score_fwd: T=%d > %d", T, T_MAX);
     hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
-                       qpk);
+                       qpk, mem_valid);
     FIRA_CHECK_LAUNCH("copy_score_fwd");
     return 0;
 }
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score) {
-    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1);
+    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1, nullptr);
 }
-int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                   const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
+int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                      const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
     hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
-                       dtgt, dw, dbias);
+                       dtgt, dw, dbias, mem_valid);
     FIRA_CHECK_LAUNCH("copy_score_bwd");
     return 0;
+}
+int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                   const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
+    return copy_score_bwd_ex(s, B, T, S, src, tgt, w, dscore, dsrc, dtgt, dw, dbias, nullptr);
 }
 int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
               float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,

@@ -22,18 +22,16 @@ int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, in
                     float dropout, uint64_t seed, uint32_t site);
 int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
                     const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site);
-// seg_*: output row r is stored at row (r / seg_len) * seg_stride + seg_off + r % seg_len (seg_len <= 0: identity)
+// y_rows (optional): output row r is stored at row y_rows[r]
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
-                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, int seg_len, int seg_stride,
-                      int seg_off);
+                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows);
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
                       uint32_t site);
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out);
-// compact[r,:] (op)= strided[(r/seg_len)*seg_stride + seg_off + r%seg_len, :]   and the inverse
-int rows_gather_seg(hipStream_t s, int M, float* compact, const float* strided, int seg_len, int seg_stride, int seg_off);
-int rows_scatter_seg(hipStream_t s, int M, const float* compact, float* strided, int seg_len, int seg_stride,
-                     int seg_off);
+// index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
+// 3 out[dst[r]]=in[src[r]]
+int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst);
 // compact[r,:] = src[rows[r],:] ;  dst[rows[r],:] += compact[r,:]
 int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows);
 int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows);
@@ -59,8 +57,11 @@ int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, i
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score);
+// mem_valid (optional, [B/qpk, S]): slots with 0 are skipped (score 0 / zero gradient): they are masked to -1e9 later
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                      const float* bias, float* score, int qpk);
+                      const float* bias, float* score, int qpk, const int32_t* mem_valid);
+int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
+                      const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid);
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
                 float* best_p);

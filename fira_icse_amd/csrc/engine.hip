@@ -42,11 +42,11 @@ struct Plan {
     std::vector<float*> X;          // nl + 1 node buffers
     std::vector<EncSave> enc;
     std::vector<DecSave> dec;
-    float *vtab_all, *H, *mem, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
+    float *vtab_all, *H, *mem, *mem_c, *kv_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *inv_ntok;
     // backward temporaries (training only)
     float *dXa, *dXb, *dNB1, *dNB2, *dCB_a, *dCB_b, *dCB_c, *dqk, *dvtab_all;
-    float *dmem, *dsrc, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_b, *dT_c, *dqkv, *dh;
+    float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_b, *dT_c, *dqkv, *dh;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
         Arena a(ws);
@@ -74,6 +74,9 @@ struct Plan {
         vtab_all = a.f((size_t)4 * nl * D);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
+        mem_c = a.f((size_t)MB * D);
+        kv_c = a.f((size_t)MB * nl * 2 * D);
+        src_c = a.f((size_t)MB * D);
         x0 = a.f((size_t)TB * D);
         kv_all = a.f((size_t)MB * nl * 2 * D);
         dec.resize(nl);
@@ -92,7 +95,8 @@ struct Plan {
             dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB1 = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
             dCB_a = a.f((size_t)CB * D); dCB_b = a.f((size_t)CB * D); dCB_c = a.f((size_t)CB * D);
             dqk = a.f((size_t)CB * 2 * D); dvtab_all = a.f((size_t)4 * nl * D);
-            dmem = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dtgt = a.f((size_t)TB * D);
+            dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
+            dkv_c = a.f((size_t)MB * nl * 2 * D); dtgt = a.f((size_t)TB * D);
             dkv_all = a.f((size_t)MB * nl * 2 * D);
             ddec = a.f((size_t)TB * D); ddec_c = a.f((size_t)TB * D);
             dT_a = a.f((size_t)TB * D); dT_b = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
@@ -144,39 +148,49 @@ struct Ctx {
 };
 
 // ------------------------------------------------------------------------------------------ encoder forward
+// The encoder runs on the batch's COMPUTED node list only (fira_batch.node_rows): padded nodes carry nothing but a
+// self-loop, are masked as attention keys / copy slots and receive exactly zero gradient (SURVEY.md §8a note N1), so
+// leaving them out changes no consumed value.  Nc = n_nodes, Cc = n_code, Mc = n_mem below.
 static int encoder_forward(Ctx& c) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
+    const fira_batch& bt = *c.bt;
     hipStream_t s = c.s;
-    const int D = FIRA_D;
+    const int D = FIRA_D, Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem, KV = p.nl * 2 * D;
     TRY(fill_pos_tables(s, p.L, p.pos_code, p.T, p.pos_tar));
-    TRY(make_masks(s, p.B, p.L, p.S, p.T, c.bt->sou, c.bt->sub_token, c.bt->tar, p.mem_valid, c.bt->tar ? p.tar_valid : nullptr));
-    // node features straight into the [B, 650, 256] buffer (gnn_transformer.py:46-52,58)
-    TRY(embed_gather_fwd(s, p.B, p.L, c.bt->sou, c.P + L.emb, p.pos_code, p.X[0], p.N, 0));
-    TRY(embed_gather_fwd(s, p.B, p.S, c.bt->sub_token, c.P + L.emb, nullptr, p.X[0], p.N, p.L));
-    TRY(embed_gather_fwd(s, p.B, p.A, c.bt->ast_change, c.P + L.ast_emb, nullptr, p.X[0], p.N, p.L + p.S));
+    TRY(make_masks(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr));
+    // node features (gnn_transformer.py:46-52,58): gathered in the dense [B,650,256] layout, then compacted
+    TRY(embed_gather_fwd(s, p.B, p.L, bt.sou, c.P + L.emb, p.pos_code, p.H, p.N, 0));
+    TRY(embed_gather_fwd(s, p.B, p.S, bt.sub_token, c.P + L.emb, nullptr, p.H, p.N, p.L));
+    TRY(embed_gather_fwd(s, p.B, p.A, bt.ast_change, c.P + L.ast_emb, nullptr, p.H, p.N, p.L + p.S));
+    TRY(rows_move(s, 0, Nc, D, p.X[0], p.H, bt.node_rows, nullptr));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
     TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
     for (int l = 0; l < p.nl; ++l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
         float* X = p.X[l];
-        // Combination (gnn_transformer.py:192-205): code rows only
-        TRY(rows_gather_seg(s, p.CB, e.Xc, X, p.L, p.N, 0));
-        TRY(linear(s, p.CB, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
-        TRY(combination_fwd(s, p.CB, e.qk, p.vtab_all + l * D, p.nl * D, c.bt->mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
-        TRY(linear(s, p.CB, D, D, e.c, D, c.P + w.wo, c.P + w.bo, e.s1, D));
-        TRY(add_layernorm_fwd(s, p.CB, e.s1, e.Xc, c.P + w.ln1g, c.P + w.ln1b, X, e.st1, c.p_drop, c.seed,
-                              site(l, SITE_COMB_OUT), p.L, p.N, 0));
+        // Combination (gnn_transformer.py:192-205): code rows only; the result overwrites them in place
+        TRY(rows_move(s, 0, Cc, D, e.Xc, X, bt.code_rows, nullptr));
+        TRY(linear(s, Cc, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
+        TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
+        TRY(linear(s, Cc, D, D, e.c, D, c.P + w.wo, c.P + w.bo, e.s1, D));
+        TRY(add_layernorm_fwd(s, Cc, e.s1, e.Xc, c.P + w.ln1g, c.P + w.ln1b, X, e.st1, c.p_drop, c.seed,
+                              site(l, SITE_COMB_OUT), bt.code_rows));
         // GCN (gnn_transformer.py:74-86): fc1 -> A_hat . -> fc2 -> +residual -> LN
-        TRY(linear(s, p.NB, D, D, X, D, c.P + w.fc1w, c.P + w.fc1b, p.H, D));
-        TRY(csr_spmm(s, p.NB, c.bt->rowptr, c.bt->col, c.bt->val, p.H, D, e.Z, D, p.N, 1));
-        TRY(linear(s, p.NB, D, D, e.Z, D, c.P + w.fc2w, c.P + w.fc2b, e.s2, D));
-        TRY(add_layernorm_fwd(s, p.NB, e.s2, X, c.P + w.ln2g, c.P + w.ln2b, p.X[l + 1], e.st2, c.p_gcn, c.seed,
-                              site(l, SITE_GCN), 0, 0, 0));
+        TRY(linear(s, Nc, D, D, X, D, c.P + w.fc1w, c.P + w.fc1b, p.H, D));
+        TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.H, D, e.Z, D, 0, 1));
+        TRY(linear(s, Nc, D, D, e.Z, D, c.P + w.fc2w, c.P + w.fc2b, e.s2, D));
+        TRY(add_layernorm_fwd(s, Nc, e.s2, X, c.P + w.ln2g, c.P + w.ln2b, p.X[l + 1], e.st2, c.p_gcn, c.seed,
+                              site(l, SITE_GCN), nullptr));
     }
-    // memory = [code ; sub-token] rows (Model.py:48)
-    TRY(rows_gather_seg(s, p.MB, p.mem, p.X[p.nl], p.L + p.S, p.N, 0));
+    // memory = [code ; sub-token] rows (Model.py:48): compact copy for the GEMMs, dense [B,370,*] rows for the
+    // attention / copy kernels (rows of masked slots are never read there)
+    TRY(rows_move(s, 0, Mc, D, p.mem_c, p.X[p.nl], bt.mem_rows, nullptr));
+    TRY(linear(s, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, c.P + L.bkv_all, p.kv_c, KV));
+    TRY(rows_move(s, 1, Mc, KV, p.kv_all, p.kv_c, nullptr, bt.mem_dst));
+    TRY(gemm_f32_ex(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
+    TRY(rows_move(s, 1, Mc, D, p.src, p.src_c, nullptr, bt.mem_dst));
     return 0;
 }
 
@@ -187,7 +201,6 @@ static int decoder_forward(Ctx& c) {
     hipStream_t s = c.s;
     const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
     TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
-    TRY(linear(s, p.MB, KV, D, p.mem, D, c.P + L.wkv_all, c.P + L.bkv_all, p.kv_all, KV));
     const float* x = p.x0;
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
@@ -195,14 +208,14 @@ static int decoder_forward(Ctx& c) {
         TRY(linear(s, p.TB, 3 * D, D, x, D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 3 * D));
         TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D));
         TRY(linear(s, p.TB, D, D, e.ao, D, c.P + w.wo_s, c.P + w.bo_s, e.s_a, D));
-        TRY(add_layernorm_fwd(s, p.TB, e.s_a, x, c.P + w.lns_g, c.P + w.lns_b, e.x_a, e.st_a, c.p_drop, c.seed, site(l, SITE_SELF), 0, 0, 0));
+        TRY(add_layernorm_fwd(s, p.TB, e.s_a, x, c.P + w.lns_g, c.P + w.lns_b, e.x_a, e.st_a, c.p_drop, c.seed, site(l, SITE_SELF), nullptr));
         TRY(linear(s, p.TB, D, D, e.x_a, D, c.P + w.wq_c, c.P + w.bq_c, e.qc, D));
         TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D));
         TRY(linear(s, p.TB, D, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.s_c, D));
-        TRY(add_layernorm_fwd(s, p.TB, e.s_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.x_c, e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS), 0, 0, 0));
+        TRY(add_layernorm_fwd(s, p.TB, e.s_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.x_c, e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS), nullptr));
         TRY(linear(s, p.TB, p.F, D, e.x_c, D, c.P + w.w1, c.P + w.b1, e.h, p.F, FIRA_GEMM_RELU));
         TRY(linear(s, p.TB, D, p.F, e.h, p.F, c.P + w.w2, c.P + w.b2, e.s_f, D));
-        TRY(add_layernorm_fwd(s, p.TB, e.s_f, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.x_f, e.st_f, c.p_drop, c.seed, site(l, SITE_FFN), 0, 0, 0));
+        TRY(add_layernorm_fwd(s, p.TB, e.s_f, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.x_f, e.st_f, c.p_drop, c.seed, site(l, SITE_FFN), nullptr));
         x = e.x_f;
     }
     return 0;
@@ -220,9 +233,8 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));
     TRY(invert_rows(s, p.TB, R, rows, p.compact_row));
     TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
-    TRY(gemm_f32(s, 0, 1, p.MB, D, D, p.mem, D, c.P + L.ws, D, p.src, D, nullptr, 0, 1));
-    TRY(gemm_f32(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 1));
-    TRY(copy_score_fwd(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score));
+    TRY(gemm_f32_ex(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
+    TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid));
     TRY(linear(s, p.TB, 2, D, dec, D, c.P + L.wp, c.P + L.bp, p.gate, 2));
     if (loss_sum) TRY(zero(s, loss_sum, sizeof(float)));
     if (n_tok) TRY(zero(s, n_tok, sizeof(int32_t)));
@@ -237,6 +249,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     const Layout& L = *c.L;
     hipStream_t s = c.s;
     const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
+    const fira_batch& bt = *c.bt;
+    const int Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem;
     const float* dec = p.dec[p.nl - 1].x_f;
     float* G = c.G;
     const bool drop = c.p_drop > 0.f, gdrop = c.p_gcn > 0.f;
@@ -245,11 +259,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
     TRY(zero(s, p.dtgt, (size_t)p.TB * D * sizeof(float)));
-    TRY(copy_score_bwd(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres));
+    TRY(copy_score_bwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres,
+                          p.mem_valid));
     TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
     TRY(linear_wgrad(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
-    TRY(linear_dgrad(s, p.MB, D, D, p.dsrc, D, c.P + L.ws, p.dmem, D, false));
-    TRY(linear_wgrad(s, p.MB, D, D, p.dsrc, D, p.mem, D, G + L.ws, nullptr));
+    TRY(rows_move(s, 0, Mc, D, p.dsrc_c, p.dsrc, bt.mem_dst, nullptr));
+    TRY(linear_dgrad(s, Mc, D, D, p.dsrc_c, D, c.P + L.ws, p.dmem_c, D, false));
+    TRY(linear_wgrad(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr));
     if (R > 0) {
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
         TRY(zero(s, p.ddec_c, (size_t)R * D * sizeof(float)));
@@ -299,50 +315,53 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     }
     // decoder embedding (no padding_idx: gnn_transformer.py:92-93)
     TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, -1));
-    // cross-attention K|V projections of all layers
-    TRY(linear_dgrad(s, p.MB, KV, D, p.dkv_all, KV, c.P + L.wkv_all, p.dmem, D, true));
-    TRY(linear_wgrad(s, p.MB, KV, D, p.dkv_all, KV, p.mem, D, G + L.wkv_all, G + L.bkv_all));
+    // cross-attention K|V projections of all layers (computed memory rows only)
+    TRY(rows_move(s, 0, Mc, KV, p.dkv_c, p.dkv_all, bt.mem_dst, nullptr));
+    TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
+    TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     if (mid_event) {                         // gradients of [0, split) are final from here on
         hipError_t e = hipEventRecord(mid_event, s);
         if (e != hipSuccess) return set_err("hipEventRecord: %s", hipGetErrorString(e));
     }
 
-    // ---- encoder layers, last to first ------------------------------------------------------------------
+    // ---- encoder layers, last to first (compact node rows) -------------------------------------------------
     float* dXn = p.dXa;
     float* other = p.dXb;
-    TRY(zero(s, dXn, (size_t)p.NB * D * sizeof(float)));          // AST/edit rows of the last layer feed nothing
-    TRY(rows_scatter_seg(s, p.MB, p.dmem, dXn, Sm, p.N, 0));
+    TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));            // AST/edit rows of the last layer feed nothing
+    TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
     TRY(zero(s, p.dvtab_all, (size_t)4 * p.nl * D * sizeof(float)));
     for (int l = p.nl - 1; l >= 0; --l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
         const float* Xg = p.X[l];                                  // GCN input (code rows already updated)
-        TRY(add_layernorm_bwd(s, p.NB, dXn, e.s2, e.st2, c.P + w.ln2g, other, gdrop ? p.dNB1 : nullptr, G + w.ln2g,
+        TRY(add_layernorm_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, gdrop ? p.dNB1 : nullptr, G + w.ln2g,
                               G + w.ln2b, c.p_gcn, c.seed, site(l, SITE_GCN)));
         const float* dY = gdrop ? p.dNB1 : other;
-        TRY(linear_wgrad(s, p.NB, D, D, dY, D, e.Z, D, G + w.fc2w, G + w.fc2b));
-        TRY(linear_dgrad(s, p.NB, D, D, dY, D, c.P + w.fc2w, p.dNB2, D, false));               // dZ
-        TRY(csr_spmm(s, p.NB, c.bt->rowptr, c.bt->col, c.bt->val, p.dNB2, D, p.dNB1, D, p.N, 1));   // dH = A_hat dZ
-        TRY(linear_wgrad(s, p.NB, D, D, p.dNB1, D, Xg, D, G + w.fc1w, G + w.fc1b));
-        TRY(linear_dgrad(s, p.NB, D, D, p.dNB1, D, c.P + w.fc1w, other, D, true));             // other = dG
+        TRY(linear_wgrad(s, Nc, D, D, dY, D, e.Z, D, G + w.fc2w, G + w.fc2b));
+        TRY(linear_dgrad(s, Nc, D, D, dY, D, c.P + w.fc2w, p.dNB2, D, false));                 // dZ
+        TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, p.dNB1, D, 0, 1));           // dH = A_hat dZ
+        TRY(linear_wgrad(s, Nc, D, D, p.dNB1, D, Xg, D, G + w.fc1w, G + w.fc1b));
+        TRY(linear_dgrad(s, Nc, D, D, p.dNB1, D, c.P + w.fc1w, other, D, true));               // other = dG
         // Combination on the code rows
-        TRY(rows_gather_seg(s, p.CB, p.dCB_a, other, p.L, p.N, 0));
-        TRY(add_layernorm_bwd(s, p.CB, p.dCB_a, e.s1, e.st1, c.P + w.ln1g, p.dCB_b, drop ? p.dCB_c : nullptr,
+        TRY(rows_move(s, 0, Cc, D, p.dCB_a, other, bt.code_rows, nullptr));
+        TRY(add_layernorm_bwd(s, Cc, p.dCB_a, e.s1, e.st1, c.P + w.ln1g, p.dCB_b, drop ? p.dCB_c : nullptr,
                               G + w.ln1g, G + w.ln1b, c.p_drop, c.seed, site(l, SITE_COMB_OUT)));
         const float* dYc = drop ? p.dCB_c : p.dCB_b;
-        TRY(linear_wgrad(s, p.CB, D, D, dYc, D, e.c, D, G + w.wo, G + w.bo));
-        TRY(linear_dgrad(s, p.CB, D, D, dYc, D, c.P + w.wo, p.dCB_a, D, false));               // d c
-        TRY(combination_bwd(s, p.CB, e.qk, p.vtab_all + l * D, p.nl * D, c.bt->mark, p.dCB_a, p.dqk,
+        TRY(linear_wgrad(s, Cc, D, D, dYc, D, e.c, D, G + w.wo, G + w.bo));
+        TRY(linear_dgrad(s, Cc, D, D, dYc, D, c.P + w.wo, p.dCB_a, D, false));                 // d c
+        TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, p.dqk,
                             p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE)));
-        TRY(linear_wgrad(s, p.CB, 2 * D, D, p.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
-        TRY(linear_dgrad(s, p.CB, 2 * D, D, p.dqk, 2 * D, c.P + w.wqk, p.dCB_b, D, true));     // dCB_b = d Xc
-        TRY(rows_scatter_seg(s, p.CB, p.dCB_b, other, p.L, p.N, 0));                           // other = dX[l]
+        TRY(linear_wgrad(s, Cc, 2 * D, D, p.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
+        TRY(linear_dgrad(s, Cc, 2 * D, D, p.dqk, 2 * D, c.P + w.wqk, p.dCB_b, D, true));       // dCB_b = d Xc
+        TRY(rows_move(s, 1, Cc, D, other, p.dCB_b, nullptr, bt.code_rows));                    // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
-    // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39)
-    TRY(embed_gather_bwd(s, p.B, p.L, c.bt->sou, G + L.emb, dXn, p.N, 0, 0));
-    TRY(embed_gather_bwd(s, p.B, p.S, c.bt->sub_token, G + L.emb, dXn, p.N, p.L, 0));
-    TRY(embed_gather_bwd(s, p.B, p.A, c.bt->ast_change, G + L.ast_emb, dXn, p.N, p.L + p.S, 0));
+    // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39); back to the dense layout
+    TRY(zero(s, p.H, (size_t)p.NB * D * sizeof(float)));
+    TRY(rows_move(s, 1, Nc, D, p.H, dXn, nullptr, bt.node_rows));
+    TRY(embed_gather_bwd(s, p.B, p.L, bt.sou, G + L.emb, p.H, p.N, 0, 0));
+    TRY(embed_gather_bwd(s, p.B, p.S, bt.sub_token, G + L.emb, p.H, p.N, p.L, 0));
+    TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
     TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
                     FIRA_GEMM_ACCUM, 1, G + L.b2_all));
@@ -355,6 +374,14 @@ static int check_batch(const fira_batch* b) {
     FIRA_REQUIRE(b && b->B > 0, "empty batch");
     FIRA_REQUIRE(b->sou && b->mark && b->ast_change && b->sub_token && b->rowptr && b->col && b->val,
                  "batch has null encoder inputs");
+    FIRA_REQUIRE(b->node_rows && b->code_rows && b->code_mark && b->mem_rows && b->mem_dst,
+                 "batch has null node lists (node_rows / code_rows / code_mark / mem_rows / mem_dst)");
+    FIRA_REQUIRE(b->n_nodes > 0 && b->n_code > 0 && b->n_mem > 0 && b->n_code <= b->n_nodes && b->n_mem <= b->n_nodes,
+                 "inconsistent node counts %d / %d / %d", b->n_nodes, b->n_code, b->n_mem);
+    return 0;
+}
+static int check_counts(const fira_batch* b, const Plan& p) {
+    FIRA_REQUIRE(b->n_nodes <= p.NB && b->n_code <= p.CB && b->n_mem <= p.MB, "node lists exceed the batch geometry");
     return 0;
 }
 
@@ -410,6 +437,7 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     Plan p;
     const size_t need = p.build(workspace, *d, batch->B, true);
     FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    TRY(check_counts(batch, p));
     Ctx c{(hipStream_t)stream, L, batch, params, grads, &p, opts ? opts->dropout : 0.f, opts ? opts->gcn_dropout : 0.f,
           opts ? opts->seed : 0};
     FIRA_REQUIRE(c.p_drop >= 0.f && c.p_drop < 1.f && c.p_gcn >= 0.f && c.p_gcn < 1.f, "dropout must be in [0,1)");
@@ -438,6 +466,7 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
     Plan p;
     const size_t need = p.build(workspace, *d, batch->B, false);
     FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    TRY(check_counts(batch, p));
     Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
     TRY(encoder_forward(c));
     TRY(decoder_forward(c));
@@ -459,10 +488,9 @@ int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch,
     fira_batch b2 = *batch;
     b2.tar = nullptr;
     Ctx c{(hipStream_t)stream, L, &b2, params, nullptr, &p, 0.f, 0.f, 0};
-    TRY(encoder_forward(c));
-    const int D = FIRA_D, KV = p.nl * 2 * D;
-    TRY(linear(c.s, p.MB, KV, D, p.mem, D, params + L->wkv_all, params + L->bkv_all, p.kv_all, KV));
-    TRY(gemm_f32(c.s, 0, 1, p.MB, D, D, p.mem, D, params + L->ws, D, p.src, D, nullptr, 0, 1));
+    TRY(check_counts(batch, p));
+    TRY(encoder_forward(c));            // also leaves kv_all (cross K|V of all layers) and src = LinearSource(memory)
+    TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers
     return 0;
 }
 
@@ -497,19 +525,19 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
         TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
         TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
         TRY(linear(s, BR, D, D, dp.ao, D, params + w.wo_s, params + w.bo_s, dp.s, D));
-        TRY(add_layernorm_fwd(s, BR, dp.s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, nullptr, 0.f, 0, 0, 0, 0, 0));
+        TRY(add_layernorm_fwd(s, BR, dp.s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, nullptr, 0.f, 0, 0, nullptr));
         TRY(linear(s, BR, D, D, dp.xa, D, params + w.wq_c, params + w.bq_c, dp.qc, D));
         TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                              p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
         TRY(linear(s, BR, D, D, dp.ao, D, params + w.wo_c, params + w.bo_c, dp.s, D));
-        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, nullptr, 0.f, 0, 0, 0, 0, 0));
+        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, nullptr, 0.f, 0, 0, nullptr));
         TRY(linear(s, BR, p.F, D, dp.xc, D, params + w.w1, params + w.b1, dp.h, p.F, FIRA_GEMM_RELU));
         TRY(linear(s, BR, D, p.F, dp.h, p.F, params + w.w2, params + w.b2, dp.s, D));
-        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, nullptr, 0.f, 0, 0, 0, 0, 0));
+        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, nullptr, 0.f, 0, 0, nullptr));
     }
     TRY(linear(s, BR, p.V, D, dp.x, D, params + L.wout, params + L.bout, dp.logits, p.ldl));
     TRY(gemm_f32(s, 0, 1, BR, D, D, dp.x, D, params + L.wt, D, dp.tgt, D, nullptr, 0, 1));
-    TRY(copy_score_fwd_ex(s, BR, 1, Sm, p.src, dp.tgt, params + L.wres, params + L.bres, dp.score, n_beam));
+    TRY(copy_score_fwd_ex(s, BR, 1, Sm, p.src, dp.tgt, params + L.wres, params + L.bres, dp.score, n_beam, p.mem_valid));
     TRY(linear(s, BR, 2, D, dp.x, D, params + L.wp, params + L.bp, dp.gate, 2));
     TRY(decode_dist(s, BR, p.V, Sm, dp.logits, p.ldl, dp.score, p.mem_valid, n_beam, dp.gate, dist, best_id, best_p));
     return 0;

@@ -154,13 +154,12 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
                                                                 const float* __restrict__ beta,
                                                                 float* __restrict__ y, float* __restrict__ stats,
                                                                 float p, float inv_keep, uint64_t seed,
-                                                                uint32_t site, int seg_len, int seg_stride,
-                                                                int seg_off) {
+                                                                uint32_t site, const int32_t* __restrict__ y_rows) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     const size_t o = (size_t)r * FIRA_D + lane * 4;
-    const size_t oy = seg_len > 0 ? ((size_t)(r / seg_len) * seg_stride + seg_off + r % seg_len) * FIRA_D + lane * 4 : o;
+    const size_t oy = y_rows ? (size_t)y_rows[r] * FIRA_D + lane * 4 : o;      // optional scatter of the output rows
     float4 a = *reinterpret_cast<const float4*>(x + o);
     if (p > 0.f) {
         const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
@@ -263,34 +262,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* 
 
 
 // ------------------------------------------------------------------------------------------------
-// row movers: segment-strided <-> compact (code rows of the [B,650,256] node buffer, memory rows), and
-// index lists (rows of the head that carry a label).
-template <int MODE>   // 0: compact = strided ; 1: strided = compact
-__global__ __launch_bounds__(256) void rows_seg_kernel(int M, float* __restrict__ compact, float* __restrict__ strided,
-                                                       int seg_len, int seg_stride, int seg_off) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= M) return;
-    const size_t oc = (size_t)r * FIRA_D + lane * 4;
-    const size_t os = ((size_t)(r / seg_len) * seg_stride + seg_off + r % seg_len) * FIRA_D + lane * 4;
-    if (MODE == 0) *reinterpret_cast<float4*>(compact + oc) = *reinterpret_cast<const float4*>(strided + os);
-    else *reinterpret_cast<float4*>(strided + os) = *reinterpret_cast<const float4*>(compact + oc);
-}
-template <int MODE>   // 0: compact[r] = src[rows[r]] ; 1: dst[rows[r]] += compact[r]
-__global__ __launch_bounds__(256) void rows_idx_kernel(int R, float* __restrict__ compact, float* __restrict__ full,
-                                                       const int32_t* __restrict__ rows) {
+// Row movers through index lists (W floats per row, W a multiple of 256):
+//   MODE 0  out[r]          = in[src[r]]          (gather;  src == nullptr: identity)
+//   MODE 1  out[dst[r]]     = in[r]               (scatter, overwrite)
+//   MODE 2  out[dst[r]]    += in[r]               (scatter-add; dst has no duplicates: plain read-modify-write)
+//   MODE 3  out[dst[r]]     = in[src[r]]          (gather + scatter)
+template <int MODE>
+__global__ __launch_bounds__(256) void rows_idx_kernel(int R, int W, float* __restrict__ out, const float* __restrict__ in,
+                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
-    const size_t oc = (size_t)r * FIRA_D + lane * 4;
-    const size_t of = (size_t)rows[r] * FIRA_D + lane * 4;
-    if (MODE == 0) {
-        *reinterpret_cast<float4*>(compact + oc) = *reinterpret_cast<const float4*>(full + of);
-    } else {
-        const float4 a = *reinterpret_cast<const float4*>(compact + oc);
-        float4 b = *reinterpret_cast<const float4*>(full + of);       // rows[] has no duplicates: plain RMW
-        b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
-        *reinterpret_cast<float4*>(full + of) = b;
+    const size_t ri = (MODE == 0 || MODE == 3) ? (size_t)(src ? src[r] : r) : (size_t)r;
+    const size_t ro = (MODE == 0) ? (size_t)r : (size_t)dst[r];
+    for (int c = lane * 4; c < W; c += 256) {
+        float4 a = *reinterpret_cast<const float4*>(in + ri * W + c);
+        if (MODE == 2) {
+            const float4 b = *reinterpret_cast<const float4*>(out + ro * W + c);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4*>(out + ro * W + c) = a;
     }
 }
 __global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t n4, float4* __restrict__ dh, const float4* __restrict__ h) {
@@ -327,34 +318,23 @@ __global__ void invert_rows_kernel(int R, const int32_t* __restrict__ rows, int3
 }
 
 // ---------------------------------------------------------------- host launchers
-int rows_gather_seg(hipStream_t s, int M, float* compact, const float* strided, int seg_len, int seg_stride, int seg_off) {
+int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst) {
+    if (R <= 0) return 0;
+    FIRA_REQUIRE(W % 256 == 0 && mode >= 0 && mode <= 3, "rows_move: bad width %d / mode %d", W, mode);
     ProfScope prof(s, PROF_ROWOPS, 0.0);
-    if (M <= 0) return 0;
-    hipLaunchKernelGGL(rows_seg_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, s, M, compact, const_cast<float*>(strided),
-                       seg_len, seg_stride, seg_off);
-    FIRA_CHECK_LAUNCH("rows_gather_seg");
-    return 0;
-}
-int rows_scatter_seg(hipStream_t s, int M, const float* compact, float* strided, int seg_len, int seg_stride,
-                     int seg_off) {
-    ProfScope prof(s, PROF_ROWOPS, 0.0);
-    if (M <= 0) return 0;
-    hipLaunchKernelGGL(rows_seg_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, s, M, const_cast<float*>(compact), strided,
-                       seg_len, seg_stride, seg_off);
-    FIRA_CHECK_LAUNCH("rows_scatter_seg");
+    dim3 g(cdiv(R, 4)), b(256);
+    if (mode == 0) hipLaunchKernelGGL(rows_idx_kernel<0>, g, b, 0, s, R, W, out, in, src, dst);
+    else if (mode == 1) hipLaunchKernelGGL(rows_idx_kernel<1>, g, b, 0, s, R, W, out, in, src, dst);
+    else if (mode == 2) hipLaunchKernelGGL(rows_idx_kernel<2>, g, b, 0, s, R, W, out, in, src, dst);
+    else hipLaunchKernelGGL(rows_idx_kernel<3>, g, b, 0, s, R, W, out, in, src, dst);
+    FIRA_CHECK_LAUNCH("rows_move");
     return 0;
 }
 int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows) {
-    if (R <= 0) return 0;
-    hipLaunchKernelGGL(rows_idx_kernel<0>, dim3(cdiv(R, 4)), dim3(256), 0, s, R, compact, const_cast<float*>(src), rows);
-    FIRA_CHECK_LAUNCH("rows_gather_idx");
-    return 0;
+    return rows_move(s, 0, R, FIRA_D, compact, src, rows, nullptr);
 }
 int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows) {
-    if (R <= 0) return 0;
-    hipLaunchKernelGGL(rows_idx_kernel<1>, dim3(cdiv(R, 4)), dim3(256), 0, s, R, const_cast<float*>(compact), dst, rows);
-    FIRA_CHECK_LAUNCH("rows_scatter_add_idx");
-    return 0;
+    return rows_move(s, 2, R, FIRA_D, dst, compact, nullptr, rows);
 }
 int relu_bwd(hipStream_t s, int64_t n, float* dh, const float* h) {
     if (n <= 0) return 0;
@@ -427,13 +407,12 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
     return 0;
 }
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
-                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, int seg_len, int seg_stride,
-                      int seg_off) {
+                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, x, res, gamma, beta, y, stats,
-                       dropout, inv_keep, seed, site, seg_len, seg_stride, seg_off);
+                       dropout, inv_keep, seed, site, y_rows);
     FIRA_CHECK_LAUNCH("add_layernorm_fwd");
     return 0;
 }
@@ -532,8 +511,8 @@ int fira_combination_bwd(void* stream, int M, const float* qk, const float* vtab
 }
 int fira_add_layernorm_fwd(void* stream, int M, float* x, const float* res, const float* gamma, const float* beta,
                            float* y, float* stats, float dropout, uint64_t seed, uint32_t stream_id) {
-    return fira::add_layernorm_fwd((hipStream_t)stream, M, x, res, gamma, beta, y, stats, dropout, seed, stream_id, 0, 0,
-                                   0);
+    return fira::add_layernorm_fwd((hipStream_t)stream, M, x, res, gamma, beta, y, stats, dropout, seed, stream_id,
+                                   nullptr);
 }
 int fira_add_layernorm_bwd(void* stream, int M, const float* dy, const float* sum, const float* stats,
                            const float* gamma, float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout,

@@ -127,10 +127,47 @@ class ParamLayout:
         return out
 
 
-class DeviceBatch:
-    """One collated batch resident in HBM: int32 id arrays + block-diagonal CSR adjacency (+ head row list)."""
+def computed_nodes(hb: HostBatch, cfg: FiraConfig, skip_padding: bool = True):
+    """Node lists of the C ABI's ``fira_batch`` (host side, numpy).
 
-    def __init__(self, hb: HostBatch, cfg: FiraConfig, device="cuda"):
+    A node is *computed* when its id is non-zero or it has an edge besides its self-loop; everything else is padding
+    that the reference computes but never consumes (masked as attention key / copy slot, zero loss
+    weight, exactly zero gradient).  ``skip_padding=False`` lists every node (the reference's dense computation).
+    Returns node_rows, compact CSR (rowptr, col, val), code_rows, code_mark, mem_rows, mem_dst.
+    """
+    B, N, L, S = len(hb), cfg.graph_len, cfg.sou_len, cfg.sub_token_len
+    deg = np.diff(hb.rowptr.astype(np.int64))
+    if skip_padding:
+        ids = np.concatenate([hb.sou, hb.sub_token, hb.ast_change], axis=1).reshape(-1)
+        real = (ids != 0) | (deg > 1)
+    else:
+        real = np.ones(B * N, dtype=bool)
+    node_rows = np.nonzero(real)[0].astype(np.int32)
+    cmap = np.full(B * N, -1, dtype=np.int64)
+    cmap[node_rows] = np.arange(node_rows.shape[0])
+    entry_row = np.repeat(np.arange(B * N), deg)
+    keep = real[entry_row]
+    col = cmap[hb.col[keep]]
+    if col.size and col.min() < 0:
+        raise AssertionError("a computed node has an edge to a skipped node")      # cannot happen: edges are symmetric
+    rowptr = np.zeros(node_rows.shape[0] + 1, dtype=np.int64)
+    np.cumsum(deg[real], out=rowptr[1:])
+    local, b = node_rows % N, node_rows // N
+    code_sel = local < L
+    code_rows = np.nonzero(code_sel)[0].astype(np.int32)
+    code_mark = hb.mark[b[code_sel], local[code_sel]].astype(np.int32)
+    mem_sel = local < L + S
+    mem_rows = np.nonzero(mem_sel)[0].astype(np.int32)
+    mem_dst = (b[mem_sel] * (L + S) + local[mem_sel]).astype(np.int32)
+    return (node_rows, rowptr.astype(np.int32), col.astype(np.int32), hb.val[keep].astype(np.float32), code_rows,
+            code_mark, mem_rows, mem_dst)
+
+
+class DeviceBatch:
+    """One collated batch resident in HBM: int32 id arrays, the computed-node lists and their CSR adjacency
+    (+ the list of target rows that need the vocabulary head)."""
+
+    def __init__(self, hb: HostBatch, cfg: FiraConfig, device="cuda", skip_padding: bool = True):
         self.cfg = cfg
         self.B = len(hb)
         V = cfg.vocab_size
@@ -139,7 +176,10 @@ class DeviceBatch:
             raise ValueError("copy label %d outside the %d-way output" % (int(hb.tar_label.max()), cfg.out_len))
 
         def dev(a, dt):
-            return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(device, non_blocking=True)
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dt)
+            return torch.from_numpy(a).to(device, non_blocking=True)
 
         self.sou = dev(hb.sou, np.int32)
         self.tar = dev(hb.tar, np.int32) if hb.tar is not None else None
@@ -147,23 +187,26 @@ class DeviceBatch:
         self.ast_change = dev(hb.ast_change, np.int32)
         self.tar_label = dev(hb.tar_label, np.int32) if hb.tar_label is not None else None
         self.sub_token = dev(hb.sub_token, np.int32)
-        self.rowptr = dev(hb.rowptr, np.int32)
-        self.col = dev(hb.col, np.int32)
-        self.val = dev(hb.val, np.float32)
-        self.nnz = int(hb.col.shape[0])
+        node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst = computed_nodes(hb, cfg, skip_padding)
+        self.n_nodes, self.n_code, self.n_mem = int(node_rows.shape[0]), int(code_rows.shape[0]), int(mem_rows.shape[0])
+        self.nnz = int(col.shape[0])
+        self.node_rows, self.rowptr, self.col, self.val = dev(node_rows, np.int32), dev(rowptr, np.int32), \
+            dev(col, np.int32), dev(val, np.float32)
+        self.code_rows, self.code_mark = dev(code_rows, np.int32), dev(code_mark, np.int32)
+        self.mem_rows, self.mem_dst = dev(mem_rows, np.int32), dev(mem_dst, np.int32)
         self.head_rows = None
         self.n_head_rows = 0
         if hb.tar_label is not None:
             shifted = np.concatenate([hb.tar_label[:, 1:], np.zeros((self.B, 1), hb.tar_label.dtype)], axis=1)
             rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0].astype(np.int32)
             self.n_head_rows = int(rows.shape[0])
-            self.head_rows = dev(rows if rows.size else np.zeros(1, np.int32), np.int32)
+            self.head_rows = dev(rows, np.int32)
+        p = lambda t: t.data_ptr() if t is not None else None
         self.struct = _lib.Batch(
-            self.B, self.nnz, self.sou.data_ptr(), self.tar.data_ptr() if self.tar is not None else None,
-            self.mark.data_ptr(), self.ast_change.data_ptr(),
-            self.tar_label.data_ptr() if self.tar_label is not None else None, self.sub_token.data_ptr(),
-            self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(),
-            self.head_rows.data_ptr() if self.head_rows is not None else None, self.n_head_rows)
+            self.B, self.nnz, p(self.sou), p(self.tar), p(self.mark), p(self.ast_change), p(self.tar_label),
+            p(self.sub_token), self.n_nodes, p(self.node_rows), p(self.rowptr), p(self.col), p(self.val), self.n_code,
+            p(self.code_rows), p(self.code_mark), self.n_mem, p(self.mem_rows), p(self.mem_dst), p(self.head_rows),
+            self.n_head_rows)
 
 
 class _FusedStep(torch.autograd.Function):

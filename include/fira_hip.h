@@ -45,13 +45,24 @@ typedef struct fira_batch {
     int32_t nnz;             /* entries of the block-diagonal adjacency                */
     const int32_t* sou;      /* [B, sou_len]  code-token ids                           */
     const int32_t* tar;      /* [B, tar_len]  decoder input ids                        */
-    const int32_t* mark;     /* [B, sou_len]  0 pad,1 deleted,2 context,3 added        */
+    const int32_t* mark;     /* [B, sou_len]  0 pad,1 deleted,2 context,3 added (dense; the kernels read code_mark) */
     const int32_t* ast_change; /* [B, ast_len]                                         */
     const int32_t* tar_label;/* [B, tar_len]  labels incl. copy ids (>= vocab)         */
     const int32_t* sub_token;/* [B, sub_len]                                           */
-    const int32_t* rowptr;   /* [B*N + 1] CSR row offsets, N = sou+sub+ast             */
-    const int32_t* col;      /* [nnz] GLOBAL node ids (b*N + local)                    */
-    const float*   val;      /* [nnz] D^-1/2 (A+I) D^-1/2 entries (fp32 of Dataset.py:291) */
+    /* ---- computed node list.  The encoder only runs on the nodes listed here; padded nodes (id 0 and no edge but
+     * their self-loop) may be left out: they are masked wherever they could be read and get zero gradient
+     * (SURVEY.md §8a N1).  Listing every node (identity lists) reproduces the reference's dense computation. ---- */
+    int32_t n_nodes;         /* Nc: computed nodes of the batch                                              */
+    const int32_t* node_rows;/* [Nc] ascending global node index b*N + local (N = sou+sub+ast)               */
+    const int32_t* rowptr;   /* [Nc + 1] CSR row offsets over the computed nodes                             */
+    const int32_t* col;      /* [nnz] COMPACT node ids (position in node_rows)                               */
+    const float*   val;      /* [nnz] D^-1/2 (A+I) D^-1/2 entries (fp32 of Dataset.py:291)                   */
+    int32_t n_code;          /* Cc: computed code-token nodes (local < sou_len)                              */
+    const int32_t* code_rows;/* [Cc] their compact ids                                                       */
+    const int32_t* code_mark;/* [Cc] their mark value (0 pad,1 deleted,2 context,3 added)                    */
+    int32_t n_mem;           /* Mc: computed memory nodes (local < sou_len + sub_len)                        */
+    const int32_t* mem_rows; /* [Mc] their compact ids                                                       */
+    const int32_t* mem_dst;  /* [Mc] their dense memory row b*(sou_len+sub_len) + local                      */
     const int32_t* head_rows;/* [n_head_rows] optional: flat (b*tar_len+t) indices of the target rows whose shifted
                                 label is a vocabulary id (0 < label < vocab), ascending, no duplicates; only these
                                 rows need the vocabulary GEMM in training.  NULL = all rows.           */

@@ -88,3 +88,35 @@ def test_dataset_class_roundtrip(tmp_path):
     assert np.array_equal(item[0], g["train_sou"][2]) and item[5].dtype == np.float64 and item[5].shape == (650, 650)
     ds2 = data.TransDataset(cfg, "test", root=str(tmp_path))           # served from the cache
     assert np.array_equal(ds2.store.tar_label, g["test_tar_label"])
+
+
+def test_computed_node_lists(store):
+    """Host side of the padded-node skipping: lists are consistent, the compact CSR is the dense one restricted to
+    computed rows, and the over-long commit's unguarded edges keep their (id 0) endpoints computed."""
+    from fira_icse_amd.model import computed_nodes
+    cfg = FiraConfig()
+    N, L, S = cfg.graph_len, cfg.sou_len, cfg.sub_token_len
+    raw = util.load_golden_raw()
+    long_i = [i for i, d in enumerate(raw["difftoken"]) if len(d) > 208][0]
+    hb = store.batch([0, long_i, 5])
+    node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst = computed_nodes(hb, cfg)
+    dn, dr, dc, dv, dcr, dcm, dmr, dmd = computed_nodes(hb, cfg, skip_padding=False)
+    assert dn.shape[0] == 3 * N and np.array_equal(dr, hb.rowptr) and np.array_equal(dc, hb.col)
+    assert node_rows.shape[0] < 3 * N and np.all(np.diff(node_rows) > 0)
+    dense = hb.dense_edge(N).reshape(3 * N, N)
+    for k in (0, 7, len(node_rows) // 2, len(node_rows) - 1):
+        g = node_rows[k]
+        cols = node_rows[col[rowptr[k]:rowptr[k + 1]]]
+        assert np.array_equal(np.sort(cols % N), np.nonzero(dense[g])[0]) and np.all(cols // N == g // N)
+        assert np.allclose(val[rowptr[k]:rowptr[k + 1]], dense[g][cols % N].astype(np.float32))
+    skipped = np.setdiff1d(np.arange(3 * N), node_rows)
+    ids = np.concatenate([hb.sou, hb.sub_token, hb.ast_change], axis=1).reshape(-1)
+    assert np.all(ids[skipped] == 0) and np.all(np.diff(hb.rowptr)[skipped] == 1)     # only self-loop padding is skipped
+    assert np.array_equal(node_rows[code_rows] % N < L, np.ones(len(code_rows), bool))
+    assert np.array_equal(code_mark, hb.mark.reshape(-1)[(node_rows[code_rows] // N) * L + node_rows[code_rows] % N])
+    assert np.array_equal(mem_dst, (node_rows[mem_rows] // N) * (L + S) + node_rows[mem_rows] % N)
+    # every unmasked memory slot (id != 0) is computed
+    mem_ids = np.concatenate([hb.sou, hb.sub_token], axis=1).reshape(-1)
+    assert np.all(np.isin(np.nonzero(mem_ids != 0)[0], mem_dst))
+    # the over-long commit: node 210 (sub-token id 0 or not) has the unguarded sequential edge -> computed
+    assert (1 * N + 210) in node_rows

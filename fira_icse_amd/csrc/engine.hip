@@ -11,6 +11,7 @@
 //   head          mem [MB,256], src [MB,256], tgt [TB,256], score [TB,370], gate [TB,2], dec_c [R,256], logits [R, ldl]
 //   backward      gradient temporaries of the same shapes (ping-pong node buffers, dkv_all, ...)
 #include "engine.h"
+#include <stdlib.h>
 
 namespace fira {
 
@@ -35,6 +36,13 @@ struct DecSave {
     float *qkv, *ao, *s_a, *st_a, *x_a, *qc, *ao2, *s_c, *st_c, *x_c, *h, *s_f, *st_f, *x_f;
 };
 
+struct EncGrad {
+    float *dY2, *dH, *dYc, *dqk;
+};
+struct DecGrad {
+    float *dYf, *dh, *dYc, *dq, *dYs, *dqkv;
+};
+
 struct Plan {
     int B, NB, CB, MB, TB, N, L, S, A, T, V, ldl, nl, F;
     float *pos_code, *pos_tar;
@@ -42,11 +50,13 @@ struct Plan {
     std::vector<float*> X;          // nl + 1 node buffers
     std::vector<EncSave> enc;
     std::vector<DecSave> dec;
+    std::vector<EncGrad> encg;      // per-layer weight-gradient operands: never reused inside a step, so the
+    std::vector<DecGrad> decg;      // wgrad GEMMs can run on the side stream while the dgrad chain continues
     float *vtab_all, *H, *mem, *mem_c, *kv_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *inv_ntok;
     // backward temporaries (training only)
-    float *dXa, *dXb, *dNB1, *dNB2, *dCB_a, *dCB_b, *dCB_c, *dqk, *dvtab_all;
-    float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_b, *dT_c, *dqkv, *dh;
+    float *dXa, *dXb, *dNB2, *dCB_a, *dCB_b, *dvtab_all;
+    float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
         Arena a(ws);
@@ -92,15 +102,24 @@ struct Plan {
         score = a.f((size_t)TB * (L + S)); gate = a.f((size_t)TB * 2);
         dec_c = a.f((size_t)TB * D); logits = a.f((size_t)TB * ldl);
         if (training) {
-            dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB1 = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
-            dCB_a = a.f((size_t)CB * D); dCB_b = a.f((size_t)CB * D); dCB_c = a.f((size_t)CB * D);
-            dqk = a.f((size_t)CB * 2 * D); dvtab_all = a.f((size_t)4 * nl * D);
+            dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
+            dCB_a = a.f((size_t)CB * D); dCB_b = a.f((size_t)CB * D);
+            dvtab_all = a.f((size_t)4 * nl * D);
             dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
             dkv_c = a.f((size_t)MB * nl * 2 * D); dtgt = a.f((size_t)TB * D);
             dkv_all = a.f((size_t)MB * nl * 2 * D);
             ddec = a.f((size_t)TB * D); ddec_c = a.f((size_t)TB * D);
-            dT_a = a.f((size_t)TB * D); dT_b = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
-            dqkv = a.f((size_t)TB * 3 * D); dh = a.f((size_t)TB * F);
+            dT_a = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
+            encg.resize(nl);
+            decg.resize(nl);
+            for (int l = 0; l < nl; ++l) {
+                EncGrad& g = encg[l];
+                g.dY2 = a.f((size_t)NB * D); g.dH = a.f((size_t)NB * D); g.dYc = a.f((size_t)CB * D);
+                g.dqk = a.f((size_t)CB * 2 * D);
+                DecGrad& h = decg[l];
+                h.dYf = a.f((size_t)TB * D); h.dh = a.f((size_t)TB * F); h.dYc = a.f((size_t)TB * D);
+                h.dq = a.f((size_t)TB * D); h.dYs = a.f((size_t)TB * D); h.dqkv = a.f((size_t)TB * 3 * D);
+            }
         }
         return a.used;
     }
@@ -127,10 +146,60 @@ static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* 
                                int lddx, bool accum) {
     return gemm_f32_ex(s, 0, 0, M, K, N, dY, lddy, W, K, dX, lddx, nullptr, accum ? FIRA_GEMM_ACCUM : 0, 0, nullptr);
 }
+// Weight gradients are off the critical path of the backward pass (nothing downstream reads them), so they are
+// issued on a second HIP stream: each one waits for the event that marks its operands ready on the main stream and
+// runs beside the dgrad chain, filling the CUs the small decoder-side kernels leave idle.  The main stream joins the
+// side stream before the mid-event (data-parallel bucket hand-off) and at the end of the backward pass.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> events;
+    size_t next = 0;
+    bool enabled = true;
+    int init() {
+        if (stream) return 0;
+        const char* off = getenv("FIRA_NO_WGRAD_OVERLAP");
+        enabled = !(off && off[0] == '1');
+        hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return set_err("hipStreamCreate: %s", hipGetErrorString(e));
+        events.resize(512);
+        for (auto& ev : events) {
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e != hipSuccess) return set_err("hipEventCreate: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    hipEvent_t ev() { hipEvent_t e = events[next]; next = (next + 1) % events.size(); return e; }
+};
+static SideStream& side() { static thread_local SideStream s; return s; }
+
+// fork: the side stream waits for everything enqueued on `main` so far
+static int side_fork(hipStream_t main_s) {
+    SideStream& sd = side();
+    hipEvent_t e = sd.ev();
+    if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(sd.stream, e, 0) != hipSuccess)
+        return set_err("side stream fork failed");
+    return 0;
+}
+// join: `main` waits for everything enqueued on the side stream so far
+static int side_join(hipStream_t main_s) {
+    SideStream& sd = side();
+    hipEvent_t e = sd.ev();
+    if (hipEventRecord(e, sd.stream) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess)
+        return set_err("side stream join failed");
+    return 0;
+}
+
 // dW += dY^T X ; db += colsum(dY)      (reduce over the M rows: split-K over rows keeps the chip busy)
+// dY and X must stay untouched until the next side_join (per-layer slots of Plan::encg / decg, saved activations).
 static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx,
                                float* dW, float* db) {
-    return gemm_f32_ex(s, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
+    SideStream& sd = side();
+    hipStream_t ws = s;
+    if (sd.stream && sd.enabled) {
+        TRY(side_fork(s));
+        ws = sd.stream;
+    }
+    return gemm_f32_ex(ws, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
 }
 
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
@@ -253,7 +322,6 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     const int Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem;
     const float* dec = p.dec[p.nl - 1].x_f;
     float* G = c.G;
-    const bool drop = c.p_drop > 0.f, gdrop = c.p_gcn > 0.f;
 
     // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
@@ -280,37 +348,35 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     for (int l = p.nl - 1; l >= 0; --l) {
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
+        DecGrad& g = p.decg[l];
         const float* x_in = l == 0 ? p.x0 : p.dec[l - 1].x_f;
         // FeedForward (gnn_transformer.py:170-174)
-        TRY(add_layernorm_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, drop ? p.dT_b : nullptr, G + w.lnf_g,
-                              G + w.lnf_b, c.p_drop, c.seed, site(l, SITE_FFN)));
-        const float* dY = drop ? p.dT_b : p.dT_a;
-        TRY(linear_wgrad(s, p.TB, D, p.F, dY, D, e.h, p.F, G + w.w2, G + w.b2));
-        TRY(linear_dgrad(s, p.TB, D, p.F, dY, D, c.P + w.w2, p.dh, p.F, false));
-        TRY(relu_bwd(s, (int64_t)p.TB * p.F, p.dh, e.h));
-        TRY(linear_wgrad(s, p.TB, p.F, D, p.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
-        TRY(linear_dgrad(s, p.TB, p.F, D, p.dh, p.F, c.P + w.w1, p.dT_a, D, true));          // dT_a = d x_c
+        TRY(add_layernorm_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
+                              c.p_drop, c.seed, site(l, SITE_FFN)));
+        TRY(linear_wgrad(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
+        TRY(linear_dgrad(s, p.TB, D, p.F, g.dYf, D, c.P + w.w2, g.dh, p.F, false));
+        TRY(relu_bwd(s, (int64_t)p.TB * p.F, g.dh, e.h));
+        TRY(linear_wgrad(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
+        TRY(linear_dgrad(s, p.TB, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
         // cross attention
-        TRY(add_layernorm_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, drop ? p.dT_b : nullptr,
-                              G + w.lnc_g, G + w.lnc_b, c.p_drop, c.seed, site(l, SITE_CROSS)));
-        dY = drop ? p.dT_b : p.dT_c;
-        TRY(linear_wgrad(s, p.TB, D, D, dY, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
-        TRY(linear_dgrad(s, p.TB, D, D, dY, D, c.P + w.wo_c, p.dT_a, D, false));              // dT_a = d ao2
+        TRY(add_layernorm_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
+                              c.p_drop, c.seed, site(l, SITE_CROSS)));
+        TRY(linear_wgrad(s, p.TB, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
+        TRY(linear_dgrad(s, p.TB, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
-                          p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, p.dT_b, D, p.dkv_all + l * 2 * D, KV,
-                          p.dkv_all + l * 2 * D + D, KV));                                      // dT_b = d qc
-        TRY(linear_wgrad(s, p.TB, D, D, p.dT_b, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
-        TRY(linear_dgrad(s, p.TB, D, D, p.dT_b, D, c.P + w.wq_c, p.dT_c, D, true));           // dT_c = d x_a
+                          p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, KV,
+                          p.dkv_all + l * 2 * D + D, KV));
+        TRY(linear_wgrad(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
+        TRY(linear_dgrad(s, p.TB, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
         // self attention
-        TRY(add_layernorm_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, drop ? p.dT_b : nullptr,
-                              G + w.lns_g, G + w.lns_b, c.p_drop, c.seed, site(l, SITE_SELF)));
-        dY = drop ? p.dT_b : p.dT_a;
-        TRY(linear_wgrad(s, p.TB, D, D, dY, D, e.ao, D, G + w.wo_s, G + w.bo_s));
-        TRY(linear_dgrad(s, p.TB, D, D, dY, D, c.P + w.wo_s, p.dT_c, D, false));              // dT_c = d ao
+        TRY(add_layernorm_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
+                              c.p_drop, c.seed, site(l, SITE_SELF)));
+        TRY(linear_wgrad(s, p.TB, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
+        TRY(linear_dgrad(s, p.TB, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
         TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
-                          e.ao, D, p.dT_c, D, p.dqkv, 3 * D, p.dqkv + D, 3 * D, p.dqkv + 2 * D, 3 * D));
-        TRY(linear_wgrad(s, p.TB, 3 * D, D, p.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
-        TRY(linear_dgrad(s, p.TB, 3 * D, D, p.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
+                          e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D));
+        TRY(linear_wgrad(s, p.TB, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
+        TRY(linear_dgrad(s, p.TB, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
         dy = p.dT_a;
     }
     // decoder embedding (no padding_idx: gnn_transformer.py:92-93)
@@ -320,6 +386,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     if (mid_event) {                         // gradients of [0, split) are final from here on
+        if (side().stream && side().enabled) TRY(side_join(s));
         hipError_t e = hipEventRecord(mid_event, s);
         if (e != hipSuccess) return set_err("hipEventRecord: %s", hipGetErrorString(e));
     }
@@ -333,26 +400,25 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     for (int l = p.nl - 1; l >= 0; --l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
+        EncGrad& g = p.encg[l];
         const float* Xg = p.X[l];                                  // GCN input (code rows already updated)
-        TRY(add_layernorm_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, gdrop ? p.dNB1 : nullptr, G + w.ln2g,
-                              G + w.ln2b, c.p_gcn, c.seed, site(l, SITE_GCN)));
-        const float* dY = gdrop ? p.dNB1 : other;
-        TRY(linear_wgrad(s, Nc, D, D, dY, D, e.Z, D, G + w.fc2w, G + w.fc2b));
-        TRY(linear_dgrad(s, Nc, D, D, dY, D, c.P + w.fc2w, p.dNB2, D, false));                 // dZ
-        TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, p.dNB1, D, 0, 1));           // dH = A_hat dZ
-        TRY(linear_wgrad(s, Nc, D, D, p.dNB1, D, Xg, D, G + w.fc1w, G + w.fc1b));
-        TRY(linear_dgrad(s, Nc, D, D, p.dNB1, D, c.P + w.fc1w, other, D, true));               // other = dG
+        TRY(add_layernorm_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, g.dY2, G + w.ln2g, G + w.ln2b, c.p_gcn,
+                              c.seed, site(l, SITE_GCN)));
+        TRY(linear_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, G + w.fc2w, G + w.fc2b));
+        TRY(linear_dgrad(s, Nc, D, D, g.dY2, D, c.P + w.fc2w, p.dNB2, D, false));              // dZ
+        TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, g.dH, D, 0, 1));             // dH = A_hat dZ
+        TRY(linear_wgrad(s, Nc, D, D, g.dH, D, Xg, D, G + w.fc1w, G + w.fc1b));
+        TRY(linear_dgrad(s, Nc, D, D, g.dH, D, c.P + w.fc1w, other, D, true));                 // other = dG
         // Combination on the code rows
         TRY(rows_move(s, 0, Cc, D, p.dCB_a, other, bt.code_rows, nullptr));
-        TRY(add_layernorm_bwd(s, Cc, p.dCB_a, e.s1, e.st1, c.P + w.ln1g, p.dCB_b, drop ? p.dCB_c : nullptr,
-                              G + w.ln1g, G + w.ln1b, c.p_drop, c.seed, site(l, SITE_COMB_OUT)));
-        const float* dYc = drop ? p.dCB_c : p.dCB_b;
-        TRY(linear_wgrad(s, Cc, D, D, dYc, D, e.c, D, G + w.wo, G + w.bo));
-        TRY(linear_dgrad(s, Cc, D, D, dYc, D, c.P + w.wo, p.dCB_a, D, false));                 // d c
-        TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, p.dqk,
+        TRY(add_layernorm_bwd(s, Cc, p.dCB_a, e.s1, e.st1, c.P + w.ln1g, p.dCB_b, g.dYc, G + w.ln1g, G + w.ln1b,
+                              c.p_drop, c.seed, site(l, SITE_COMB_OUT)));
+        TRY(linear_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
+        TRY(linear_dgrad(s, Cc, D, D, g.dYc, D, c.P + w.wo, p.dCB_a, D, false));               // d c
+        TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, g.dqk,
                             p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE)));
-        TRY(linear_wgrad(s, Cc, 2 * D, D, p.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
-        TRY(linear_dgrad(s, Cc, 2 * D, D, p.dqk, 2 * D, c.P + w.wqk, p.dCB_b, D, true));       // dCB_b = d Xc
+        TRY(linear_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
+        TRY(linear_dgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, c.P + w.wqk, p.dCB_b, D, true));       // dCB_b = d Xc
         TRY(rows_move(s, 1, Cc, D, other, p.dCB_b, nullptr, bt.code_rows));                    // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
@@ -367,6 +433,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                     FIRA_GEMM_ACCUM, 1, G + L.b2_all));
     TRY(linear_dgrad(s, 4, p.nl * D, D, p.dvtab_all, p.nl * D, c.P + L.w2_all, G + L.mark_emb, D, true));
     TRY(zero(s, G + L.mark_emb, (size_t)D * sizeof(float)));       // padding_idx row 0 never gets a gradient
+    if (side().stream && side().enabled) TRY(side_join(s));        // every weight gradient is complete past this point
     return 0;
 }
 
@@ -441,6 +508,7 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     Ctx c{(hipStream_t)stream, L, batch, params, grads, &p, opts ? opts->dropout : 0.f, opts ? opts->gcn_dropout : 0.f,
           opts ? opts->seed : 0};
     FIRA_REQUIRE(c.p_drop >= 0.f && c.p_drop < 1.f && c.p_gcn >= 0.f && c.p_gcn < 1.f, "dropout must be in [0,1)");
+    TRY(side().init());
     TRY(encoder_forward(c));
     TRY(decoder_forward(c));
     int R = p.TB;

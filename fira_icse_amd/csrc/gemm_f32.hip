@@ -278,14 +278,14 @@ static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const floa
 struct TileChoice { int tile; int splitk; double cost; };
 static TileChoice choose(int M, int N, int K, bool can_split) {
     static const int BMs[3] = {128, 64, 64}, BNs[3] = {128, 128, 64};
-    static const double eff[3] = {0.80, 0.72, 0.55};       // fraction of the CU's MFMA peak a tile sustains
+    static const double eff[3] = {0.62, 0.64, 0.66};       // measured fraction of a CU's MFMA peak per round (K = 256)
     TileChoice best{0, 1, 1e30};
     for (int t = 0; t < 3; ++t) {
         const long tiles = (long)cdiv(M, BMs[t]) * cdiv(N, BNs[t]);
         const int max_split = can_split ? std::max(1, K / 128) : 1;
         for (int sk = 1; sk <= max_split; sk = (sk < 4 ? sk + 1 : sk * 2)) {
             const double kk = (double)cdiv(cdiv(K, sk), BK) * BK;
-            const double t_wg = 2.0 * BMs[t] * BNs[t] * kk / (614e9 * eff[t]) + 3.0e-6 + (sk > 1 ? 1.0e-6 : 0.0);
+            const double t_wg = 2.0 * BMs[t] * BNs[t] * kk / (614e9 * eff[t]) + 2.0e-6 + (sk > 1 ? 1.0e-6 : 0.0);
             const double cost = std::ceil((double)(tiles * sk) / 256.0) * t_wg;
             if (cost < best.cost * 0.97) best = TileChoice{t, sk, cost};
         }

@@ -295,9 +295,18 @@ class TransModel(nn.Module):
         _lib.check(lib.fira_train_fwd_bwd(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                           _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
                                           C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok),
-                                          C.c_void_p(mid_event.cuda_event) if mid_event is not None else None),
+                                          self._event_handle(mid_event)),
                    "fira_train_fwd_bwd")
         return self.loss_sum, self.n_tok
+
+    @staticmethod
+    def _event_handle(ev):
+        if ev is None:
+            return None
+        h = ev.cuda_event
+        if not h:
+            raise RuntimeError("mid_event has no native handle yet: call event.record() once before passing it")
+        return C.c_void_p(h)
 
     def forward_dev(self, db: DeviceBatch) -> torch.Tensor:
         """Teacher-forced argmax ids [B, tar_len] (reference Model.py:85-86)."""

@@ -28,7 +28,10 @@ class Trainer:
         self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
         self.reducer = GradReducer(model.layout.split, model.layout.live) if distributed else None
-        self.mid_event = torch.cuda.Event() if distributed else None
+        self.mid_event = None
+        if distributed:
+            self.mid_event = torch.cuda.Event()
+            self.mid_event.record()            # torch creates the hipEvent lazily: force it so its handle can be passed
 
     def step(self, db: DeviceBatch):
         """One optimisation step on this rank's shard of the global batch."""

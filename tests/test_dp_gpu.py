@@ -56,5 +56,8 @@ def test_two_rank_training_equals_single_process(tmp_path):
         assert abs(x - y) / x < 1e-5, (a["losses"], b["losses"])        # GLOBAL mean token loss on every rank
     # Adam normalises the update magnitude to ~lr, so compare the parameter *change* over the three steps
     cfg = FiraConfig()
-    diff = (a["flat"] - b["flat"]).abs().max().item()
-    assert diff < 0.05 * 3 * cfg.lr, diff
+    # (element-wise; the attention fc_k.bias entries are excluded by the quantile: their true gradient is zero, both
+    # runs hold rounding noise there and Adam turns noise of either sign into a +-lr step)
+    diff = (a["flat"] - b["flat"]).abs()
+    assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
+    assert float(diff.mean()) < 1e-3 * cfg.lr

@@ -55,32 +55,83 @@ class Searcher:
         return torch.where(idx >= V + L, from_sub, torch.where(idx >= V, from_sou, idx))
 
     # ------------------------------------------------------------------ greedy (beam 1): no sort, no dist tensor
-    @torch.no_grad()
-    def greedy(self, db: DeviceBatch, sync_every: int = 4) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Returns (tokens [B,T] int64 starting with <start>, lengths [B], probability [B])."""
+    def _greedy_state(self, B):
+        """Static device buffers + captured hipGraphs of the step loop for batch size B (built on first use)."""
+        key = ("greedy", B)
+        if key in self._ws:
+            return self._ws[key]
         cfg, dev = self.cfg, self.model.device_
+        T = cfg.tar_len
+        st = dict(
+            sou=torch.zeros((B, cfg.sou_len), dtype=torch.int64, device=dev),
+            sub=torch.zeros((B, cfg.sub_token_len), dtype=torch.int64, device=dev),
+            out=torch.zeros((B, T), dtype=torch.int64, device=dev),
+            length=torch.ones(B, dtype=torch.int64, device=dev),
+            prob=torch.ones(B, dtype=torch.float32, device=dev),
+            alive=torch.ones(B, dtype=torch.bool, device=dev),
+            tok=torch.full((B,), START, dtype=torch.int32, device=dev),
+            best_id=torch.empty(B, dtype=torch.int32, device=dev),
+            best_p=torch.empty(B, dtype=torch.float32, device=dev),
+            graphs=None)
+        self._ws[key] = st
+        return st
+
+    def _greedy_steps(self, st, ws, B, lo, hi):
+        """Steps lo..hi-1 of run_model.py:225-340 at beam 1, entirely on the device (no host round trip)."""
+        for step in range(lo, hi):
+            self._step(ws, B, 1, step, st["tok"], None, None, st["best_id"], st["best_p"])
+            nxt = self._resolve(st["best_id"].long()[:, None], st["sou"], st["sub"])[:, 0]
+            alive = st["alive"]
+            st["out"][:, step + 1] = torch.where(alive, nxt, st["out"][:, step + 1])
+            st["prob"].copy_(torch.where(alive, st["prob"] * st["best_p"], st["prob"]))
+            st["length"].add_(alive.long())
+            st["alive"].copy_(alive & (nxt != EOS))
+            st["tok"].copy_(torch.where(st["alive"], nxt, torch.zeros_like(nxt)).to(torch.int32))
+
+    @torch.no_grad()
+    def greedy(self, db: DeviceBatch, chunk: int = 5, use_graphs: bool = True):
+        """Returns (tokens [B,T] int64 starting with <start>, lengths [B], probability [B]).
+
+        The step loop is launch-bound (~85 tiny kernels per generated token), so it is captured once per batch size
+        into hipGraphs of ``chunk`` steps each and replayed; between chunks one flag is read back to stop as soon as
+        every hypothesis has emitted <eos> (run_model.py:276-279)."""
+        cfg = self.cfg
         B, T = db.B, cfg.tar_len
         ws = self._begin(db, 1)
-        sou, sub = db.sou.long(), db.sub_token.long()
-        out = torch.zeros((B, T), dtype=torch.int64, device=dev)
-        out[:, 0] = START
-        length = torch.ones(B, dtype=torch.int64, device=dev)
-        prob = torch.ones(B, dtype=torch.float32, device=dev)
-        alive = torch.ones(B, dtype=torch.bool, device=dev)
-        tok = torch.full((B,), START, dtype=torch.int32, device=dev)
-        best_id = torch.empty(B, dtype=torch.int32, device=dev)
-        best_p = torch.empty(B, dtype=torch.float32, device=dev)
-        for step in range(T - 1):
-            self._step(ws, B, 1, step, tok, None, None, best_id, best_p)
-            nxt = self._resolve(best_id.long()[:, None], sou, sub)[:, 0]
-            out[:, step + 1] = torch.where(alive, nxt, out[:, step + 1])
-            prob = torch.where(alive, prob * best_p, prob)
-            length = length + alive.long()
-            alive = alive & (nxt != EOS)
-            tok = torch.where(alive, nxt, torch.zeros_like(nxt)).to(torch.int32)
-            if (step + 1) % sync_every == 0 and not bool(alive.any()):      # run_model.py:276-279
+        st = self._greedy_state(B)
+        st["sou"].copy_(db.sou)
+        st["sub"].copy_(db.sub_token)
+        st["out"].zero_()
+        st["out"][:, 0] = START
+        st["length"].fill_(1)
+        st["prob"].fill_(1.0)
+        st["alive"].fill_(True)
+        st["tok"].fill_(START)
+        bounds = [(lo, min(lo + chunk, T - 1)) for lo in range(0, T - 1, chunk)]
+        if use_graphs and st["graphs"] is None:
+            # warm-up outside capture (lazy initialisation inside the library / torch), then capture every chunk
+            snap = {k: v.clone() for k, v in st.items() if isinstance(v, torch.Tensor)}
+            self._greedy_steps(st, ws, B, 0, 1)
+            torch.cuda.synchronize()
+            for k, v in snap.items():
+                st[k].copy_(v)
+            graphs = []
+            for lo, hi in bounds:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._greedy_steps(st, ws, B, lo, hi)
+                graphs.append(g)
+            st["graphs"] = graphs
+            for k, v in snap.items():           # capture does not execute: restore nothing but be explicit
+                st[k].copy_(v)
+        for i, (lo, hi) in enumerate(bounds):
+            if use_graphs:
+                st["graphs"][i].replay()
+            else:
+                self._greedy_steps(st, ws, B, lo, hi)
+            if hi < T - 1 and not bool(st["alive"].any()):
                 break
-        return out, length, prob
+        return st["out"].clone(), st["length"].clone(), st["prob"].clone()
 
     # ------------------------------------------------------------------ beam search with the reference's semantics
     @torch.no_grad()

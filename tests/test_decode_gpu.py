@@ -40,8 +40,12 @@ def lines_of(hyps, raw, ids):
 def test_greedy_matches_reference_output_lines(setup):
     cfg, raw, ids, hb, sd, model, db, search = setup
     gold = json.load(open(os.path.join(util.GOLDEN, "decode_ref.json")))["beam1"]
-    out, length, prob = search.greedy(db)
+    out, length, prob = search.greedy(db)                            # captures the step loop into hipGraphs
     assert lines_of(search.best(out, length, prob), raw, ids) == gold
+    out_r, length_r, prob_r = search.greedy(db)                      # graph replay
+    out_e, length_e, prob_e = search.greedy(db, use_graphs=False)    # eager launches
+    assert torch.equal(out, out_r) and torch.equal(out, out_e) and torch.equal(length, length_e)
+    assert torch.allclose(prob, prob_e, rtol=1e-5, atol=0) and torch.equal(prob, prob_r)
     out2, length2, prob2 = search.beam(db, 1)                       # the general path at beam 1 is the same search
     assert lines_of(search.best(out2, length2, prob2), raw, ids) == gold
 

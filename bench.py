@@ -170,9 +170,13 @@ def main():
         barrier()
         ddt = (time.perf_counter() - t0) / reps
         toks = int((length - 1).sum().item())          # emitted tokens up to and including <eos>, cap 29
+        steps_run = int(length.max().item()) - 1
         decode = {"tokens_per_s": toks * world / ddt, "commits_per_s": a.decode_batch * world / ddt,
+                  "step_tokens_per_s": a.decode_batch * steps_run * world / ddt, "steps_run": steps_run,
                   "batch": a.decode_batch, "beam": 1, "ms_per_batch": ddt * 1e3, "tokens_per_batch": toks,
-                  "note": "random-init weights never emit <eos>: every commit runs the full 29 steps"}
+                  "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
+                          "steps executed, the unit of BASELINE.md's CPU figure (109 step-tokens/s). Random-init weights: "
+                          "most hypotheses copy <eos> within a few steps while a few run all 29"}
         model.train()
 
     cpu = None

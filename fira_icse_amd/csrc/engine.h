@@ -12,6 +12,8 @@ int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A,
 // splitk = 0: automatic tile / split selection; colsum (transA only): colsum[m] += sum_k A[k][m] (fused bias gradient)
 int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                 float* C, int ldc, const float* bias, int flags, int splitk, float* colsum);
+bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, const float* bias, int flags, int* rc);
 int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
              int ldx, float* Y, int ldy, int graph_rows, int variant);
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,

@@ -301,6 +301,10 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU);
     int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic
+    if (tile < 0 && splitk <= 1 && !colsum) {                   // skinny forward / dgrad shapes: latency kernel
+        int rc;
+        if (gemm_small_try(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, &rc)) return rc;
+    }
     if (splitk == 0 || tile < 0) {
         const TileChoice c = choose(M, N, K, can_split && splitk == 0);
         if (tile < 0) tile = c.tile;

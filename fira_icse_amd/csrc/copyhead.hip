@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ score, int qpk,
-                                                             const int32_t* __restrict__ mem_valid) {
+                                                             const int32_t* __restrict__ mem_valid, int slots) {
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
     src += (size_t)(b / qpk) * S * FIRA_D - (size_t)b * S * FIRA_D;     // qpk target batches share one memory
@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
     __syncthreads();
     const float4 w4 = *reinterpret_cast<const float4*>(w + lane * 4);
     const float c = bias[0];
-    const int j_end = min(S, (int)(blockIdx.x + 1) * 32);
-    for (int j = blockIdx.x * 32 + wave; j < j_end; j += 4) {
+    const int j_end = min(S, (int)(blockIdx.x + 1) * slots);
+    for (int j = blockIdx.x * slots + wave; j < j_end; j += 4) {
         if (mv && mv[j] == 0) {                       // masked slot: its score is replaced by -1e9 downstream
             if (lane < T) score[((size_t)b * T + lane) * S + j] = 0.f;
             continue;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
                                                              const float* __restrict__ dscore,
                                                              float* __restrict__ dsrc, float* __restrict__ dtgt,
                                                              float* __restrict__ dw, float* __restrict__ dbias,
-                                                             const int32_t* __restrict__ mem_valid) {
+                                                             const int32_t* __restrict__ mem_valid, int slots) {
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     __shared__ float sm_dt[T_MAX * FIRA_D];
     __shared__ float sm_dw[FIRA_D + 1];
@@ -83,12 +83,14 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
         for (int e = 0; e < 4; ++e) dt[t][e] = 0.f;
     float dwa[4] = {0.f, 0.f, 0.f, 0.f};
     float dba = 0.f;
-    const int j_end = min(S, (int)(blockIdx.x + 1) * 32);
-    for (int j = blockIdx.x * 32 + wave; j < j_end; j += 4) {
+    bool any = false;
+    const int j_end = min(S, (int)(blockIdx.x + 1) * slots);
+    for (int j = blockIdx.x * slots + wave; j < j_end; j += 4) {
         if (mem_valid && mem_valid[(size_t)b * S + j] == 0) {     // masked slot: no gradient flows through masked_fill
             *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             continue;
         }
+        any = true;
         const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
         float ds[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -110,16 +112,19 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
         }
         *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(ds[0], ds[1], ds[2], ds[3]);
     }
+    if (any) {                                      // waves whose slots were all masked contribute nothing
 #pragma unroll
-    for (int t = 0; t < T_MAX; ++t)
-        if (t < T) {
+        for (int t = 0; t < T_MAX; ++t)
+            if (t < T) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[t * FIRA_D + lane * 4 + e], dt[t][e]);
-        }
+                for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[t * FIRA_D + lane * 4 + e], dt[t][e]);
+            }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
-    if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
-    __syncthreads();
+        for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
+        if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
+    }
+    const int any_block = __syncthreads_or(any ? 1 : 0);
+    if (!any_block) return;
     for (int i = t0; i < T * FIRA_D; i += 256) unsafeAtomicAdd(&dtgt[(size_t)b * T * FIRA_D + i], sm_dt[i]);
     for (int i = t0; i < FIRA_D; i += 256) unsafeAtomicAdd(&dw[i], sm_dw[i]);
     if (t0 == 0) unsafeAtomicAdd(dbias, sm_dw[FIRA_D]);
@@ -350,8 +355,9 @@ int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, cons
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX && qpk >= 1, "copy_score_fwd: T=%d > %d", T, T_MAX);
-    hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
-                       qpk, mem_valid);
+    const int slots = 8;          // memory slots per workgroup: small chunks so that masked stretches cost nothing
+    hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
+                       qpk, mem_valid, slots);
     FIRA_CHECK_LAUNCH("copy_score_fwd");
     return 0;
 }
@@ -364,8 +370,9 @@ int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, cons
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
-    hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, 32), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
-                       dtgt, dw, dbias, mem_valid);
+    const int slots = 16;
+    hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
+                       dtgt, dw, dbias, mem_valid, slots);
     FIRA_CHECK_LAUNCH("copy_score_bwd");
     return 0;
 }

@@ -20,6 +20,8 @@ int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const floa
                      int out_bstride, int out_off);
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
                      int out_bstride, int out_off, int padding_idx);
+int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
+                           int out_bstride, int out_off, int padding_idx, int table_rows);
 int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark, float* out,
                     float dropout, uint64_t seed, uint32_t site);
 int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,

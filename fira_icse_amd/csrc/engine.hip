@@ -427,7 +427,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(rows_move(s, 1, Nc, D, p.H, dXn, nullptr, bt.node_rows));
     TRY(embed_gather_bwd(s, p.B, p.L, bt.sou, G + L.emb, p.H, p.N, 0, 0));
     TRY(embed_gather_bwd(s, p.B, p.S, bt.sub_token, G + L.emb, p.H, p.N, p.L, 0));
-    TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
+    if (L.d.ast_vocab <= 128)
+        TRY(embed_gather_bwd_small(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0, L.d.ast_vocab));
+    else
+        TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
     TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
                     FIRA_GEMM_ACCUM, 1, G + L.b2_all));

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, co
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int flags, int* rc) {
     *rc = 0;
-    if (tA || M > 4096 || K % 32 != 0 || K < 64 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0) return false;
+    // beyond ~4 rounds of 32x32 tiles the LDS-tiled kernel's operand reuse wins; M <= 64 (decode) always lands here
+    const long tiles = (long)cdiv(M, 32) * cdiv(N, 32);
+    if (tA || (M > 64 && tiles > 1024) || K % 32 != 0 || K < 64 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0) return false;
     if (tB && (ldb % 4 != 0 || ((uintptr_t)B % 16) != 0)) return false;
     dim3 grid(cdiv(N, 32), cdiv(M, 32));
     if (tB) hipLaunchKernelGGL(gemm_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags);

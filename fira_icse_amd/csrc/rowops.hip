@@ -47,6 +47,33 @@ __global__ __launch_bounds__(256) void embed_gather_bwd_kernel(int rows, int L, 
     unsafeAtomicAdd(p + 3, g.w);
 }
 
+// Same for a SMALL table (the 71-row AST/edit-operation vocabulary): thousands of rows hit the same few table rows, so
+// global atomics serialise; each workgroup first reduces its slice of rows into an LDS copy of the table.
+__global__ __launch_bounds__(256) void embed_gather_bwd_small_kernel(int rows, int L, const int32_t* __restrict__ idx,
+                                                                     float* __restrict__ dtable,
+                                                                     const float* __restrict__ dout, int out_bstride,
+                                                                     int out_off, int padding_idx, int table_rows,
+                                                                     int rows_per_block) {
+    extern __shared__ float tab[];                       // [table_rows][256]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < table_rows * FIRA_D; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int r_beg = blockIdx.x * rows_per_block, r_end = min(rows, r_beg + rows_per_block);
+    for (int r = r_beg + wave; r < r_end; r += 4) {
+        const int id = idx[r];
+        if (id == padding_idx) continue;
+        const int b = r / L, i = r - b * L;
+        const float4 g = *reinterpret_cast<const float4*>(dout + ((size_t)b * out_bstride + out_off + i) * FIRA_D + lane * 4);
+        float* p = tab + (size_t)id * FIRA_D + lane * 4;
+        atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+    }
+    __syncthreads();
+    for (int i = t; i < table_rows * FIRA_D; i += 256) {
+        const float v = tab[i];
+        if (v != 0.f) unsafeAtomicAdd(&dtable[i], v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // CombinationLayer (reference combination_layer.py:7-17): per element
 //   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
@@ -373,6 +400,24 @@ int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const floa
     hipLaunchKernelGGL(embed_gather_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, L, idx, table, pos, out,
                        out_bstride, out_off);
     FIRA_CHECK_LAUNCH("embed_gather_fwd");
+    return 0;
+}
+int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
+                           int out_bstride, int out_off, int padding_idx, int table_rows) {
+    const int rows = B * L;
+    if (rows <= 0) return 0;
+    FIRA_REQUIRE(table_rows > 0 && table_rows * FIRA_D * 4 <= 150 * 1024, "embed_gather_bwd_small: table of %d rows does not fit LDS", table_rows);
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)embed_gather_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    const int rpb = std::max(64, cdiv(rows, 96));
+    hipLaunchKernelGGL(embed_gather_bwd_small_kernel, dim3(cdiv(rows, rpb)), dim3(256),
+                       (size_t)table_rows * FIRA_D * sizeof(float), s, rows, L, idx, dtable, dout, out_bstride, out_off,
+                       padding_idx, table_rows, rpb);
+    FIRA_CHECK_LAUNCH("embed_gather_bwd_small");
     return 0;
 }
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,

@@ -142,16 +142,24 @@ def main():
     prof = prof_report()
     lib.fira_prof_enable(0)
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
+    try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        with open(os.path.join(HERE, "profiles", "traffic.json")) as f:
+            traffic = json.load(f)
+    except Exception:
+        traffic = {}
     gemm, spmm = prof["gemm"], prof["spmm"]
     spmm_bytes = spmm["work"] + 8.0 * nnz_mean * spmm["count"]              # + (col,val) of the batch's nnz
     roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                 "achieved": gemm["work"] / (gemm["ms"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
+                "frac": gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+                "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
+                "algorithmic_flop_per_launch": gemm["work"] / max(gemm["count"], 1),
                 "launches_per_step": gemm["count"] // prof_steps, "avg_launch_us": 1e3 * gemm["ms"] / max(gemm["count"], 1),
                 "share_of_kernel_time": gemm["ms"] / total_ms}
     spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes / (spmm["ms"] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes / (spmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_us": 1e3 * spmm["ms"] / max(spmm["count"], 1),
+                "traffic": traffic.get("spmm", {}).get("hbm_bytes_per_launch"),
+                "avg_launch_us": 1e3 * spmm["ms"] / max(spmm["count"], 1),
                 "bytes_per_launch": spmm_bytes / max(spmm["count"], 1), "share_of_kernel_time": spmm["ms"] / total_ms}
 
     # ---- greedy decode (BASELINE configs[3]): tokens/s, batch 64, encoder included

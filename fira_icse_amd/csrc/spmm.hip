@@ -9,7 +9,8 @@
 //   256-wide row as float4 (one coalesced 1 KiB load per neighbour row); col/val of the row are fetched
 //   64 at a time with one coalesced load and broadcast lane-to-lane (readlane), neighbour loads are
 //   issued 4 deep before the FMAs.  No atomics: the reduction over neighbours is a per-lane register sum.
-//   Neighbour re-reads (each H row is used ~4x) hit L2: a graph's H is 665 KB.
+//   Neighbour re-reads (each H row is used ~4x) hit L2: a graph's H is 665 KB and the workgroup->row mapping is
+//   XCD-aware (each XCD's private L2 serves whole graphs).
 // variant 2 (dense stress graphs, SURVEY.md config 5, ~120 nnz/row): one workgroup per (graph, 64-column
 //   slab); the slab of H (rows x 64 floats) is staged once into LDS with coalesced float4 loads and every
 //   neighbour gather is an LDS read (ds_read_b128: a 16-lane group covers one 64-float row and owns one
@@ -24,7 +25,13 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
                                                            const float* __restrict__ X, int ldx,
                                                            float* __restrict__ Y, int ldy) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware row mapping: workgroup b runs on XCD b % 8 and each XCD has its own L2, so workgroup b is given the
+    // row group (b % 8) * ceil(nwg / 8) + b / 8: every XCD then owns one contiguous eighth of the rows (whole graphs of
+    // the block-diagonal batch), and the ~4x re-reads of a graph's H rows hit that XCD's L2 instead of each XCD
+    // fetching them again (PMC: 2.6x the compulsory read traffic with the round-robin mapping).
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int grp = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int row = grp * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -135,8 +142,9 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
         hipLaunchKernelGGL(spmm_lds_kernel, dim3(FIRA_D / SLAB, n_rows / graph_rows), dim3(512), lds, s, graph_rows,
                            rowptr, col, val, X, ldx, Y, ldy);
     } else {
-        hipLaunchKernelGGL(spmm_rowwave_kernel, dim3(cdiv(n_rows, 4)), dim3(256), 0, s, n_rows, rowptr, col, val, X,
-                           ldx, Y, ldy);
+        // grid rounded up to a multiple of 8 so that the XCD remap above is a bijection onto the row groups
+        hipLaunchKernelGGL(spmm_rowwave_kernel, dim3(cdiv(cdiv(n_rows, 4), 8) * 8), dim3(256), 0, s, n_rows, rowptr, col,
+                           val, X, ldx, Y, ldy);
     }
     FIRA_CHECK_LAUNCH("csr_spmm");
     return 0;

@@ -94,48 +94,69 @@ __global__ __launch_bounds__(512) void spmm_lds_kernel(int graph_rows, const int
     const int sub = lane >> 4, l16 = lane & 15;
     const int q = l16 * 4;
     int2* stage = reinterpret_cast<int2*>(slab + (size_t)graph_rows * SLAB) + (wave * 4 + sub) * STAGE;
+
+    auto gather = [&](float4& acc, int n) {          // acc += sum over stage[0..n) of val * slab[col]
+        int j = 0;
+        for (; j + 8 <= n; j += 8) {
+            int2 e[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) e[u] = stage[j + u];
+            float4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(&slab[e[u].x * SLAB + q]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = __int_as_float(e[u].y);
+                acc.x = fmaf(v, x[u].x, acc.x); acc.y = fmaf(v, x[u].y, acc.y);
+                acc.z = fmaf(v, x[u].z, acc.z); acc.w = fmaf(v, x[u].w, acc.w);
+            }
+        }
+        for (; j < n; ++j) {
+            const int2 e = stage[j];
+            const float4 x = *reinterpret_cast<const float4*>(&slab[e.x * SLAB + q]);
+            const float v = __int_as_float(e.y);
+            acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y);
+            acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+        }
+    };
+    // (col, val) of a row's first STAGE entries, one register pair per lane and pass slot
+    int2 pre[STAGE / 16];
+    int beg = 0, end = 0;
+    auto prefetch = [&](int r) {
+        const bool live = r < graph_rows;
+        beg = live ? rowptr[row0 + r] : 0;
+        end = live ? rowptr[row0 + r + 1] : 0;
+#pragma unroll
+        for (int u = 0; u < STAGE / 16; ++u) {
+            const int i = beg + u * 16 + l16;
+            pre[u] = i < end ? make_int2(col[i] - row0, __float_as_int(val[i])) : make_int2(0, 0);
+        }
+    };
+    prefetch(wave * 4 + sub);
     for (int r4 = wave * 4; r4 < graph_rows; r4 += 32) {
         const int r = r4 + sub;
-        const bool live = r < graph_rows;
-        const int beg = live ? rowptr[row0 + r] : 0;
-        const int end = live ? rowptr[row0 + r + 1] : 0;
+        const int cbeg = beg, cend = end;
+#pragma unroll
+        for (int u = 0; u < STAGE / 16; ++u) stage[u * 16 + l16] = pre[u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        prefetch(r + 32);                              // next row's index list streams in under this row's gathers
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int base = beg; base < end; base += STAGE) {
-            const int n = min(STAGE, end - base);
-            // stage this pass's (col - row0, val) pairs: 16 lanes x up to 8 coalesced loads
+        gather(acc, min(STAGE, cend - cbeg));
+        for (int base = cbeg + STAGE; base < cend; base += STAGE) {      // rows longer than one staging pass
+            __builtin_amdgcn_wave_barrier();
+            const int n = min(STAGE, cend - base);
 #pragma unroll
             for (int u = 0; u < STAGE / 16; ++u) {
                 const int i = u * 16 + l16;
                 if (i < n) stage[i] = make_int2(col[base + i] - row0, __float_as_int(val[base + i]));
             }
-            // same-wave producer/consumer through LDS: the compiler orders the ds_write/ds_read by lgkmcnt
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int j = 0;
-            for (; j + 8 <= n; j += 8) {
-                int2 e[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) e[u] = stage[j + u];
-                float4 x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(&slab[e[u].x * SLAB + q]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float v = __int_as_float(e[u].y);
-                    acc.x = fmaf(v, x[u].x, acc.x); acc.y = fmaf(v, x[u].y, acc.y);
-                    acc.z = fmaf(v, x[u].z, acc.z); acc.w = fmaf(v, x[u].w, acc.w);
-                }
-            }
-            for (; j < n; ++j) {
-                const int2 e = stage[j];
-                const float4 x = *reinterpret_cast<const float4*>(&slab[e.x * SLAB + q]);
-                const float v = __int_as_float(e.y);
-                acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y);
-                acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
-            }
-            __builtin_amdgcn_wave_barrier();
+            gather(acc, n);
         }
-        if (live) *reinterpret_cast<float4*>(Y + (size_t)(row0 + r) * ldy + c0 + q) = acc;
+        __builtin_amdgcn_wave_barrier();
+        if (r < graph_rows) *reinterpret_cast<float4*>(Y + (size_t)(row0 + r) * ldy + c0 + q) = acc;
     }
 }
 

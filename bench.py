@@ -123,6 +123,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         trainer.step(batches[i % a.pool])
+    t_enq = time.perf_counter() - t0                  # host time to enqueue the steps (the stream is still draining)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -199,6 +200,7 @@ def main():
             "metric": "training commits/sec (FIRA default config)", "value": commits_per_s, "unit": "commits/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": "BASELINE configs[1]: FIRA training step (fwd+bwd+Adam, dropout 0.1/0.2), "
                                    "batch %d commits/GPU, fp32, 650-node graphs (mean nnz %.0f/graph), vocab 24650" %
                                    (B, nnz_mean / B),

@@ -77,11 +77,29 @@ SIGNATURES = {
 }
 
 
+def _ensure_built():
+    """Build the library on first use if it is missing (same command as `python -m fira_icse_amd.build`).
+    This is a build step, not a compute fallback: without hipcc the import fails."""
+    if os.path.exists(LIB_PATH):
+        return
+    import fcntl
+    from . import build as _build
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:      # ranks of one node import concurrently
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB_PATH):
+                _build.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def load():
-    if not os.path.exists(LIB_PATH):
+    try:
+        _ensure_built()
+    except Exception as e:
         raise ImportError(
-            "fira_icse_amd: %s is missing. Build it with `python -m fira_icse_amd.build` (needs hipcc, "
-            "gfx950). There is no CPU fallback." % LIB_PATH)
+            "fira_icse_amd: %s is missing and could not be built (%s). Build it with `python -m fira_icse_amd.build` "
+            "(needs hipcc, gfx950). There is no CPU fallback." % (LIB_PATH, e))
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

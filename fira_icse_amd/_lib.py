@@ -72,6 +72,7 @@ SIGNATURES = {
     "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P]),
     "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
     "fira_decode_step": (_I, [_P, _DP, _P, _P, _Z, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "fira_decoder_forward": (_I, [_P, _DP, _P, _P, _Z, _I, _P, _P, _P, _P]),
     "fira_decode_memory": (_P, [_DP, _P, _I, _I]),
     "fira_decode_mem_valid": (_P, [_DP, _P, _I, _I]),
 }

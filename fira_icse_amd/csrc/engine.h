@@ -43,6 +43,7 @@ int relu_bwd(hipStream_t s, int64_t n, float* dh, const float* h);
 int make_masks(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
                int32_t* mem_valid, int32_t* tar_valid);
 int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar);
+int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid);
 int invert_rows(hipStream_t s, int BT, int R, const int32_t* rows, int32_t* compact_row);
 int iota_rows(hipStream_t s, int n, int32_t* out);
 // beam re-ordering of the decoder self-attention cache: dst[r, 0:len) = src[parent[r], 0:len) for nl layers of K and V,

@@ -614,6 +614,33 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
     return 0;
 }
 
+// Decoder.forward on caller-supplied memory (the piecewise surface the reference's test loop uses:
+// model.decoder(ids, memory, mem_mask, tar_pad_mask), run_model.py:256): full 30-position recompute.
+int fira_decoder_forward(void* stream, const fira_dims* d, const float* params, void* workspace, size_t workspace_bytes,
+                         int B, const int32_t* tar, const float* memory, const int32_t* mem_valid, float* out) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    FIRA_REQUIRE(params && workspace && tar && memory && mem_valid && out && B > 0, "bad argument");
+    Plan p;
+    const size_t need = p.build(workspace, *d, B, false);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = FIRA_D, KV = p.nl * 2 * D;
+    fira_batch b{};
+    b.B = B;
+    b.tar = tar;
+    Ctx c{s, L, &b, params, nullptr, &p, 0.f, 0.f, 0};
+    TRY(fill_pos_tables(s, p.L, p.pos_code, p.T, p.pos_tar));
+    hipError_t e = hipMemcpyAsync(p.mem_valid, mem_valid, (size_t)p.MB * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return set_err("hipMemcpyAsync: %s", hipGetErrorString(e));
+    TRY(tar_mask(s, p.TB, tar, p.tar_valid));
+    TRY(linear(s, p.MB, KV, D, memory, D, params + L->wkv_all, params + L->bkv_all, p.kv_all, KV));
+    TRY(decoder_forward(c));
+    e = hipMemcpyAsync(out, p.dec[p.nl - 1].x_f, (size_t)p.TB * D * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return set_err("hipMemcpyAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
 const float* fira_decode_memory(const fira_dims* d, void* workspace, int B, int n_beam) {
     if (!get_layout(d) || !workspace) return nullptr;
     DecodePlan dp;

@@ -379,6 +379,15 @@ int make_masks(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, co
     FIRA_CHECK_LAUNCH("make_masks");
     return 0;
 }
+__global__ void tar_mask_kernel(int n, const int32_t* __restrict__ tar, int32_t* __restrict__ valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) valid[i] = tar[i] != 0;
+}
+int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid) {
+    hipLaunchKernelGGL(tar_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, tar, valid);
+    FIRA_CHECK_LAUNCH("tar_mask");
+    return 0;
+}
 int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar) {
     hipLaunchKernelGGL(pos_table_kernel, dim3(cdiv(L * FIRA_D, 256)), dim3(256), 0, s, L, pos_code);
     hipLaunchKernelGGL(pos_table_kernel, dim3(cdiv(T * FIRA_D, 256)), dim3(256), 0, s, T, pos_tar);

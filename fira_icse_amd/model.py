@@ -209,6 +209,16 @@ class DeviceBatch:
             self.n_head_rows)
 
 
+def _as_tensor(ptr: int, shape, device) -> torch.Tensor:
+    """Zero-copy fp32 view of library-owned device memory (valid until the workspace is reused)."""
+    n = int(np.prod(shape))
+
+    class _Mem:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+    return torch.as_tensor(_Mem(), device=device).view(shape)
+
+
 class _FusedStep(torch.autograd.Function):
     """Autograd hook for the drop-in ``forward(..., 'train')``: the engine computes d(loss_sum)/d(params) together
     with the loss; ``backward`` only scales it by the incoming gradient (1 / n_tok in the reference driver)."""
@@ -320,6 +330,62 @@ class TransModel(nn.Module):
                                         _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok)), "fira_forward_dev")
         return ids
 
+    # ------------------------------------------------------------------ piecewise surface of the reference's test loop
+    # (run_model.py:204,256-259 call model.encoder / model.decoder / model.out_fc / model.copy_net directly).  These
+    # run the same kernels as the fused paths; they exist for drop-in compatibility, the fast search is decode.Searcher.
+    def encoder(self, input_token, sou_mask, attr, mark, ast_change, edge, sub_token):
+        """-> (code states [B,210,256], sub-token states [B,160,256]) (gnn_transformer.py:45-62)."""
+        cfg = self.cfg
+        db = edge if isinstance(edge, DeviceBatch) else self.make_batch(
+            input_token, None, mark, ast_change, edge, None, sub_token)
+        lib = _lib.lib()
+        n = lib.fira_decode_workspace_bytes(C.byref(self.dims), db.B, 1)
+        ws = self._ws.setdefault(("enc", db.B), torch.empty(n, dtype=torch.uint8, device=self.device_))
+        _lib.check(lib.fira_decode_begin(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
+                                         _lib.ptr(self.flat.data), _lib.ptr(ws), ws.numel(), 1), "fira_decode_begin")
+        # rows of padded slots are not computed (the reference computes values nobody reads there): zero them
+        ptr = lib.fira_decode_memory(C.byref(self.dims), _lib.ptr(ws), db.B, 1)
+        mem = torch.zeros((db.B, cfg.mem_len, 256), dtype=torch.float32, device=self.device_)
+        valid = torch.zeros((db.B * cfg.mem_len,), dtype=torch.bool, device=self.device_)
+        valid[db.mem_dst.long()] = True
+        src = _as_tensor(ptr, (db.B, cfg.mem_len, 256), self.device_)
+        mem.view(-1, 256)[valid] = src.view(-1, 256)[valid]
+        return mem[:, :cfg.sou_len], mem[:, cfg.sou_len:]
+
+    def decoder(self, output_token, input_em, sou_mask, tar_mask_pad=None):
+        """Full-recompute Decoder.forward (gnn_transformer.py:108-122): ids [B,30], memory [B,370,256], mask [B,370]."""
+        B = output_token.shape[0]
+        lib = _lib.lib()
+        ws = self.workspace(B, 0)
+        out = torch.empty((B, self.cfg.tar_len, 256), dtype=torch.float32, device=self.device_)
+        tar = output_token.to(self.device_, torch.int32).contiguous()
+        mem = input_em.to(self.device_, torch.float32).contiguous()
+        mv = sou_mask.to(self.device_).to(torch.int32).contiguous()
+        _lib.check(lib.fira_decoder_forward(_lib.cur_stream(), C.byref(self.dims), _lib.ptr(self.flat.data),
+                                            _lib.ptr(ws), ws.numel(), B, _lib.ptr(tar), _lib.ptr(mem), _lib.ptr(mv),
+                                            _lib.ptr(out)), "fira_decoder_forward")
+        return out
+
+    def out_fc(self, x):
+        from . import ops
+        v = self._views
+        y = ops.gemm(x.reshape(-1, 256).contiguous(), v["out_fc.weight"], bias=v["out_fc.bias"])
+        return y.view(*x.shape[:-1], self.cfg.vocab_size)
+
+    def copy_net(self, source, target):
+        """-> (copy scores [B,T,S], gate probabilities [B,T,2]) (Model.py:15-20)."""
+        from . import ops
+        v = self._views
+        B, S, _ = source.shape
+        T = target.shape[1]
+        src = ops.gemm(source.reshape(-1, 256).contiguous(), v["copy_net.LinearSource.weight"]).view(B, S, 256)
+        tgt = ops.gemm(target.reshape(-1, 256).contiguous(), v["copy_net.LinearTarget.weight"]).view(B, T, 256)
+        score = ops.copy_score_fwd(src, tgt, v["copy_net.LinearRes.weight"].reshape(-1).contiguous(),
+                                   v["copy_net.LinearRes.bias"])
+        z = ops.gemm(target.reshape(-1, 256).contiguous(), v["copy_net.LinearProb.weight"],
+                     bias=v["copy_net.LinearProb.bias"]).view(B, T, 2)
+        return score, torch.softmax(z, dim=-1)       # 2-way gate: the only torch arithmetic, compatibility path only
+
     # ------------------------------------------------------------------ the reference's call signature
     def make_batch(self, sou, tar, mark, ast_change, edge, tar_label, sub_token) -> DeviceBatch:
         """Build a DeviceBatch from the reference's tensors; ``edge`` may be the dense [B,N,N] adjacency
@@ -334,8 +400,9 @@ class TransModel(nn.Module):
         counts = torch.bincount(rows_b * N + rows_i, minlength=B * N)
         rowptr = torch.zeros(B * N + 1, dtype=torch.int64)
         rowptr[1:] = torch.cumsum(counts, 0)
-        hb = HostBatch(sou.cpu().numpy(), tar.cpu().numpy(), mark.cpu().numpy(), ast_change.cpu().numpy(),
-                       tar_label.cpu().numpy(), sub_token.cpu().numpy(), rowptr.numpy().astype(np.int32),
+        npy = lambda t: None if t is None else t.cpu().numpy()
+        hb = HostBatch(npy(sou), npy(tar), npy(mark), npy(ast_change), npy(tar_label), npy(sub_token),
+                       rowptr.numpy().astype(np.int32),
                        (rows_b * N + cols).numpy().astype(np.int32), e[nz].to(torch.float32).numpy())
         return DeviceBatch(hb, self.cfg, self.device_)
 

@@ -219,6 +219,12 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
                      size_t workspace_bytes, int B, int n_beam, int step, const int32_t* tokens,
                      const int32_t* parent, float* dist, int32_t* best_id, float* best_p);
 
+/* Decoder.forward over all tar_len positions on caller-supplied memory [B, sou+sub, 256] / mem_valid [B, sou+sub]
+ * (gnn_transformer.py:108-122; the call of run_model.py:256).  Workspace: fira_workspace_bytes(d, B, 0).          */
+int fira_decoder_forward(void* stream, const fira_dims* d, const float* params, void* workspace,
+                         size_t workspace_bytes, int B, const int32_t* tar, const float* memory,
+                         const int32_t* mem_valid, float* out);
+
 /* read-only views into a decode workspace (device pointers), for tests and the Python driver */
 const float*   fira_decode_memory(const fira_dims* d, void* workspace, int B, int n_beam);
 const int32_t* fira_decode_mem_valid(const fira_dims* d, void* workspace, int B, int n_beam);

@@ -33,6 +33,7 @@ if HERE not in sys.path:
 from fira_icse_amd import data, metrics, text                      # noqa: E402
 from fira_icse_amd.config import EOS, FiraConfig                  # noqa: E402
 from fira_icse_amd.parallel import gather_lines, init_from_env, shard_indices   # noqa: E402
+from fira_icse_amd.prefetch import prefetch                        # noqa: E402
 
 
 def seed_everything(seed=0):
@@ -148,7 +149,12 @@ class Run:
         n_batches = -(-len(store) // cfg.batch_size)
         for epoch in range(cfg.epoches):
             total_data, t0 = 0, time.time()
-            for idx_b, gidx in enumerate(data.iterate_batches(len(store), cfg.batch_size, shuffle=True)):
+            def prepare(gidx):                                     # worker thread: collate + H2D of this rank's shard
+                mine = shard_indices(gidx, self.rank, self.world)   # DataParallel.scatter's contiguous chunks
+                return gidx, (self.device_batch(store, mine) if mine else None)
+
+            batches = prefetch(data.iterate_batches(len(store), cfg.batch_size, shuffle=True), prepare, depth=2)
+            for idx_b, (gidx, db) in enumerate(batches):
                 if epoch >= a.dev_from_epoch and idx_b % a.dev_every == 0:
                     cur_bleu, output_str = self.dev(epoch)
                     if self.rank == 0:
@@ -164,9 +170,8 @@ class Run:
                             with open(self.out("dev_output"), "w") as f:
                                 f.write(output_str)
                     self.model.train(not a.no_dropout)
-                mine = shard_indices(gidx, self.rank, self.world)      # DataParallel.scatter's contiguous chunks
-                if mine:
-                    trainer.step(self.device_batch(store, mine))
+                if db is not None:
+                    trainer.step(db)
                 total_data += len(gidx)
                 steps += 1
                 if idx_b % 10 == 0 and self.rank == 0:

@@ -1,0 +1,36 @@
+import threading
+import time
+
+import pytest
+
+from fira_icse_amd.prefetch import prefetch
+
+
+def test_order_and_overlap():
+    seen = []
+
+    def prepare(i):
+        time.sleep(0.02)
+        seen.append((i, threading.current_thread().name))
+        return i * i
+
+    t0 = time.time()
+    out = []
+    for v in prefetch(range(6), prepare, depth=2):
+        time.sleep(0.02)                      # the consumer's own work overlaps the worker's
+        out.append(v)
+    assert out == [i * i for i in range(6)]
+    assert all(name != threading.current_thread().name for _, name in seen)
+    assert time.time() - t0 < 6 * 0.04 - 0.03
+
+
+def test_errors_surface_at_the_consumer():
+    def prepare(i):
+        if i == 2:
+            raise ValueError("bad batch")
+        return i
+
+    it = prefetch(range(5), prepare)
+    assert next(it) == 0 and next(it) == 1
+    with pytest.raises(ValueError):
+        next(it)

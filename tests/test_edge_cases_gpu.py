@@ -1,0 +1,96 @@
+"""Edge cases of the hot path against the CPU oracle: single commit, a commit without sub-tokens / AST / edits, a
+message made only of copied tokens (no row needs the vocabulary head), a maximum-length message, an over-long diff."""
+import numpy as np
+import pytest
+import torch
+
+import util
+from fira_icse_amd import data, synth
+from fira_icse_amd.config import FiraConfig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model_sd():
+    from fira_icse_amd.model import TransModel, reference_init_state_dict
+    cfg = FiraConfig()
+    torch.manual_seed(0)
+    sd = util.perturb_state_dict(reference_init_state_dict(cfg), seed=1)
+    model = TransModel(cfg, init=False)
+    model.load_state_dict(sd)
+    model.eval()
+    return cfg, model, sd
+
+
+def special_raw():
+    """4 hand-made commits in the raw schema."""
+    ds = synth.generate_dataset(4, seed=7)
+    words = [w for w in ds["word_vocab"] if w.startswith("w0")][:40]
+    # commit 0: no identifiers (no sub-token nodes), no AST, no edit operations
+    ds["difftoken"][0] = words[:12]
+    ds["diffatt"][0] = [[] for _ in range(12)]
+    ds["diffmark"][0] = [2] * 12
+    ds["ast"][0], ds["change"][0] = [], []
+    for k in ("edge_ast", "edge_ast_code", "edge_change_ast", "edge_change_code"):
+        ds[k][0] = []
+    ds["msg"][0] = ["fix", words[20]]
+    ds["variable"][0] = {}
+    # commit 1: every message token is copied from the diff -> no target row needs the vocabulary GEMM
+    ds["msg"][1] = [t for t in ds["difftoken"][1][:6]]
+    # commit 2: maximum-length message (28 tokens + <start>/<eos> = 30 positions)
+    ds["msg"][2] = [words[i % 40] for i in range(28)]
+    # commit 3: over-long diff (truncated at 208 tokens; unguarded sequential edges)
+    ds["difftoken"][3] = [words[i % 40] for i in range(230)]
+    ds["diffatt"][3] = [[] for _ in range(230)]
+    ds["diffmark"][3] = [2] * 230
+    ds["edge_ast_code"][3] = [[0, j] for j in range(0, 230, 7)] if ds["ast"][3] else []
+    ds["edge_change_code"][3] = [e for e in ds["edge_change_code"][3] if e[1] < 230]
+    return ds
+
+
+@pytest.mark.parametrize("sel", [[0], [1], [2], [3], [0, 1, 2, 3]])
+def test_loss_grad_and_ids_vs_oracle(model_sd, sel):
+    from oracle import fira_oracle as O
+    from fira_icse_amd.model import DeviceBatch
+    cfg, model, sd = model_sd
+    store = data.process_raw(cfg, special_raw())
+    hb = store.batch(sel)
+    db = DeviceBatch(hb, cfg)
+    if sel == [1]:
+        assert db.n_head_rows <= 1                      # only the <eos> row can still need the generator
+    tb = util.to_torch_batch(hb, cfg)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ls, nt = O.forward(P, cfg, tb["sou"], tb["tar"], tb["mark"], tb["ast_change"], tb["edge"], tb["tar_label"],
+                       tb["sub_token"], "train")
+    ls.backward()
+    loss, ntok = model.train_fwd_bwd(db)
+    assert int(ntok) == int(nt)
+    assert abs(float(loss) - float(ls.detach())) <= 1e-5 * float(ls.detach())
+    gv = model.grad_views()
+    num = sum(float((gv[k].cpu().double() - p.grad.double()).norm() ** 2) for k, p in P.items() if p.grad is not None)
+    den = sum(float(p.grad.double().norm() ** 2) for p in P.values() if p.grad is not None)
+    assert (num / den) ** 0.5 < 1e-4
+    with torch.no_grad():
+        ids = O.forward(sd, cfg, tb["sou"], tb["tar"], tb["mark"], tb["ast_change"], tb["edge"], tb["tar_label"],
+                        tb["sub_token"], "dev")
+    real = tb["tar"] != 0                                # positions past the message are never read by dev()
+    assert torch.equal(model.forward_dev(db).cpu().long()[real], ids[real])
+
+
+def test_greedy_early_stop_and_single_commit(model_sd):
+    """A batch whose every hypothesis ends immediately stops the chunked graph replay early; batch of one works."""
+    from fira_icse_amd.model import DeviceBatch, TransModel
+    from fira_icse_amd.decode import Searcher
+    cfg, model, sd = model_sd
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["out_fc.bias"][1] += 1e4                         # <eos> wins every step
+    sd2["copy_net.LinearProb.bias"][0] += 50.0           # generator branch only
+    m2 = TransModel(cfg, init=False)
+    m2.load_state_dict(sd2)
+    m2.eval()
+    store = data.process_raw(cfg, special_raw())
+    for sel in ([2], [0, 1, 2, 3]):
+        out, length, prob = Searcher(m2).greedy(DeviceBatch(store.batch(sel), cfg))
+        assert length.tolist() == [2] * len(sel) and out[:, 1].tolist() == [1] * len(sel)
+        assert float(prob.min()) > 0.99

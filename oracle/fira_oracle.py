@@ -73,11 +73,13 @@ def gcn(P: Params, pre: str, x: torch.Tensor, adj32: torch.Tensor) -> torch.Tens
 def encoder(P: Params, cfg, sou, mark, ast_change, edge, sub_token) -> Tuple[torch.Tensor, torch.Tensor]:
     """Reference gnn_transformer.py:45-62. ``edge`` is the [B,N,N] adjacency (any float dtype)."""
     L, S = cfg.sou_len, cfg.sub_token_len
+    # padding_idx=0 on the three encoder tables (gnn_transformer.py:32-39): row 0 never receives a gradient, which is
+    # observable when an over-long diff chains id-0 sub-token nodes into the graph (SURVEY.md N2)
     emb = P["encoder.embedding.weight"]
-    x = emb[sou] + position_table(L, cfg.embedding_dim)
-    mark_em = P["encoder.mark_embedding.weight"][mark]
-    ast_em = P["encoder.ast_change_embedding.weight"][ast_change]
-    sub_em = emb[sub_token]
+    x = F.embedding(sou, emb, padding_idx=0) + position_table(L, cfg.embedding_dim)
+    mark_em = F.embedding(mark, P["encoder.mark_embedding.weight"], padding_idx=0)
+    ast_em = F.embedding(ast_change, P["encoder.ast_change_embedding.weight"], padding_idx=0)
+    sub_em = F.embedding(sub_token, emb, padding_idx=0)
     adj32 = edge.float()
     for i in range(cfg.num_layers):
         x = combination(P, "encoder.combination_list2.%d" % i, x, mark_em, cfg.d_head)

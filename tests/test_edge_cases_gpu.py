@@ -23,38 +23,12 @@ def model_sd():
     return cfg, model, sd
 
 
-def special_raw():
-    """4 hand-made commits in the raw schema."""
-    ds = synth.generate_dataset(4, seed=7)
-    words = [w for w in ds["word_vocab"] if w.startswith("w0")][:40]
-    # commit 0: no identifiers (no sub-token nodes), no AST, no edit operations
-    ds["difftoken"][0] = words[:12]
-    ds["diffatt"][0] = [[] for _ in range(12)]
-    ds["diffmark"][0] = [2] * 12
-    ds["ast"][0], ds["change"][0] = [], []
-    for k in ("edge_ast", "edge_ast_code", "edge_change_ast", "edge_change_code"):
-        ds[k][0] = []
-    ds["msg"][0] = ["fix", words[20]]
-    ds["variable"][0] = {}
-    # commit 1: every message token is copied from the diff -> no target row needs the vocabulary GEMM
-    ds["msg"][1] = [t for t in ds["difftoken"][1][:6]]
-    # commit 2: maximum-length message (28 tokens + <start>/<eos> = 30 positions)
-    ds["msg"][2] = [words[i % 40] for i in range(28)]
-    # commit 3: over-long diff (truncated at 208 tokens; unguarded sequential edges, SURVEY.md N2)
-    ds["difftoken"][3] = [words[i % 40] for i in range(230)]
-    ds["diffatt"][3] = [[] for _ in range(230)]
-    ds["diffmark"][3] = [2] * 230
-    ds["edge_ast_code"][3] = [[0, j] for j in range(0, 230, 7)] if ds["ast"][3] else []
-    ds["edge_change_code"][3] = [e for e in ds["edge_change_code"][3] if e[1] < 230]
-    return ds
-
-
 @pytest.mark.parametrize("sel", [[0], [1], [2], [3], [0, 1, 2, 3]])
 def test_loss_grad_and_ids_vs_oracle(model_sd, sel):
     from oracle import fira_oracle as O
     from fira_icse_amd.model import DeviceBatch
     cfg, model, sd = model_sd
-    store = data.process_raw(cfg, special_raw())
+    store = data.process_raw(cfg, util.edge_case_raw())
     hb = store.batch(sel)
     db = DeviceBatch(hb, cfg)
     if sel == [1]:
@@ -89,7 +63,7 @@ def test_greedy_early_stop_and_single_commit(model_sd):
     m2 = TransModel(cfg, init=False)
     m2.load_state_dict(sd2)
     m2.eval()
-    store = data.process_raw(cfg, special_raw())
+    store = data.process_raw(cfg, util.edge_case_raw())
     for sel in ([2], [0, 1, 2, 3]):
         out, length, prob = Searcher(m2).greedy(DeviceBatch(store.batch(sel), cfg))
         assert length.tolist() == [2] * len(sel) and out[:, 1].tolist() == [1] * len(sel)

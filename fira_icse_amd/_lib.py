@@ -28,7 +28,8 @@ class Batch(C.Structure):
                 ("n_nodes", C.c_int32), ("node_rows", C.c_void_p), ("rowptr", C.c_void_p), ("col", C.c_void_p),
                 ("val", C.c_void_p), ("n_code", C.c_int32), ("code_rows", C.c_void_p), ("code_mark", C.c_void_p),
                 ("n_mem", C.c_int32), ("mem_rows", C.c_void_p), ("mem_dst", C.c_void_p), ("head_rows", C.c_void_p),
-                ("n_head_rows", C.c_int32)]
+                ("n_head_rows", C.c_int32), ("n_emb_items", C.c_int32), ("emb_item_tok", C.c_void_p),
+                ("emb_item_ptr", C.c_void_p), ("emb_rows", C.c_void_p)]
 
 
 class TrainOpts(C.Structure):

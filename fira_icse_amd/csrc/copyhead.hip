@@ -27,14 +27,23 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ score, int qpk,
-                                                             const int32_t* __restrict__ mem_valid, int slots) {
+                                                             const int32_t* __restrict__ mem_valid, int slots,
+                                                             const int32_t* __restrict__ tar_label, int V) {
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
+    __shared__ unsigned sm_mask;
     const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
+    // training: only rows whose label is a copied token read their copy scores (the NLL takes one entry of
+    // [gen ; copy], Model.py:80-86); the others are left unwritten and head_loss neither reads nor propagates them
+    if (t0 == 0) sm_mask = tar_label ? 0u : 0xffffffffu;
+    __syncthreads();
+    if (tar_label && t0 < T - 1 && tar_label[b * T + t0 + 1] >= V) atomicOr(&sm_mask, 1u << t0);
     src += (size_t)(b / qpk) * S * FIRA_D - (size_t)b * S * FIRA_D;     // qpk target batches share one memory
     const int32_t* mv = mem_valid ? mem_valid + (size_t)(b / qpk) * S : nullptr;
     for (int i = t0; i < T * (FIRA_D / 4); i += 256)
         reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
     __syncthreads();
+    const unsigned mask = sm_mask;
+    if (mask == 0u) return;
     const float4 w4 = *reinterpret_cast<const float4*>(w + lane * 4);
     const float c = bias[0];
     const int j_end = min(S, (int)(blockIdx.x + 1) * slots);
@@ -45,6 +54,7 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
         }
         const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
         for (int t = 0; t < T; ++t) {
+            if (!((mask >> t) & 1u)) continue;
             const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
             float a = w4.x * tanh_fast(s4.x + x.x);
             a = fmaf(w4.y, tanh_fast(s4.y + x.y), a);
@@ -59,6 +69,9 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
 // backward (tanh re-computed): dsrc[b,j,:] = sum_t g*w*(1-th^2)   (owned by one wave: plain store)
 //                              dtgt[b,t,:] += sum_j (same)        (registers -> LDS -> global atomics)
 //                              dw += sum g*th ; dbias += sum g
+// Only target rows whose label is a copied token carry a non-zero dscore row (Model.py:80-86: the NLL picks one entry
+// of the [gen ; copy] distribution), typically a handful of the 30 positions: the workgroup stages its [T, slots]
+// tile of dscore in LDS, derives the set of rows with any non-zero entry and spends tanh work only on those.
 __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const float* __restrict__ src,
                                                              const float* __restrict__ tgt,
                                                              const float* __restrict__ w,
@@ -66,16 +79,37 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
                                                              float* __restrict__ dsrc, float* __restrict__ dtgt,
                                                              float* __restrict__ dw, float* __restrict__ dbias,
                                                              const int32_t* __restrict__ mem_valid, int slots) {
+    constexpr int SLOTS_MAX = 16;
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     __shared__ float sm_dt[T_MAX * FIRA_D];
     __shared__ float sm_dw[FIRA_D + 1];
+    __shared__ float sm_g[T_MAX * SLOTS_MAX];
+    __shared__ unsigned sm_mask;
     const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
+    const int j0 = blockIdx.x * slots, j_end = min(S, j0 + slots);
+    if (t0 == 0) sm_mask = 0u;
+    __syncthreads();
+    for (int i = t0; i < T * slots; i += 256) {
+        const int t = i / slots, j = j0 + i % slots;
+        float g = 0.f;
+        if (j < j_end && !(mem_valid && mem_valid[(size_t)b * S + j] == 0)) g = dscore[((size_t)b * T + t) * S + j];
+        sm_g[t * SLOTS_MAX + i % slots] = g;
+        if (g != 0.f) atomicOr(&sm_mask, 1u << t);
+    }
+    __syncthreads();
+    const unsigned mask = sm_mask;                                 // uniform: rows of this tile with any gradient
+    if (mask == 0u) {                                              // nothing flows into this tile's memory slots
+        for (int j = j0 + wave; j < j_end; j += 4)
+            *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     for (int i = t0; i < T * (FIRA_D / 4); i += 256)
         reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
     for (int i = t0; i < T_MAX * FIRA_D; i += 256) sm_dt[i] = 0.f;
     for (int i = t0; i < FIRA_D + 1; i += 256) sm_dw[i] = 0.f;
     __syncthreads();
     const float4 w4 = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
     float dt[T_MAX][4];
 #pragma unroll
     for (int t = 0; t < T_MAX; ++t)
@@ -83,49 +117,42 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
         for (int e = 0; e < 4; ++e) dt[t][e] = 0.f;
     float dwa[4] = {0.f, 0.f, 0.f, 0.f};
     float dba = 0.f;
-    bool any = false;
-    const int j_end = min(S, (int)(blockIdx.x + 1) * slots);
-    for (int j = blockIdx.x * slots + wave; j < j_end; j += 4) {
-        if (mem_valid && mem_valid[(size_t)b * S + j] == 0) {     // masked slot: no gradient flows through masked_fill
-            *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        any = true;
-        const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
+    for (int j = j0 + wave; j < j_end; j += 4) {
         float ds[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!(mem_valid && mem_valid[(size_t)b * S + j] == 0)) {  // masked slot: no gradient flows through masked_fill
+            const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
 #pragma unroll
-        for (int t = 0; t < T_MAX; ++t) {
-            if (t < T) {
-                const float g = dscore[((size_t)b * T + t) * S + j];
-                const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
-                const float th[4] = {tanh_fast(s4.x + x.x), tanh_fast(s4.y + x.y), tanh_fast(s4.z + x.z), tanh_fast(s4.w + x.w)};
-                const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            for (int t = 0; t < T_MAX; ++t) {
+                if ((mask >> t) & 1u) {
+                    const float g = sm_g[t * SLOTS_MAX + (j - j0)];
+                    const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
+                    const float th[4] = {tanh_fast(s4.x + x.x), tanh_fast(s4.y + x.y), tanh_fast(s4.z + x.z),
+                                         tanh_fast(s4.w + x.w)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u = g * wv[e] * (1.f - th[e] * th[e]);
-                    ds[e] += u;
-                    dt[t][e] += u;
-                    dwa[e] = fmaf(g, th[e], dwa[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = g * wv[e] * (1.f - th[e] * th[e]);
+                        ds[e] += u;
+                        dt[t][e] += u;
+                        dwa[e] = fmaf(g, th[e], dwa[e]);
+                    }
+                    dba += g;
                 }
-                dba += g;
             }
         }
         *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(ds[0], ds[1], ds[2], ds[3]);
     }
-    if (any) {                                      // waves whose slots were all masked contribute nothing
 #pragma unroll
-        for (int t = 0; t < T_MAX; ++t)
-            if (t < T) {
+    for (int t = 0; t < T_MAX; ++t)
+        if ((mask >> t) & 1u) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[t * FIRA_D + lane * 4 + e], dt[t][e]);
-            }
+            for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[t * FIRA_D + lane * 4 + e], dt[t][e]);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
-        if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
-    }
-    const int any_block = __syncthreads_or(any ? 1 : 0);
-    if (!any_block) return;
-    for (int i = t0; i < T * FIRA_D; i += 256) unsafeAtomicAdd(&dtgt[(size_t)b * T * FIRA_D + i], sm_dt[i]);
+    for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
+    if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
+    __syncthreads();
+    for (int i = t0; i < T * FIRA_D; i += 256)
+        if ((mask >> (i / FIRA_D)) & 1u) unsafeAtomicAdd(&dtgt[(size_t)b * T * FIRA_D + i], sm_dt[i]);
     for (int i = t0; i < FIRA_D; i += 256) unsafeAtomicAdd(&dw[i], sm_dw[i]);
     if (t0 == 0) unsafeAtomicAdd(dbias, sm_dw[FIRA_D]);
 }
@@ -163,7 +190,10 @@ __device__ __forceinline__ void block_argmax(float& v, int& idx, float* smv, int
         if (smv[k] > v || (smv[k] == v && smi[k] < idx)) { v = smv[k]; idx = smi[k]; }
 }
 
-// one workgroup per (b,t) row.
+// one workgroup per (b,t) row.  REG: the row's V logits stay in registers (HL_PAIRS float2 per thread) between the
+// soft-max statistics and the in-place gradient, so the [R,V] matrix is read once and written once.
+constexpr int HL_PAIRS = 49;                     // 2 * 256 * 49 = 25088 >= the reference vocabulary (24650)
+template <bool REG>
 __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, const int32_t* __restrict__ compact_row,
                                                         float* __restrict__ logits, int ldl,
                                                         float* __restrict__ score,
@@ -187,29 +217,54 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
     const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
     const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
 
-    // copy soft-max statistics over the S memory slots (-1e9 where masked)
-    float cmax = -INFINITY;
+    // copy soft-max statistics over the S memory slots (-1e9 where masked); rows whose label is a generated token
+    // only need them for the arg-max output (their copy scores may not even have been computed, see copy_score_fwd)
+    float cmax = -INFINITY, csum = 1.f;
     int cidx = 0x7fffffff;
-    for (int j = tid; j < S; j += 256) {
-        const float x = mv[j] ? srow[j] : -1e9f;
-        if (x > cmax) { cmax = x; cidx = j; }
+    if (argmax_out || (y >= V && y - V < S)) {
+        for (int j = tid; j < S; j += 256) {
+            const float x = mv[j] ? srow[j] : -1e9f;
+            if (x > cmax) { cmax = x; cidx = j; }
+        }
+        block_argmax(cmax, cidx, smf, smi);
+        csum = 0.f;
+        for (int j = tid; j < S; j += 256) csum += expf((mv[j] ? srow[j] : -1e9f) - cmax);
+        csum = block_sum(csum, smf);
     }
-    block_argmax(cmax, cidx, smf, smi);
-    float csum = 0.f;
-    for (int j = tid; j < S; j += 256) csum += expf((mv[j] ? srow[j] : -1e9f) - cmax);
-    csum = block_sum(csum, smf);
 
     // generator soft-max statistics over the V logits
     float gmax = -INFINITY, gsum = 1.f;
     int gidx = 0x7fffffff;
+    float2 reg[REG ? HL_PAIRS : 1];
+    const int n2 = V >> 1;
     if (lrow) {
-        for (int j = tid; j < V; j += 256) {
-            const float x = lrow[j];
-            if (x > gmax) { gmax = x; gidx = j; }
+        if (REG) {
+            const float2* l2 = reinterpret_cast<const float2*>(lrow);
+#pragma unroll
+            for (int i = 0; i < HL_PAIRS; ++i) {
+                const int j2 = tid + 256 * i;
+                reg[i] = j2 < n2 ? l2[j2] : make_float2(-INFINITY, -INFINITY);
+            }
+#pragma unroll
+            for (int i = 0; i < HL_PAIRS; ++i) {             // ascending index within the thread: first maximum wins
+                const int j = 2 * (tid + 256 * i);
+                if (reg[i].x > gmax) { gmax = reg[i].x; gidx = j; }
+                if (reg[i].y > gmax) { gmax = reg[i].y; gidx = j + 1; }
+            }
+        } else {
+            for (int j = tid; j < V; j += 256) {
+                const float x = lrow[j];
+                if (x > gmax) { gmax = x; gidx = j; }
+            }
         }
         block_argmax(gmax, gidx, smf, smi);
         gsum = 0.f;
-        for (int j = tid; j < V; j += 256) gsum += expf(lrow[j] - gmax);
+        if (REG) {
+#pragma unroll
+            for (int i = 0; i < HL_PAIRS; ++i) gsum += expf(reg[i].x - gmax) + expf(reg[i].y - gmax);
+        } else {
+            for (int j = tid; j < V; j += 256) gsum += expf(lrow[j] - gmax);
+        }
         gsum = block_sum(gsum, smf);
     }
 
@@ -256,10 +311,26 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
     // d loss / d logits, in place
     if (lrow) {
         const bool gen_grad = pass && !is_copy;
-        for (int j = tid; j < V; j += 256) {
-            float d = 0.f;
-            if (gen_grad) d = expf(lrow[j] - gmax) / gsum - (j == y ? 1.f : 0.f);
-            lrow[j] = d;
+        if (REG) {
+            float2* l2 = reinterpret_cast<float2*>(lrow);
+#pragma unroll
+            for (int i = 0; i < HL_PAIRS; ++i) {
+                const int j2 = tid + 256 * i;
+                if (j2 < n2) {
+                    float2 d = make_float2(0.f, 0.f);
+                    if (gen_grad) {
+                        d.x = expf(reg[i].x - gmax) / gsum - (2 * j2 == y ? 1.f : 0.f);
+                        d.y = expf(reg[i].y - gmax) / gsum - (2 * j2 + 1 == y ? 1.f : 0.f);
+                    }
+                    l2[j2] = d;
+                }
+            }
+        } else {
+            for (int j = tid; j < V; j += 256) {
+                float d = 0.f;
+                if (gen_grad) d = expf(lrow[j] - gmax) / gsum - (j == y ? 1.f : 0.f);
+                lrow[j] = d;
+            }
         }
     }
 }
@@ -351,26 +422,27 @@ int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl
 }
 
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                      const float* bias, float* score, int qpk, const int32_t* mem_valid) {
+                      const float* bias, float* score, int qpk, const int32_t* mem_valid, const int32_t* tar_label,
+                      int V) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX && qpk >= 1, "copy_score_fwd: T=%d > %d", T, T_MAX);
     const int slots = 8;          // memory slots per workgroup: small chunks so that masked stretches cost nothing
     hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
-                       qpk, mem_valid, slots);
+                       qpk, mem_valid, slots, tar_label, V);
     FIRA_CHECK_LAUNCH("copy_score_fwd");
     return 0;
 }
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score) {
-    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1, nullptr);
+    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1, nullptr, nullptr, 0);
 }
 int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
-    const int slots = 16;
+    const int slots = 16;                                   // == SLOTS_MAX of the kernel
     hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
                        dtgt, dw, dbias, mem_valid, slots);
     FIRA_CHECK_LAUNCH("copy_score_bwd");
@@ -385,8 +457,13 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
               int32_t* n_tok, int32_t* argmax_out, int want_grad) {
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (BT <= 0) return 0;
-    hipLaunchKernelGGL(head_loss_kernel, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
-                       mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
+    const bool reg = (V % 2 == 0) && (V / 2 <= 256 * HL_PAIRS) && (ldl % 2 == 0) && ((uintptr_t)logits % 8 == 0);
+    if (reg)
+        hipLaunchKernelGGL(head_loss_kernel<true>, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
+                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
+    else
+        hipLaunchKernelGGL(head_loss_kernel<false>, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
+                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
     FIRA_CHECK_LAUNCH("head_loss");
     return 0;
 }

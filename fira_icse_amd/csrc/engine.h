@@ -18,6 +18,8 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
              int ldx, float* Y, int ldy, int graph_rows, int variant);
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
                      int out_bstride, int out_off);
+int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const int32_t* item_ptr, const int32_t* rows,
+                      float* dtable, const float* dnode);
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
                      int out_bstride, int out_off, int padding_idx);
 int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
@@ -64,7 +66,8 @@ int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const f
                    const float* bias, float* score);
 // mem_valid (optional, [B/qpk, S]): slots with 0 are skipped (score 0 / zero gradient): they are masked to -1e9 later
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                      const float* bias, float* score, int qpk, const int32_t* mem_valid);
+                      const float* bias, float* score, int qpk, const int32_t* mem_valid,
+                      const int32_t* tar_label = nullptr, int V = 0);
 int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid);
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,

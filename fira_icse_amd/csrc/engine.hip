@@ -303,7 +303,9 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     TRY(invert_rows(s, p.TB, R, rows, p.compact_row));
     TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
     TRY(gemm_f32_ex(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
-    TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid));
+    // teacher-forced ids (dev) need every row's copy distribution; the training loss only the copy-labelled rows
+    TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid,
+                          argmax_out ? nullptr : c.bt->tar_label, p.V));
     TRY(linear(s, p.TB, 2, D, dec, D, c.P + L.wp, c.P + L.bp, p.gate, 2));
     if (loss_sum) TRY(zero(s, loss_sum, sizeof(float)));
     if (n_tok) TRY(zero(s, n_tok, sizeof(int32_t)));
@@ -379,8 +381,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_dgrad(s, p.TB, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
         dy = p.dT_a;
     }
-    // decoder embedding (no padding_idx: gnn_transformer.py:92-93)
-    TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, -1));
+    // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions
+    // carry an exactly-zero gradient (never attended as keys, zero loss weight): skipping id 0 only drops the
+    // hundreds of serialised atomic additions of 0.0 onto table row 0.
+    TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
     // cross-attention K|V projections of all layers (computed memory rows only)
     TRY(rows_move(s, 0, Mc, KV, p.dkv_c, p.dkv_all, bt.mem_dst, nullptr));
     TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
@@ -425,8 +429,12 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39); back to the dense layout
     TRY(zero(s, p.H, (size_t)p.NB * D * sizeof(float)));
     TRY(rows_move(s, 1, Nc, D, p.H, dXn, nullptr, bt.node_rows));
-    TRY(embed_gather_bwd(s, p.B, p.L, bt.sou, G + L.emb, p.H, p.N, 0, 0));
-    TRY(embed_gather_bwd(s, p.B, p.S, bt.sub_token, G + L.emb, p.H, p.N, p.L, 0));
+    if (bt.emb_item_tok && bt.emb_item_ptr && bt.emb_rows) {
+        TRY(embed_grouped_bwd(s, bt.n_emb_items, bt.emb_item_tok, bt.emb_item_ptr, bt.emb_rows, G + L.emb, p.H));
+    } else {
+        TRY(embed_gather_bwd(s, p.B, p.L, bt.sou, G + L.emb, p.H, p.N, 0, 0));
+        TRY(embed_gather_bwd(s, p.B, p.S, bt.sub_token, G + L.emb, p.H, p.N, p.L, 0));
+    }
     if (L.d.ast_vocab <= 128)
         TRY(embed_gather_bwd_small(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0, L.d.ast_vocab));
     else

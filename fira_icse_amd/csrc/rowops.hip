@@ -47,6 +47,38 @@ __global__ __launch_bounds__(256) void embed_gather_bwd_kernel(int rows, int L, 
     unsafeAtomicAdd(p + 3, g.w);
 }
 
+// Grouped form: the positions were grouped by table row on the host (fira_batch.emb_*).  One wave per item sums its
+// <= 32 gradient rows in registers and adds the result to the table row once: a token that occurs 1000 times in the
+// batch costs 32 same-address atomics per element instead of 1000 serialised ones.
+__global__ __launch_bounds__(256) void embed_grouped_bwd_kernel(int n_items, const int32_t* __restrict__ item_tok,
+                                                                const int32_t* __restrict__ item_ptr,
+                                                                const int32_t* __restrict__ rows,
+                                                                float* __restrict__ dtable,
+                                                                const float* __restrict__ dnode) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int beg = item_ptr[item], cnt = min(item_ptr[item + 1] - beg, 64);
+    const int mine = lane < cnt ? rows[beg + lane] : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < cnt; k += 4) {
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = __shfl(mine, min(k + u, cnt - 1), 64);
+            g[u] = *reinterpret_cast<const float4*>(dnode + (size_t)r * FIRA_D + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u < cnt) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
+    }
+    float* p = dtable + (size_t)item_tok[item] * FIRA_D + lane * 4;
+    unsafeAtomicAdd(p + 0, acc.x);
+    unsafeAtomicAdd(p + 1, acc.y);
+    unsafeAtomicAdd(p + 2, acc.z);
+    unsafeAtomicAdd(p + 3, acc.w);
+}
+
 // Same for a SMALL table (the 71-row AST/edit-operation vocabulary): thousands of rows hit the same few table rows, so
 // global atomics serialise; each workgroup first reduces its slice of rows into an LDS copy of the table.
 __global__ __launch_bounds__(256) void embed_gather_bwd_small_kernel(int rows, int L, const int32_t* __restrict__ idx,
@@ -231,30 +263,45 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
     const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
     const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
-    for (int r = r_beg + wave; r < r_end; r += 4) {
-        const size_t o = (size_t)r * FIRA_D + lane * 4;
-        const float4 d = *reinterpret_cast<const float4*>(dy + o);
-        const float4 sv = *reinterpret_cast<const float4*>(sum + o);
-        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
-        const float xh0 = (sv.x - mean) * rstd, xh1 = (sv.y - mean) * rstd, xh2 = (sv.z - mean) * rstd,
-                    xh3 = (sv.w - mean) * rstd;
-        dg.x += d.x * xh0; dg.y += d.y * xh1; dg.z += d.z * xh2; dg.w += d.w * xh3;
-        db.x += d.x; db.y += d.y; db.z += d.z; db.w += d.w;
-        const float h0 = d.x * g.x, h1 = d.y * g.y, h2 = d.z * g.z, h3 = d.w * g.w;
-        const float m1 = wave_sum(h0 + h1 + h2 + h3) * (1.0f / FIRA_D);
-        const float m2 = wave_sum(h0 * xh0 + h1 * xh1 + h2 * xh2 + h3 * xh3) * (1.0f / FIRA_D);
-        float4 o4 = make_float4(rstd * (h0 - m1 - xh0 * m2), rstd * (h1 - m1 - xh1 * m2), rstd * (h2 - m1 - xh2 * m2),
-                                rstd * (h3 - m1 - xh3 * m2));
-        *reinterpret_cast<float4*>(ds + o) = o4;
-        if (dx_drop) {
-            if (p > 0.f) {
-                const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
-                o4.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
-                o4.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
-                o4.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
-                o4.w *= dropout_scale(seed, site, e0 + 3, p, inv_keep);
+    // two rows per wave and iteration: both rows' loads are in flight before the first reduction starts
+    for (int r0 = r_beg + 2 * wave; r0 < r_end; r0 += 8) {
+        const int nr = min(2, r_end - r0);
+        float4 d[2], sv[2];
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = u < nr ? r0 + u : r0;
+            const size_t o = (size_t)r * FIRA_D + lane * 4;
+            d[u] = *reinterpret_cast<const float4*>(dy + o);
+            sv[u] = *reinterpret_cast<const float4*>(sum + o);
+            mean[u] = stats[2 * r];
+            rstd[u] = stats[2 * r + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u >= nr) break;
+            const int r = r0 + u;
+            const size_t o = (size_t)r * FIRA_D + lane * 4;
+            const float xh0 = (sv[u].x - mean[u]) * rstd[u], xh1 = (sv[u].y - mean[u]) * rstd[u],
+                        xh2 = (sv[u].z - mean[u]) * rstd[u], xh3 = (sv[u].w - mean[u]) * rstd[u];
+            dg.x += d[u].x * xh0; dg.y += d[u].y * xh1; dg.z += d[u].z * xh2; dg.w += d[u].w * xh3;
+            db.x += d[u].x; db.y += d[u].y; db.z += d[u].z; db.w += d[u].w;
+            const float h0 = d[u].x * g.x, h1 = d[u].y * g.y, h2 = d[u].z * g.z, h3 = d[u].w * g.w;
+            const float m1 = wave_sum(h0 + h1 + h2 + h3) * (1.0f / FIRA_D);
+            const float m2 = wave_sum(h0 * xh0 + h1 * xh1 + h2 * xh2 + h3 * xh3) * (1.0f / FIRA_D);
+            float4 o4 = make_float4(rstd[u] * (h0 - m1 - xh0 * m2), rstd[u] * (h1 - m1 - xh1 * m2),
+                                    rstd[u] * (h2 - m1 - xh2 * m2), rstd[u] * (h3 - m1 - xh3 * m2));
+            *reinterpret_cast<float4*>(ds + o) = o4;
+            if (dx_drop) {
+                if (p > 0.f) {
+                    const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
+                    o4.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
+                    o4.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
+                    o4.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
+                    o4.w *= dropout_scale(seed, site, e0 + 3, p, inv_keep);
+                }
+                *reinterpret_cast<float4*>(dx_drop + o) = o4;
             }
-            *reinterpret_cast<float4*>(dx_drop + o) = o4;
         }
     }
     atomicAdd(&red[lane * 4 + 0], dg.x); atomicAdd(&red[lane * 4 + 1], dg.y);
@@ -429,6 +476,15 @@ int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, floa
     FIRA_CHECK_LAUNCH("embed_gather_bwd_small");
     return 0;
 }
+int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const int32_t* item_ptr, const int32_t* rows,
+                      float* dtable, const float* dnode) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    if (n_items <= 0) return 0;
+    hipLaunchKernelGGL(embed_grouped_bwd_kernel, dim3(cdiv(n_items, 4)), dim3(256), 0, s, n_items, item_tok, item_ptr,
+                       rows, dtable, dnode);
+    FIRA_CHECK_LAUNCH("embed_grouped_bwd");
+    return 0;
+}
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
                      int out_bstride, int out_off, int padding_idx) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
@@ -454,7 +510,7 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
-    const int rpb = 32;
+    const int rpb = 16;
     hipLaunchKernelGGL(combination_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, qk, vtab, ldv, mark, dout, dqk,
                        dvtab, lddv, dropout, inv_keep, seed, site, rpb);
     FIRA_CHECK_LAUNCH("combination_bwd");
@@ -477,7 +533,7 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     // ~500 workgroups: enough to fill the chip, few enough that the dgamma/dbeta atomics do not serialise
-    const int rpb = std::max(8, std::min(128, cdiv(cdiv(M, 512), 4) * 4));
+    const int rpb = std::max(8, std::min(128, cdiv(cdiv(M, 512), 8) * 8));
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
                        dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");

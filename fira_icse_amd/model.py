@@ -163,6 +163,26 @@ def computed_nodes(hb: HostBatch, cfg: FiraConfig, skip_padding: bool = True):
             code_mark, mem_rows, mem_dst)
 
 
+def embedding_items(hb: HostBatch, cfg: FiraConfig, chunk: int = 32):
+    """Code / sub-token positions grouped by word id (``fira_batch.emb_*``): item_tok [n], item_ptr [n+1], rows."""
+    B, N, L, S = len(hb), cfg.graph_len, cfg.sou_len, cfg.sub_token_len
+    ids = np.concatenate([hb.sou, hb.sub_token], axis=1).astype(np.int64)               # [B, L+S]: local == column
+    rows = (np.arange(B, dtype=np.int64)[:, None] * N + np.arange(L + S, dtype=np.int64)[None, :])
+    sel = ids != 0
+    tok, pos = ids[sel], rows[sel]
+    order = np.argsort(tok, kind="stable")
+    tok, pos = tok[order], pos[order]
+    if tok.size == 0:
+        return np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
+    starts = np.flatnonzero(np.concatenate([[True], tok[1:] != tok[:-1]]))
+    counts = np.diff(np.append(starts, tok.size))
+    nchunk = (counts + chunk - 1) // chunk
+    seg = np.repeat(np.arange(starts.size), nchunk)
+    k = np.arange(seg.size) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
+    item_start = starts[seg] + chunk * k
+    return tok[item_start].astype(np.int32), np.append(item_start, tok.size).astype(np.int32), pos.astype(np.int32)
+
+
 class DeviceBatch:
     """One collated batch resident in HBM: int32 id arrays, the computed-node lists and their CSR adjacency
     (+ the list of target rows that need the vocabulary head)."""
@@ -201,12 +221,16 @@ class DeviceBatch:
             rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0].astype(np.int32)
             self.n_head_rows = int(rows.shape[0])
             self.head_rows = dev(rows, np.int32)
+        item_tok, item_ptr, emb_rows = embedding_items(hb, cfg)
+        self.n_emb_items = int(item_tok.shape[0])
+        self.emb_item_tok, self.emb_item_ptr, self.emb_rows = dev(item_tok, np.int32), dev(item_ptr, np.int32), \
+            dev(emb_rows, np.int32)
         p = lambda t: t.data_ptr() if t is not None else None
         self.struct = _lib.Batch(
             self.B, self.nnz, p(self.sou), p(self.tar), p(self.mark), p(self.ast_change), p(self.tar_label),
             p(self.sub_token), self.n_nodes, p(self.node_rows), p(self.rowptr), p(self.col), p(self.val), self.n_code,
             p(self.code_rows), p(self.code_mark), self.n_mem, p(self.mem_rows), p(self.mem_dst), p(self.head_rows),
-            self.n_head_rows)
+            self.n_head_rows, self.n_emb_items, p(self.emb_item_tok), p(self.emb_item_ptr), p(self.emb_rows))
 
 
 def _as_tensor(ptr: int, shape, device) -> torch.Tensor:

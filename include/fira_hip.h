@@ -67,6 +67,13 @@ typedef struct fira_batch {
                                 label is a vocabulary id (0 < label < vocab), ascending, no duplicates; only these
                                 rows need the vocabulary GEMM in training.  NULL = all rows.           */
     int32_t n_head_rows;
+    /* ---- optional (emb_items NULL = scatter with atomics per position): the code / sub-token positions of the batch
+     * grouped by word id for the embedding gradient (gnn_transformer.py:46-52 backward).  Frequent tokens ('(' ';' ...)
+     * occur hundreds of times per batch; one wave sums up to 32 positions of one id before touching the table row. */
+    int32_t n_emb_items;
+    const int32_t* emb_item_tok; /* [n_emb_items] word id of the item (never 0 = padding_idx)                      */
+    const int32_t* emb_item_ptr; /* [n_emb_items + 1] offsets into emb_rows; at most 32 rows per item              */
+    const int32_t* emb_rows;     /* global node index b*N + local (local < sou_len + sub_len), grouped by word id  */
 } fira_batch;
 
 typedef struct fira_train_opts {

@@ -120,3 +120,23 @@ def test_computed_node_lists(store):
     assert np.all(np.isin(np.nonzero(mem_ids != 0)[0], mem_dst))
     # the over-long commit: node 210 (sub-token id 0 or not) has the unguarded sequential edge -> computed
     assert (1 * N + 210) in node_rows
+
+
+def test_embedding_items_cover_every_nonpad_position_once():
+    """fira_batch.emb_*: every code / sub-token position with a non-zero id appears in exactly one item of its id,
+    items hold at most 32 positions, and a scatter through the items equals the plain per-position scatter."""
+    from fira_icse_amd.model import embedding_items
+    cfg = FiraConfig()
+    store = data.process_raw(cfg, util.edge_case_raw())
+    hb = store.batch([0, 1, 2, 3])
+    tok, ptr, rows = embedding_items(hb, cfg)
+    assert ptr[0] == 0 and ptr[-1] == rows.shape[0] and np.all(np.diff(ptr) >= 1) and np.all(np.diff(ptr) <= 32)
+    assert np.all(tok != 0)
+    ids = np.concatenate([hb.sou, hb.sub_token], axis=1)
+    B, N, W = ids.shape[0], cfg.graph_len, ids.shape[1]
+    flat = {int(b * N + i): int(ids[b, i]) for b in range(B) for i in range(W) if ids[b, i] != 0}
+    assert sorted(rows.tolist()) == sorted(flat)
+    for k in range(tok.shape[0]):
+        assert all(flat[int(r)] == int(tok[k]) for r in rows[ptr[k]:ptr[k + 1]])
+    # an item boundary never separates two ids in the wrong order: ids ascend over the items
+    assert np.all(np.diff(tok.astype(np.int64)) >= 0)

@@ -250,10 +250,34 @@ def test_copy_score_fwd_bwd():
     assert rel_err(dw, w.grad) < 1e-5 and rel_err(db, b.grad) < 1e-5
 
 
-@pytest.mark.parametrize("compact", [False, True])
-def test_head_loss_fwd_bwd(compact):
+def test_copy_score_bwd_sparse_rows_and_masked_slots():
+    """The engine's shape of dscore: a few non-zero target rows (copy labels), whole commits without any, zeros on
+    masked slots; the kernel skips the rows / tiles without gradient."""
     from fira_icse_amd import ops
-    B, T, V, S = 4, 30, 24650, 370
+    B, T, S = 4, 30, 370
+    src = randn(B, S, 256, seed=1).double().requires_grad_(True)
+    tgt = randn(B, T, 256, seed=2).double().requires_grad_(True)
+    w = randn(256, seed=3, scale=0.1).double().requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    valid = (torch.rand(B, S, generator=g) > 0.4).to(torch.int32).to(DEV)
+    ds = torch.zeros(B, T, S, device=DEV)
+    for b, t in ((0, 1), (0, 7), (2, 0), (2, 29), (3, 12)):          # commit 1 has no copy row at all
+        ds[b, t] = randn(S, seed=10 + t) * valid[b]
+    ds[3, 12, 100:] = 0                                                # a row that is zero on most slot tiles
+    ref = (torch.tanh(src[:, None] + tgt[:, :, None]) * w).sum(-1)
+    ref.backward(ds.double())
+    dsrc, dtgt, dw, db = ops.copy_score_bwd(src.detach().float(), tgt.detach().float(), w.detach().float(), ds)
+    assert rel_err(dsrc, src.grad) < 5e-6 and rel_err(dtgt, tgt.grad) < 5e-6 and rel_err(dw, w.grad) < 1e-5
+    assert float(dsrc[1].abs().max()) == 0.0 and float(dtgt[1].abs().max()) == 0.0
+    assert abs(float(db) - float(ds.sum())) < 1e-4 * float(ds.abs().sum())
+
+
+@pytest.mark.parametrize("compact,V,ldl", [(False, 24650, 24704), (True, 24650, 24704), (False, 1001, 1001),
+                                           (True, 1000, 1000)])
+def test_head_loss_fwd_bwd(compact, V, ldl):
+    """V = 24650 / 1000: the register-resident row path; V = 1001 (odd): the streaming path."""
+    from fira_icse_amd import ops
+    B, T, S = 4, 30, 370
     g = torch.Generator().manual_seed(0)
     logits = randn(B * T, V, seed=1, scale=2.0).double().requires_grad_(True)
     score = randn(B * T, S, seed=2, scale=2.0).double().requires_grad_(True)
@@ -281,7 +305,7 @@ def test_head_loss_fwd_bwd(compact):
     nll.sum().backward()
     ids_ref = logp.argmax(-1)
 
-    lg = torch.zeros(B * T, 24704, device=DEV)
+    lg = torch.zeros(B * T, ldl, device=DEV)
     lg[:, :V] = logits.detach().float()
     sc, gl = score.detach().float().clone(), gate.detach().float().clone()
     compact_row = None

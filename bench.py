@@ -186,6 +186,20 @@ def main():
                   "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
                           "steps executed, the unit of BASELINE.md's CPU figure (109 step-tokens/s). Random-init weights: "
                           "most hypotheses copy <eos> within a few steps while a few run all 29"}
+        # the reference's own test configuration: beam 3, batch 20 (run_model.py:401-415)
+        dbb = DeviceBatch(store.batch(range(20)), cfg, model.device_)
+        for _ in range(2):
+            gen, blen, bp = search.beam(dbb, 3)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            gen, blen, bp = search.beam(dbb, 3)
+        barrier()
+        bdt = (time.perf_counter() - t0) / reps
+        best = search.best(gen, blen, bp)
+        decode["beam3"] = {"batch": 20, "ms_per_batch": bdt * 1e3, "commits_per_s": 20 * world / bdt,
+                           "tokens_per_s": sum(len(h) - 1 for h in best) * world / bdt,
+                           "steps_run": int(blen.max().item()) - 1}
         model.train()
 
     cpu = None

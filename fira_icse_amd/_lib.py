@@ -72,6 +72,8 @@ SIGNATURES = {
     "fira_param_groups": (_I, [_DP, C.POINTER(_L), C.POINTER(_L)]),
     "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P]),
     "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
+    "fira_beam_prepare": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "fira_beam_select": (_I, [_P, _DP, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fira_decode_step": (_I, [_P, _DP, _P, _P, _Z, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fira_decoder_forward": (_I, [_P, _DP, _P, _P, _Z, _I, _P, _P, _P, _P]),
     "fira_decode_memory": (_P, [_DP, _P, _I, _I]),

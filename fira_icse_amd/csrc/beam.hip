@@ -1,0 +1,177 @@
+// Hypothesis bookkeeping of the reference's test-time search (run_model.py:225-340), one launch pair per step.
+//
+// The reference keeps the hypotheses in python lists: per step and beam slot it re-pads them, rebuilds tensors, runs
+// the decoder, multiplies the distribution by the hypothesis probability, overwrites finished rows with -1,
+// concatenates the slots that still run plus the probabilities of the finished hypotheses (padded with -1), sorts
+// all ~75 000 candidates of every commit and rebuilds the lists from the first `beam` entries.  Here the state stays in
+// HBM (double-buffered [B, beam, T] ids / lengths / probabilities) and two kernels do that work:
+//   beam_prepare  which hypotheses are finished, which slots still run, the decoder's input token of this step
+//   beam_select   per commit: the `beam` best candidates by (probability descending, index ascending) in one pass
+//                 over the step's distribution rows -- no sort --, copy-id resolution, new hypotheses, cache parents
+// Nothing returns to the host; `done` latches when no slot runs any more (run_model.py:276-279) and turns the
+// remaining steps into state copies, so a driver may poll it every few steps.
+#include <limits.h>
+#include "engine.h"
+
+namespace fira {
+
+constexpr int BEAM_MAX = 8;
+
+__global__ __launch_bounds__(256) void beam_prepare_kernel(int rows, int beam, int T, int step,
+                                                           const int32_t* __restrict__ gen,
+                                                           const int32_t* __restrict__ length,
+                                                           int32_t* __restrict__ tok, int32_t* __restrict__ fin,
+                                                           int32_t* __restrict__ active, int32_t* __restrict__ done) {
+    __shared__ int act[BEAM_MAX];
+    const int t = threadIdx.x;
+    if (t < BEAM_MAX) act[t] = 0;
+    __syncthreads();
+    for (int r = t; r < rows; r += 256) {
+        const int len = length[r];
+        const int f = gen[(size_t)r * T + len - 1] == 1;            // last token is <eos> (run_model.py:235)
+        fin[r] = f;
+        if (!f) atomicOr(&act[r % beam], 1);                         // the slot runs iff some commit is unfinished in it
+        tok[r] = len > step ? gen[(size_t)r * T + step] : 0;         // the <pad>-extended hypothesis at this position
+    }
+    __syncthreads();
+    if (t == 0) {
+        int n = 0;
+        for (int j = 0; j < beam; ++j) { active[j] = act[j]; n += act[j]; }
+        active[BEAM_MAX] = n;
+        if (n == 0) *done = 1;
+    }
+}
+
+struct Cand { float v; int i; };
+__device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
+
+__global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W, int V, int L, int S,
+                                                          const float* __restrict__ dist,
+                                                          const int32_t* __restrict__ fin,
+                                                          const int32_t* __restrict__ active,
+                                                          const int32_t* __restrict__ done,
+                                                          const int32_t* __restrict__ sou,
+                                                          const int32_t* __restrict__ sub,
+                                                          const int32_t* __restrict__ gen_in,
+                                                          const int32_t* __restrict__ len_in,
+                                                          const float* __restrict__ prob_in,
+                                                          int32_t* __restrict__ gen_out, int32_t* __restrict__ len_out,
+                                                          float* __restrict__ prob_out, int32_t* __restrict__ parent) {
+    __shared__ float smv[4];
+    __shared__ int smi[4];
+    __shared__ float sel_v[BEAM_MAX];
+    __shared__ int sel_i[BEAM_MAX], act_slot[BEAM_MAX], order[BEAM_MAX], src_of[BEAM_MAX], tok_of[BEAM_MAX],
+        carry_of[BEAM_MAX];
+    const int b = blockIdx.x, t = threadIdx.x, r0 = b * beam;
+    if (*done) {                                                     // search over: hand the state on unchanged
+        for (int x = t; x < beam * T; x += 256) gen_out[(size_t)r0 * T + x] = gen_in[(size_t)r0 * T + x];
+        if (t < beam) { len_out[r0 + t] = len_in[r0 + t]; prob_out[r0 + t] = prob_in[r0 + t]; parent[r0 + t] = r0 + t; }
+        return;
+    }
+    const int n_act = active[BEAM_MAX];
+    // thread-local best `beam` candidates, kept sorted
+    float lv[BEAM_MAX];
+    int li[BEAM_MAX];
+#pragma unroll
+    for (int q = 0; q < BEAM_MAX; ++q) { lv[q] = -INFINITY; li[q] = INT_MAX; }
+    auto offer = [&](float v, int i) {
+        if (!better(v, i, lv[BEAM_MAX - 1], li[BEAM_MAX - 1])) return;
+        lv[BEAM_MAX - 1] = v; li[BEAM_MAX - 1] = i;
+#pragma unroll
+        for (int q = BEAM_MAX - 1; q > 0; --q)
+            if (better(lv[q], li[q], lv[q - 1], li[q - 1])) {
+                const float tv = lv[q]; lv[q] = lv[q - 1]; lv[q - 1] = tv;
+                const int ti = li[q]; li[q] = li[q - 1]; li[q - 1] = ti;
+            }
+    };
+    int k = 0;
+    for (int j = 0; j < beam; ++j) {
+        if (!active[j]) continue;
+        if (t == 0) act_slot[k] = j;
+        const bool f = fin[r0 + j] != 0;
+        const float pj = prob_in[r0 + j];
+        const float* row = dist + (size_t)(r0 + j) * W;
+        for (int w = t; w < W; w += 256) offer(f ? -1.0f : row[w] * pj, k * W + w);   // run_model.py:268-272
+        ++k;
+    }
+    if (t == 0) {                                                    // finished hypotheses, slot order, -1 padding (:283-296)
+        int c = 0;
+        for (int j = 0; j < beam; ++j)
+            if (fin[r0 + j]) { order[c] = j; offer(prob_in[r0 + j], n_act * W + c); ++c; }
+        for (int q = c; q < beam; ++q) { order[q] = 0; offer(-1.0f, n_act * W + q); }
+    }
+    // `beam` rounds of a block-wide arg-max over the list heads; the owner of the winner pops it
+    for (int round = 0; round < beam; ++round) {
+        float v = lv[0];
+        int i = li[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(i, o, 64);
+            if (better(ov, oi, v, i)) { v = ov; i = oi; }
+        }
+        __syncthreads();
+        if ((t & 63) == 0) { smv[t >> 6] = v; smi[t >> 6] = i; }
+        __syncthreads();
+        v = smv[0]; i = smi[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (better(smv[q], smi[q], v, i)) { v = smv[q]; i = smi[q]; }
+        if (t == 0) { sel_v[round] = v; sel_i[round] = i; }
+        if (li[0] == i) {
+#pragma unroll
+            for (int q = 0; q < BEAM_MAX - 1; ++q) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
+            lv[BEAM_MAX - 1] = -INFINITY; li[BEAM_MAX - 1] = INT_MAX;
+        }
+    }
+    __syncthreads();
+    if (t < beam) {                                                  // run_model.py:305-340
+        const int idx = sel_i[t];
+        const int which = idx / W, w = idx - which * W;
+        const int carry = which >= n_act;
+        const int src = carry ? order[min(w, beam - 1)] : act_slot[which];
+        int nt = w;
+        if (w >= V + L) nt = sub[(size_t)b * S + min(w - V - L, S - 1)];
+        else if (w >= V) nt = sou[(size_t)b * L + (w - V)];
+        src_of[t] = src; tok_of[t] = nt; carry_of[t] = carry;
+        const int sl = len_in[r0 + src];
+        len_out[r0 + t] = carry ? sl : sl + 1;
+        prob_out[r0 + t] = sel_v[t];
+        parent[r0 + t] = r0 + src;
+    }
+    __syncthreads();
+    for (int x = t; x < beam * T; x += 256) {
+        const int c = x / T, p = x - c * T;
+        const int src = src_of[c];
+        int g = gen_in[(size_t)(r0 + src) * T + p];
+        if (!carry_of[c] && p == min(len_in[r0 + src], T - 1)) g = tok_of[c];
+        gen_out[(size_t)(r0 + c) * T + p] = g;
+    }
+}
+
+}  // namespace fira
+
+extern "C" {
+int fira_beam_prepare(void* stream, int B, int n_beam, int T, int step, const int32_t* gen, const int32_t* length,
+                      int32_t* tokens, int32_t* finished, int32_t* active, int32_t* done) {
+    FIRA_REQUIRE(B > 0 && n_beam >= 1 && n_beam <= fira::BEAM_MAX, "fira_beam_prepare: beam %d outside 1..%d", n_beam,
+                 fira::BEAM_MAX);
+    hipLaunchKernelGGL(fira::beam_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, B * n_beam, n_beam, T, step,
+                       gen, length, tokens, finished, active, done);
+    FIRA_CHECK_LAUNCH("beam_prepare");
+    return 0;
+}
+int fira_beam_select(void* stream, const fira_dims* d, int B, int n_beam, const float* dist, const int32_t* finished,
+                     const int32_t* active, const int32_t* done, const int32_t* sou, const int32_t* sub_token,
+                     const int32_t* gen_in, const int32_t* len_in, const float* prob_in, int32_t* gen_out,
+                     int32_t* len_out, float* prob_out, int32_t* parent) {
+    FIRA_REQUIRE(d && B > 0 && n_beam >= 1 && n_beam <= fira::BEAM_MAX, "fira_beam_select: beam %d outside 1..%d", n_beam,
+                 fira::BEAM_MAX);
+    const int S = d->sub_len, L = d->sou_len, W = d->vocab + L + S;
+    hipLaunchKernelGGL(fira::beam_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, n_beam, d->tar_len, W,
+                       d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in, gen_out,
+                       len_out, prob_out, parent);
+    FIRA_CHECK_LAUNCH("beam_select");
+    return 0;
+}
+}

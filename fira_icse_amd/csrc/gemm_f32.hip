@@ -270,22 +270,27 @@ static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const floa
     return 0;
 }
 
-// Tile / split choice.  A workgroup's cost is its MFMA time plus a fixed prologue/epilogue (first-tile load latency,
-// C stores); the launch costs ceil(workgroups / 256 CUs) such rounds -- co-resident workgroups share the CU's matrix
-// pipes, so residency does not shorten a round.  With fp32 MFMA (614 GFLOP/s per CU) the quantisation of M into
-// tiles is the dominant loss on the K = 256 shapes (e.g. M = 20800, N = 256: 326 tiles of 128x128 = 2 rounds for
-// 1.27 rounds of work), so the tile is picked by that cost model instead of "largest that fits".
+// Tile / split choice by a cost model fitted to the timings of scripts/gemm_step_shapes.py (profiles/r1e_gemm_shapes.md).
+// A launch costs ceil(workgroups / 256 CUs) rounds of one workgroup's time: MFMA time at the tile's steady-state
+// fraction of the CU's fp32 peak (614 GFLOP/s) plus a fill/drain cost that the co-resident workgroups of the small
+// tile hide (4 of 64x64 fit a CU, 2 of 128x128) -- so with K = 256, where a workgroup runs only 8 k-steps, 64x64 wins
+// on every shape of the training step, and 128x128 only pays off from K of a few thousand.  A split-K epilogue costs
+// its BM*BN atomics (all 256 CUs drain into the same memory channels at once); a grid that does not fill the chip
+// loses the overlap between co-resident workgroups.
 struct TileChoice { int tile; int splitk; double cost; };
 static TileChoice choose(int M, int N, int K, bool can_split) {
     static const int BMs[3] = {128, 64, 64}, BNs[3] = {128, 128, 64};
-    static const double eff[3] = {0.62, 0.64, 0.66};       // measured fraction of a CU's MFMA peak per round (K = 256)
+    static const double eff[3] = {0.72, 0.66, 0.60};
+    static const double fill[3] = {6.0e-6, 2.0e-6, 0.0};
     TileChoice best{0, 1, 1e30};
     for (int t = 0; t < 3; ++t) {
         const long tiles = (long)cdiv(M, BMs[t]) * cdiv(N, BNs[t]);
         const int max_split = can_split ? std::max(1, K / 128) : 1;
         for (int sk = 1; sk <= max_split; sk = (sk < 4 ? sk + 1 : sk * 2)) {
             const double kk = (double)cdiv(cdiv(K, sk), BK) * BK;
-            const double t_wg = 2.0 * BMs[t] * BNs[t] * kk / (614e9 * eff[t]) + 2.0e-6 + (sk > 1 ? 1.0e-6 : 0.0);
+            double t_wg = 2.0 * BMs[t] * BNs[t] * kk / (614e9 * eff[t]) + fill[t];
+            if (sk > 1) t_wg += BMs[t] * BNs[t] * 0.83e-9;
+            if (sk == 1 && tiles <= 256) t_wg *= 1.3;
             const double cost = std::ceil((double)(tiles * sk) / 256.0) * t_wg;
             if (cost < best.cost * 0.97) best = TileChoice{t, sk, cost};
         }
@@ -326,6 +331,6 @@ int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A,
 
 extern "C" int fira_gemm_f32(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
                              const float* B, int ldb, float* C, int ldc, const float* bias, int flags, int splitk) {
-    FIRA_REQUIRE(splitk >= 1, "fira_gemm_f32: splitk must be >= 1");
+    FIRA_REQUIRE(splitk >= 0, "fira_gemm_f32: splitk must be >= 0 (0 = automatic)");
     return fira::gemm_f32((hipStream_t)stream, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk);
 }

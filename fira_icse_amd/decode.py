@@ -134,9 +134,89 @@ class Searcher:
         return st["out"].clone(), st["length"].clone(), st["prob"].clone()
 
     # ------------------------------------------------------------------ beam search with the reference's semantics
+    def _beam_state(self, B, beam):
+        key = ("beam", B, beam)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dev = self.cfg, self.model.device_
+        BR, T = B * beam, cfg.tar_len
+        i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev)
+        st = dict(gen=[i32(BR, T), i32(BR, T)], length=[i32(BR), i32(BR)],
+                  prob=[torch.zeros(BR, dtype=torch.float32, device=dev) for _ in range(2)],
+                  tok=i32(BR), parent=i32(BR), fin=i32(BR), active=i32(9), done=i32(1),
+                  dist=torch.empty((BR, cfg.out_len), dtype=torch.float32, device=dev),
+                  sou=i32(B, cfg.sou_len), sub=i32(B, cfg.sub_token_len), graphs=None)
+        self._ws[key] = st
+        return st
+
+    def _beam_reset(self, st, B, beam):
+        for k in ("gen", "length", "prob"):
+            st[k][0].zero_()
+            st[k][1].zero_()
+        st["gen"][0][:, 0] = START
+        st["length"][0].fill_(1)
+        st["prob"][0].view(B, beam)[:, 0] = 1.0
+        st["done"].zero_()
+
+    def _beam_steps(self, st, ws, B, beam, lo, hi):
+        """Steps lo..hi-1 of run_model.py:225-340: prepare -> KV-cached decoder step -> select, all on the device."""
+        lib, s, T = _lib.lib(), _lib.cur_stream(), self.cfg.tar_len
+        for step in range(lo, hi):
+            cur, nxt = step & 1, (step + 1) & 1
+            _lib.check(lib.fira_beam_prepare(s, B, beam, T, step, _lib.ptr(st["gen"][cur]), _lib.ptr(st["length"][cur]),
+                                             _lib.ptr(st["tok"]), _lib.ptr(st["fin"]), _lib.ptr(st["active"]),
+                                             _lib.ptr(st["done"])), "fira_beam_prepare")
+            self._step(ws, B, beam, step, st["tok"], st["parent"] if step > 0 else None, st["dist"], None, None)
+            _lib.check(lib.fira_beam_select(s, C.byref(self.model.dims), B, beam, _lib.ptr(st["dist"]),
+                                            _lib.ptr(st["fin"]), _lib.ptr(st["active"]), _lib.ptr(st["done"]),
+                                            _lib.ptr(st["sou"]), _lib.ptr(st["sub"]), _lib.ptr(st["gen"][cur]),
+                                            _lib.ptr(st["length"][cur]), _lib.ptr(st["prob"][cur]),
+                                            _lib.ptr(st["gen"][nxt]), _lib.ptr(st["length"][nxt]),
+                                            _lib.ptr(st["prob"][nxt]), _lib.ptr(st["parent"])), "fira_beam_select")
+
     @torch.no_grad()
-    def beam(self, db: DeviceBatch, beam: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Returns (hypotheses [B,beam,T] int64, lengths [B,beam], probabilities [B,beam])."""
+    def beam(self, db: DeviceBatch, beam: int, chunk: int = 4, use_graphs: bool = True):
+        """Returns (hypotheses [B,beam,T] int64, lengths [B,beam], probabilities [B,beam]).
+
+        Per step: fira_beam_prepare, fira_decode_step, fira_beam_select (csrc/beam.hip) -- three library calls, no torch
+        op and no host round trip; the loop is captured into hipGraphs of ``chunk`` steps per (batch, beam) shape, and
+        the ``done`` latch is read back between chunks (run_model.py:276-279)."""
+        cfg = self.cfg
+        B, T = db.B, cfg.tar_len
+        ws = self._begin(db, beam)
+        st = self._beam_state(B, beam)
+        st["sou"].copy_(db.sou)
+        st["sub"].copy_(db.sub_token)
+        self._beam_reset(st, B, beam)
+        bounds = [(lo, min(lo + chunk, T - 1)) for lo in range(0, T - 1, chunk)]
+        if use_graphs and st["graphs"] is None:
+            self._beam_steps(st, ws, B, beam, 0, 1)            # warm-up outside capture
+            torch.cuda.synchronize()
+            graphs = []
+            for lo, hi in bounds:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._beam_steps(st, ws, B, beam, lo, hi)
+                graphs.append(g)
+            st["graphs"] = graphs
+            self._beam_reset(st, B, beam)
+        last = 0
+        for i, (lo, hi) in enumerate(bounds):
+            if use_graphs:
+                st["graphs"][i].replay()
+            else:
+                self._beam_steps(st, ws, B, beam, lo, hi)
+            last = hi
+            if hi < T - 1 and bool(st["done"].item()):
+                break
+        cur = last & 1
+        return (st["gen"][cur].view(B, beam, T).long(), st["length"][cur].view(B, beam).long(),
+                st["prob"][cur].view(B, beam).clone())
+
+    @torch.no_grad()
+    def beam_torch(self, db: DeviceBatch, beam: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The same search with the bookkeeping written in torch ops (descending sort of all candidates, one host sync
+        per step): kept as an independent statement of run_model.py:268-340 that the tests hold ``beam`` against."""
         cfg, dev = self.cfg, self.model.device_
         B, T, W = db.B, cfg.tar_len, cfg.out_len
         BR = B * beam

@@ -114,7 +114,7 @@ int  fira_prof_report(int n_class, double* ms, double* work, int64_t* count);
 /* C[M,N] (+)= op(A)·op(B) (+ bias[n]) (relu).  Replaces every nn.Linear / its backward
  * (addmm/mm calls listed in SURVEY.md §2.3).  transA=0: A stored [M,K] (lda); transA=1: A stored
  * [K,M].  transB=1: B stored [N,K] (the nn.Linear weight layout); transB=0: B stored [K,N].
- * flags: bit0 relu, bit1 accumulate into C (C += ...), splitk >= 1 partitions K over grid.z
+ * flags: bit0 relu, bit1 accumulate into C (C += ...), splitk >= 1 partitions K over grid.z (0 = automatic tile / split choice, what the fused entry points use)
  * (partials combined with fp32 atomics; requires accumulate semantics, C pre-initialised).     */
 #define FIRA_GEMM_RELU 1
 #define FIRA_GEMM_ACCUM 2
@@ -225,6 +225,22 @@ int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch,
 int fira_decode_step(void* stream, const fira_dims* d, const float* params, void* workspace,
                      size_t workspace_bytes, int B, int n_beam, int step, const int32_t* tokens,
                      const int32_t* parent, float* dist, int32_t* best_id, float* best_p);
+
+/* Hypothesis bookkeeping of the search loop on the device (run_model.py:225-246 and :268-340).  State per commit:
+ * gen [B*n_beam, tar_len] ids starting with <start>, length [B*n_beam], prob [B*n_beam] (slot 0 starts at 1, the others
+ * at 0), double-buffered by the caller.  `active` has 9 ints (flags of up to 8 slots + their count), `done` 1 int that
+ * latches once no slot runs; after that fira_beam_select only copies the state through.
+ *   fira_beam_prepare : finished[r] = last token is <eos>; active[j] = some commit unfinished in slot j;
+ *                       tokens[r] = id at position `step` (0 once the hypothesis is shorter) -> fira_decode_step
+ *   fira_beam_select  : the n_beam best of { dist[slot j] * prob[j] (-1 if finished) for running slots, in slot order }
+ *                       ++ { prob of finished hypotheses, slot order, -1 padded }, ranked by (value desc, index asc);
+ *                       copy ids resolved through sou / sub_token; writes the new state and parent[] for the KV cache */
+int fira_beam_prepare(void* stream, int B, int n_beam, int tar_len, int step, const int32_t* gen, const int32_t* length,
+                      int32_t* tokens, int32_t* finished, int32_t* active, int32_t* done);
+int fira_beam_select(void* stream, const fira_dims* d, int B, int n_beam, const float* dist, const int32_t* finished,
+                     const int32_t* active, const int32_t* done, const int32_t* sou, const int32_t* sub_token,
+                     const int32_t* gen_in, const int32_t* len_in, const float* prob_in, int32_t* gen_out,
+                     int32_t* len_out, float* prob_out, int32_t* parent);
 
 /* Decoder.forward over all tar_len positions on caller-supplied memory [B, sou+sub, 256] / mem_valid [B, sou+sub]
  * (gnn_transformer.py:108-122; the call of run_model.py:256).  Workspace: fira_workspace_bytes(d, B, 0).          */

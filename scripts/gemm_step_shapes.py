@@ -1,0 +1,50 @@
+"""Every GEMM shape of one batch-32 training step, timed in isolation through fira_gemm_f32 with the library's automatic
+kernel / tile / split choice (what the engine uses) and with each main-kernel tile forced, to audit the dispatch.
+Typical node counts of the synthetic batch: Nc computed nodes, Cc code nodes, Mc memory nodes, R head rows."""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fira_icse_amd import ops
+from scripts.bench_kernels import timeit
+
+Nc, Cc, Mc, R, TB = 12000, 5000, 8500, 700, 960
+SHAPES = [  # name, M, N, K, tA, tB, accumulate, launches per step
+    ("enc fc fwd", Nc, 256, 256, 0, 1, 0, 12), ("enc qk fwd", Cc, 512, 256, 0, 1, 0, 6), ("enc o fwd", Cc, 256, 256, 0, 1, 0, 6),
+    ("kv_all fwd", Mc, 3072, 256, 0, 1, 0, 1), ("src fwd", Mc, 256, 256, 0, 1, 0, 1),
+    ("dec 256 fwd", TB, 256, 256, 0, 1, 0, 19), ("dec qkv fwd", TB, 768, 256, 0, 1, 0, 6),
+    ("dec ffn1 fwd", TB, 1024, 256, 0, 1, 0, 6), ("dec ffn2 fwd", TB, 256, 1024, 0, 1, 0, 6),
+    ("out_fc fwd", R, 24650, 256, 0, 1, 0, 1),
+    ("enc fc dgrad", Nc, 256, 256, 0, 0, 0, 12), ("enc qk dgrad", Cc, 256, 512, 0, 0, 0, 6), ("enc o dgrad", Cc, 256, 256, 0, 0, 0, 6),
+    ("kv_all dgrad", Mc, 256, 3072, 0, 0, 1, 1), ("dec 256 dgrad", TB, 256, 256, 0, 0, 0, 19),
+    ("dec qkv dgrad", TB, 256, 768, 0, 0, 0, 6), ("dec ffn1 dgrad", TB, 256, 1024, 0, 0, 0, 6),
+    ("dec ffn2 dgrad", TB, 1024, 256, 0, 0, 0, 6), ("out_fc dgrad", R, 256, 24650, 0, 0, 1, 1),
+    ("enc fc wgrad", 256, 256, Nc, 1, 0, 1, 12), ("enc qk wgrad", 512, 256, Cc, 1, 0, 1, 6), ("enc o wgrad", 256, 256, Cc, 1, 0, 1, 6),
+    ("kv_all wgrad", 3072, 256, Mc, 1, 0, 1, 1), ("dec 256 wgrad", 256, 256, TB, 1, 0, 1, 19),
+    ("dec qkv wgrad", 768, 256, TB, 1, 0, 1, 6), ("dec ffn1 wgrad", 1024, 256, TB, 1, 0, 1, 6),
+    ("dec ffn2 wgrad", 256, 1024, TB, 1, 0, 1, 6), ("out_fc wgrad", 24650, 256, R, 1, 0, 1, 1),
+]
+
+
+def main():
+    rows, total = [], {"auto": 0.0, "best": 0.0}
+    for name, M, N, K, tA, tB, acc, cnt in SHAPES:
+        A = torch.randn((K, M) if tA else (M, K), device="cuda")
+        B = torch.randn((N, K) if tB else (K, N), device="cuda")
+        C = torch.zeros(M, N, device="cuda")
+        res = {}
+        for label, tile in (("auto", 0), ("t128", 1), ("t64x128", 2), ("t64", 3)):
+            t = timeit(lambda: ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=C, accumulate=bool(acc), splitk=0,
+                                        tile=tile), iters=30)
+            res[label] = t * 1e6
+        best = min(res, key=res.get)
+        total["auto"] += cnt * res["auto"]
+        total["best"] += cnt * res[best]
+        rows.append("%-16s %6d %6d %6d  x%-2d  auto %7.1f us %6.1f TF | t128 %7.1f  t64x128 %7.1f  t64 %7.1f | best %s" % (
+            name, M, N, K, cnt, res["auto"], 2.0 * M * N * K / res["auto"] / 1e6, res["t128"], res["t64x128"], res["t64"],
+            best))
+    print("\n".join(rows))
+    print("sum over the step: auto %.0f us, best-of-forced %.0f us" % (total["auto"], total["best"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -95,3 +95,24 @@ def test_step_distribution_equals_full_recompute(setup):
         assert torch.equal(got.argmax(-1), ref[:, step].argmax(-1))
     mem = _lib.lib().fira_decode_memory(C.byref(model.dims), _lib.ptr(ws), B, 1)
     assert mem
+
+
+@pytest.mark.parametrize("beam", [2, 3, 5])
+def test_device_beam_bookkeeping_equals_torch_statement(setup, beam):
+    """csrc/beam.hip (selection without a sort, state in HBM, hipGraph replay) against the same search written in
+    torch ops: identical hypotheses, lengths and probabilities, eager == captured == replayed."""
+    from fira_icse_amd.model import DeviceBatch
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    store = data.process_raw(cfg, raw)
+    for sel in (None, list(range(7))):                       # the fixture batch, and 7 other commits (odd batch)
+        d = db if sel is None else DeviceBatch(store.batch(sel), cfg)
+        gen_t, len_t, p_t = search.beam_torch(d, beam)
+        gen_e, len_e, p_e = search.beam(d, beam, use_graphs=False)
+        gen_g, len_g, p_g = search.beam(d, beam)
+        gen_r, len_r, p_r = search.beam(d, beam)
+        for gen, length, p in ((gen_e, len_e, p_e), (gen_g, len_g, p_g), (gen_r, len_r, p_r)):
+            assert torch.equal(length, len_t)
+            assert torch.equal(p, p_t)
+            T = gen.shape[-1]
+            live = torch.arange(T, device=gen.device)[None, None, :] < length[:, :, None]
+            assert torch.equal(gen * live, gen_t * live)

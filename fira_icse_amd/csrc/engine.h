@@ -29,9 +29,6 @@ int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, in
 int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
                     const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site);
 // y_rows (optional): output row r is stored at row y_rows[r]
-bool linear_layernorm_try(hipStream_t s, int M, int K, const float* A, int lda, const float* W, const float* bias,
-                          const float* res, const float* gamma, const float* beta, float* sum_out, float* y,
-                          const int32_t* y_rows, float* stats, float dropout, uint64_t seed, uint32_t site, int* rc);
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows);
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,

@@ -147,14 +147,6 @@ int fira_combination_bwd(void* stream, int M, const float* qk, const float* vtab
                          const float* dout, float* dqk, float* dvtab /* [4,256] += */,
                          float dropout, uint64_t seed, uint32_t stream_id);
 
-/* y = LayerNorm(dropout(A W^T + bias) + res) for the model width (W is an nn.Linear weight [256, K]), one fused kernel:
- * `self.layernorm(self.dropout(self.fc_o(x)) + residual)` of gnn_transformer.py:84-86,159-161,172-174,203-205.
- * sum_out [M,256] receives the pre-norm sum and stats [M,2] (mean, rstd) for fira_add_layernorm_bwd (either may be NULL
- * when K % 32 == 0 and A is 16-byte aligned; other shapes run GEMM + fira_add_layernorm_fwd and need sum_out).       */
-int fira_linear_layernorm_fwd(void* stream, int M, int K, const float* A, int lda, const float* W, const float* bias,
-                              const float* res, const float* gamma, const float* beta, float* sum_out, float* y,
-                              float* stats, float dropout, uint64_t seed, uint32_t stream_id);
-
 /* y = LayerNorm(dropout(x) + res) * gamma + beta  (eps 1e-5), rows of 256.  x is overwritten with the
  * pre-norm sum (kept for backward); stats[row] = {mean, rstd}.  Post-LN residual blocks of
  * gnn_transformer.py:86,161,174,205.                                                            */

@@ -38,6 +38,8 @@ int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out);
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
 // 3 out[dst[r]]=in[src[r]]
 int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst);
+int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, const float* in, int ld_in,
+                 const int32_t* src, const int32_t* dst);
 // compact[r,:] = src[rows[r],:] ;  dst[rows[r],:] += compact[r,:]
 int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows);
 int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows);

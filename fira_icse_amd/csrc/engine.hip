@@ -189,6 +189,20 @@ static int side_join(hipStream_t main_s) {
     return 0;
 }
 
+static inline bool side_on() { SideStream& sd = side(); return sd.stream && sd.enabled; }
+// mark: an event at the current tail of the side stream;  wait: `main` waits for such a mark
+static int side_mark(hipEvent_t* out) {
+    SideStream& sd = side();
+    hipEvent_t e = sd.ev();
+    if (hipEventRecord(e, sd.stream) != hipSuccess) return set_err("side stream mark failed");
+    *out = e;
+    return 0;
+}
+static int main_wait(hipStream_t main_s, hipEvent_t e) {
+    if (hipStreamWaitEvent(main_s, e, 0) != hipSuccess) return set_err("stream wait failed");
+    return 0;
+}
+
 // dW += dY^T X ; db += colsum(dY)      (reduce over the M rows: split-K over rows keeps the chip busy)
 // dY and X must stay untouched until the next side_join (per-layer slots of Plan::encg / decg, saved activations).
 static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx,
@@ -214,13 +228,17 @@ struct Ctx {
     Plan* pl;
     float p_drop, p_gcn;
     uint64_t seed;
+    // memory-side projections deferred to the side stream by encoder_forward (see there): marks to wait for
+    bool deferred = false;
+    hipEvent_t ev_kv[16] = {};
+    hipEvent_t ev_src = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------ encoder forward
 // The encoder runs on the batch's COMPUTED node list only (fira_batch.node_rows): padded nodes carry nothing but a
 // self-loop, are masked as attention keys / copy slots and receive exactly zero gradient (SURVEY.md §8a note N1), so
 // leaving them out changes no consumed value.  Nc = n_nodes, Cc = n_code, Mc = n_mem below.
-static int encoder_forward(Ctx& c) {
+static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
     const fira_batch& bt = *c.bt;
@@ -256,6 +274,25 @@ static int encoder_forward(Ctx& c) {
     // memory = [code ; sub-token] rows (Model.py:48): compact copy for the GEMMs, dense [B,370,*] rows for the
     // attention / copy kernels (rows of masked slots are never read there)
     TRY(rows_move(s, 0, Mc, D, p.mem_c, p.X[p.nl], bt.mem_rows, nullptr));
+    c.deferred = false;
+    if (defer_memory_proj && side_on() && p.nl <= 16) {
+        // The decoder consumes layer l's K|V only at its l-th cross attention and LinearSource(memory) only in the
+        // copy head, and the decoder's own chain is a string of small latency-bound kernels: the projections run per
+        // layer on the side stream under it; decoder_forward / head_forward wait for the mark they need.
+        TRY(side_fork(s));
+        hipStream_t ss = side().stream;
+        for (int l = 0; l < p.nl; ++l) {
+            const size_t o = (size_t)l * 2 * D;
+            TRY(linear(ss, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, c.P + L.bkv_all + o, p.kv_c + o, KV));
+            TRY(rows_move_ld(ss, 1, Mc, 2 * D, p.kv_all + o, KV, p.kv_c + o, KV, nullptr, bt.mem_dst));
+            TRY(side_mark(&c.ev_kv[l]));
+        }
+        TRY(gemm_f32_ex(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
+        TRY(rows_move(ss, 1, Mc, D, p.src, p.src_c, nullptr, bt.mem_dst));
+        TRY(side_mark(&c.ev_src));
+        c.deferred = true;
+        return 0;
+    }
     TRY(linear(s, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, c.P + L.bkv_all, p.kv_c, KV));
     TRY(rows_move(s, 1, Mc, KV, p.kv_all, p.kv_c, nullptr, bt.mem_dst));
     TRY(gemm_f32_ex(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
@@ -279,6 +316,7 @@ static int decoder_forward(Ctx& c) {
         TRY(linear(s, p.TB, D, D, e.ao, D, c.P + w.wo_s, c.P + w.bo_s, e.s_a, D));
         TRY(add_layernorm_fwd(s, p.TB, e.s_a, x, c.P + w.lns_g, c.P + w.lns_b, e.x_a, e.st_a, c.p_drop, c.seed, site(l, SITE_SELF), nullptr));
         TRY(linear(s, p.TB, D, D, e.x_a, D, c.P + w.wq_c, c.P + w.bq_c, e.qc, D));
+        if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
         TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D));
         TRY(linear(s, p.TB, D, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.s_c, D));
         TRY(add_layernorm_fwd(s, p.TB, e.s_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.x_c, e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS), nullptr));
@@ -303,6 +341,7 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     TRY(invert_rows(s, p.TB, R, rows, p.compact_row));
     TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
     TRY(gemm_f32_ex(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
+    if (c.deferred) TRY(main_wait(s, c.ev_src));                   // LinearSource(memory) (side stream)
     // teacher-forced ids (dev) need every row's copy distribution; the training loss only the copy-labelled rows
     TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid,
                           argmax_out ? nullptr : c.bt->tar_label, p.V));
@@ -326,6 +365,20 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     float* G = c.G;
 
     // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
+    // The vocabulary dgrad ([R, V] x [V, 256], the head's largest product) and the copy branch are independent until
+    // both land in ddec: the former runs on the side stream under the latter.
+    const bool so = side_on();
+    hipStream_t ss = so ? side().stream : s;
+    hipEvent_t ev_dfc = nullptr;
+    if (R > 0) {
+        if (so) TRY(side_fork(s));
+        TRY(zero(ss, p.ddec_c, (size_t)R * D * sizeof(float)));
+        // ddec_rows = dlogits W_out, split over the vocabulary axis
+        TRY(gemm_f32_ex(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
+                        nullptr));
+        if (so) TRY(side_mark(&ev_dfc));
+        TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
+    }
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
     TRY(zero(s, p.dtgt, (size_t)p.TB * D * sizeof(float)));
@@ -334,14 +387,14 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
     TRY(linear_wgrad(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
     TRY(rows_move(s, 0, Mc, D, p.dsrc_c, p.dsrc, bt.mem_dst, nullptr));
-    TRY(linear_dgrad(s, Mc, D, D, p.dsrc_c, D, c.P + L.ws, p.dmem_c, D, false));
+    // d memory (compact rows) = dsrc Ws + sum_l dKV_l Wkv_l: nothing reads it before the encoder's backward pass, so
+    // the whole accumulation lives on the side stream (in order: this product initialises dmem_c, the per-layer
+    // products of the decoder loop below add to it)
+    if (so) TRY(side_fork(s));
+    TRY(linear_dgrad(ss, Mc, D, D, p.dsrc_c, D, c.P + L.ws, p.dmem_c, D, false));
     TRY(linear_wgrad(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr));
     if (R > 0) {
-        TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
-        TRY(zero(s, p.ddec_c, (size_t)R * D * sizeof(float)));
-        // ddec_rows = dlogits W_out : [R, V] x [V, 256], split over the vocabulary axis
-        TRY(gemm_f32_ex(s, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
-                        nullptr));
+        if (ev_dfc) TRY(main_wait(s, ev_dfc));
         TRY(rows_scatter_add_idx(s, R, p.ddec_c, p.ddec, rows));
     }
 
@@ -368,6 +421,12 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                           p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, KV,
                           p.dkv_all + l * 2 * D + D, KV));
+        if (so) {                                // this layer's dK|dV -> compact rows -> d memory, beside the chain
+            const size_t o = (size_t)l * 2 * D;
+            TRY(side_fork(s));
+            TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, KV, bt.mem_dst, nullptr));
+            TRY(linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true));
+        }
         TRY(linear_wgrad(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
         TRY(linear_dgrad(s, p.TB, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
         // self attention
@@ -386,8 +445,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // hundreds of serialised atomic additions of 0.0 onto table row 0.
     TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
     // cross-attention K|V projections of all layers (computed memory rows only)
-    TRY(rows_move(s, 0, Mc, KV, p.dkv_c, p.dkv_all, bt.mem_dst, nullptr));
-    TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
+    hipEvent_t ev_dmem = nullptr;
+    if (so) {
+        TRY(side_mark(&ev_dmem));                // dmem_c is complete at this point of the side stream
+    } else {
+        TRY(rows_move(s, 0, Mc, KV, p.dkv_c, p.dkv_all, bt.mem_dst, nullptr));
+        TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
+    }
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     if (mid_event) {                         // gradients of [0, split) are final from here on
         if (side().stream && side().enabled) TRY(side_join(s));
@@ -399,6 +463,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     float* dXn = p.dXa;
     float* other = p.dXb;
     TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));            // AST/edit rows of the last layer feed nothing
+    if (ev_dmem) TRY(main_wait(s, ev_dmem));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
     TRY(zero(s, p.dvtab_all, (size_t)4 * p.nl * D * sizeof(float)));
     for (int l = p.nl - 1; l >= 0; --l) {
@@ -520,7 +585,7 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
           opts ? opts->seed : 0};
     FIRA_REQUIRE(c.p_drop >= 0.f && c.p_drop < 1.f && c.p_gcn >= 0.f && c.p_gcn < 1.f, "dropout must be in [0,1)");
     TRY(side().init());
-    TRY(encoder_forward(c));
+    TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
     int R = p.TB;
     const int32_t* rows = p.iota;
@@ -547,7 +612,7 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
     FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     TRY(check_counts(batch, p));
     Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
-    TRY(encoder_forward(c));
+    TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
     TRY(iota_rows(c.s, p.TB, p.iota));
     TRY(head_forward(c, p.TB, p.iota, loss_sum, n_tok, ids_out, 0));
@@ -568,7 +633,7 @@ int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch,
     b2.tar = nullptr;
     Ctx c{(hipStream_t)stream, L, &b2, params, nullptr, &p, 0.f, 0.f, 0};
     TRY(check_counts(batch, p));
-    TRY(encoder_forward(c));            // also leaves kv_all (cross K|V of all layers) and src = LinearSource(memory)
+    TRY(encoder_forward(c, false));     // also leaves kv_all (cross K|V of all layers) and src = LinearSource(memory)
     TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers
     return 0;
 }

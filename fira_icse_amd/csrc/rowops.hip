@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* 
 //   MODE 2  out[dst[r]]    += in[r]               (scatter-add; dst has no duplicates: plain read-modify-write)
 //   MODE 3  out[dst[r]]     = in[src[r]]          (gather + scatter)
 template <int MODE>
-__global__ __launch_bounds__(256) void rows_idx_kernel(int R, int W, float* __restrict__ out, const float* __restrict__ in,
+__global__ __launch_bounds__(256) void rows_idx_kernel(int R, int W, float* __restrict__ out, int ld_out,
+                                                       const float* __restrict__ in, int ld_in,
                                                        const int32_t* __restrict__ src, const int32_t* __restrict__ dst) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -350,12 +351,12 @@ __global__ __launch_bounds__(256) void rows_idx_kernel(int R, int W, float* __re
     const size_t ri = (MODE == 0 || MODE == 3) ? (size_t)(src ? src[r] : r) : (size_t)r;
     const size_t ro = (MODE == 0) ? (size_t)r : (size_t)dst[r];
     for (int c = lane * 4; c < W; c += 256) {
-        float4 a = *reinterpret_cast<const float4*>(in + ri * W + c);
+        float4 a = *reinterpret_cast<const float4*>(in + ri * ld_in + c);
         if (MODE == 2) {
-            const float4 b = *reinterpret_cast<const float4*>(out + ro * W + c);
+            const float4 b = *reinterpret_cast<const float4*>(out + ro * ld_out + c);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        *reinterpret_cast<float4*>(out + ro * W + c) = a;
+        *reinterpret_cast<float4*>(out + ro * ld_out + c) = a;
     }
 }
 __global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t n4, float4* __restrict__ dh, const float4* __restrict__ h) {
@@ -392,17 +393,23 @@ __global__ void invert_rows_kernel(int R, const int32_t* __restrict__ rows, int3
 }
 
 // ---------------------------------------------------------------- host launchers
-int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst) {
+// W floats of each row are moved; rows are ld_out / ld_in floats apart (a column block of a wider matrix)
+int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, const float* in, int ld_in,
+                 const int32_t* src, const int32_t* dst) {
     if (R <= 0) return 0;
-    FIRA_REQUIRE(W % 256 == 0 && mode >= 0 && mode <= 3, "rows_move: bad width %d / mode %d", W, mode);
+    FIRA_REQUIRE(W % 256 == 0 && ld_out % 4 == 0 && ld_in % 4 == 0 && mode >= 0 && mode <= 3,
+                 "rows_move: bad width %d / mode %d", W, mode);
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     dim3 g(cdiv(R, 4)), b(256);
-    if (mode == 0) hipLaunchKernelGGL(rows_idx_kernel<0>, g, b, 0, s, R, W, out, in, src, dst);
-    else if (mode == 1) hipLaunchKernelGGL(rows_idx_kernel<1>, g, b, 0, s, R, W, out, in, src, dst);
-    else if (mode == 2) hipLaunchKernelGGL(rows_idx_kernel<2>, g, b, 0, s, R, W, out, in, src, dst);
-    else hipLaunchKernelGGL(rows_idx_kernel<3>, g, b, 0, s, R, W, out, in, src, dst);
+    if (mode == 0) hipLaunchKernelGGL(rows_idx_kernel<0>, g, b, 0, s, R, W, out, ld_out, in, ld_in, src, dst);
+    else if (mode == 1) hipLaunchKernelGGL(rows_idx_kernel<1>, g, b, 0, s, R, W, out, ld_out, in, ld_in, src, dst);
+    else if (mode == 2) hipLaunchKernelGGL(rows_idx_kernel<2>, g, b, 0, s, R, W, out, ld_out, in, ld_in, src, dst);
+    else hipLaunchKernelGGL(rows_idx_kernel<3>, g, b, 0, s, R, W, out, ld_out, in, ld_in, src, dst);
     FIRA_CHECK_LAUNCH("rows_move");
     return 0;
+}
+int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst) {
+    return rows_move_ld(s, mode, R, W, out, W, in, W, src, dst);
 }
 int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows) {
     return rows_move(s, 0, R, FIRA_D, compact, src, rows, nullptr);

@@ -152,15 +152,23 @@ static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* 
 // side stream before the mid-event (data-parallel bucket hand-off) and at the end of the backward pass.
 struct SideStream {
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;   // high priority: the few off-chain products the main stream waits for later
     std::vector<hipEvent_t> events;
     size_t next = 0;
     bool enabled = true;
+    bool wide = true;            // FIRA_SIDE_WGRAD_ONLY=1: only the weight gradients use the side stream (A/B switch)
     int init() {
         if (stream) return 0;
         const char* off = getenv("FIRA_NO_WGRAD_OVERLAP");
         enabled = !(off && off[0] == '1');
+        const char* narrow = getenv("FIRA_SIDE_WGRAD_ONLY");
+        wide = !(narrow && narrow[0] == '1');
         hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
         if (e != hipSuccess) return set_err("hipStreamCreate: %s", hipGetErrorString(e));
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);
+        if (e != hipSuccess) return set_err("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
         events.resize(512);
         for (auto& ev : events) {
             e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -189,12 +197,20 @@ static int side_join(hipStream_t main_s) {
     return 0;
 }
 
-static inline bool side_on() { SideStream& sd = side(); return sd.stream && sd.enabled; }
-// mark: an event at the current tail of the side stream;  wait: `main` waits for such a mark
+static inline bool side_on() { SideStream& sd = side(); return sd.stream && sd.enabled && sd.wide; }
+// the auxiliary stream waits for everything enqueued on `main` so far
+static int aux_fork(hipStream_t main_s) {
+    SideStream& sd = side();
+    hipEvent_t e = sd.ev();
+    if (hipEventRecord(e, main_s) != hipSuccess || hipStreamWaitEvent(sd.aux, e, 0) != hipSuccess)
+        return set_err("aux stream fork failed");
+    return 0;
+}
+// mark: an event at the current tail of the auxiliary stream;  wait: a stream waits for such a mark
 static int side_mark(hipEvent_t* out) {
     SideStream& sd = side();
     hipEvent_t e = sd.ev();
-    if (hipEventRecord(e, sd.stream) != hipSuccess) return set_err("side stream mark failed");
+    if (hipEventRecord(e, sd.aux) != hipSuccess) return set_err("aux stream mark failed");
     *out = e;
     return 0;
 }
@@ -279,8 +295,8 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // The decoder consumes layer l's K|V only at its l-th cross attention and LinearSource(memory) only in the
         // copy head, and the decoder's own chain is a string of small latency-bound kernels: the projections run per
         // layer on the side stream under it; decoder_forward / head_forward wait for the mark they need.
-        TRY(side_fork(s));
-        hipStream_t ss = side().stream;
+        TRY(aux_fork(s));
+        hipStream_t ss = side().aux;
         for (int l = 0; l < p.nl; ++l) {
             const size_t o = (size_t)l * 2 * D;
             TRY(linear(ss, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, c.P + L.bkv_all + o, p.kv_c + o, KV));
@@ -368,10 +384,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // The vocabulary dgrad ([R, V] x [V, 256], the head's largest product) and the copy branch are independent until
     // both land in ddec: the former runs on the side stream under the latter.
     const bool so = side_on();
-    hipStream_t ss = so ? side().stream : s;
+    hipStream_t ss = so ? side().aux : s;
     hipEvent_t ev_dfc = nullptr;
     if (R > 0) {
-        if (so) TRY(side_fork(s));
+        if (so) TRY(aux_fork(s));
         TRY(zero(ss, p.ddec_c, (size_t)R * D * sizeof(float)));
         // ddec_rows = dlogits W_out, split over the vocabulary axis
         TRY(gemm_f32_ex(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
@@ -390,7 +406,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // d memory (compact rows) = dsrc Ws + sum_l dKV_l Wkv_l: nothing reads it before the encoder's backward pass, so
     // the whole accumulation lives on the side stream (in order: this product initialises dmem_c, the per-layer
     // products of the decoder loop below add to it)
-    if (so) TRY(side_fork(s));
+    if (so) TRY(aux_fork(s));
     TRY(linear_dgrad(ss, Mc, D, D, p.dsrc_c, D, c.P + L.ws, p.dmem_c, D, false));
     TRY(linear_wgrad(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr));
     if (R > 0) {
@@ -423,7 +439,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                           p.dkv_all + l * 2 * D + D, KV));
         if (so) {                                // this layer's dK|dV -> compact rows -> d memory, beside the chain
             const size_t o = (size_t)l * 2 * D;
-            TRY(side_fork(s));
+            TRY(aux_fork(s));
             TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, KV, bt.mem_dst, nullptr));
             TRY(linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true));
         }
@@ -447,7 +463,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // cross-attention K|V projections of all layers (computed memory rows only)
     hipEvent_t ev_dmem = nullptr;
     if (so) {
-        TRY(side_mark(&ev_dmem));                // dmem_c is complete at this point of the side stream
+        TRY(side_mark(&ev_dmem));                // dmem_c / dkv_c are complete at this point of the auxiliary stream
+        TRY(main_wait(side().stream, ev_dmem));  // the K|V weight gradient below reads dkv_c
     } else {
         TRY(rows_move(s, 0, Mc, KV, p.dkv_c, p.dkv_all, bt.mem_dst, nullptr));
         TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));

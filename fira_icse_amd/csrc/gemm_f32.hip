@@ -152,29 +152,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
         for (int i = 0; i < LA::NV; ++i) { cs.x += v[i].x; cs.y += v[i].y; cs.z += v[i].z; cs.w += v[i].w; }
     };
 
-    float4 ra[LA::NV], rb[LB::NV];
+    // Two register stages: while tile `it` is consumed from LDS, tile it+1 waits in one register set (loaded during the
+    // previous iteration) and tile it+2 is being fetched into the other.  With K = 256 a 64x64 workgroup runs only
+    // 8 iterations of 16 MFMAs (~0.4 us) each, far less than a global-load latency: one tile of look-ahead left the
+    // loop latency-bound, two tiles cover it together with the co-resident workgroups.
+    float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
     const bool a_in = vecA && m0 + BM <= M, b_in = vecB && n0 + BN <= N;       // block-uniform
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, float4 (&ra)[LA::NV], float4 (&rb)[LB::NV]) {
         if (a_in && k0 + BK <= kend) LA::load_fast(ra, A, lda, m0, k0, t);
         else LA::load(ra, A, lda, m0, M, k0, kend, vecA != 0, t);
         if (b_in && k0 + BK <= kend) LB::load_fast(rb, B, ldb, n0, k0, t);
         else LB::load(rb, B, ldb, n0, N, k0, kend, vecB != 0, t);
+        if (do_cs) cs_add(ra);
     };
     if (ntile > 0) {
-        fetch(kbeg);
-        if (do_cs) cs_add(ra);
-        LA::store(ra, smA[0], t);
-        LB::store(rb, smB[0], t);
+        fetch(kbeg, ra0, rb0);
+        LA::store(ra0, smA[0], t);
+        LB::store(rb0, smB[0], t);
+        if (ntile > 1) fetch(kbeg + BK, ra0, rb0);
     }
     __syncthreads();
 
     int cur = 0;
-    for (int it = 0; it < ntile; ++it) {
-        const bool more = it + 1 < ntile;
-        if (more) {
-            fetch(kbeg + (it + 1) * BK);
-            if (do_cs) cs_add(ra);
-        }
+    // one iteration: `pa/pb` hold tile it+1, `qa/qb` receive tile it+2
+    auto step = [&](int it, float4 (&pa)[LA::NV], float4 (&pb)[LB::NV], float4 (&qa)[LA::NV], float4 (&qb)[LB::NV]) {
+        if (it + 2 < ntile) fetch(kbeg + (it + 2) * BK, qa, qb);
         const float* sa = smA[cur] + kh * LA::LD + wm * WM + l31;
         const float* sb = smB[cur] + kh * LB::LD + wn * WN + l31;
         // operand fragments of k-pair kk+1 are read from LDS before the MFMAs of k-pair kk are issued
@@ -202,12 +204,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (more) {
-            LA::store(ra, smA[cur ^ 1], t);
-            LB::store(rb, smB[cur ^ 1], t);
+        if (it + 1 < ntile) {
+            LA::store(pa, smA[cur ^ 1], t);
+            LB::store(pb, smB[cur ^ 1], t);
         }
         __syncthreads();
         cur ^= 1;
+    };
+    for (int it = 0; it < ntile; it += 2) {
+        step(it, ra0, rb0, ra1, rb1);
+        if (it + 1 < ntile) step(it + 1, ra1, rb1, ra0, rb0);
     }
 
     if (do_cs) {                                   // block-level combine of the column sums, then one atomic per column

@@ -37,6 +37,12 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out);
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
 // 3 out[dst[r]]=in[src[r]]
+int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
+         int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
+         int32_t* compact_row, int32_t* iota);
+int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
+                  const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
+                  float* X);
 int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst);
 int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, const float* in, int ld_in,
                  const int32_t* src, const int32_t* dst);

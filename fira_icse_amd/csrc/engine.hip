@@ -245,6 +245,9 @@ struct Ctx {
     float p_drop, p_gcn;
     uint64_t seed;
     // memory-side projections deferred to the side stream by encoder_forward (see there): marks to wait for
+    // target rows that need the vocabulary head (fira_batch.head_rows, or nullptr = every row -> Plan::iota)
+    int R = 0;
+    const int32_t* rows = nullptr;
     bool deferred = false;
     hipEvent_t ev_kv[16] = {};
     hipEvent_t ev_src = nullptr;
@@ -260,13 +263,11 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     const fira_batch& bt = *c.bt;
     hipStream_t s = c.s;
     const int D = FIRA_D, Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem, KV = p.nl * 2 * D;
-    TRY(fill_pos_tables(s, p.L, p.pos_code, p.T, p.pos_tar));
-    TRY(make_masks(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr));
-    // node features (gnn_transformer.py:46-52,58): gathered in the dense [B,650,256] layout, then compacted
-    TRY(embed_gather_fwd(s, p.B, p.L, bt.sou, c.P + L.emb, p.pos_code, p.H, p.N, 0));
-    TRY(embed_gather_fwd(s, p.B, p.S, bt.sub_token, c.P + L.emb, nullptr, p.H, p.N, p.L));
-    TRY(embed_gather_fwd(s, p.B, p.A, bt.ast_change, c.P + L.ast_emb, nullptr, p.H, p.N, p.L + p.S));
-    TRY(rows_move(s, 0, Nc, D, p.X[0], p.H, bt.node_rows, nullptr));
+    // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
+    TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
+             p.pos_tar, c.R, c.rows, bt.tar ? p.compact_row : nullptr, c.rows ? nullptr : p.iota));
+    TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
+                      p.pos_code, p.X[0]));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
     TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
     for (int l = 0; l < p.nl; ++l) {
@@ -353,8 +354,7 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     hipStream_t s = c.s;
     const int D = FIRA_D, Sm = p.L + p.S;
     const float* dec = p.dec[p.nl - 1].x_f;
-    TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));
-    TRY(invert_rows(s, p.TB, R, rows, p.compact_row));
+    TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));             // compact_row (its inverse) comes from prep()
     TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
     TRY(gemm_f32_ex(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
     if (c.deferred) TRY(main_wait(s, c.ev_src));                   // LinearSource(memory) (side stream)
@@ -602,17 +602,17 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
           opts ? opts->seed : 0};
     FIRA_REQUIRE(c.p_drop >= 0.f && c.p_drop < 1.f && c.p_gcn >= 0.f && c.p_gcn < 1.f, "dropout must be in [0,1)");
     TRY(side().init());
-    TRY(encoder_forward(c, true));
-    TRY(decoder_forward(c));
     int R = p.TB;
     const int32_t* rows = p.iota;
     if (opts && opts->compact_head && batch->head_rows) {
         R = batch->n_head_rows;
         rows = batch->head_rows;
         FIRA_REQUIRE(R >= 0 && R <= p.TB, "bad n_head_rows %d", R);
-    } else {
-        TRY(iota_rows(c.s, p.TB, p.iota));
+        c.R = R;
+        c.rows = rows;
     }
+    TRY(encoder_forward(c, true));
+    TRY(decoder_forward(c));
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
     TRY(backward(c, R, rows, (hipEvent_t)mid_event));
     return 0;
@@ -631,7 +631,6 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
     Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
     TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
-    TRY(iota_rows(c.s, p.TB, p.iota));
     TRY(head_forward(c, p.TB, p.iota, loss_sum, n_tok, ids_out, 0));
     return 0;
 }

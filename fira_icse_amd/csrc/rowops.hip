@@ -387,6 +387,72 @@ __global__ void pos_table_kernel(int L, float* __restrict__ out) {
     const double a = (double)pos / pow(10000.0, (double)(2 * j) / (double)FIRA_D);
     out[i] = (float)((c & 1) ? cos(a) : sin(a));
 }
+// Everything a step derives from the ids alone, in one launch: both sinusoidal tables, the key masks, and the inverse
+// of the head-row list (compact_row[flat target row] = position in the ascending `rows` list, or -1; rows == nullptr:
+// every row, identity) together with the identity list itself.
+__global__ void prep_kernel(int B, int L, int S, int T, const int32_t* __restrict__ sou, const int32_t* __restrict__ sub,
+                            const int32_t* __restrict__ tar, int32_t* __restrict__ mem_valid,
+                            int32_t* __restrict__ tar_valid, float* __restrict__ pos_code, float* __restrict__ pos_tar,
+                            int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row,
+                            int32_t* __restrict__ iota) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int W = L + S;
+    if (i < B * W) {
+        const int b = i / W, j = i - b * W;
+        mem_valid[i] = (j < L ? sou[b * L + j] : sub[b * S + j - L]) != 0;
+    }
+    if (tar && i < B * T) {
+        tar_valid[i] = tar[i] != 0;
+        if (compact_row) {
+            int v = i;
+            if (rows) {                          // binary search in the ascending list
+                int lo = 0, hi = R;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rows[mid] < i) lo = mid + 1; else hi = mid;
+                }
+                v = (lo < R && rows[lo] == i) ? lo : -1;
+            }
+            compact_row[i] = v;
+        }
+        if (iota) iota[i] = i;
+    }
+    if (i < (L + T) * FIRA_D) {
+        const bool code = i < L * FIRA_D;
+        const int k = code ? i : i - L * FIRA_D;
+        const int pos = k / FIRA_D, c = k % FIRA_D, j = c >> 1;
+        const double a = (double)pos / pow(10000.0, (double)(2 * j) / (double)FIRA_D);
+        (code ? pos_code : pos_tar)[k] = (float)((c & 1) ? cos(a) : sin(a));
+    }
+}
+
+// Node features of the COMPUTED nodes straight into the compact layout (gnn_transformer.py:46-52,58): one wave per
+// node; code tokens add their position row.
+__global__ __launch_bounds__(256) void node_features_kernel(int Nc, const int32_t* __restrict__ node_rows, int N, int L,
+                                                            int S, const int32_t* __restrict__ sou,
+                                                            const int32_t* __restrict__ sub,
+                                                            const int32_t* __restrict__ ast,
+                                                            const float* __restrict__ emb,
+                                                            const float* __restrict__ ast_emb,
+                                                            const float* __restrict__ pos_code,
+                                                            float* __restrict__ X) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= Nc) return;
+    const int g = node_rows[r], b = g / N, loc = g - b * N, A = N - L - S;
+    float4 v;
+    if (loc < L) {
+        v = *reinterpret_cast<const float4*>(emb + (size_t)sou[b * L + loc] * FIRA_D + lane * 4);
+        const float4 p = *reinterpret_cast<const float4*>(pos_code + (size_t)loc * FIRA_D + lane * 4);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    } else if (loc < L + S) {
+        v = *reinterpret_cast<const float4*>(emb + (size_t)sub[b * S + loc - L] * FIRA_D + lane * 4);
+    } else {
+        v = *reinterpret_cast<const float4*>(ast_emb + (size_t)ast[b * A + loc - L - S] * FIRA_D + lane * 4);
+    }
+    *reinterpret_cast<float4*>(X + (size_t)r * FIRA_D + lane * 4) = v;
+}
+
 __global__ void invert_rows_kernel(int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r < R) compact_row[rows[r]] = r;
@@ -440,6 +506,25 @@ __global__ void tar_mask_kernel(int n, const int32_t* __restrict__ tar, int32_t*
 int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid) {
     hipLaunchKernelGGL(tar_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, tar, valid);
     FIRA_CHECK_LAUNCH("tar_mask");
+    return 0;
+}
+int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
+         int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
+         int32_t* compact_row, int32_t* iota) {
+    const int n = std::max(std::max(B * (L + S), B * T), (L + T) * FIRA_D);
+    hipLaunchKernelGGL(prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid, tar_valid,
+                       pos_code, pos_tar, R, rows, compact_row, iota);
+    FIRA_CHECK_LAUNCH("prep");
+    return 0;
+}
+int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
+                  const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
+                  float* X) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    if (Nc <= 0) return 0;
+    hipLaunchKernelGGL(node_features_kernel, dim3(cdiv(Nc, 4)), dim3(256), 0, s, Nc, node_rows, N, L, S, sou, sub, ast, emb,
+                       ast_emb, pos_code, X);
+    FIRA_CHECK_LAUNCH("node_features");
     return 0;
 }
 int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar) {

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfira_hip.so")
+# FIRA_HIP_LIB: load another build of the same ABI instead (A/B timing of two builds on one GPU box)
+LIB_PATH = os.environ.get("FIRA_HIP_LIB") or os.path.join(HERE, "libfira_hip.so")
 
 
 class FiraError(RuntimeError):
@@ -29,7 +30,8 @@ class Batch(C.Structure):
                 ("val", C.c_void_p), ("n_code", C.c_int32), ("code_rows", C.c_void_p), ("code_mark", C.c_void_p),
                 ("n_mem", C.c_int32), ("mem_rows", C.c_void_p), ("mem_dst", C.c_void_p), ("head_rows", C.c_void_p),
                 ("n_head_rows", C.c_int32), ("n_emb_items", C.c_int32), ("emb_item_tok", C.c_void_p),
-                ("emb_item_ptr", C.c_void_p), ("emb_rows", C.c_void_p)]
+                ("emb_item_ptr", C.c_void_p), ("emb_rows", C.c_void_p), ("n_ast_items", C.c_int32),
+                ("ast_rows", C.c_void_p), ("ast_ids", C.c_void_p)]
 
 
 class TrainOpts(C.Structure):
@@ -109,7 +111,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fira_abi_version() != 1:
+    if lib.fira_abi_version() != 2:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib
 

@@ -11,15 +11,20 @@ int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A,
              float* C, int ldc, const float* bias, int flags, int splitk);
 // splitk = 0: automatic tile / split selection; colsum (transA only): colsum[m] += sum_k A[k][m] (fused bias gradient)
 int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                float* C, int ldc, const float* bias, int flags, int splitk, float* colsum);
+                float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
+                const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
+// c_rows: output row r is written to C row c_rows[r];  relu_mask [M,N] (ld = ldc): output zeroed where mask <= 0
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, const float* bias, int flags, int* rc);
+                    float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows = nullptr,
+                    const float* relu_mask = nullptr);
 int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
              int ldx, float* Y, int ldy, int graph_rows, int variant);
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
                      int out_bstride, int out_off);
 int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const int32_t* item_ptr, const int32_t* rows,
                       float* dtable, const float* dnode);
+int embed_list_bwd_small(hipStream_t s, int n, const int32_t* rows, const int32_t* ids, float* dtable, const float* dnode,
+                         int table_rows);
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
                      int out_bstride, int out_off, int padding_idx);
 int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
@@ -33,7 +38,7 @@ int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const fl
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows);
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
-                      uint32_t site);
+                      uint32_t site, const int32_t* rows = nullptr);   // rows: dy and ds are row-mapped (dy[rows[r]], ds[rows[r]])
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out);
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
 // 3 out[dst[r]]=in[src[r]]

@@ -425,8 +425,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(add_layernorm_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
                               c.p_drop, c.seed, site(l, SITE_FFN)));
         TRY(linear_wgrad(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
-        TRY(linear_dgrad(s, p.TB, D, p.F, g.dYf, D, c.P + w.w2, g.dh, p.F, false));
-        TRY(relu_bwd(s, (int64_t)p.TB * p.F, g.dh, e.h));
+        // d hidden = (dYf W2) masked by the saved activation > 0: ReLU backward in the GEMM epilogue
+        TRY(gemm_f32_ex(s, 0, 0, p.TB, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
         TRY(linear_wgrad(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
         TRY(linear_dgrad(s, p.TB, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
         // cross attention
@@ -495,32 +495,34 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, g.dH, D, 0, 1));             // dH = A_hat dZ
         TRY(linear_wgrad(s, Nc, D, D, g.dH, D, Xg, D, G + w.fc1w, G + w.fc1b));
         TRY(linear_dgrad(s, Nc, D, D, g.dH, D, c.P + w.fc1w, other, D, true));                 // other = dG
-        // Combination on the code rows
-        TRY(rows_move(s, 0, Cc, D, p.dCB_a, other, bt.code_rows, nullptr));
-        TRY(add_layernorm_bwd(s, Cc, p.dCB_a, e.s1, e.st1, c.P + w.ln1g, p.dCB_b, g.dYc, G + w.ln1g, G + w.ln1b,
-                              c.p_drop, c.seed, site(l, SITE_COMB_OUT)));
+        // Combination on the code rows, in place inside `other` through the code-row map: the LayerNorm backward reads
+        // dG[code rows] and leaves the residual-branch gradient there; the q|k projection's dgrad adds to the same rows
+        TRY(add_layernorm_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,
+                              c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
         TRY(linear_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
         TRY(linear_dgrad(s, Cc, D, D, g.dYc, D, c.P + w.wo, p.dCB_a, D, false));               // d c
         TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, g.dqk,
                             p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE)));
         TRY(linear_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
-        TRY(linear_dgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, c.P + w.wqk, p.dCB_b, D, true));       // dCB_b = d Xc
-        TRY(rows_move(s, 1, Cc, D, other, p.dCB_b, nullptr, bt.code_rows));                    // other = dX[l]
+        TRY(gemm_f32_ex(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
+                        bt.code_rows));                                                        // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
-    // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39); back to the dense layout
-    TRY(zero(s, p.H, (size_t)p.NB * D * sizeof(float)));
-    TRY(rows_move(s, 1, Nc, D, p.H, dXn, nullptr, bt.node_rows));
-    if (bt.emb_item_tok && bt.emb_item_ptr && bt.emb_rows) {
-        TRY(embed_grouped_bwd(s, bt.n_emb_items, bt.emb_item_tok, bt.emb_item_ptr, bt.emb_rows, G + L.emb, p.H));
-    } else {
+    // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39)
+    if (bt.emb_item_tok && bt.emb_item_ptr && bt.emb_rows && bt.ast_rows && bt.ast_ids && L.d.ast_vocab <= 128) {
+        // the batch lists its id-carrying nodes by compact row: the gradient is read where the backward pass left it
+        TRY(embed_grouped_bwd(s, bt.n_emb_items, bt.emb_item_tok, bt.emb_item_ptr, bt.emb_rows, G + L.emb, dXn));
+        TRY(embed_list_bwd_small(s, bt.n_ast_items, bt.ast_rows, bt.ast_ids, G + L.ast_emb, dXn, L.d.ast_vocab));
+    } else {                                                       // id arrays only: back to the dense [B,650,256] layout
+        TRY(zero(s, p.H, (size_t)p.NB * D * sizeof(float)));
+        TRY(rows_move(s, 1, Nc, D, p.H, dXn, nullptr, bt.node_rows));
         TRY(embed_gather_bwd(s, p.B, p.L, bt.sou, G + L.emb, p.H, p.N, 0, 0));
         TRY(embed_gather_bwd(s, p.B, p.S, bt.sub_token, G + L.emb, p.H, p.N, p.L, 0));
+        if (L.d.ast_vocab <= 128)
+            TRY(embed_gather_bwd_small(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0, L.d.ast_vocab));
+        else
+            TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     }
-    if (L.d.ast_vocab <= 128)
-        TRY(embed_gather_bwd_small(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0, L.d.ast_vocab));
-    else
-        TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
     TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
                     FIRA_GEMM_ACCUM, 1, G + L.b2_all));

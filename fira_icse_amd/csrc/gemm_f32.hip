@@ -119,7 +119,9 @@ template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                        const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                        int ldc, const float* __restrict__ bias, int flags,
-                                                       int k_chunk, int vecA, int vecB, float* __restrict__ colsum) {
+                                                       int k_chunk, int vecA, int vecB, float* __restrict__ colsum,
+                                                       const int32_t* __restrict__ c_rows,
+                                                       const float* __restrict__ relu_mask) {
     using LA = TileLoader<BM, !TA>;       // A stored [M,K] (k contiguous) unless TA
     using LB = TileLoader<BN, TB>;        // B stored [N,K] (k contiguous) when TB
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -244,12 +246,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                 if (row >= M) continue;
                 float v = acc[i][j][r] + bv;
-                float* p = C + (size_t)row * ldc + col;
+                float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;       // optional output row map (scatter)
                 if (atomic) {
                     unsafeAtomicAdd(p, v);
                 } else {
                     if (accum) v += *p;
                     if (relu) v = fmaxf(v, 0.f);
+                    // ReLU backward fused into the dgrad that produces d(hidden): keep where the saved activation is > 0
+                    if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;
                     *p = v;
                 }
             }
@@ -259,14 +263,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 
 template <int BM, int BN>
 static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum) {
+                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum, const int32_t* c_rows,
+                  const float* relu_mask) {
     dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk);
     int k_chunk = cdiv(cdiv(K, splitk), BK) * BK;
     const int vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     const int vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
 #define FIRA_GEMM_GO(TA, TB)                                                                                     \
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
-                       bias, flags, k_chunk, vecA, vecB, colsum)
+                       bias, flags, k_chunk, vecA, vecB, colsum, c_rows, relu_mask)
     if (!tA && tB) FIRA_GEMM_GO(false, true);
     else if (!tA && !tB) FIRA_GEMM_GO(false, false);
     else if (tA && !tB) FIRA_GEMM_GO(true, false);
@@ -305,16 +310,18 @@ static TileChoice choose(int M, int N, int K, bool can_split) {
 }
 
 int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                float* C, int ldc, const float* bias, int flags, int splitk, float* colsum) {
+                float* C, int ldc, const float* bias, int flags, int splitk, float* colsum, const int32_t* c_rows,
+                const float* relu_mask) {
     if (M <= 0 || N <= 0) return 0;
+    FIRA_REQUIRE(!(relu_mask && (splitk > 1 || c_rows)), "gemm_f32: the fused ReLU mask needs a plain (unsplit, unmapped) output");
     FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_f32: bad K=%d splitk=%d", K, splitk);
     FIRA_REQUIRE(!(colsum && !tA), "gemm_f32: fused column sums need the transA layout");
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
-    const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU);
+    const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic
     if (tile < 0 && splitk <= 1 && !colsum) {                   // skinny forward / dgrad shapes: latency kernel
         int rc;
-        if (gemm_small_try(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, &rc)) return rc;
+        if (gemm_small_try(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, &rc, c_rows, relu_mask)) return rc;
     }
     if (splitk == 0 || tile < 0) {
         const TileChoice c = choose(M, N, K, can_split && splitk == 0);
@@ -323,14 +330,14 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     }
     FIRA_REQUIRE(!(splitk > 1 && !can_split), "gemm_f32: split-K needs accumulate semantics and no relu");
     flags &= 3;
-    if (tile == 0) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
-    if (tile == 1) return launch<64, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
-    return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum);
+    if (tile == 0) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+    if (tile == 1) return launch<64, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+    return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
 }
 
 int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
              float* C, int ldc, const float* bias, int flags, int splitk) {
-    return gemm_f32_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, nullptr);
+    return gemm_f32_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, nullptr, nullptr, nullptr);
 }
 
 }  // namespace fira

@@ -21,7 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool B_KCONTIG>
 __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
                                                          const float* __restrict__ B, int ldb, float* __restrict__ C,
-                                                         int ldc, const float* __restrict__ bias, int flags) {
+                                                         int ldc, const float* __restrict__ bias, int flags,
+                                                         const int32_t* __restrict__ c_rows,
+                                                         const float* __restrict__ relu_mask) {
     __shared__ float red[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -78,24 +80,26 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, co
         if (row >= M || col >= N) continue;
         float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
         if (bias) v += bias[col];
-        float* p = C + (size_t)row * ldc + col;
+        float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;
         if (accum) v += *p;
         if (relu) v = fmaxf(v, 0.f);
+        if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;     // fused ReLU backward (see gemm_f32.hip)
         *p = v;
     }
 }
 
 // true if this kernel took the call
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, const float* bias, int flags, int* rc) {
+                    float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,
+                    const float* relu_mask) {
     *rc = 0;
     // beyond ~4 rounds of 32x32 tiles the LDS-tiled kernel's operand reuse wins; M <= 64 (decode) always lands here
     const long tiles = (long)cdiv(M, 32) * cdiv(N, 32);
     if (tA || (M > 64 && tiles > 1024) || K % 32 != 0 || K < 64 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0) return false;
     if (tB && (ldb % 4 != 0 || ((uintptr_t)B % 16) != 0)) return false;
     dim3 grid(cdiv(N, 32), cdiv(M, 32));
-    if (tB) hipLaunchKernelGGL(gemm_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags);
-    else hipLaunchKernelGGL(gemm_small_kernel<false>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags);
+    if (tB) hipLaunchKernelGGL(gemm_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask);
+    else hipLaunchKernelGGL(gemm_small_kernel<false>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) *rc = set_err("gemm_small: %s", hipGetErrorString(e));
     return true;

@@ -106,6 +106,29 @@ __global__ __launch_bounds__(256) void embed_gather_bwd_small_kernel(int rows, i
     }
 }
 
+// List form of the small-table scatter: (compact node row, table id) pairs instead of the dense [B, L] id array.
+__global__ __launch_bounds__(256) void embed_list_bwd_small_kernel(int n, const int32_t* __restrict__ rows,
+                                                                   const int32_t* __restrict__ ids,
+                                                                   float* __restrict__ dtable,
+                                                                   const float* __restrict__ dnode, int table_rows,
+                                                                   int per_block) {
+    extern __shared__ float tab[];                       // [table_rows][256]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < table_rows * FIRA_D; i += 256) tab[i] = 0.f;
+    __syncthreads();
+    const int beg = blockIdx.x * per_block, end = min(n, beg + per_block);
+    for (int k = beg + wave; k < end; k += 4) {
+        const float4 g = *reinterpret_cast<const float4*>(dnode + (size_t)rows[k] * FIRA_D + lane * 4);
+        float* p = tab + (size_t)ids[k] * FIRA_D + lane * 4;
+        atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+    }
+    __syncthreads();
+    for (int i = t; i < table_rows * FIRA_D; i += 256) {
+        const float v = tab[i];
+        if (v != 0.f) unsafeAtomicAdd(&dtable[i], v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // CombinationLayer (reference combination_layer.py:7-17): per element
 //   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
@@ -248,14 +271,15 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
 
 // backward of the block above.  ds = gradient wrt the pre-norm sum (also the residual-branch gradient);
 // dx_drop (optional) = ds * keep-mask / (1-p): the gradient wrt the un-dropped GEMM output.
-__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const float* dy,   // may alias ds (row-mapped, in place)
                                                                 const float* __restrict__ sum,
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ gamma,
-                                                                float* __restrict__ ds, float* __restrict__ dx_drop,
+                                                                float* ds, float* __restrict__ dx_drop,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float p, float inv_keep, uint64_t seed, uint32_t site,
-                                                                int rows_per_block) {
+                                                                int rows_per_block,
+                                                                const int32_t* __restrict__ rows) {
     __shared__ float red[2 * FIRA_D];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < 2 * FIRA_D; i += 256) red[i] = 0.f;
@@ -272,7 +296,8 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
         for (int u = 0; u < 2; ++u) {
             const int r = u < nr ? r0 + u : r0;
             const size_t o = (size_t)r * FIRA_D + lane * 4;
-            d[u] = *reinterpret_cast<const float4*>(dy + o);
+            const size_t om = rows ? (size_t)rows[r] * FIRA_D + lane * 4 : o;       // dy / ds live in the mapped rows
+            d[u] = *reinterpret_cast<const float4*>(dy + om);
             sv[u] = *reinterpret_cast<const float4*>(sum + o);
             mean[u] = stats[2 * r];
             rstd[u] = stats[2 * r + 1];
@@ -291,7 +316,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
             const float m2 = wave_sum(h0 * xh0 + h1 * xh1 + h2 * xh2 + h3 * xh3) * (1.0f / FIRA_D);
             float4 o4 = make_float4(rstd[u] * (h0 - m1 - xh0 * m2), rstd[u] * (h1 - m1 - xh1 * m2),
                                     rstd[u] * (h2 - m1 - xh2 * m2), rstd[u] * (h3 - m1 - xh3 * m2));
-            *reinterpret_cast<float4*>(ds + o) = o4;
+            *reinterpret_cast<float4*>(ds + (rows ? (size_t)rows[r] * FIRA_D + lane * 4 : o)) = o4;
             if (dx_drop) {
                 if (p > 0.f) {
                     const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
@@ -577,6 +602,22 @@ int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const
     FIRA_CHECK_LAUNCH("embed_grouped_bwd");
     return 0;
 }
+int embed_list_bwd_small(hipStream_t s, int n, const int32_t* rows, const int32_t* ids, float* dtable, const float* dnode,
+                         int table_rows) {
+    if (n <= 0) return 0;
+    FIRA_REQUIRE(table_rows > 0 && table_rows * FIRA_D * 4 <= 150 * 1024, "embed_list_bwd_small: table of %d rows does not fit LDS", table_rows);
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)embed_list_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    const int per = std::max(64, cdiv(n, 96));
+    hipLaunchKernelGGL(embed_list_bwd_small_kernel, dim3(cdiv(n, per)), dim3(256),
+                       (size_t)table_rows * FIRA_D * sizeof(float), s, n, rows, ids, dtable, dnode, table_rows, per);
+    FIRA_CHECK_LAUNCH("embed_list_bwd_small");
+    return 0;
+}
 int embed_gather_bwd(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,
                      int out_bstride, int out_off, int padding_idx) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
@@ -620,14 +661,14 @@ int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const fl
 }
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
-                      uint32_t site) {
+                      uint32_t site, const int32_t* rows) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     // ~500 workgroups: enough to fill the chip, few enough that the dgamma/dbeta atomics do not serialise
     const int rpb = std::max(8, std::min(128, cdiv(cdiv(M, 512), 8) * 8));
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
-                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb);
+                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb, rows);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");
     return 0;
 }

@@ -164,7 +164,8 @@ def computed_nodes(hb: HostBatch, cfg: FiraConfig, skip_padding: bool = True):
 
 
 def embedding_items(hb: HostBatch, cfg: FiraConfig, chunk: int = 32):
-    """Code / sub-token positions grouped by word id (``fira_batch.emb_*``): item_tok [n], item_ptr [n+1], rows."""
+    """Code / sub-token positions grouped by word id (``fira_batch.emb_*``): item_tok [n], item_ptr [n+1], rows
+    (global node index b*N + local; ``DeviceBatch`` maps them to compact node ids)."""
     B, N, L, S = len(hb), cfg.graph_len, cfg.sou_len, cfg.sub_token_len
     ids = np.concatenate([hb.sou, hb.sub_token], axis=1).astype(np.int64)               # [B, L+S]: local == column
     rows = (np.arange(B, dtype=np.int64)[:, None] * N + np.arange(L + S, dtype=np.int64)[None, :])
@@ -222,6 +223,19 @@ class DeviceBatch:
             self.n_head_rows = int(rows.shape[0])
             self.head_rows = dev(rows, np.int32)
         item_tok, item_ptr, emb_rows = embedding_items(hb, cfg)
+        cmap = np.full(self.B * cfg.graph_len, -1, dtype=np.int64)
+        cmap[node_rows] = np.arange(node_rows.shape[0])
+        emb_rows = cmap[emb_rows]
+        ast_sel = (node_rows % cfg.graph_len) >= cfg.sou_len + cfg.sub_token_len
+        ast_rows = np.nonzero(ast_sel)[0]
+        g = node_rows[ast_sel]
+        ast_ids = hb.ast_change[g // cfg.graph_len, g % cfg.graph_len - cfg.sou_len - cfg.sub_token_len]
+        keep = ast_ids != 0
+        ast_rows, ast_ids = ast_rows[keep], ast_ids[keep]
+        if emb_rows.size and emb_rows.min() < 0:
+            raise AssertionError("a node with a non-zero id is not in the computed list")
+        self.n_ast_items = int(ast_rows.shape[0])
+        self.ast_rows, self.ast_ids = dev(ast_rows, np.int32), dev(ast_ids, np.int32)
         self.n_emb_items = int(item_tok.shape[0])
         self.emb_item_tok, self.emb_item_ptr, self.emb_rows = dev(item_tok, np.int32), dev(item_ptr, np.int32), \
             dev(emb_rows, np.int32)
@@ -230,7 +244,8 @@ class DeviceBatch:
             self.B, self.nnz, p(self.sou), p(self.tar), p(self.mark), p(self.ast_change), p(self.tar_label),
             p(self.sub_token), self.n_nodes, p(self.node_rows), p(self.rowptr), p(self.col), p(self.val), self.n_code,
             p(self.code_rows), p(self.code_mark), self.n_mem, p(self.mem_rows), p(self.mem_dst), p(self.head_rows),
-            self.n_head_rows, self.n_emb_items, p(self.emb_item_tok), p(self.emb_item_ptr), p(self.emb_rows))
+            self.n_head_rows, self.n_emb_items, p(self.emb_item_tok), p(self.emb_item_ptr), p(self.emb_rows),
+            self.n_ast_items, p(self.ast_rows), p(self.ast_ids))
 
 
 def _as_tensor(ptr: int, shape, device) -> torch.Tensor:

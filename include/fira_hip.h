@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 1
+#define FIRA_ABI_VERSION 2
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -73,7 +73,12 @@ typedef struct fira_batch {
     int32_t n_emb_items;
     const int32_t* emb_item_tok; /* [n_emb_items] word id of the item (never 0 = padding_idx)                      */
     const int32_t* emb_item_ptr; /* [n_emb_items + 1] offsets into emb_rows; at most 32 rows per item              */
-    const int32_t* emb_rows;     /* global node index b*N + local (local < sou_len + sub_len), grouped by word id  */
+    const int32_t* emb_rows;     /* COMPACT node ids (position in node_rows) of code / sub-token nodes, grouped by word id */
+    /* ---- optional, together with emb_*: the computed AST / edit-operation nodes with a non-zero id, so that the whole
+     * embedding gradient is taken from the compact node rows (no dense [B,650,256] scatter in the backward pass) */
+    int32_t n_ast_items;
+    const int32_t* ast_rows;     /* [n_ast_items] compact node ids                                               */
+    const int32_t* ast_ids;      /* [n_ast_items] their ast_change ids (never 0)                                  */
 } fira_batch;
 
 typedef struct fira_train_opts {

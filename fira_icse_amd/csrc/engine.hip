@@ -232,6 +232,22 @@ static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* 
     return gemm_f32_ex(ws, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
 }
 
+// The same for the small reductions over the B*30 target rows (decoder layers, gate / target projections of the head):
+// queued and launched as ONE grouped kernel after the decoder's backward loop (gemm_f32.hip), instead of ~40 launches
+// of ~15 us that are mostly fill and drain.  Operands must stay untouched until then (they are per-layer slots).
+static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X,
+                                       int ldx, float* dW, float* db) {
+    SideStream& sd = side();
+    if (!(sd.stream && sd.enabled)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
+}
+static inline int flush_grouped_wgrads(hipStream_t s) {
+    SideStream& sd = side();
+    if (!(sd.stream && sd.enabled)) return 0;
+    TRY(side_fork(s));
+    return gemm_group_flush(sd.stream);
+}
+
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
 static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
 
@@ -380,6 +396,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     const float* dec = p.dec[p.nl - 1].x_f;
     float* G = c.G;
 
+    gemm_group_reset();
     // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
     // The vocabulary dgrad ([R, V] x [V, 256], the head's largest product) and the copy branch are independent until
     // both land in ddec: the former runs on the side stream under the latter.
@@ -396,12 +413,12 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
     }
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
-    TRY(linear_wgrad(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
+    TRY(linear_wgrad_grouped(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
     TRY(zero(s, p.dtgt, (size_t)p.TB * D * sizeof(float)));
     TRY(copy_score_bwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres,
                           p.mem_valid));
     TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
-    TRY(linear_wgrad(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
+    TRY(linear_wgrad_grouped(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
     TRY(rows_move(s, 0, Mc, D, p.dsrc_c, p.dsrc, bt.mem_dst, nullptr));
     // d memory (compact rows) = dsrc Ws + sum_l dKV_l Wkv_l: nothing reads it before the encoder's backward pass, so
     // the whole accumulation lives on the side stream (in order: this product initialises dmem_c, the per-layer
@@ -424,15 +441,15 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         // FeedForward (gnn_transformer.py:170-174)
         TRY(add_layernorm_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
                               c.p_drop, c.seed, site(l, SITE_FFN)));
-        TRY(linear_wgrad(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
+        TRY(linear_wgrad_grouped(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
         // d hidden = (dYf W2) masked by the saved activation > 0: ReLU backward in the GEMM epilogue
         TRY(gemm_f32_ex(s, 0, 0, p.TB, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
-        TRY(linear_wgrad(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
+        TRY(linear_wgrad_grouped(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
         TRY(linear_dgrad(s, p.TB, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
         // cross attention
         TRY(add_layernorm_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
                               c.p_drop, c.seed, site(l, SITE_CROSS)));
-        TRY(linear_wgrad(s, p.TB, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
+        TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
         TRY(linear_dgrad(s, p.TB, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                           p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, KV,
@@ -443,19 +460,20 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
             TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, KV, bt.mem_dst, nullptr));
             TRY(linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true));
         }
-        TRY(linear_wgrad(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
+        TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
         TRY(linear_dgrad(s, p.TB, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
         // self attention
         TRY(add_layernorm_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
                               c.p_drop, c.seed, site(l, SITE_SELF)));
-        TRY(linear_wgrad(s, p.TB, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
+        TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
         TRY(linear_dgrad(s, p.TB, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
         TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
                           e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D));
-        TRY(linear_wgrad(s, p.TB, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
+        TRY(linear_wgrad_grouped(s, p.TB, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
         TRY(linear_dgrad(s, p.TB, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
         dy = p.dT_a;
     }
+    TRY(flush_grouped_wgrads(s));                                  // the decoder's and the head's small weight gradients
     // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions
     // carry an exactly-zero gradient (never attended as keys, zero loss weight): skipping id 0 only drops the
     // hundreds of serialised atomic additions of 0.0 onto table row 0.

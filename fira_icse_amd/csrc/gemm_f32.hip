@@ -115,13 +115,16 @@ struct TileLoader {
     }
 };
 
+// One BM x BN output tile over the K range [kbeg, kend) by the 256 threads of a workgroup.  `atomic`: the tile is one of
+// several K splits (partials combined with fp32 atomics); `first`: this split adds the bias; `cs_tile`: this workgroup
+// owns the fused column sums of its A tile.
 template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                       const float* __restrict__ B, int ldb, float* __restrict__ C,
-                                                       int ldc, const float* __restrict__ bias, int flags,
-                                                       int k_chunk, int vecA, int vecB, float* __restrict__ colsum,
-                                                       const int32_t* __restrict__ c_rows,
-                                                       const float* __restrict__ relu_mask) {
+__device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __restrict__ A, int lda,
+                                          const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                          const float* __restrict__ bias, int flags, int vecA, int vecB,
+                                          float* __restrict__ colsum, const int32_t* __restrict__ c_rows,
+                                          const float* __restrict__ relu_mask, int m0, int n0, int kbeg, int kend,
+                                          bool atomic, bool first, bool cs_tile) {
     using LA = TileLoader<BM, !TA>;       // A stored [M,K] (k contiguous) unless TA
     using LB = TileLoader<BN, TB>;        // B stored [N,K] (k contiguous) when TB
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -132,9 +135,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     const int lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * k_chunk;
-    const int kend = min(K, kbeg + k_chunk);
     const int ntile = (kend - kbeg + BK - 1) / BK;
 
     f32x16 acc[TM][TN];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
 
     // fused bias gradient (wgrad layout only): colsum[m] += sum_k A[k][m] over this block's K range, taken from the
     // A-tile registers on their way to LDS (thread t always carries the same 4 columns of the tile)
-    const bool do_cs = TA && colsum != nullptr && blockIdx.x == 0;
+    const bool do_cs = TA && colsum != nullptr && cs_tile;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     auto cs_add = [&](const float4 (&v)[LA::NV]) {
 #pragma unroll
@@ -232,8 +232,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool relu = flags & FIRA_GEMM_RELU;
     const bool accum = flags & FIRA_GEMM_ACCUM;
-    const bool atomic = gridDim.z > 1;
-    const bool add_bias = bias != nullptr && blockIdx.z == 0;
+    const bool add_bias = bias != nullptr && first;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
@@ -259,6 +258,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
             }
         }
     }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                       const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                       int ldc, const float* __restrict__ bias, int flags,
+                                                       int k_chunk, int vecA, int vecB, float* __restrict__ colsum,
+                                                       const int32_t* __restrict__ c_rows,
+                                                       const float* __restrict__ relu_mask) {
+    const int kbeg = blockIdx.z * k_chunk;
+    gemm_tile<BM, BN, TA, TB>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, vecA, vecB, colsum, c_rows, relu_mask,
+                              blockIdx.y * BM, blockIdx.x * BN, kbeg, min(K, kbeg + k_chunk), gridDim.z > 1,
+                              blockIdx.z == 0, blockIdx.x == 0);
+}
+
+// Grouped weight gradients: dW_i (+)= dY_i^T X_i for up to GROUP_MAX independent problems in ONE launch.  The decoder's
+// 36 weight gradients reduce over only B*30 target rows each (0.1-0.5 GFLOP): launched one by one they cost ~15 us
+// apiece, mostly fill and drain; as one grid of ~2000 workgroups they run at the throughput of a single large GEMM.
+// The problem table travels in the kernel arguments.
+struct GroupProblem {
+    const float* A;      // dY  [K, M] (transA layout)
+    const float* B;      // X   [K, N]
+    float* C;            // dW  [M, N], accumulated
+    float* colsum;       // db  [M] or nullptr
+    int M, N, K, lda, ldb, ldc, tiles_n, splitk, k_chunk;
+};
+constexpr int GROUP_MAX = 40;
+struct GroupTable {
+    int n;
+    int wg_start[GROUP_MAX + 1];
+    GroupProblem p[GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void gemm_grouped_wgrad_kernel(GroupTable g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.wg_start[i + 1]) ++i;          // uniform scan of <= 40 entries
+    const GroupProblem& q = g.p[i];
+    const int w = blockIdx.x - g.wg_start[i];
+    const int tile = w / q.splitk, z = w - tile * q.splitk;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    const int kbeg = z * q.k_chunk;
+    const int vecA = ((uintptr_t)q.A % 16 == 0) && (q.lda % 4 == 0), vecB = ((uintptr_t)q.B % 16 == 0) && (q.ldb % 4 == 0);
+    gemm_tile<64, 64, true, false>(q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, nullptr, FIRA_GEMM_ACCUM, vecA, vecB,
+                                   q.colsum, nullptr, nullptr, tm * 64, tn * 64, kbeg, min(q.K, kbeg + q.k_chunk),
+                                   q.splitk > 1, z == 0, tn == 0);
 }
 
 template <int BM, int BN>
@@ -333,6 +376,46 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     if (tile == 0) return launch<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
     if (tile == 1) return launch<64, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
     return launch<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+}
+
+// ---- grouped weight gradients (host side): problems are collected, then launched together
+struct GroupBuilder {
+    GroupTable t;
+    GroupBuilder() { t.n = 0; t.wg_start[0] = 0; }
+};
+static GroupBuilder& group() { static thread_local GroupBuilder g; return g; }
+
+void gemm_group_reset() { group().t.n = 0; }
+int gemm_group_flush(hipStream_t s) {
+    GroupTable& t = group().t;
+    if (t.n == 0) return 0;
+    double flop = 0;
+    for (int i = 0; i < t.n; ++i) flop += 2.0 * t.p[i].M * (double)t.p[i].N * t.p[i].K;
+    ProfScope prof(s, PROF_GEMM, flop);
+    hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(t.wg_start[t.n]), dim3(256), 0, s, t);
+    t.n = 0;
+    FIRA_CHECK_LAUNCH("gemm_grouped_wgrad");
+    return 0;
+}
+// dW[M,N] += A^T B with A = dY [K,M], B = X [K,N]; db[M] += column sums of dY.  Queued; runs at the next flush on `s`.
+int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                         int ldc, float* colsum) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    GroupTable& t = group().t;
+    if (t.n == GROUP_MAX) {
+        int rc = gemm_group_flush(s);
+        if (rc) return rc;
+    }
+    GroupProblem& q = t.p[t.n];
+    q.A = A; q.B = B; q.C = C; q.colsum = colsum;
+    q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+    q.tiles_n = cdiv(N, 64);
+    // the whole group shares the chip: two K splits per tile keep the tail short without drowning the result in atomics
+    q.splitk = K >= 512 ? 2 : 1;
+    q.k_chunk = cdiv(cdiv(K, q.splitk), BK) * BK;
+    t.wg_start[t.n + 1] = t.wg_start[t.n] + cdiv(M, 64) * q.tiles_n * q.splitk;
+    ++t.n;
+    return 0;
 }
 
 int gemm_f32(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,

@@ -40,6 +40,9 @@ __device__ __forceinline__ void load_frag(float (&f)[16], const float* __restric
 }
 
 constexpr float SQRT_DH = 5.656854249492381f;
+// the kernels multiply by reciprocals (IEEE division is a ~10-instruction VALU sequence and these kernels are bound by
+// their non-MFMA VALU work: profiles/r1e_probes.md); the result differs from a true division by at most 1 ulp
+constexpr float INV_SQRT_DH = 1.0f / SQRT_DH;
 constexpr int MAX_TK = 384;
 
 // Rows of masked keys are never read (their K/V fragments are zero-filled): their score is -1e9 whatever K holds and
@@ -49,7 +52,7 @@ __device__ __forceinline__ float mask_score(float raw, int key, int query, int T
                                             bool& masked) {
     if (key >= Tk) { masked = true; return -INFINITY; }
     masked = (kv[key] == 0) || (causal && key > query + q_pos0);
-    return masked ? -1e9f : raw / SQRT_DH;
+    return masked ? -1e9f : raw * INV_SQRT_DH;
 }
 
 template <int NW, int TPW>
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
         for (int w = 0; w < NW; ++w) sum += sm_red[w][l31];
     }
+    const float inv_sum = 1.0f / sum;
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
                 vv[s] = (key < Tk && sm_kv[key < Tk ? key : 0] != 0) ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] / sum, vv[s], o);
+            for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] * inv_sum, vv[s], o);
         }
     }
     // o[r]: query = acc_row(r, kh), d = l31
@@ -248,9 +252,10 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
         for (int w = 0; w < NW; ++w) sum += sm_red[w][l31];
     }
+    const float inv_sum = 1.0f / sum;
     if (wave == 0 && kh == 0) {
         sm_m[l31] = mx;
-        sm_sum[l31] = sum;
+        sm_sum[l31] = inv_sum;                       // reciprocal of the soft-max denominator
         sm_delta[l31] = delta;
     }
     __syncthreads();
@@ -281,8 +286,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
                 const bool dead = kr >= Tk || sm_kv[kr < Tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
-                const float p = st[i][s] / sum;
-                const float ds = dead ? 0.f : p * (dpt[s] - delta) / SQRT_DH;
+                const float p = st[i][s] * inv_sum;
+                const float ds = dead ? 0.f : p * (dpt[s] - delta) * INV_SQRT_DH;
                 dq = MFMA32(ds, kvv[s], dq);                                    // dQ += dS K
             }
         }
@@ -339,8 +344,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
                 const int q = acc_row(s, kh);
                 bool masked;
                 const float x = mask_score(sN[s], key, q, Tk, sm_kv, causal, q_pos0, masked);
-                const float p = expf(x - sm_m[q]) / sm_sum[q];
-                const float ds = masked ? 0.f : p * (dpN[s] - sm_delta[q]) / SQRT_DH;
+                const float p = expf(x - sm_m[q]) * sm_sum[q];
+                const float ds = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
                 dk = MFMA32(ds, qrow[s], dk);         // dK += dS^T Q
                 dv = MFMA32(p, dorow[s], dv);         // dV += P^T dO
             }

@@ -303,14 +303,16 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
     }
     // d loss / d copy scores (masked slots receive none: masked_fill)
     const bool copy_grad = pass && is_copy;
+    const float inv_csum = 1.0f / csum;
     for (int j = tid; j < S; j += 256) {
         float d = 0.f;
-        if (copy_grad && mv[j]) d = expf(srow[j] - cmax) / csum - (j == y - V ? 1.f : 0.f);
+        if (copy_grad && mv[j]) d = expf(srow[j] - cmax) * inv_csum - (j == y - V ? 1.f : 0.f);
         srow[j] = d;
     }
     // d loss / d logits, in place
     if (lrow) {
         const bool gen_grad = pass && !is_copy;
+        const float inv_gsum = 1.0f / gsum;          // one reciprocal per row instead of a division per logit
         if (REG) {
             float2* l2 = reinterpret_cast<float2*>(lrow);
 #pragma unroll
@@ -319,8 +321,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
                 if (j2 < n2) {
                     float2 d = make_float2(0.f, 0.f);
                     if (gen_grad) {
-                        d.x = expf(reg[i].x - gmax) / gsum - (2 * j2 == y ? 1.f : 0.f);
-                        d.y = expf(reg[i].y - gmax) / gsum - (2 * j2 + 1 == y ? 1.f : 0.f);
+                        d.x = expf(reg[i].x - gmax) * inv_gsum - (2 * j2 == y ? 1.f : 0.f);
+                        d.y = expf(reg[i].y - gmax) * inv_gsum - (2 * j2 + 1 == y ? 1.f : 0.f);
                     }
                     l2[j2] = d;
                 }
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
         } else {
             for (int j = tid; j < V; j += 256) {
                 float d = 0.f;
-                if (gen_grad) d = expf(lrow[j] - gmax) / gsum - (j == y ? 1.f : 0.f);
+                if (gen_grad) d = expf(lrow[j] - gmax) * inv_gsum - (j == y ? 1.f : 0.f);
                 lrow[j] = d;
             }
         }
@@ -401,8 +403,9 @@ __global__ __launch_bounds__(256) void decode_dist_kernel(int V, int S, const fl
     gsum = block_sum(gsum, smf);
     if (dist) {
         float* drow = dist + (size_t)r * (V + S);
-        for (int j = tid; j < V; j += 256) drow[j] = g0 * (expf(lrow[j] - gmax) / gsum);
-        for (int j = tid; j < S; j += 256) drow[V + j] = g1 * (expf((mv[j] ? srow[j] : -1e9f) - cmax) / csum);
+        const float sg = g0 * (1.0f / gsum), sc = g1 * (1.0f / csum);
+        for (int j = tid; j < V; j += 256) drow[j] = sg * expf(lrow[j] - gmax);
+        for (int j = tid; j < S; j += 256) drow[V + j] = sc * expf((mv[j] ? srow[j] : -1e9f) - cmax);
     }
     if (tid == 0 && best_id) {
         const float pg = g0 * (1.0f / gsum), pc = g1 * (1.0f / csum);

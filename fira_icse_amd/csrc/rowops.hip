@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256) void embed_list_bwd_small_kernel(int n, const 
 //   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
 // The head split/transposes of gnn_transformer.py:197-202 cancel.
 __device__ __forceinline__ void gate_elem(float q, float k, float v, float& g0, float& g1) {
-    const float s = 5.656854249492381f;          // sqrt(32)
-    const float a = q * k / s, b = q * v / s;
+    const float is = 1.0f / 5.656854249492381f;  // 1 / sqrt(32): reciprocal multiplies instead of divisions (<= 1 ulp)
+    const float a = q * k * is, b = q * v * is;
     const float m = fmaxf(a, b);
     const float ea = expf(a - m), eb = expf(b - m);
-    const float den = ea + eb;
-    g0 = ea / den;
-    g1 = eb / den;
+    const float iden = 1.0f / (ea + eb);
+    g0 = ea * iden;
+    g1 = eb * iden;
 }
 
 __global__ __launch_bounds__(256) void combination_fwd_kernel(int M, const float* __restrict__ qk,
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dv_acc[a][e] = 0.f;
-    const float s = 5.656854249492381f;
+    const float is = 1.0f / 5.656854249492381f;
     const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
     for (int r = r_beg + wave; r < r_end; r += 4) {
         const float4 q4 = *reinterpret_cast<const float4*>(qk + (size_t)r * 2 * FIRA_D + lane * 4);
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
             const float dg0 = dc[e] * k[e], dg1 = dc[e] * v[e];
             const float dot = g0 * dg0 + g1 * dg1;
             const float da = g0 * (dg0 - dot), db = g1 * (dg1 - dot);
-            dq[e] = (da * k[e] + db * v[e]) / s;
-            dk[e] = dc[e] * g0 + da * q[e] / s;
-            dv[e] = dc[e] * g1 + db * q[e] / s;
+            dq[e] = (da * k[e] + db * v[e]) * is;
+            dk[e] = dc[e] * g0 + da * q[e] * is;
+            dv[e] = dc[e] * g1 + db * q[e] * is;
         }
         *reinterpret_cast<float4*>(dqk + (size_t)r * 2 * FIRA_D + lane * 4) = make_float4(dq[0], dq[1], dq[2], dq[3]);
         *reinterpret_cast<float4*>(dqk + (size_t)r * 2 * FIRA_D + FIRA_D + lane * 4) = make_float4(dk[0], dk[1], dk[2], dk[3]);

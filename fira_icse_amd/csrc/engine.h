@@ -59,13 +59,8 @@ int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, 
 // compact[r,:] = src[rows[r],:] ;  dst[rows[r],:] += compact[r,:]
 int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, const int32_t* rows);
 int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows);
-int relu_bwd(hipStream_t s, int64_t n, float* dh, const float* h);
-int make_masks(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
-               int32_t* mem_valid, int32_t* tar_valid);
 int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar);
 int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid);
-int invert_rows(hipStream_t s, int BT, int R, const int32_t* rows, int32_t* compact_row);
-int iota_rows(hipStream_t s, int n, int32_t* out);
 // beam re-ordering of the decoder self-attention cache: dst[r, 0:len) = src[parent[r], 0:len) for nl layers of K and V,
 // plus the key-valid history; then hist_dst[r, step] = tokens[r] != 0
 int permute_cache(hipStream_t s, int nl, int BR, int T, int len, const int32_t* parent, const float* ksrc,

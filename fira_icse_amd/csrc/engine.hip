@@ -55,7 +55,7 @@ struct Plan {
     float *vtab_all, *H, *mem, *mem_c, *kv_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *inv_ntok;
     // backward temporaries (training only)
-    float *dXa, *dXb, *dNB2, *dCB_a, *dCB_b, *dvtab_all;
+    float *dXa, *dXb, *dNB2, *dCB_a, *dvtab_all;
     float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
@@ -103,7 +103,7 @@ struct Plan {
         dec_c = a.f((size_t)TB * D); logits = a.f((size_t)TB * ldl);
         if (training) {
             dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
-            dCB_a = a.f((size_t)CB * D); dCB_b = a.f((size_t)CB * D);
+            dCB_a = a.f((size_t)CB * D);
             dvtab_all = a.f((size_t)4 * nl * D);
             dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
             dkv_c = a.f((size_t)MB * nl * 2 * D); dtgt = a.f((size_t)TB * D);

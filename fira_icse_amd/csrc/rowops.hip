@@ -384,26 +384,6 @@ __global__ __launch_bounds__(256) void rows_idx_kernel(int R, int W, float* __re
         *reinterpret_cast<float4*>(out + ro * ld_out + c) = a;
     }
 }
-__global__ __launch_bounds__(256) void relu_bwd_kernel(int64_t n4, float4* __restrict__ dh, const float4* __restrict__ h) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 d = dh[i];
-    const float4 a = h[i];
-    d.x = a.x > 0.f ? d.x : 0.f; d.y = a.y > 0.f ? d.y : 0.f; d.z = a.z > 0.f ? d.z : 0.f; d.w = a.w > 0.f ? d.w : 0.f;
-    dh[i] = d;
-}
-// mem_valid[b, 0:L] = sou != 0, mem_valid[b, L:L+S] = sub != 0 (Model.py:42-50); tar_valid = tar != 0
-__global__ void make_masks_kernel(int B, int L, int S, int T, const int32_t* __restrict__ sou,
-                                  const int32_t* __restrict__ sub, const int32_t* __restrict__ tar,
-                                  int32_t* __restrict__ mem_valid, int32_t* __restrict__ tar_valid) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int W = L + S;
-    if (i < B * W) {
-        const int b = i / W, j = i - b * W;
-        mem_valid[i] = (j < L ? sou[b * L + j] : sub[b * S + (j - L)]) != 0;
-    }
-    if (tar && i < B * T) tar_valid[i] = tar[i] != 0;
-}
 // sinusoidal tables (gnn_transformer.py:10-19): evaluated in fp64 like the reference's python floats, stored fp32
 __global__ void pos_table_kernel(int L, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -478,11 +458,6 @@ __global__ __launch_bounds__(256) void node_features_kernel(int Nc, const int32_
     *reinterpret_cast<float4*>(X + (size_t)r * FIRA_D + lane * 4) = v;
 }
 
-__global__ void invert_rows_kernel(int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < R) compact_row[rows[r]] = r;
-}
-
 // ---------------------------------------------------------------- host launchers
 // W floats of each row are moved; rows are ld_out / ld_in floats apart (a column block of a wider matrix)
 int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, const float* in, int ld_in,
@@ -507,22 +482,6 @@ int rows_gather_idx(hipStream_t s, int R, float* compact, const float* src, cons
 }
 int rows_scatter_add_idx(hipStream_t s, int R, const float* compact, float* dst, const int32_t* rows) {
     return rows_move(s, 2, R, FIRA_D, dst, compact, nullptr, rows);
-}
-int relu_bwd(hipStream_t s, int64_t n, float* dh, const float* h) {
-    if (n <= 0) return 0;
-    FIRA_REQUIRE(n % 4 == 0, "relu_bwd: n must be a multiple of 4");
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, n / 4,
-                       reinterpret_cast<float4*>(dh), reinterpret_cast<const float4*>(h));
-    FIRA_CHECK_LAUNCH("relu_bwd");
-    return 0;
-}
-int make_masks(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
-               int32_t* mem_valid, int32_t* tar_valid) {
-    const int n = B * (L + S) > B * T ? B * (L + S) : B * T;
-    hipLaunchKernelGGL(make_masks_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid,
-                       tar_valid);
-    FIRA_CHECK_LAUNCH("make_masks");
-    return 0;
 }
 __global__ void tar_mask_kernel(int n, const int32_t* __restrict__ tar, int32_t* __restrict__ valid) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -556,13 +515,6 @@ int fill_pos_tables(hipStream_t s, int L, float* pos_code, int T, float* pos_tar
     hipLaunchKernelGGL(pos_table_kernel, dim3(cdiv(L * FIRA_D, 256)), dim3(256), 0, s, L, pos_code);
     hipLaunchKernelGGL(pos_table_kernel, dim3(cdiv(T * FIRA_D, 256)), dim3(256), 0, s, T, pos_tar);
     FIRA_CHECK_LAUNCH("fill_pos_tables");
-    return 0;
-}
-int invert_rows(hipStream_t s, int BT, int R, const int32_t* rows, int32_t* compact_row) {
-    hipError_t e = hipMemsetAsync(compact_row, 0xFF, (size_t)BT * sizeof(int32_t), s);
-    if (e != hipSuccess) return set_err("invert_rows: %s", hipGetErrorString(e));
-    if (R > 0) hipLaunchKernelGGL(invert_rows_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, R, rows, compact_row);
-    FIRA_CHECK_LAUNCH("invert_rows");
     return 0;
 }
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
@@ -681,16 +633,6 @@ int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out) {
     return 0;
 }
 
-__global__ void iota_kernel(int n, int32_t* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = i;
-}
-int iota_rows(hipStream_t s, int n, int32_t* out) {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(iota_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, n, out);
-    FIRA_CHECK_LAUNCH("iota_rows");
-    return 0;
-}
 // grid (len, BR, 2*nl): one wave-row copy per block of 64 threads
 __global__ __launch_bounds__(64) void permute_cache_kernel(int BR, int T, const int32_t* __restrict__ parent,
                                                            const float* __restrict__ ksrc, const float* __restrict__ vsrc,

@@ -24,6 +24,8 @@ bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const fl
                     const float* relu_mask = nullptr);
 int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
              int ldx, float* Y, int ldy, int graph_rows, int variant);
+int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum);
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
                      int out_bstride, int out_off);
 int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const int32_t* item_ptr, const int32_t* rows,
@@ -40,11 +42,13 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
                     const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site);
 // y_rows (optional): output row r is stored at row y_rows[r]
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
-                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows);
+                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row = nullptr,
+                      const float* r1_col = nullptr);   // x += r1_row[r] * r1_col[:] before the dropout
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
                       uint32_t site, const int32_t* rows = nullptr);   // rows: dy and ds are row-mapped (dy[rows[r]], ds[rows[r]])
-int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out);
+int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float* dc, float* dW2, float* db1);
+int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight = nullptr);
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
 // 3 out[dst[r]]=in[src[r]]
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,

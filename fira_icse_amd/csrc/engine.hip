@@ -37,7 +37,7 @@ struct DecSave {
 };
 
 struct EncGrad {
-    float *dY2, *dH, *dYc, *dqk;
+    float *dY2, *dYc, *dqk;
 };
 struct DecGrad {
     float *dYf, *dh, *dYc, *dq, *dYs, *dqkv;
@@ -53,6 +53,8 @@ struct Plan {
     std::vector<EncGrad> encg;      // per-layer weight-gradient operands: never reused inside a step, so the
     std::vector<DecGrad> decg;      // wgrad GEMMs can run on the side stream while the dgrad chain continues
     float *vtab_all, *H, *mem, *mem_c, *kv_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
+    float *W21, *c21, *rsum;        // GCN: per layer fc2.weight . fc1.weight [256,256] and fc2.weight . fc1.bias [256]; A_hat 1
+    float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
     // backward temporaries (training only)
     float *dXa, *dXb, *dNB2, *dCB_a, *dvtab_all;
@@ -82,6 +84,7 @@ struct Plan {
             e.Z = a.f((size_t)NB * D); e.s2 = a.f((size_t)NB * D); e.st2 = a.f((size_t)NB * 2);
         }
         vtab_all = a.f((size_t)4 * nl * D);
+        W21 = a.f((size_t)nl * D * D); c21 = a.f((size_t)nl * D); rsum = a.f((size_t)NB);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
         mem_c = a.f((size_t)MB * D);
@@ -105,6 +108,7 @@ struct Plan {
             dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
             dCB_a = a.f((size_t)CB * D);
             dvtab_all = a.f((size_t)4 * nl * D);
+            dW21 = a.f((size_t)nl * D * D + (size_t)nl * D); dc21 = dW21 + (size_t)nl * D * D;
             dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
             dkv_c = a.f((size_t)MB * nl * 2 * D); dtgt = a.f((size_t)TB * D);
             dkv_all = a.f((size_t)MB * nl * 2 * D);
@@ -114,7 +118,7 @@ struct Plan {
             decg.resize(nl);
             for (int l = 0; l < nl; ++l) {
                 EncGrad& g = encg[l];
-                g.dY2 = a.f((size_t)NB * D); g.dH = a.f((size_t)NB * D); g.dYc = a.f((size_t)CB * D);
+                g.dY2 = a.f((size_t)NB * D); g.dYc = a.f((size_t)CB * D);
                 g.dqk = a.f((size_t)CB * 2 * D);
                 DecGrad& h = decg[l];
                 h.dYf = a.f((size_t)TB * D); h.dh = a.f((size_t)TB * F); h.dYc = a.f((size_t)TB * D);
@@ -286,6 +290,23 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
                       p.pos_code, p.X[0]));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
     TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
+    // GCN (gnn_transformer.py:74-86) has no non-linearity between fc1, the aggregation and fc2, so
+    //     fc2(A_hat fc1(X)) = (A_hat X) (W2 W1)^T + (A_hat 1) (W2 b1)^T + b2 :
+    // one [Nc,256]x[256,256] product per layer instead of two (and one dgrad, one wgrad in the backward pass); the folded
+    // 256x256 weights are formed here, per step, from the current parameters (same value up to fp32 re-association).
+    // They only read parameters: with the auxiliary stream they run beside the embedding / first Combination kernels.
+    hipEvent_t ev_fold = nullptr;
+    {
+        const bool ax = side_on();
+        hipStream_t fs = ax ? side().aux : s;
+        if (ax) TRY(aux_fork(s));
+        for (int l = 0; l < p.nl; ++l) {
+            const EncLayer& w = L.enc[l];
+            TRY(gemm_f32_ex(fs, 0, 0, D, D, D, c.P + w.fc2w, D, c.P + w.fc1w, D, p.W21 + (size_t)l * D * D, D, nullptr, 0, 0, nullptr));
+            TRY(gemm_f32_ex(fs, 0, 1, D, 1, D, c.P + w.fc2w, D, c.P + w.fc1b, D, p.c21 + (size_t)l * D, 1, nullptr, 0, 0, nullptr));
+        }
+        if (ax) TRY(side_mark(&ev_fold));
+    }
     for (int l = 0; l < p.nl; ++l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
@@ -297,12 +318,12 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         TRY(linear(s, Cc, D, D, e.c, D, c.P + w.wo, c.P + w.bo, e.s1, D));
         TRY(add_layernorm_fwd(s, Cc, e.s1, e.Xc, c.P + w.ln1g, c.P + w.ln1b, X, e.st1, c.p_drop, c.seed,
                               site(l, SITE_COMB_OUT), bt.code_rows));
-        // GCN (gnn_transformer.py:74-86): fc1 -> A_hat . -> fc2 -> +residual -> LN
-        TRY(linear(s, Nc, D, D, X, D, c.P + w.fc1w, c.P + w.fc1b, p.H, D));
-        TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.H, D, e.Z, D, 0, 1));
-        TRY(linear(s, Nc, D, D, e.Z, D, c.P + w.fc2w, c.P + w.fc2b, e.s2, D));
+        // GCN in folded form: U = A_hat X (kept for the weight gradient) -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
+        if (l == 0 && ev_fold) TRY(main_wait(s, ev_fold));
+        TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
+        TRY(linear(s, Nc, D, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, e.s2, D));
         TRY(add_layernorm_fwd(s, Nc, e.s2, X, c.P + w.ln2g, c.P + w.ln2b, p.X[l + 1], e.st2, c.p_gcn, c.seed,
-                              site(l, SITE_GCN), nullptr));
+                              site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D));
     }
     // memory = [code ; sub-token] rows (Model.py:48): compact copy for the GEMMs, dense [B,370,*] rows for the
     // attention / copy kernels (rows of masked slots are never read there)
@@ -501,18 +522,30 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     if (ev_dmem) TRY(main_wait(s, ev_dmem));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
     TRY(zero(s, p.dvtab_all, (size_t)4 * p.nl * D * sizeof(float)));
+    TRY(zero(s, p.dW21, ((size_t)p.nl * D * D + (size_t)p.nl * D) * sizeof(float)));
     for (int l = p.nl - 1; l >= 0; --l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
         EncGrad& g = p.encg[l];
-        const float* Xg = p.X[l];                                  // GCN input (code rows already updated)
         TRY(add_layernorm_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, g.dY2, G + w.ln2g, G + w.ln2b, c.p_gcn,
                               c.seed, site(l, SITE_GCN)));
-        TRY(linear_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, G + w.fc2w, G + w.fc2b));
-        TRY(linear_dgrad(s, Nc, D, D, g.dY2, D, c.P + w.fc2w, p.dNB2, D, false));              // dZ
-        TRY(csr_spmm(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, g.dH, D, 0, 1));             // dH = A_hat dZ
-        TRY(linear_wgrad(s, Nc, D, D, g.dH, D, Xg, D, G + w.fc1w, G + w.fc1b));
-        TRY(linear_dgrad(s, Nc, D, D, g.dH, D, c.P + w.fc1w, other, D, true));                 // other = dG
+        // GCN, folded form (see encoder_forward): Y = U W21^T + r c^T + b2 with U = A_hat X
+        //   weight space: dW21 += dY^T U (+ db2 by the fused column sums), dc += dY^T r           (side stream)
+        //   data space:   dU = dY W21, dX += A_hat dU                                              (main stream)
+        //   and back to the reference's parameters: dW2 += dW21 W1^T + dc b1^T, dW1 += W2^T dW21, db1 += W2^T dc
+        float* dW21 = p.dW21 + (size_t)l * D * D;
+        float* dc21 = p.dc21 + (size_t)l * D;
+        TRY(linear_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, dW21, G + w.fc2b));
+        {
+            hipStream_t ws = s;
+            if (side().stream && side().enabled) { TRY(side_fork(s)); ws = side().stream; }
+            TRY(colsum(ws, Nc, D, g.dY2, D, dc21, p.rsum));
+            TRY(gemm_f32_ex(ws, 0, 1, D, D, D, dW21, D, c.P + w.fc1w, D, G + w.fc2w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
+            TRY(gemm_f32_ex(ws, 1, 0, D, D, D, c.P + w.fc2w, D, dW21, D, G + w.fc1w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
+            TRY(gcn_bias_unfold(ws, c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b));
+        }
+        TRY(linear_dgrad(s, Nc, D, D, g.dY2, D, p.W21 + (size_t)l * D * D, p.dNB2, D, false));  // dU
+        TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, other, D, 0, 1, 1, nullptr));   // other = ds + A_hat dU
         // Combination on the code rows, in place inside `other` through the code-row map: the LayerNorm backward reads
         // dG[code rows] and leaves the residual-branch gradient there; the q|k projection's dgrad adds to the same rows
         TRY(add_layernorm_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,

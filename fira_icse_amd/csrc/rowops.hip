@@ -236,13 +236,20 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
                                                                 const float* __restrict__ beta,
                                                                 float* __restrict__ y, float* __restrict__ stats,
                                                                 float p, float inv_keep, uint64_t seed,
-                                                                uint32_t site, const int32_t* __restrict__ y_rows) {
+                                                                uint32_t site, const int32_t* __restrict__ y_rows,
+                                                                const float* __restrict__ r1_row,
+                                                                const float* __restrict__ r1_col) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     const size_t o = (size_t)r * FIRA_D + lane * 4;
     const size_t oy = y_rows ? (size_t)y_rows[r] * FIRA_D + lane * 4 : o;      // optional scatter of the output rows
     float4 a = *reinterpret_cast<const float4*>(x + o);
+    if (r1_row) {                                    // rank-1 part of the branch output: x += r1_row[r] * r1_col[:]
+        const float w = r1_row[r];
+        const float4 c4 = *reinterpret_cast<const float4*>(r1_col + lane * 4);
+        a.x = fmaf(w, c4.x, a.x); a.y = fmaf(w, c4.y, a.y); a.z = fmaf(w, c4.z, a.z); a.w = fmaf(w, c4.w, a.w);
+    }
     if (p > 0.f) {
         const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
         a.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
@@ -340,17 +347,30 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
     }
 }
 
+// Bias part of the folded GCN's parameter gradients (engine.hip): with c = W2 b1,
+//   dW2[i,k] += dc[i] * b1[k]          db1[k] += sum_i W2[i,k] * dc[i]
+// One workgroup per output row i of dW2 / per column block of db1; 256 x 256 problem, latency only.
+__global__ __launch_bounds__(256) void gcn_bias_unfold_kernel(const float* __restrict__ W2, const float* __restrict__ b1,
+                                                              const float* __restrict__ dc, float* __restrict__ dW2,
+                                                              float* __restrict__ db1) {
+    const int i = blockIdx.x, k = threadIdx.x;
+    const float dci = dc[i];
+    dW2[(size_t)i * FIRA_D + k] += dci * b1[k];
+    unsafeAtomicAdd(&db1[k], W2[(size_t)i * FIRA_D + k] * dci);
+}
+
 // ------------------------------------------------------------------------------------------------
 // out[n] += sum_m X[m,n]: bias gradients.  Block = 256 threads over 64 columns x 4 row-phases.
 __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ X, int ldx,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ out, int rows_per_block,
+                                                     const float* __restrict__ w) {   // optional row weights
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int ph = threadIdx.x >> 6;
     const int r_beg = blockIdx.y * rows_per_block, r_end = min(M, r_beg + rows_per_block);
     float acc = 0.f;
     if (c < N)
-        for (int r = r_beg + ph; r < r_end; r += 4) acc += X[(size_t)r * ldx + c];
+        for (int r = r_beg + ph; r < r_end; r += 4) acc += (w ? w[r] : 1.0f) * X[(size_t)r * ldx + c];
     red[ph][threadIdx.x & 63] = acc;
     __syncthreads();
     if (ph == 0 && c < N) {
@@ -602,12 +622,13 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
     return 0;
 }
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
-                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows) {
+                      float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows,
+                      const float* r1_row, const float* r1_col) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, x, res, gamma, beta, y, stats,
-                       dropout, inv_keep, seed, site, y_rows);
+                       dropout, inv_keep, seed, site, y_rows, r1_row, r1_col);
     FIRA_CHECK_LAUNCH("add_layernorm_fwd");
     return 0;
 }
@@ -624,11 +645,16 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");
     return 0;
 }
-int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out) {
+int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float* dc, float* dW2, float* db1) {
+    hipLaunchKernelGGL(gcn_bias_unfold_kernel, dim3(FIRA_D), dim3(FIRA_D), 0, s, W2, b1, dc, dW2, db1);
+    FIRA_CHECK_LAUNCH("gcn_bias_unfold");
+    return 0;
+}
+int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0 || N <= 0) return 0;
     const int rpb = 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, s, M, N, X, ldx, out, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, s, M, N, X, ldx, out, rpb, row_weight);
     FIRA_CHECK_LAUNCH("colsum");
     return 0;
 }

@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
                                                            const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
                                                            const float* __restrict__ X, int ldx,
-                                                           float* __restrict__ Y, int ldy) {
+                                                           float* __restrict__ Y, int ldy, int accum,
+                                                           float* __restrict__ rowsum) {
     const int lane = threadIdx.x & 63;
     // XCD-aware row mapping: workgroup b runs on XCD b % 8 and each XCD has its own L2, so workgroup b is given the
     // row group (b % 8) * ceil(nwg / 8) + b / 8: every XCD then owns one contiguous eighth of the rows (whole graphs of
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
     if (row >= n_rows) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float vsum = 0.f;
     for (int base = beg; base < end; base += 64) {
         const int n = min(64, end - base);
         int c = 0;
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
             c = col[base + lane];
             v = val[base + lane];
         }
+        vsum += v;
         int j = 0;
         for (; j + 4 <= n; j += 4) {
             const int c0 = __shfl(c, j, 64), c1 = __shfl(c, j + 1, 64), c2 = __shfl(c, j + 2, 64),
@@ -65,7 +68,16 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
             acc.x = fmaf(v0, x0.x, acc.x); acc.y = fmaf(v0, x0.y, acc.y); acc.z = fmaf(v0, x0.z, acc.z); acc.w = fmaf(v0, x0.w, acc.w);
         }
     }
-    *reinterpret_cast<float4*>(Y + (size_t)row * ldy + lane * 4) = acc;
+    float4* yp = reinterpret_cast<float4*>(Y + (size_t)row * ldy + lane * 4);
+    if (accum) {                                     // Y += A X (the aggregation's backward lands on a residual gradient)
+        const float4 y0 = *yp;
+        acc.x += y0.x; acc.y += y0.y; acc.z += y0.z; acc.w += y0.w;
+    }
+    *yp = acc;
+    if (rowsum) {                                    // r = A 1, needed where a bias travels through the aggregation
+        vsum = wave_sum(vsum);
+        if (lane == 0) rowsum[row] = vsum;
+    }
 }
 
 // LDS-staged variant: grid (4 column slabs, n_graphs); block 1024 threads = 16 waves.
@@ -165,9 +177,16 @@ __global__ __launch_bounds__(1024) void spmm_lds_kernel(int graph_rows, const in
     }
 }
 
+int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum);
 int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
              int ldx, float* Y, int ldy, int graph_rows, int variant) {
+    return csr_spmm_ex(s, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant, 0, nullptr);
+}
+int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum) {
     if (n_rows <= 0) return 0;
+    FIRA_REQUIRE(!((accum || rowsum) && variant == 2), "csr_spmm: accumulate / row sums need the row-per-wave variant");
     FIRA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0),
                  "csr_spmm: feature rows must be 16-byte aligned");
     if (variant == 0) variant = 1;
@@ -188,7 +207,7 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
     } else {
         // grid rounded up to a multiple of 8 so that the XCD remap above is a bijection onto the row groups
         hipLaunchKernelGGL(spmm_rowwave_kernel, dim3(cdiv(cdiv(n_rows, 4), 8) * 8), dim3(256), 0, s, n_rows, rowptr, col,
-                           val, X, ldx, Y, ldy);
+                           val, X, ldx, Y, ldy, accum, rowsum);
     }
     FIRA_CHECK_LAUNCH("csr_spmm");
     return 0;

@@ -335,7 +335,7 @@ class TransModel(nn.Module):
         run_model.py:104-108 minus the optimizer).  Dropout follows ``self.training`` unless given."""
         lib = _lib.lib()
         if zero_grad:
-            self.gbuf.zero_()
+            self.gbuf[:self.layout.live].zero_()           # tensors past `live` never receive a gradient (SURVEY.md F6)
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
         pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
         self.dropout_seed += 1

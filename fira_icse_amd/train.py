@@ -44,16 +44,20 @@ class Trainer:
             self.reducer.finish(m.gbuf, self.stats)
             torch.reciprocal(self.stats[1:2].clamp_min(1.0), out=self.inv)
         else:
-            self.stats[0:1].copy_(loss_sum)
-            self.stats[1:2].copy_(n_tok)
-            ops.inv_count(n_tok, self.inv)
+            ops.inv_count(n_tok, self.inv)                      # loss_sum / n_tok stay in the model's own buffers
         self.t += 1
-        ops.adam_step(m.flat.data, m.gbuf, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps,
-                      inv_scale=self.inv)
+        # [live, total) holds the tensors no kernel touches (encoder.lstm, combination_list1, gate_fc): their gradient is
+        # None in the reference, so torch.optim.Adam skips them too
+        n = m.layout.live
+        ops.adam_step(m.flat.data[:n], m.gbuf[:n], self.m[:n], self.v[:n], self.lr, self.t, self.betas[0], self.betas[1],
+                      self.eps, inv_scale=self.inv)
 
     def last_loss(self) -> float:
         """Mean token loss of the last (global) batch; synchronises."""
-        s = self.stats.tolist()
+        if self.reducer is not None and self.reducer.world > 1:
+            s = self.stats.tolist()
+        else:
+            s = [float(self.model.loss_sum.item()), float(self.model.n_tok.item())]
         return s[0] / max(s[1], 1.0)
 
     def state_dict(self):

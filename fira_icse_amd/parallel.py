@@ -56,6 +56,7 @@ class GradReducer:
         self.split, self.live, self.group = split, live, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._pending = None
+        self._late = None
         self._side = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def start_early_bucket(self, gbuf: torch.Tensor, mid_event=None):
@@ -69,16 +70,34 @@ class GradReducer:
         else:
             self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self, gbuf: torch.Tensor, stats: torch.Tensor):
-        """Reduce the encoder bucket and the 2-element stats (fp32: loss_sum, n_tok); wait for the early bucket."""
+    def reduce_stats_and_start_late_bucket(self, gbuf: torch.Tensor, stats: torch.Tensor):
+        """After the backward pass: all-reduce the 2-element stats (needed first: the token normaliser of every Adam
+        call), then launch the encoder bucket asynchronously.  ``wait_early`` / ``wait_late`` then let the caller run
+        Adam on the head+decoder slice while the encoder slice is still on the wire."""
         if self.world == 1:
             return
         if self._pending is None:
             self.start_early_bucket(gbuf, None)
-        dist.all_reduce(gbuf[self.split:self.live], op=dist.ReduceOp.SUM, group=self.group)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
-        self._pending.wait()
-        self._pending = None
+        self._late = dist.all_reduce(gbuf[self.split:self.live], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait_early(self):
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    def wait_late(self):
+        if getattr(self, "_late", None) is not None:
+            self._late.wait()
+            self._late = None
+
+    def finish(self, gbuf: torch.Tensor, stats: torch.Tensor):
+        """Reduce the encoder bucket and the 2-element stats (fp32: loss_sum, n_tok); wait for both buckets."""
+        if self.world == 1:
+            return
+        self.reduce_stats_and_start_late_bucket(gbuf, stats)
+        self.wait_early()
+        self.wait_late()
 
 
 def gather_lines(lines: List[str], group=None) -> List[str]:

@@ -37,20 +37,30 @@ class Trainer:
         """One optimisation step on this rank's shard of the global batch."""
         m = self.model
         loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
+        b1, b2 = self.betas
         if self.reducer is not None and self.reducer.world > 1:
-            self.reducer.start_early_bucket(m.gbuf, self.mid_event)
+            red, split, live = self.reducer, m.layout.split, m.layout.live
+            red.start_early_bucket(m.gbuf, self.mid_event)
             self.stats[0:1].copy_(loss_sum)
             self.stats[1:2].copy_(n_tok)                       # int32 -> fp32 (exact below 2^24 tokens)
-            self.reducer.finish(m.gbuf, self.stats)
+            red.reduce_stats_and_start_late_bucket(m.gbuf, self.stats)
             torch.reciprocal(self.stats[1:2].clamp_min(1.0), out=self.inv)
-        else:
-            ops.inv_count(n_tok, self.inv)                      # loss_sum / n_tok stay in the model's own buffers
+            self.t += 1
+            # Adam on the head+decoder slice runs while the encoder slice is still being reduced
+            red.wait_early()
+            ops.adam_step(m.flat.data[:split], m.gbuf[:split], self.m[:split], self.v[:split], self.lr, self.t, b1, b2,
+                          self.eps, inv_scale=self.inv)
+            red.wait_late()
+            ops.adam_step(m.flat.data[split:live], m.gbuf[split:live], self.m[split:live], self.v[split:live], self.lr,
+                          self.t, b1, b2, self.eps, inv_scale=self.inv)
+            return
+        ops.inv_count(n_tok, self.inv)                          # loss_sum / n_tok stay in the model's own buffers
         self.t += 1
         # [live, total) holds the tensors no kernel touches (encoder.lstm, combination_list1, gate_fc): their gradient is
         # None in the reference, so torch.optim.Adam skips them too
         n = m.layout.live
-        ops.adam_step(m.flat.data[:n], m.gbuf[:n], self.m[:n], self.v[:n], self.lr, self.t, self.betas[0], self.betas[1],
-                      self.eps, inv_scale=self.inv)
+        ops.adam_step(m.flat.data[:n], m.gbuf[:n], self.m[:n], self.v[:n], self.lr, self.t, b1, b2, self.eps,
+                      inv_scale=self.inv)
 
     def last_loss(self) -> float:
         """Mean token loss of the last (global) batch; synchronises."""

@@ -184,6 +184,24 @@ def embedding_items(hb: HostBatch, cfg: FiraConfig, chunk: int = 32):
     return tok[item_start].astype(np.int32), np.append(item_start, tok.size).astype(np.int32), pos.astype(np.int32)
 
 
+def compact_embedding_lists(hb: HostBatch, cfg: FiraConfig, node_rows: np.ndarray):
+    """The id-carrying nodes of a batch by COMPACT node id (position in ``node_rows``), for the embedding gradient:
+    word-embedding items (``embedding_items`` mapped to compact ids) and the (row, id) pairs of the AST / edit nodes."""
+    B, N, L, S = len(hb), cfg.graph_len, cfg.sou_len, cfg.sub_token_len
+    item_tok, item_ptr, emb_rows = embedding_items(hb, cfg)
+    cmap = np.full(B * N, -1, dtype=np.int64)
+    cmap[node_rows] = np.arange(node_rows.shape[0])
+    emb_rows = cmap[emb_rows]
+    if emb_rows.size and emb_rows.min() < 0:
+        raise AssertionError("a node with a non-zero id is not in the computed list")
+    ast_sel = (node_rows % N) >= L + S
+    ast_rows = np.nonzero(ast_sel)[0]
+    g = node_rows[ast_sel]
+    ast_ids = hb.ast_change[g // N, g % N - L - S]
+    keep = ast_ids != 0
+    return item_tok, item_ptr, emb_rows.astype(np.int32), ast_rows[keep].astype(np.int32), ast_ids[keep].astype(np.int32)
+
+
 class DeviceBatch:
     """One collated batch resident in HBM: int32 id arrays, the computed-node lists and their CSR adjacency
     (+ the list of target rows that need the vocabulary head)."""
@@ -222,18 +240,7 @@ class DeviceBatch:
             rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0].astype(np.int32)
             self.n_head_rows = int(rows.shape[0])
             self.head_rows = dev(rows, np.int32)
-        item_tok, item_ptr, emb_rows = embedding_items(hb, cfg)
-        cmap = np.full(self.B * cfg.graph_len, -1, dtype=np.int64)
-        cmap[node_rows] = np.arange(node_rows.shape[0])
-        emb_rows = cmap[emb_rows]
-        ast_sel = (node_rows % cfg.graph_len) >= cfg.sou_len + cfg.sub_token_len
-        ast_rows = np.nonzero(ast_sel)[0]
-        g = node_rows[ast_sel]
-        ast_ids = hb.ast_change[g // cfg.graph_len, g % cfg.graph_len - cfg.sou_len - cfg.sub_token_len]
-        keep = ast_ids != 0
-        ast_rows, ast_ids = ast_rows[keep], ast_ids[keep]
-        if emb_rows.size and emb_rows.min() < 0:
-            raise AssertionError("a node with a non-zero id is not in the computed list")
+        item_tok, item_ptr, emb_rows, ast_rows, ast_ids = compact_embedding_lists(hb, cfg, node_rows)
         self.n_ast_items = int(ast_rows.shape[0])
         self.ast_rows, self.ast_ids = dev(ast_rows, np.int32), dev(ast_ids, np.int32)
         self.n_emb_items = int(item_tok.shape[0])

@@ -140,3 +140,23 @@ def test_embedding_items_cover_every_nonpad_position_once():
         assert all(flat[int(r)] == int(tok[k]) for r in rows[ptr[k]:ptr[k + 1]])
     # an item boundary never separates two ids in the wrong order: ids ascend over the items
     assert np.all(np.diff(tok.astype(np.int64)) >= 0)
+
+
+@pytest.mark.parametrize("skip_padding", [True, False])
+def test_compact_embedding_lists_point_at_the_right_nodes(skip_padding):
+    """Word items and AST (row, id) pairs index the compact node list: node_rows[row] is a node that carries that id,
+    every id-carrying node is listed exactly once, padding (id 0) never."""
+    from fira_icse_amd.model import compact_embedding_lists, computed_nodes
+    cfg = FiraConfig()
+    hb = data.process_raw(cfg, util.edge_case_raw()).batch([0, 1, 2, 3])
+    node_rows = computed_nodes(hb, cfg, skip_padding)[0]
+    tok, ptr, rows, ast_rows, ast_ids = compact_embedding_lists(hb, cfg, node_rows)
+    N, L, S = cfg.graph_len, cfg.sou_len, cfg.sub_token_len
+    words = np.concatenate([hb.sou, hb.sub_token], axis=1)
+    for k in range(tok.shape[0]):
+        g = node_rows[rows[ptr[k]:ptr[k + 1]]]
+        assert np.all(g % N < L + S) and np.all(words[g // N, g % N] == tok[k])
+    assert rows.shape[0] == int((words != 0).sum()) == np.unique(rows).shape[0]
+    g = node_rows[ast_rows]
+    assert np.all(g % N >= L + S) and np.array_equal(hb.ast_change[g // N, g % N - L - S], ast_ids)
+    assert ast_rows.shape[0] == int((hb.ast_change != 0).sum()) == np.unique(ast_rows).shape[0] and np.all(ast_ids != 0)

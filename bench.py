@@ -1,21 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the FIRA hot path on MI355X: training commits/s (+ greedy-decode tokens/s), BASELINE.json's metric.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16]
 
 A "step" is one optimisation step of run_model.py:101-112 (forward + backward + [RCCL all-reduce] + Adam) over one
 batch of synthetic commits in the reference's raw schema (there is no network for the real DataSet; seed-0 generator,
-SURVEY.md §8d), with the reference's dropout (0.1 / 0.2) ON and fp32 arithmetic.  The N=1 workload is BASELINE
-configs[1] ("1xMI355X, batch=32, fp32"); every rank keeps batch 32 as N grows (weak scaling).  Inputs are resident in
+SURVEY.md §8d), with the reference's dropout (0.1 / 0.2) ON.  The default workload is BASELINE configs[1]
+("1xMI355X, batch=32, fp32"); ``--dtype bf16`` is configs[2]'s per-GPU workload (batch 64 per GPU, nn.Linear products on
+the bf16 MFMA with fp32 accumulation).  Every rank keeps its batch as N grows (weak scaling).  Inputs are resident in
 HBM before the timed region (pre-collated device batches, cycled).  One JSON line is printed by rank 0.
 
-Extra objects on the line:
-  roofline      dominant kernel of the step by GPU time (the fp32 MFMA GEMM): algorithmic FLOP / summed launch time,
-                both measured with HIP events inside the library on the launch stream during extra profiled steps
-                (fira_prof_*); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).  `spmm` carries the same for the
-                GCN aggregation against HBM (algorithmic bytes).
-  cpu_baseline  the CPU oracle (a port of the reference's PyTorch path, oracle/fira_oracle.py) timed on this host on a
-                bounded sample (a few batch-4 steps), rank 0 at N=1 only.
+``--gpus N`` with N > 1: when the process was not started by torch.distributed.run (no WORLD_SIZE in the environment)
+bench.py re-launches itself under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1`` (one process per GPU, RCCL) and passes the child's line through -- the reference's multi-GPU entry is one
+command too (run_model.py:392-394).  ``--dp-same-device`` puts every rank on cuda:0 with the gloo transport, which is
+how the N > 1 path is exercised on a one-GPU box (tests/test_dp_gpu.py).
+
+Extra objects on the line (all measured outside the timed region):
+  roofline      the dominant kernel class of the step by GPU time (the MFMA GEMMs): algorithmic FLOP / summed launch
+                time, measured with HIP events on the launch stream inside the library during extra profiled steps
+                (fira_prof_*); peak = 157.3 TFLOP/s fp32 MFMA or 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).  In
+                bf16 the same launches are also priced against HBM (`roofline_hbm`: algorithmic operand bytes / time):
+                at K = 256 the products sit at 64 FLOP/B, far left of the 400 FLOP/B ridge.
+  spmm / spmm_b64 / spmm_cfg5   the GCN aggregation against HBM (algorithmic bytes of SURVEY.md §8d): inside the step,
+                stand-alone on a realistic batch-64 graph batch, and on BASELINE config 5 (128 x 512-node dense graphs).
+  host_inclusive  the same step fed by the data path (vectorised collate -> pinned arena -> one async H2D copy per
+                batch, two batches ahead on a worker thread): fresh batches every step.
+  decode        greedy (batch 64) and beam-3 (batch 20) search on a checkpoint trained for a few hundred steps inside
+                the setup (untimed) so that message lengths are realistic; `roofline` = HBM bytes a step must move.
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch path, oracle/fira_oracle.py, checked equal to the
+                reference by tests/test_oracle.py) timed on this host on a bounded sample: train steps at batch 4 and 32
+                and a few greedy / beam-3 search steps; rank 0 at N=1 only.
 """
 from __future__ import annotations
 
@@ -23,6 +38,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,81 +49,265 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from fira_icse_amd import _lib, data, synth                      # noqa: E402
-from fira_icse_amd.config import FiraConfig                     # noqa: E402
-from fira_icse_amd.parallel import init_from_env                # noqa: E402
-
 FP32_MFMA_PEAK_TF = 157.3
+BF16_MFMA_PEAK_TF = 2500.0
 HBM_PEAK_GBS = 8000.0
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--batch", type=int, default=0, help="commits per GPU per step (default 32 for f32 = BASELINE "
+                                                         "configs[1], 64 for bf16 = configs[2])")
+    ap.add_argument("--decode-batch", type=int, default=64)
+    ap.add_argument("--decode-train-steps", type=int, default=300)
+    ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone SpMM / host-inclusive legs")
+    ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--dp-same-device", action="store_true", help="all ranks on cuda:0 over gloo (one-GPU testing)")
+    return ap.parse_args()
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a) -> int:
+    """One process per GPU under torch.distributed.run; the child (rank 0) prints the JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def prof_report():
+    from fira_icse_amd import _lib
     n = 7
-    ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
-    _lib.lib().fira_prof_report(n, ms, work, cnt)
+    ms, work, byts, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+    _lib.lib().fira_prof_report(n, ms, work, byts, cnt)
     names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam"]
-    return {k: dict(ms=ms[i], work=work[i], count=int(cnt[i])) for i, k in enumerate(names)}
+    return {k: dict(ms=ms[i], work=work[i], bytes=byts[i], count=int(cnt[i])) for i, k in enumerate(names)}
 
 
-def cpu_baseline(cfg, store, seconds_budget=25.0):
-    """Reference-equivalent CPU path (oracle port): train steps at batch 4 on this host's cores."""
+def time_gpu(fn, iters=30, warmup=3):
+    """Average seconds per call, HIP events on torch's current stream (the stream the op wrappers launch on)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def spmm_bytes(n_rows, nnz, d=256):
+    """Compulsory traffic of Z = A_hat H: rowptr + (col, val) + features in + features out."""
+    return 4 * (n_rows + 1) + 8 * nnz + 2 * n_rows * d * 4
+
+
+def spmm_standalone(cfg, store):
+    from fira_icse_amd import graphs, ops
+    out = {}
+    # realistic graphs, batch 64, every node listed (the reference's dense 650-node layout: 41 600 rows)
+    hb = store.batch(range(64))
+    rp, c, v = (torch.from_numpy(x).cuda() for x in (hb.rowptr, hb.col, hb.val))
+    X = torch.randn(64 * cfg.graph_len, 256, device="cuda")
+    t = time_gpu(lambda: ops.csr_spmm(rp, c, v, X, graph_rows=cfg.graph_len, variant=1))
+    by = spmm_bytes(X.shape[0], c.numel())
+    out["spmm_b64"] = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "rows": int(X.shape[0]), "nnz": int(c.numel()),
+                       "avg_launch_us": t * 1e6, "bytes_per_launch": by, "achieved": by / t / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS}
+    # BASELINE config 5: 128 graphs x 512 nodes x 4 edge types x 8192 edges
+    B, N = 128, 512
+    rp, c, v = (torch.from_numpy(x).cuda() for x in graphs.dense_stress_batch(B, N))
+    X = torch.randn(B * N, 256, device="cuda")
+    by = spmm_bytes(B * N, c.numel())
+    cfg5 = {"bound": "hbm", "rows": B * N, "nnz": int(c.numel()), "bytes_per_launch": by, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s"}
+    for variant, name in ((1, "spmm_rowwave_kernel"), (2, "spmm_lds_kernel")):
+        t = time_gpu(lambda: ops.csr_spmm(rp, c, v, X, graph_rows=N, variant=variant), iters=10)
+        cfg5["v%d" % variant] = {"kernel": name, "avg_launch_us": t * 1e6, "achieved": by / t / 1e9,
+                                 "frac": by / t / 1e9 / HBM_PEAK_GBS,
+                                 "gathered_GBs": (8 * c.numel() + c.numel() * 1024 + B * N * 1024) / t / 1e9}
+    out["spmm_cfg5"] = cfg5
+    return out
+
+
+def host_inclusive(cfg, store, trainer, B, steps):
+    """Steps fed by the real data path: collate + pinned arena + one H2D copy per batch on a worker thread."""
+    from fira_icse_amd.model import DeviceBatch
+    from fira_icse_amd.prefetch import prefetch
+    n = len(store)
+    order = [[(i * B + k) % n for k in range(B)] for i in range(steps + 2)]
+    dev = trainer.model.device_
+    it = prefetch(order, lambda idx: DeviceBatch(store.batch(idx), cfg, dev), depth=2)
+    trainer.step(next(it)); trainer.step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for db in it:
+        trainer.step(db)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for idx in order[:8]:
+        store.batch(idx)
+    collate_ms = (time.perf_counter() - t1) / 8 * 1e3
+    return {"commits_per_s": steps * B / dt, "ms_per_step": dt / steps * 1e3, "collate_ms_per_batch": collate_ms,
+            "note": "fresh batch every step: vectorised CSR collate -> pinned arena -> one async H2D copy, prepared two "
+                    "batches ahead on a worker thread"}
+
+
+def cpu_baseline(cfg, store, seconds_budget=30.0):
+    """Reference-equivalent CPU path (oracle port): train steps at batch 4 and 32, a few search steps."""
     from oracle import fira_oracle as O
     from fira_icse_amd.model import reference_init_state_dict
     # more threads than ~32 only add contention on these small-matrix ops (measured: 256 threads are >100x slower)
     threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    P = {k: v.clone().requires_grad_(True) for k, v in reference_init_state_dict(cfg).items()}
-    opt = torch.optim.Adam(list(P.values()), cfg.lr)
-    hb = store.batch(range(4))
+    sd = reference_init_state_dict(cfg)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-    edge = t(hb.dense_edge(cfg.graph_len))
-    args = (cfg, t(hb.sou), t(hb.tar), t(hb.mark), t(hb.ast_change), edge, t(hb.tar_label), t(hb.sub_token))
-    times = []
     t_all = time.time()
-    for i in range(12):
+
+    def train_leg(B, max_steps, budget):
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.Adam(list(P.values()), cfg.lr)
+        hb = store.batch(range(B))
+        args = (cfg, t(hb.sou), t(hb.tar), t(hb.mark), t(hb.ast_change), t(hb.dense_edge(cfg.graph_len)),
+                t(hb.tar_label), t(hb.sub_token))
+        times, t_leg = [], time.time()
+        for i in range(max_steps):
+            t0 = time.time()
+            ls, nt = O.forward(P, *args, "train")
+            opt.zero_grad(set_to_none=True)
+            (ls / nt).backward()
+            opt.step()
+            times.append(time.time() - t0)
+            if time.time() - t_leg > budget and len(times) >= 2:
+                break
+        med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+        return B / med, len(times)
+
+    v4, n4 = train_leg(4, 8, 0.2 * seconds_budget)
+    v32, n32 = train_leg(32, 4, 0.4 * seconds_budget)
+
+    def search_leg(B, beam, steps):
+        hb = store.batch(range(B))
         t0 = time.time()
-        ls, nt = O.forward(P, *args, "train")
-        opt.zero_grad(set_to_none=True)
-        (ls / nt).backward()
-        opt.step()
-        times.append(time.time() - t0)
-        if time.time() - t_all > seconds_budget and len(times) >= 2:
-            break
-    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return {"value": 4.0 / med, "unit": "commits/s", "cores": threads, "kind": "port",
-            "sample": "%d train steps (fwd+bwd+Adam, dropout off) at batch 4, fp32, median; dense f64->f32 adjacency "
-                      "as the reference feeds it" % len(times)}
+        O.beam_decode(sd, cfg, t(hb.sou), t(hb.mark), t(hb.ast_change), t(hb.dense_edge(cfg.graph_len)),
+                      t(hb.sub_token), beam, max_steps=steps)
+        return B * steps / (time.time() - t0)
+
+    g20 = search_leg(20, 1, 3)
+    b20 = search_leg(20, 3, 2)
+    return {"value": v32, "unit": "commits/s", "cores": threads, "kind": "port",
+            "sample": "train steps (fwd+bwd+Adam, dropout off, fp32, dense f64->f32 adjacency as the reference feeds "
+                      "it): %d at batch 32 (value), %d at batch 4; search: 3 greedy / 2 beam-3 steps at batch 20 with "
+                      "the encoder pass (full recompute per step as the reference does); %.0f s in total" %
+                      (n32, n4, time.time() - t_all),
+            "train_batch4_commits_per_s": v4, "train_batch32_commits_per_s": v32,
+            "greedy_batch20_step_tokens_per_s": g20, "beam3_batch20_step_tokens_per_s": b20,
+            "port_checked_equal_to_reference": "tests/test_oracle.py (fixtures generated by the reference + live import)"}
+
+
+def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
+    """Greedy (batch 64) and beam-3 (batch 20) search, on weights trained for a few hundred steps (untimed) so that the
+    hypotheses have realistic lengths (random-init weights copy <eos> after 1-2 tokens)."""
+    from fira_icse_amd.model import DeviceBatch
+    from fira_icse_amd.decode import Searcher
+    for i in range(a.decode_train_steps):
+        trainer.step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    model.eval()
+    search = Searcher(model)
+    dbd = DeviceBatch(store.batch(range(a.decode_batch)), cfg, model.device_)
+    for _ in range(2):
+        out, length, p = search.greedy(dbd)
+    barrier()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out, length, p = search.greedy(dbd)
+    barrier()
+    ddt = (time.perf_counter() - t0) / reps
+    toks = int((length - 1).sum().item())          # emitted tokens up to and including <eos>, cap 29
+    steps_run = int(length.max().item()) - 1
+    # HBM bytes one KV-cached step must move: every decoder / head weight once + the cross-attention K|V of the batch's
+    # memory rows + the copy head's source projection + the logits row per hypothesis (write + read)
+    lay = model.layout
+    w_bytes = 4 * sum(int(np.prod(shp)) for k, (off, shp) in lay.entries.items()
+                      if k.startswith(("decoder.", "out_fc", "copy_net")) and "embedding" not in k)
+    Bd, Sm = a.decode_batch, cfg.mem_len
+    kv_bytes = 4 * Bd * Sm * 256 * (2 * cfg.num_layers + 1)
+    logit_bytes = 2 * 4 * Bd * cfg.out_len
+    step_bytes = w_bytes + kv_bytes + logit_bytes
+    step_s = ddt / max(steps_run, 1)
+    decode = {"tokens_per_s": toks * world / ddt, "commits_per_s": a.decode_batch * world / ddt,
+              "step_tokens_per_s": a.decode_batch * steps_run * world / ddt, "steps_run": steps_run,
+              "mean_tokens_per_commit": toks / a.decode_batch, "batch": a.decode_batch, "beam": 1,
+              "ms_per_batch": ddt * 1e3, "ms_per_step": step_s * 1e3, "tokens_per_batch": toks,
+              "trained_steps": a.decode_train_steps,
+              "roofline": {"bound": "hbm", "bytes_per_step": step_bytes, "achieved": step_bytes / step_s / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                           "note": "encoder pass included in the step time; the loop is launch-bound (one small "
+                                   "kernel per layer op), not bandwidth-bound"},
+              "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
+                      "steps executed, the unit of BASELINE.md's CPU figure.  Weights: %d training steps on the "
+                      "synthetic commits (untimed), fp32 search" % a.decode_train_steps}
+    # the reference's own test configuration: beam 3, batch 20 (run_model.py:401-415)
+    dbb = DeviceBatch(store.batch(range(20)), cfg, model.device_)
+    for _ in range(2):
+        gen, blen, bp = search.beam(dbb, 3)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gen, blen, bp = search.beam(dbb, 3)
+    barrier()
+    bdt = (time.perf_counter() - t0) / reps
+    best = search.best(gen, blen, bp)
+    decode["beam3"] = {"batch": 20, "ms_per_batch": bdt * 1e3, "commits_per_s": 20 * world / bdt,
+                       "tokens_per_s": sum(len(h) - 1 for h in best) * world / bdt,
+                       "steps_run": int(blen.max().item()) - 1}
+    model.train()
+    return decode
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="commits per GPU per step (BASELINE configs[1])")
-    ap.add_argument("--decode-batch", type=int, default=64)
-    ap.add_argument("--no-decode", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
-    a = ap.parse_args()
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
 
-    rank, world, local = init_from_env()
+    from fira_icse_amd import _lib, data, synth
+    from fira_icse_amd.config import FiraConfig
+    from fira_icse_amd.parallel import init_from_env
+
+    if a.dp_same_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = init_from_env("gloo" if a.dp_same_device else None)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (a.gpus, a.gpus))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     torch.cuda.set_device(local)
     from fira_icse_amd.model import TransModel, DeviceBatch
     from fira_icse_amd.train import Trainer
-    from fira_icse_amd.decode import Searcher
 
     cfg = FiraConfig()
-    B = a.batch
-    n_commits = max(a.pool * B, a.decode_batch)
+    B = a.batch or (64 if a.dtype == "bf16" else 32)
+    n_commits = max(a.pool * B, a.decode_batch, 64)
     store = data.process_raw(cfg, synth.generate_dataset(n_commits, seed=1000 + rank))
     torch.manual_seed(0)
     model = TransModel(cfg, device="cuda:%d" % local)
+    model.compute_dtype = a.dtype
+    model.set_dropout_stream(0, rank)
     model.train()                                      # dropout on, as the reference trains
     trainer = Trainer(model, distributed=world > 1)
     batches = [DeviceBatch(store.batch(range(i * B, (i + 1) * B)), cfg, model.device_) for i in range(a.pool)]
@@ -145,84 +346,80 @@ def main():
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         with open(os.path.join(HERE, "profiles", "traffic.json")) as f:
-            traffic = json.load(f)
+            tj = json.load(f)
+            traffic = tj.get(a.dtype) or (tj if a.dtype == "f32" and "gemm" in tj else {})
     except Exception:
         traffic = {}
     gemm, spmm = prof["gemm"], prof["spmm"]
-    spmm_bytes = spmm["work"] + 8.0 * nnz_mean * spmm["count"]              # + (col,val) of the batch's nnz
-    roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-                "achieved": gemm["work"] / (gemm["ms"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": gemm["work"] / (gemm["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+    g_s = gemm["ms"] * 1e-3
+    peak_tf = BF16_MFMA_PEAK_TF if a.dtype == "bf16" else FP32_MFMA_PEAK_TF
+    kern = "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if a.dtype == "bf16" else \
+        "gemm_f32_kernel / gemm_small_kernel (v_mfma_f32_32x32x2_f32)"
+    roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
                 "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
                 "algorithmic_flop_per_launch": gemm["work"] / max(gemm["count"], 1),
                 "launches_per_step": gemm["count"] // prof_steps, "avg_launch_us": 1e3 * gemm["ms"] / max(gemm["count"], 1),
                 "share_of_kernel_time": gemm["ms"] / total_ms}
-    spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes / (spmm["ms"] * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes / (spmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    roofline_hbm = {"bound": "hbm", "kernel": kern, "achieved": gemm["bytes"] / g_s / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gemm["bytes"] / g_s / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": gemm["bytes"] / max(gemm["count"], 1),
+                    "flop_per_byte": gemm["work"] / max(gemm["bytes"], 1.0),
+                    "note": "operands and result counted once in fp32 storage: 4*(M*K + N*K + M*N) per product"}
+    spmm_bytes_step = spmm["work"] + 8.0 * nnz_mean * spmm["count"]         # + (col,val) of the batch's nnz
+    spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic.get("spmm", {}).get("hbm_bytes_per_launch"),
                 "avg_launch_us": 1e3 * spmm["ms"] / max(spmm["count"], 1),
-                "bytes_per_launch": spmm_bytes / max(spmm["count"], 1), "share_of_kernel_time": spmm["ms"] / total_ms}
+                "bytes_per_launch": spmm_bytes_step / max(spmm["count"], 1), "share_of_kernel_time": spmm["ms"] / total_ms}
 
-    # ---- greedy decode (BASELINE configs[3]): tokens/s, batch 64, encoder included
+    extras = {}
+    single = rank == 0 and world == 1
+    if single and not a.no_extras:
+        try:
+            extras.update(spmm_standalone(cfg, store))
+            extras["host_inclusive"] = host_inclusive(cfg, store, trainer, B, max(10, a.steps))
+        except Exception as e:                          # an auxiliary leg must never take the bench line down
+            extras["extras_error"] = repr(e)
+
     decode = None
     if not a.no_decode:
-        model.eval()
-        search = Searcher(model)
-        dbd = DeviceBatch(store.batch(range(a.decode_batch)), cfg, model.device_)
-        for _ in range(2):
-            out, length, p = search.greedy(dbd)
-        barrier()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            out, length, p = search.greedy(dbd)
-        barrier()
-        ddt = (time.perf_counter() - t0) / reps
-        toks = int((length - 1).sum().item())          # emitted tokens up to and including <eos>, cap 29
-        steps_run = int(length.max().item()) - 1
-        decode = {"tokens_per_s": toks * world / ddt, "commits_per_s": a.decode_batch * world / ddt,
-                  "step_tokens_per_s": a.decode_batch * steps_run * world / ddt, "steps_run": steps_run,
-                  "batch": a.decode_batch, "beam": 1, "ms_per_batch": ddt * 1e3, "tokens_per_batch": toks,
-                  "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
-                          "steps executed, the unit of BASELINE.md's CPU figure (109 step-tokens/s). Random-init weights: "
-                          "most hypotheses copy <eos> within a few steps while a few run all 29"}
-        # the reference's own test configuration: beam 3, batch 20 (run_model.py:401-415)
-        dbb = DeviceBatch(store.batch(range(20)), cfg, model.device_)
-        for _ in range(2):
-            gen, blen, bp = search.beam(dbb, 3)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            gen, blen, bp = search.beam(dbb, 3)
-        barrier()
-        bdt = (time.perf_counter() - t0) / reps
-        best = search.best(gen, blen, bp)
-        decode["beam3"] = {"batch": 20, "ms_per_batch": bdt * 1e3, "commits_per_s": 20 * world / bdt,
-                           "tokens_per_s": sum(len(h) - 1 for h in best) * world / bdt,
-                           "steps_run": int(blen.max().item()) - 1}
-        model.train()
+        try:
+            decode = decode_leg(cfg, store, model, trainer, batches, a, world, barrier)
+        except Exception as e:
+            decode = {"error": repr(e)}
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if single and not a.no_cpu_baseline:
         try:
             cpu = cpu_baseline(cfg, store)
-        except Exception as e:                          # the baseline leg must never take the bench line down
+        except Exception as e:
             cpu = {"error": repr(e)}
 
     if rank == 0:
+        pg = None
+        if world > 1:
+            pg = {"rccl_world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend()}
+        wl = ("BASELINE configs[1]: FIRA training step (fwd+bwd+Adam, dropout 0.1/0.2), batch %d commits/GPU, fp32"
+              if a.dtype == "f32" else
+              "BASELINE configs[2] per-GPU workload: FIRA training step (fwd+bwd+Adam, dropout 0.1/0.2), batch %d "
+              "commits/GPU, bf16 MFMA products with fp32 accumulation / storage / LayerNorm / loss / Adam")
         line = {
             "metric": "training commits/sec (FIRA default config)", "value": commits_per_s, "unit": "commits/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
-            "config": {"workload": "BASELINE configs[1]: FIRA training step (fwd+bwd+Adam, dropout 0.1/0.2), "
-                                   "batch %d commits/GPU, fp32, 650-node graphs (mean nnz %.0f/graph), vocab 24650" %
-                                   (B, nnz_mean / B),
+            "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "loss": loss},
             "roofline": roofline, "spmm": spmm_obj, "decode": decode, "cpu_baseline": cpu,
             "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in prof.items()},
         }
-        print(json.dumps(line))
+        if a.dtype == "bf16":
+            line["roofline_hbm"] = roofline_hbm
+        if pg:
+            line["process_group"] = pg
+        line.update(extras)
+        print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -35,7 +35,8 @@ class Batch(C.Structure):
 
 
 class TrainOpts(C.Structure):
-    _fields_ = [("dropout", C.c_float), ("gcn_dropout", C.c_float), ("seed", C.c_uint64), ("compact_head", C.c_int32)]
+    _fields_ = [("dropout", C.c_float), ("gcn_dropout", C.c_float), ("seed", C.c_uint64), ("compact_head", C.c_int32),
+                ("dtype", C.c_int32)]
 
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
@@ -52,6 +53,7 @@ SIGNATURES = {
     "fira_workspace_bytes": (_Z, [_DP, _I, _I]),
     "fira_decode_workspace_bytes": (_Z, [_DP, _I, _I]),
     "fira_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
+    "fira_gemm_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_csr_spmm_f32": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I]),
     "fira_embed_gather_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I]),
     "fira_embed_gather_bwd": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I]),
@@ -70,12 +72,13 @@ SIGNATURES = {
     "fira_inv_count": (_I, [_P, _P, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_prof_enable": (None, [_I]),
-    "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
+    "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
     "fira_param_groups": (_I, [_DP, C.POINTER(_L), C.POINTER(_L)]),
-    "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P]),
+    "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P, _I]),
     "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
     "fira_beam_prepare": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "fira_beam_select": (_I, [_P, _DP, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "fira_greedy_advance": (_I, [_P, _DP, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fira_decode_step": (_I, [_P, _DP, _P, _P, _Z, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fira_decoder_forward": (_I, [_P, _DP, _P, _P, _Z, _I, _P, _P, _P, _P]),
     "fira_decode_memory": (_P, [_DP, _P, _I, _I]),
@@ -111,7 +114,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fira_abi_version() != 2:
+    if lib.fira_abi_version() != 3:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib
 

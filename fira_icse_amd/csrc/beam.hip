@@ -149,9 +149,53 @@ __global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W
     }
 }
 
+// Greedy (beam 1) bookkeeping of one step, run_model.py:305-340 with one hypothesis per commit: resolve the chosen
+// output index to a vocabulary id (copy slots read the commit's code / sub-token ids), append it, multiply the running
+// probability, and stop the hypothesis at <eos>.  n_alive[step] (zeroed by the caller before the first step) receives
+// the number of hypotheses still running after this step, so the host can stop early with ONE read-back per chunk.
+__global__ __launch_bounds__(256) void greedy_advance_kernel(int B, int T, int V, int L, int S, int step,
+                                                             const int32_t* __restrict__ best_id,
+                                                             const float* __restrict__ best_p,
+                                                             const int32_t* __restrict__ sou,
+                                                             const int32_t* __restrict__ sub, int32_t* __restrict__ out,
+                                                             int32_t* __restrict__ length, float* __restrict__ prob,
+                                                             int32_t* __restrict__ alive, int32_t* __restrict__ tok,
+                                                             int32_t* __restrict__ n_alive) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    int still = 0;
+    if (b < B) {
+        if (alive[b]) {
+            const int w = best_id[b];
+            int nt = w;
+            if (w >= V + L) nt = sub[(size_t)b * S + min(w - V - L, S - 1)];
+            else if (w >= V) nt = sou[(size_t)b * L + (w - V)];
+            out[(size_t)b * T + step + 1] = nt;
+            prob[b] *= best_p[b];
+            length[b] += 1;
+            still = nt != 1;                       // <eos> = 1 (config.EOS; the CLI checks the vocabulary agrees)
+            alive[b] = still;
+            tok[b] = still ? nt : 0;
+        } else {
+            tok[b] = 0;
+        }
+    }
+    const unsigned long long m = __ballot(still);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_alive[step], __popcll(m));
+}
+
 }  // namespace fira
 
 extern "C" {
+int fira_greedy_advance(void* stream, const fira_dims* d, int B, int step, const int32_t* best_id, const float* best_p,
+                        const int32_t* sou, const int32_t* sub_token, int32_t* out, int32_t* length, float* prob,
+                        int32_t* alive, int32_t* tokens, int32_t* n_alive) {
+    FIRA_REQUIRE(d && B > 0 && step >= 0 && step + 1 < d->tar_len, "fira_greedy_advance: bad step %d", step);
+    hipLaunchKernelGGL(fira::greedy_advance_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B,
+                       d->tar_len, d->vocab, d->sou_len, d->sub_len, step, best_id, best_p, sou, sub_token, out, length,
+                       prob, alive, tokens, n_alive);
+    FIRA_CHECK_LAUNCH("greedy_advance");
+    return 0;
+}
 int fira_beam_prepare(void* stream, int B, int n_beam, int T, int step, const int32_t* gen, const int32_t* length,
                       int32_t* tokens, int32_t* finished, int32_t* active, int32_t* done) {
     FIRA_REQUIRE(B > 0 && n_beam >= 1 && n_beam <= fira::BEAM_MAX, "fira_beam_prepare: beam %d outside 1..%d", n_beam,

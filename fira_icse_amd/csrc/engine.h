@@ -14,6 +14,11 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
                 float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                 const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
 // c_rows: output row r is written to C row c_rows[r];  relu_mask [M,N] (ld = ldc): output zeroed where mask <= 0
+// the same product with both operands rounded to bf16 on their way into LDS (bf16 MFMA, fp32 accumulate, fp32 storage);
+// shapes the bf16 kernel does not take (tiny / unaligned) are forwarded to gemm_f32_ex
+int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
+                 const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
 // grouped weight gradients (one launch for many small dW += dY^T X problems; see gemm_f32.hip)
 int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                          int ldc, float* colsum);

@@ -140,15 +140,32 @@ static int zero(hipStream_t s, void* p, size_t bytes) {
     return 0;
 }
 
+// Compute dtype of the model-level entry points (fira_train_opts.dtype / the dtype argument of fira_forward_dev):
+// 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 MFMA with fp32 accumulation and fp32 storage (BASELINE
+// configs[2]).  Only the nn.Linear products switch; LayerNorm, soft-max, the gate, the loss and Adam stay fp32, and
+// so do the products on parameters alone (the folded GCN weights) and the tiny ones gemm_bf16_ex forwards.
+static thread_local int g_dtype = 0;
+struct DtypeScope {
+    int prev;
+    explicit DtypeScope(int d) : prev(g_dtype) { g_dtype = d; }
+    ~DtypeScope() { g_dtype = prev; }
+};
+static inline int gemm_any(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B,
+                           int ldb, float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
+                           const int32_t* c_rows = nullptr, const float* relu_mask = nullptr) {
+    if (g_dtype == 1) return gemm_bf16_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+    return gemm_f32_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+}
+
 // Y = X W^T + b
 static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int ldx, const float* W, const float* b,
                          float* Y, int ldy, int flags = 0) {
-    return gemm_f32_ex(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 0, nullptr);
+    return gemm_any(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 0, nullptr);
 }
 // dX (+)= dY W          (W stored [N,K]; reduce over N)
 static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* W, float* dX,
                                int lddx, bool accum) {
-    return gemm_f32_ex(s, 0, 0, M, K, N, dY, lddy, W, K, dX, lddx, nullptr, accum ? FIRA_GEMM_ACCUM : 0, 0, nullptr);
+    return gemm_any(s, 0, 0, M, K, N, dY, lddy, W, K, dX, lddx, nullptr, accum ? FIRA_GEMM_ACCUM : 0, 0, nullptr);
 }
 // Weight gradients are off the critical path of the backward pass (nothing downstream reads them), so they are
 // issued on a second HIP stream: each one waits for the event that marks its operands ready on the main stream and
@@ -233,7 +250,7 @@ static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* 
         TRY(side_fork(s));
         ws = sd.stream;
     }
-    return gemm_f32_ex(ws, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
+    return gemm_any(ws, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
 }
 
 // The same for the small reductions over the B*30 target rows (decoder layers, gate / target projections of the head):
@@ -242,7 +259,7 @@ static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* 
 static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X,
                                        int ldx, float* dW, float* db) {
     SideStream& sd = side();
-    if (!(sd.stream && sd.enabled)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    if (!(sd.stream && sd.enabled) || g_dtype == 1) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
     return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
 }
 static inline int flush_grouped_wgrads(hipStream_t s) {
@@ -341,7 +358,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             TRY(rows_move_ld(ss, 1, Mc, 2 * D, p.kv_all + o, KV, p.kv_c + o, KV, nullptr, bt.mem_dst));
             TRY(side_mark(&c.ev_kv[l]));
         }
-        TRY(gemm_f32_ex(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
+        TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
         TRY(rows_move(ss, 1, Mc, D, p.src, p.src_c, nullptr, bt.mem_dst));
         TRY(side_mark(&c.ev_src));
         c.deferred = true;
@@ -349,7 +366,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     }
     TRY(linear(s, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, c.P + L.bkv_all, p.kv_c, KV));
     TRY(rows_move(s, 1, Mc, KV, p.kv_all, p.kv_c, nullptr, bt.mem_dst));
-    TRY(gemm_f32_ex(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
+    TRY(gemm_any(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
     TRY(rows_move(s, 1, Mc, D, p.src, p.src_c, nullptr, bt.mem_dst));
     return 0;
 }
@@ -393,7 +410,7 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     const float* dec = p.dec[p.nl - 1].x_f;
     TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));             // compact_row (its inverse) comes from prep()
     TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
-    TRY(gemm_f32_ex(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
+    TRY(gemm_any(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
     if (c.deferred) TRY(main_wait(s, c.ev_src));                   // LinearSource(memory) (side stream)
     // teacher-forced ids (dev) need every row's copy distribution; the training loss only the copy-labelled rows
     TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid,
@@ -428,7 +445,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         if (so) TRY(aux_fork(s));
         TRY(zero(ss, p.ddec_c, (size_t)R * D * sizeof(float)));
         // ddec_rows = dlogits W_out, split over the vocabulary axis
-        TRY(gemm_f32_ex(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
+        TRY(gemm_any(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
                         nullptr));
         if (so) TRY(side_mark(&ev_dfc));
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
@@ -464,7 +481,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                               c.p_drop, c.seed, site(l, SITE_FFN)));
         TRY(linear_wgrad_grouped(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
         // d hidden = (dYf W2) masked by the saved activation > 0: ReLU backward in the GEMM epilogue
-        TRY(gemm_f32_ex(s, 0, 0, p.TB, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
+        TRY(gemm_any(s, 0, 0, p.TB, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
         TRY(linear_wgrad_grouped(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
         TRY(linear_dgrad(s, p.TB, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
         // cross attention
@@ -555,7 +572,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, g.dqk,
                             p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE)));
         TRY(linear_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
-        TRY(gemm_f32_ex(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
+        TRY(gemm_any(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
                         bt.code_rows));                                                        // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
@@ -654,6 +671,8 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     Ctx c{(hipStream_t)stream, L, batch, params, grads, &p, opts ? opts->dropout : 0.f, opts ? opts->gcn_dropout : 0.f,
           opts ? opts->seed : 0};
     FIRA_REQUIRE(c.p_drop >= 0.f && c.p_drop < 1.f && c.p_gcn >= 0.f && c.p_gcn < 1.f, "dropout must be in [0,1)");
+    FIRA_REQUIRE(!opts || opts->dtype == 0 || opts->dtype == 1, "fira_train_opts.dtype must be 0 (fp32) or 1 (bf16)");
+    DtypeScope dtype_scope(opts ? opts->dtype : 0);
     TRY(side().init());
     int R = p.TB;
     const int32_t* rows = p.iota;
@@ -672,9 +691,11 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
 }
 
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,
-                     size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok) {
+                     size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok, int dtype) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
+    FIRA_REQUIRE(dtype == 0 || dtype == 1, "fira_forward_dev: dtype must be 0 (fp32) or 1 (bf16)");
+    DtypeScope dtype_scope(dtype);
     TRY(check_batch(batch));
     FIRA_REQUIRE(batch->tar && batch->tar_label && params && workspace && ids_out, "null pointer argument");
     Plan p;

@@ -359,7 +359,7 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     FIRA_REQUIRE(!(relu_mask && (splitk > 1 || c_rows)), "gemm_f32: the fused ReLU mask needs a plain (unsplit, unmapped) output");
     FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_f32: bad K=%d splitk=%d", K, splitk);
     FIRA_REQUIRE(!(colsum && !tA), "gemm_f32: fused column sums need the transA layout");
-    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K);
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic
     if (tile < 0 && splitk <= 1 && !colsum) {                   // skinny forward / dgrad shapes: latency kernel
@@ -389,9 +389,13 @@ void gemm_group_reset() { group().t.n = 0; }
 int gemm_group_flush(hipStream_t s) {
     GroupTable& t = group().t;
     if (t.n == 0) return 0;
-    double flop = 0;
-    for (int i = 0; i < t.n; ++i) flop += 2.0 * t.p[i].M * (double)t.p[i].N * t.p[i].K;
-    ProfScope prof(s, PROF_GEMM, flop);
+    double flop = 0, bytes = 0;
+    for (int i = 0; i < t.n; ++i) {
+        const double M = t.p[i].M, N = t.p[i].N, K = t.p[i].K;
+        flop += 2.0 * M * N * K;
+        bytes += 4.0 * (M * K + N * K + M * N);
+    }
+    ProfScope prof(s, PROF_GEMM, flop, bytes);
     hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(t.wg_start[t.n]), dim3(256), 0, s, t);
     t.n = 0;
     FIRA_CHECK_LAUNCH("gemm_grouped_wgrad");

@@ -25,7 +25,7 @@ int set_err(const char* fmt, ...) {
 
 // ---------------------------------------------------------------- event profiler
 namespace {
-struct ProfRec { int cls; double work; hipEvent_t a, b; };
+struct ProfRec { int cls; double work, bytes; hipEvent_t a, b; };
 struct ProfState {
     std::mutex mu;
     bool on = false;
@@ -41,10 +41,10 @@ struct ProfState {
 ProfState& PS() { static ProfState s; return s; }
 }  // namespace
 bool prof_on() { return PS().on; }
-void prof_begin(hipStream_t s, int cls, double work) {
+void prof_begin(hipStream_t s, int cls, double work, double bytes) {
     ProfState& p = PS();
     std::lock_guard<std::mutex> g(p.mu);
-    ProfRec r{cls, work, p.get(), p.get()};
+    ProfRec r{cls, work, bytes, p.get(), p.get()};
     hipEventRecord(r.a, s);
     p.recs.push_back(r);
 }
@@ -292,15 +292,18 @@ void fira_prof_enable(int on) {
     std::lock_guard<std::mutex> g(p.mu);
     p.on = on != 0;
 }
-int fira_prof_report(int n_class, double* ms, double* work, int64_t* count) {
+int fira_prof_report(int n_class, double* ms, double* work, double* bytes, int64_t* count) {
     fira::ProfState& p = fira::PS();
     std::lock_guard<std::mutex> g(p.mu);
-    for (int i = 0; i < n_class; ++i) { ms[i] = 0; work[i] = 0; count[i] = 0; }
+    for (int i = 0; i < n_class; ++i) { ms[i] = 0; work[i] = 0; count[i] = 0; if (bytes) bytes[i] = 0; }
     for (auto& r : p.recs) {
         hipEventSynchronize(r.b);
         float t = 0.f;
         hipEventElapsedTime(&t, r.a, r.b);
-        if (r.cls < n_class) { ms[r.cls] += t; work[r.cls] += r.work; count[r.cls] += 1; }
+        if (r.cls < n_class) {
+            ms[r.cls] += t; work[r.cls] += r.work; count[r.cls] += 1;
+            if (bytes) bytes[r.cls] += r.bytes;
+        }
         p.pool.push_back(r.a);
         p.pool.push_back(r.b);
     }

@@ -210,20 +210,21 @@ class GraphStore:
                 self.dense_edge(i), self.tar_label[i], self.sub_token[i]]
 
     def batch(self, idx: Sequence[int]) -> "HostBatch":
+        """Collate commits ``idx`` into one block-diagonal CSR batch (replaces the reference's dense
+        ``.toarray()`` + default collate, Dataset.py:336-343).  Vectorised: no per-commit Python loop."""
         idx = np.asarray(idx, dtype=np.int64)
         B, N = len(idx), self.cfg.graph_len
         nnz = self.nnz[idx]
         base = np.zeros(B + 1, dtype=np.int64)
         np.cumsum(nnz, out=base[1:])
+        total = int(base[-1])
         rowptr = np.empty(B * N + 1, dtype=np.int32)
-        col = np.empty(int(base[-1]), dtype=np.int32)
-        val = np.empty(int(base[-1]), dtype=np.float32)
-        for b, i in enumerate(idx):
-            lo, hi = self.offset[i], self.offset[i + 1]
-            rowptr[b * N:(b + 1) * N] = self.rowptr[i, :-1] + base[b]
-            col[base[b]:base[b + 1]] = self.col[lo:hi] + b * N        # block-diagonal: global node ids
-            val[base[b]:base[b + 1]] = self.val[lo:hi]
-        rowptr[B * N] = base[-1]
+        rowptr[:B * N] = (self.rowptr[idx, :-1].astype(np.int64) + base[:-1, None]).reshape(-1)
+        rowptr[B * N] = total
+        # entry k of the batch comes from store entry src[k]; its column moves into graph b's node block
+        src = np.repeat(self.offset[idx] - base[:-1], nnz) + np.arange(total, dtype=np.int64)
+        col = (self.col[src].astype(np.int64) + np.repeat(np.arange(B, dtype=np.int64) * N, nnz)).astype(np.int32)
+        val = self.val[src]
         return HostBatch(self.sou[idx], self.tar[idx], self.mark[idx], self.ast_change[idx],
                          self.tar_label[idx], self.sub_token[idx], rowptr, col, val, self.attr[idx])
 

@@ -47,7 +47,7 @@ def reference_init_state_dict(cfg: FiraConfig) -> "OrderedDict[str, torch.Tensor
 
     The reference relies on PyTorch's default initialisers; building the same leaf modules in the same order
     (gnn_transformer.py:21-43, 88-106, 124-136, 163-169, 176-190; Model.py:7-14, 24-36) consumes the global RNG
-    identically.  (Checked against the reference in tests/test_model_host.py.)
+    identically.  (Checked against the live reference in tests/test_oracle.py.)
     """
     D, V = cfg.embedding_dim, cfg.vocab_size
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -202,9 +202,35 @@ def compact_embedding_lists(hb: HostBatch, cfg: FiraConfig, node_rows: np.ndarra
     return item_tok, item_ptr, emb_rows.astype(np.int32), ast_rows[keep].astype(np.int32), ast_ids[keep].astype(np.int32)
 
 
+class _PinnedRing:
+    """Page-locked staging buffers for the host->device copy of a batch: a small ring per thread, each slot reused only
+    after the copy that last read it has completed (its event), so the copies are truly asynchronous (a pageable source
+    makes ``non_blocking=True`` a synchronous staged copy) and consecutive batches double-buffer."""
+
+    def __init__(self, slots: int = 3):
+        self.slots = [None] * slots            # (pinned uint8 tensor, event of its last copy)
+        self.next = 0
+
+    def get(self, nbytes: int):
+        i = self.next
+        self.next = (self.next + 1) % len(self.slots)
+        buf, ev = self.slots[i] if self.slots[i] is not None else (None, None)
+        if ev is not None:
+            ev.synchronize()
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        ev = torch.cuda.Event()
+        self.slots[i] = (buf, ev)
+        return buf, ev
+
+
+_pinned = __import__("threading").local()
+
+
 class DeviceBatch:
     """One collated batch resident in HBM: int32 id arrays, the computed-node lists and their CSR adjacency
-    (+ the list of target rows that need the vocabulary head)."""
+    (+ the list of target rows that need the vocabulary head).  All arrays are packed into ONE pinned host arena and
+    moved with ONE asynchronous copy into ONE device arena (256-byte aligned slices); the fields are views of it."""
 
     def __init__(self, hb: HostBatch, cfg: FiraConfig, device="cuda", skip_padding: bool = True):
         self.cfg = cfg
@@ -213,39 +239,55 @@ class DeviceBatch:
         if hb.tar_label is not None and hb.tar_label.size and int(hb.tar_label.max()) >= cfg.out_len:
             # the reference's nll_loss would raise "Target out of bounds" here (SURVEY.md §8a note N3)
             raise ValueError("copy label %d outside the %d-way output" % (int(hb.tar_label.max()), cfg.out_len))
-
-        def dev(a, dt):
-            a = np.ascontiguousarray(a, dtype=dt)
-            if a.size == 0:
-                a = np.zeros(1, dtype=dt)
-            return torch.from_numpy(a).to(device, non_blocking=True)
-
-        self.sou = dev(hb.sou, np.int32)
-        self.tar = dev(hb.tar, np.int32) if hb.tar is not None else None
-        self.mark = dev(hb.mark, np.int32)
-        self.ast_change = dev(hb.ast_change, np.int32)
-        self.tar_label = dev(hb.tar_label, np.int32) if hb.tar_label is not None else None
-        self.sub_token = dev(hb.sub_token, np.int32)
         node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst = computed_nodes(hb, cfg, skip_padding)
         self.n_nodes, self.n_code, self.n_mem = int(node_rows.shape[0]), int(code_rows.shape[0]), int(mem_rows.shape[0])
         self.nnz = int(col.shape[0])
-        self.node_rows, self.rowptr, self.col, self.val = dev(node_rows, np.int32), dev(rowptr, np.int32), \
-            dev(col, np.int32), dev(val, np.float32)
-        self.code_rows, self.code_mark = dev(code_rows, np.int32), dev(code_mark, np.int32)
-        self.mem_rows, self.mem_dst = dev(mem_rows, np.int32), dev(mem_dst, np.int32)
-        self.head_rows = None
+        head_rows = None
         self.n_head_rows = 0
         if hb.tar_label is not None:
             shifted = np.concatenate([hb.tar_label[:, 1:], np.zeros((self.B, 1), hb.tar_label.dtype)], axis=1)
-            rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0].astype(np.int32)
-            self.n_head_rows = int(rows.shape[0])
-            self.head_rows = dev(rows, np.int32)
+            head_rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0]
+            self.n_head_rows = int(head_rows.shape[0])
         item_tok, item_ptr, emb_rows, ast_rows, ast_ids = compact_embedding_lists(hb, cfg, node_rows)
-        self.n_ast_items = int(ast_rows.shape[0])
-        self.ast_rows, self.ast_ids = dev(ast_rows, np.int32), dev(ast_ids, np.int32)
-        self.n_emb_items = int(item_tok.shape[0])
-        self.emb_item_tok, self.emb_item_ptr, self.emb_rows = dev(item_tok, np.int32), dev(item_ptr, np.int32), \
-            dev(emb_rows, np.int32)
+        self.n_ast_items, self.n_emb_items = int(ast_rows.shape[0]), int(item_tok.shape[0])
+        fields = [("sou", hb.sou, np.int32), ("tar", hb.tar, np.int32), ("mark", hb.mark, np.int32),
+                  ("ast_change", hb.ast_change, np.int32), ("tar_label", hb.tar_label, np.int32),
+                  ("sub_token", hb.sub_token, np.int32), ("node_rows", node_rows, np.int32),
+                  ("rowptr", rowptr, np.int32), ("col", col, np.int32), ("val", val, np.float32),
+                  ("code_rows", code_rows, np.int32), ("code_mark", code_mark, np.int32),
+                  ("mem_rows", mem_rows, np.int32), ("mem_dst", mem_dst, np.int32), ("head_rows", head_rows, np.int32),
+                  ("ast_rows", ast_rows, np.int32), ("ast_ids", ast_ids, np.int32),
+                  ("emb_item_tok", item_tok, np.int32), ("emb_item_ptr", item_ptr, np.int32),
+                  ("emb_rows", emb_rows, np.int32)]
+        plan, off = [], 0
+        for name, a, dt in fields:
+            if a is None:
+                plan.append((name, None, 0, 0, dt))
+                continue
+            a = np.ascontiguousarray(a, dtype=dt)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dt)            # never hand the library a null pointer for an empty list
+            plan.append((name, a, off, a.nbytes, dt))
+            off += (a.nbytes + 255) // 256 * 256
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            ring = getattr(_pinned, "ring", None)
+            if ring is None:
+                ring = _pinned.ring = _PinnedRing()
+            stage, ev = ring.get(off)
+        else:                                        # CPU tensors: host-side tests of the packing
+            stage, ev = torch.empty(max(off, 1), dtype=torch.uint8), None
+        host = stage.numpy()
+        for name, a, o, nb, dt in plan:
+            if a is not None:
+                host[o:o + nb] = a.reshape(-1).view(np.uint8)
+        self.arena = torch.empty(max(off, 1), dtype=torch.uint8, device=dev)
+        self.arena.copy_(stage[:max(off, 1)], non_blocking=True)
+        if ev is not None:
+            ev.record()
+        tdt = {np.int32: torch.int32, np.float32: torch.float32}
+        for name, a, o, nb, dt in plan:
+            setattr(self, name, None if a is None else self.arena[o:o + nb].view(tdt[dt]).view(a.shape))
         p = lambda t: t.data_ptr() if t is not None else None
         self.struct = _lib.Batch(
             self.B, self.nnz, p(self.sou), p(self.tar), p(self.mark), p(self.ast_change), p(self.tar_label),
@@ -297,8 +339,13 @@ class TransModel(nn.Module):
         self._ws: Dict[tuple, torch.Tensor] = {}
         self.loss_sum = torch.zeros(1, dtype=torch.float32, device=self.device_)
         self.n_tok = torch.zeros(1, dtype=torch.int32, device=self.device_)
-        self.dropout_seed = 0
+        # dropout stream: masks of step k on rank r under CLI seed s are a function of (s, r, k) -- the reference's
+        # DataParallel replicas draw independent masks too, and a resumed run continues the sequence (Trainer.state_dict)
+        self.dropout_base = 0
+        self.dropout_rank = 0
+        self.dropout_step = 0
         self.compact_head = True
+        self.compute_dtype = "f32"             # "f32" (the reference's arithmetic) | "bf16" (BASELINE configs[2])
         if init:
             self.load_state_dict(reference_init_state_dict(self.cfg))
 
@@ -345,8 +392,8 @@ class TransModel(nn.Module):
             self.gbuf[:self.layout.live].zero_()           # tensors past `live` never receive a gradient
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
         pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
-        self.dropout_seed += 1
-        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0)
+        self.dropout_step += 1
+        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0, self._dtype_code())
         ws = self.workspace(db.B, 1)
         _lib.check(lib.fira_train_fwd_bwd(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                           _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
@@ -354,6 +401,24 @@ class TransModel(nn.Module):
                                           self._event_handle(mid_event)),
                    "fira_train_fwd_bwd")
         return self.loss_sum, self.n_tok
+
+    def _dtype_code(self) -> int:
+        try:
+            return {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[self.compute_dtype]
+        except KeyError:
+            raise ValueError("compute_dtype must be 'f32' or 'bf16', not %r" % (self.compute_dtype,))
+
+    @property
+    def dropout_seed(self) -> int:
+        """64-bit seed of the current step's masks: splitmix64 over (base seed, rank, step)."""
+        x = (self.dropout_base * 0x9E3779B97F4A7C15 + self.dropout_rank * 0xBF58476D1CE4E5B9 + self.dropout_step) \
+            & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return x ^ (x >> 31)
+
+    def set_dropout_stream(self, seed: int, rank: int = 0):
+        self.dropout_base, self.dropout_rank = int(seed), int(rank)
 
     @staticmethod
     def _event_handle(ev):
@@ -373,7 +438,8 @@ class TransModel(nn.Module):
             ws = self.workspace(db.B, 0)
         _lib.check(lib.fira_forward_dev(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                         _lib.ptr(self.flat.data), _lib.ptr(ws), ws.numel(), _lib.ptr(ids),
-                                        _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok)), "fira_forward_dev")
+                                        _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok), self._dtype_code()),
+                   "fira_forward_dev")
         return ids
 
     # ------------------------------------------------------------------ piecewise surface of the reference's test loop
@@ -386,7 +452,9 @@ class TransModel(nn.Module):
             input_token, None, mark, ast_change, edge, None, sub_token)
         lib = _lib.lib()
         n = lib.fira_decode_workspace_bytes(C.byref(self.dims), db.B, 1)
-        ws = self._ws.setdefault(("enc", db.B), torch.empty(n, dtype=torch.uint8, device=self.device_))
+        if ("enc", db.B) not in self._ws:
+            self._ws[("enc", db.B)] = torch.empty(n, dtype=torch.uint8, device=self.device_)
+        ws = self._ws[("enc", db.B)]
         _lib.check(lib.fira_decode_begin(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                          _lib.ptr(self.flat.data), _lib.ptr(ws), ws.numel(), 1), "fira_decode_begin")
         # rows of padded slots are not computed (the reference computes values nobody reads there): zero them

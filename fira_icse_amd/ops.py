@@ -23,8 +23,9 @@ def _i32(t):
 
 
 def gemm(A, B, *, transA=False, transB=True, bias=None, relu=False, out=None, accumulate=False, splitk=1,
-         tile=0):
-    """C = op(A) op(B) (+bias)(relu).  transB=True: B is an nn.Linear weight [N,K]."""
+         tile=0, dtype="f32"):
+    """C = op(A) op(B) (+bias)(relu).  transB=True: B is an nn.Linear weight [N,K].  dtype "bf16": operands rounded to
+    bf16 on the way to the matrix cores, fp32 accumulation and storage (fira_gemm_bf16)."""
     for t in (A, B):
         assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
     M, K = (A.shape[1], A.shape[0]) if transA else A.shape
@@ -34,8 +35,9 @@ def gemm(A, B, *, transA=False, transB=True, bias=None, relu=False, out=None, ac
         out = torch.zeros((M, N), dtype=torch.float32, device=A.device) if accumulate else \
             torch.empty((M, N), dtype=torch.float32, device=A.device)
     flags = (1 if relu else 0) | (2 if accumulate else 0) | (tile << 4)     # tile: 0 auto, 1 128x128, 2 64x128, 3 64x64
-    check(_lib.lib().fira_gemm_f32(cur_stream(), int(transA), int(transB), M, N, K, ptr(A), A.stride(0), ptr(B),
-                                   B.stride(0), ptr(out), out.stride(0), ptr(bias), flags, splitk), "fira_gemm_f32")
+    fn = _lib.lib().fira_gemm_bf16 if dtype == "bf16" else _lib.lib().fira_gemm_f32
+    check(fn(cur_stream(), int(transA), int(transB), M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out),
+             out.stride(0), ptr(bias), flags, splitk), "fira_gemm_%s" % dtype)
     return out
 
 

@@ -1,9 +1,10 @@
 """Background preparation of device batches (device-resident, prefetched data path).
 
-Collating a batch (CSR concatenation, computed-node lists, pinned host->device copies of ~0.5 MB) costs the host
-1-2 ms at batch 32; the training step itself is enqueued asynchronously, so one worker thread preparing batch k+1
-(and k+2) while the GPU runs batch k keeps the host off the critical path.  The reference does this work -- plus a
-108 MB dense float64 adjacency per 32 commits -- synchronously inside the step loop (run_model.py:87-103).
+Collating a batch (CSR concatenation, computed-node lists, one pinned host->device copy of ~0.5 MB, see
+``model.DeviceBatch``) costs the host about a millisecond at batch 32; the training step itself is enqueued
+asynchronously, so one worker thread preparing batch k+1 (and k+2) while the GPU runs batch k keeps the host off the
+critical path.  The reference does this work -- plus a 108 MB dense float64 adjacency per 32 commits -- synchronously
+inside the step loop (run_model.py:87-103).
 """
 from __future__ import annotations
 
@@ -15,28 +16,69 @@ T = TypeVar("T")
 U = TypeVar("U")
 
 
-def prefetch(items: Iterable[T], prepare: Callable[[T], U], depth: int = 2) -> Iterator[U]:
-    """Yield ``prepare(item)`` for every item, computed up to ``depth`` items ahead on a worker thread.
-    Exceptions raised by ``prepare`` (or by the iterable) surface at the consumer, in order."""
-    q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
-    done = object()
+class prefetch(Iterator[U]):
+    """Iterator over ``prepare(item)`` for every item, computed up to ``depth`` items ahead on a worker thread.
+    Exceptions raised by ``prepare`` (or by the iterable) surface at the consumer, in order.  ``close()`` (also called
+    when the iterator is exhausted or garbage-collected) stops the worker and drops what it had prepared, so an early
+    ``break`` out of the consuming loop does not leave a thread blocked on a full queue holding device batches."""
 
-    def work():
-        try:
-            for it in items:
-                q.put((prepare(it), None))
-        except BaseException as e:        # noqa: BLE001 - forwarded to the consumer
-            q.put((None, e))
-            return
-        q.put((done, None))
+    _DONE = object()
 
-    th = threading.Thread(target=work, daemon=True)
-    th.start()
-    while True:
-        val, err = q.get()
+    def __init__(self, items: Iterable[T], prepare: Callable[[T], U], depth: int = 2):
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, depth))
+        self._stop = threading.Event()
+        self._finished = False
+
+        def put(x) -> bool:                       # False once the consumer has gone away
+            while not self._stop.is_set():
+                try:
+                    self._q.put(x, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def work():
+            try:
+                for it in items:
+                    if self._stop.is_set() or not put((prepare(it), None)):
+                        return
+            except BaseException as e:            # noqa: BLE001 - forwarded to the consumer
+                put((None, e))
+                return
+            put((self._DONE, None))
+
+        self._th = threading.Thread(target=work, daemon=True)
+        self._th.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> U:
+        if self._finished:
+            raise StopIteration
+        val, err = self._q.get()
         if err is not None:
+            self.close()
             raise err
-        if val is done:
-            break
-        yield val
-    th.join()
+        if val is self._DONE:
+            self.close()
+            raise StopIteration
+        return val
+
+    def close(self):
+        self._finished = True
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()              # release the prepared batches
+        except queue.Empty:
+            pass
+        if self._th.is_alive() and threading.current_thread() is not self._th:
+            self._th.join(timeout=5.0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

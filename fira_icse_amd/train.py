@@ -33,10 +33,24 @@ class Trainer:
             self.mid_event = torch.cuda.Event()
             self.mid_event.record()            # torch creates the hipEvent lazily: force it so its handle can be passed
 
-    def step(self, db: DeviceBatch):
-        """One optimisation step on this rank's shard of the global batch."""
+    def step(self, db: Optional[DeviceBatch]):
+        """One optimisation step on this rank's shard of the global batch.
+
+        ``db is None`` = this rank's shard of the global batch is empty (``shard_range`` chunks like
+        ``DataParallel.scatter``: the tail batch of an epoch can leave trailing ranks without commits).  Such a rank
+        still joins every collective of the step with a zero gradient and zero (loss_sum, n_tok) and applies the same
+        Adam update as the others, so the replicas stay identical and nobody waits for a peer that never arrives."""
         m = self.model
-        loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
+        if db is None:
+            if self.reducer is None or self.reducer.world == 1:
+                return                                           # nothing to learn from, nobody to keep in step
+            m.gbuf[:m.layout.live].zero_()
+            m.loss_sum.zero_()
+            m.n_tok.zero_()
+            self.mid_event.record()
+            loss_sum, n_tok = m.loss_sum, m.n_tok
+        else:
+            loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
         b1, b2 = self.betas
         if self.reducer is not None and self.reducer.world > 1:
             red, split, live = self.reducer, m.layout.split, m.layout.live
@@ -71,7 +85,10 @@ class Trainer:
         return s[0] / max(s[1], 1.0)
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "t": self.t}
+        """Everything a restart needs besides the weights: Adam moments, Adam step and the dropout step counter (so
+        that a resumed run continues the mask sequence instead of replaying it from step 1)."""
+        return {"m": self.m, "v": self.v, "t": self.t, "dropout_step": self.model.dropout_step}
 
     def load_state_dict(self, sd):
         self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
+        self.model.dropout_step = int(sd.get("dropout_step", self.t))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 2
+#define FIRA_ABI_VERSION 3
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -86,7 +86,12 @@ typedef struct fira_train_opts {
     float    gcn_dropout;    /* 0.2 (gnn_transformer.py:43)                             */
     uint64_t seed;           /* dropout stream seed; masks are re-derived in backward   */
     int32_t  compact_head;   /* 1 = run the vocabulary head only on rows whose label != 0 (results identical) */
+    int32_t  dtype;          /* FIRA_F32 (reference arithmetic) or FIRA_BF16: nn.Linear products on the bf16 MFMA with
+                                fp32 accumulation (operands rounded to bf16, everything stored in fp32) -- BASELINE
+                                configs[2]; LayerNorm / soft-max / loss / Adam are fp32 in both modes           */
 } fira_train_opts;
+#define FIRA_F32 0
+#define FIRA_BF16 1
 
 const char* fira_last_error(void);
 int         fira_abi_version(void);
@@ -112,7 +117,8 @@ size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam);
  * returns per class the summed event time [ms], summed work and launch count since the last report, and resets. */
 #define FIRA_PROF_NCLASS 7
 void fira_prof_enable(int on);
-int  fira_prof_report(int n_class, double* ms, double* work, int64_t* count);
+/* bytes (may be NULL): for the GEMM class, the algorithmic operand + result bytes 4*(M*K + N*K + M*N) of its launches */
+int  fira_prof_report(int n_class, double* ms, double* work, double* bytes, int64_t* count);
 
 /* =========================== op level (one reference op each) ============================== */
 
@@ -128,6 +134,12 @@ int  fira_prof_report(int n_class, double* ms, double* work, int64_t* count);
 int fira_gemm_f32(void* stream, int transA, int transB, int M, int N, int K,
                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   const float* bias, int flags, int splitk);
+/* The same product on the bf16 MFMA (v_mfma_f32_32x32x16_bf16): A and B are fp32 in memory, rounded to bf16
+ * (nearest-even) while they are staged, accumulated and stored in fp32 -- torch.autocast(bfloat16) around F.linear.
+ * Tile bits: 0 auto, 1 128x128, 2/3 64x64.  Products it does not take (M, N or K < 32, unaligned) run in fp32.   */
+int fira_gemm_bf16(void* stream, int transA, int transB, int M, int N, int K,
+                   const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, int flags, int splitk);
 
 /* Y[r,:] = sum_j val[j] * X[col[j],:]  over CSR row r (d = 256).  The GCN aggregation
  * torch.bmm(edge.float(), x) (gnn_transformer.py:80); its backward is the same call because
@@ -216,7 +228,8 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
 
 /* TransModel.forward(..., 'dev') (Model.py:85-86): teacher-forced argmax ids [B, tar_len].         */
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
-                     void* workspace, size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok);
+                     void* workspace, size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok,
+                     int dtype /* FIRA_F32 | FIRA_BF16 */);
 
 /* Encoder once per batch (run_model.py:202-207) + everything of the decode loop that does not depend
  * on the generated prefix: memory [B,S,256], mem_valid [B,S], cross-attention K/V of all layers,
@@ -246,6 +259,15 @@ int fira_beam_select(void* stream, const fira_dims* d, int B, int n_beam, const 
                      const int32_t* active, const int32_t* done, const int32_t* sou, const int32_t* sub_token,
                      const int32_t* gen_in, const int32_t* len_in, const float* prob_in, int32_t* gen_out,
                      int32_t* len_out, float* prob_out, int32_t* parent);
+
+/* Greedy search bookkeeping (the same loop at beam 1 without the [B, vocab+S] distribution): consumes the arg-max
+ * index / probability fira_decode_step wrote, resolves copy indices through sou / sub_token, appends the id at
+ * out[b, step+1], multiplies prob, bumps length, clears alive[b] at <eos>, writes the next step's input ids to `tokens`
+ * (0 for ended hypotheses) and adds the number of still-running hypotheses to n_alive[step] (caller zeroes n_alive
+ * [tar_len] before the first step).  run_model.py:305-340 with beam_size 1.                                       */
+int fira_greedy_advance(void* stream, const fira_dims* d, int B, int step, const int32_t* best_id, const float* best_p,
+                        const int32_t* sou, const int32_t* sub_token, int32_t* out, int32_t* length, float* prob,
+                        int32_t* alive, int32_t* tokens, int32_t* n_alive);
 
 /* Decoder.forward over all tar_len positions on caller-supplied memory [B, sou+sub, 256] / mem_valid [B, sou+sub]
  * (gnn_transformer.py:108-122; the call of run_model.py:256).  Workspace: fira_workspace_bytes(d, B, 0).          */

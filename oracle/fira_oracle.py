@@ -163,7 +163,8 @@ def forward(P: Params, cfg, sou, tar, mark, ast_change, edge, tar_label, sub_tok
 
 # ----------------------------------------------------------------------------- decode loop
 def beam_decode(P: Params, cfg, sou, mark, ast_change, edge, sub_token, beam: int,
-                start_id: int = 2, eos_id: int = 1, pad_id: int = 0, trace=None) -> Tuple[List[List[List[int]]], List[List[float]]]:
+                start_id: int = 2, eos_id: int = 1, pad_id: int = 0, trace=None,
+                max_steps: int = None) -> Tuple[List[List[List[int]]], List[List[float]]]:
     """The reference's test-time search (run_model.py:202-340), full recompute per step.
 
     Returns (hypotheses [B][beam] -> vocab-id list starting with <start>, probabilities [B][beam]).
@@ -177,7 +178,7 @@ def beam_decode(P: Params, cfg, sou, mark, ast_change, edge, sub_token, beam: in
         W = cfg.out_len
         hyp = [[[start_id] for _ in range(beam)] for _ in range(B)]
         prob = [[1.0 if j == 0 else 0.0 for j in range(beam)] for _ in range(B)]
-        for step in range(T - 1):
+        for step in range(T - 1 if max_steps is None else min(T - 1, max_steps)):   # max_steps: bounded timing runs
             blocks, active = [], []
             for j in range(beam):
                 alive = [hyp[i][j][-1] != eos_id for i in range(B)]

@@ -31,7 +31,7 @@ if HERE not in sys.path:
     sys.path.insert(0, HERE)
 
 from fira_icse_amd import data, metrics, text                      # noqa: E402
-from fira_icse_amd.config import EOS, FiraConfig                  # noqa: E402
+from fira_icse_amd.config import EOS, PAD, START, UNK, FiraConfig                 # noqa: E402
 from fira_icse_amd.parallel import gather_lines, init_from_env, shard_indices   # noqa: E402
 from fira_icse_amd.prefetch import prefetch                        # noqa: E402
 
@@ -75,6 +75,11 @@ class Run:
         with open(os.path.join(self.root, "DataSet", "ast_change_vocab.json")) as f:
             ast_vocab = json.load(f)
         self.r_vocab = {v: k for k, v in self.vocab.items()}
+        # the kernels and the search loop use the special ids as constants (config.PAD/EOS/START/UNK); the reference looks
+        # them up in word_vocab.json (run_model.py:205-222): refuse a vocabulary that numbers them differently
+        for tok, want in (("<pad>", PAD), ("<eos>", EOS), ("<start>", START), ("<unkm>", UNK)):
+            if self.vocab.get(tok) != want:
+                raise ValueError("word_vocab.json maps %r to %r; this engine requires %d" % (tok, self.vocab.get(tok), want))
         with open(os.path.join(self.root, "DataSet", "variable.json")) as f:
             self.var_maps = json.load(f)
         bs = a.batch_size if a.batch_size else 170 * self.world
@@ -140,6 +145,7 @@ class Run:
         self.model = TransModel(cfg, device="cuda:%d" % self.local)       # consumes the torch RNG like the reference
         if a.resume and os.path.exists(os.path.join(self.root, "best_model.pt")):
             self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
+        self.model.set_dropout_stream(a.seed, self.rank)           # masks depend on (--seed, rank, step)
         trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1)
         state_path = os.path.join(self.root, "fira_train_state.pt")
         if a.resume and os.path.exists(state_path):
@@ -170,8 +176,7 @@ class Run:
                             with open(self.out("dev_output"), "w") as f:
                                 f.write(output_str)
                     self.model.train(not a.no_dropout)
-                if db is not None:
-                    trainer.step(db)
+                trainer.step(db)                     # db None (empty shard of a short tail batch): still joins the collectives
                 total_data += len(gidx)
                 steps += 1
                 if idx_b % 10 == 0 and self.rank == 0:
@@ -180,6 +185,7 @@ class Run:
                         total_data / max(time.time() - t0, 1e-9)), flush=True)
                 if a.max_steps and steps >= a.max_steps:
                     break
+            batches.close()                          # stops the worker thread and drops its prepared batches
             if a.max_steps and steps >= a.max_steps:
                 break
         if best_bleu < 0 and self.rank == 0:            # never reached a dev point (short runs): keep the last weights

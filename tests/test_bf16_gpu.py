@@ -1,0 +1,148 @@
+"""bf16 compute path (BASELINE configs[2]; SURVEY.md §8b "Dtypes fp32 and bf16 (fp32 accumulate)").
+
+Gates: the bf16 GEMM equals an fp32/fp64 product of the bf16-ROUNDED operands to fp32 summation-order
+accuracy (2e-6 relative: the only difference to the fp32 kernel is the rounding of the inputs, which the test applies to
+the reference too); whole model: loss within 1e-2 relative of the fp32 engine and of the reference's golden value,
+teacher-forced argmax ids >= 99 % identical, and a 20-step Adam loss curve at batch 32 that tracks the reference's fp32
+curve within 2e-2.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import util
+from fira_icse_amd import data, synth
+from fira_icse_amd.config import FiraConfig
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def randn(*shape, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(DEV)
+
+
+def bf(x):
+    return x.to(torch.bfloat16).double()          # round-to-nearest-even, the MFMA path's input rounding
+
+
+@pytest.mark.parametrize("M,N,K", [(960, 256, 256), (20800, 256, 256), (130, 70, 50), (64, 24650, 256),
+                                   (333, 256, 24650), (1920, 1024, 256), (1920, 256, 1024), (700, 768, 256),
+                                   (65, 129, 200)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt", "nt-t1", "nn-t1", "tn-t1", "nt-t3", "tn-t3"])
+def test_gemm_bf16_layouts(M, N, K, layout):
+    from fira_icse_amd import ops
+    tile = int(layout[-1]) if "-t" in layout else 0          # 1: 128x128, 3: 64x64, 0: automatic
+    tA, tB = {"nt": (False, True), "nn": (False, False), "tn": (True, False), "tt": (True, True)}[layout[:2]]
+    if (K * M if tA else M * K) % 4 or M % 4 and tA or N % 4 and not tB:
+        pass                                               # unaligned leading dimensions fall back to fp32 inside
+    A = randn(*((K, M) if tA else (M, K)), seed=1)
+    B = randn(*((N, K) if tB else (K, N)), seed=2)           # asymmetric operands: a swapped tile cannot pass
+    bias = randn(N, seed=3)
+    aligned = A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0 and min(M, N, K) >= 32
+    rd = bf if aligned else (lambda x: x.double())           # what the library computes for shapes it forwards to fp32
+    ref = (rd(A.t() if tA else A) @ rd(B.t() if tB else B)) + bias.double()
+    tol = 2e-6 if K <= 4096 else 6e-6
+    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, tile=tile, dtype="bf16")
+    assert rel_err(out, ref) < tol
+    out = ops.gemm(A, B, transA=tA, transB=tB, bias=bias, relu=True, tile=tile, dtype="bf16")
+    assert rel_err(out, ref.clamp_min(0)) < tol
+    C0 = randn(M, N, seed=9)
+    for sk in (1, 0, 3):                                       # plain accumulate, automatic split, forced split-K
+        out = ops.gemm(A, B, transA=tA, transB=tB, out=C0.clone(), accumulate=True, tile=tile, splitk=sk, dtype="bf16")
+        assert rel_err(out, ref - bias.double() + C0.double()) < tol, sk
+
+
+def test_gemm_bf16_rounding_is_nearest_even_and_differs_from_fp32():
+    from fira_icse_amd import ops
+    A, B = randn(256, 256, seed=4), randn(256, 256, seed=5)
+    out = ops.gemm(A, B, dtype="bf16")
+    exact = A.double() @ B.double().t()
+    assert rel_err(out, bf(A) @ bf(B).t()) < 2e-6
+    assert 1e-3 < rel_err(out, exact) < 1e-2              # bf16 inputs: ~2^-9 relative per element
+
+
+def test_gemm_bf16_strided_output_row_map_and_padded_ld():
+    from fira_icse_amd import ops
+    dl = torch.zeros(100, 24704, device=DEV)
+    dl[:, :24650] = randn(100, 24650, seed=9)
+    dl[:, 24650:] = float("nan")                           # the K tail must be masked, not multiplied by zero
+    Wo = randn(24650, 256, seed=10)
+    out = ops.gemm(dl[:, :24650], Wo, transB=False, dtype="bf16")
+    assert rel_err(out, bf(dl[:, :24650]) @ bf(Wo)) < 6e-6
+
+
+@pytest.fixture(scope="module")
+def small():
+    from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict
+    cfg = FiraConfig()
+    store = data.process_raw(cfg, util.load_golden_raw())
+    idx = data.split_index(*util.GOLDEN_SPLIT, seed=0)
+    hb = store.batch(idx["train"][:util.GOLDEN_B])
+    torch.manual_seed(0)
+    sd = util.perturb_state_dict(reference_init_state_dict(cfg), seed=1)
+    model = TransModel(cfg, init=False)
+    model.load_state_dict(sd)
+    model.eval()
+    return cfg, model, DeviceBatch(hb, cfg), sd
+
+
+def test_model_bf16_loss_grad_and_ids_vs_fp32(small):
+    cfg, model, db, sd = small
+    g = util.golden_npz("model_ref.npz")
+    model.compute_dtype = "f32"
+    l32, n32 = model.train_fwd_bwd(db)
+    l32, g32 = float(l32), model.gbuf.clone()
+    ids32 = model.forward_dev(db)
+    model.compute_dtype = "bf16"
+    try:
+        l16, n16 = model.train_fwd_bwd(db)
+        l16, g16 = float(l16), model.gbuf.clone()
+        ids16 = model.forward_dev(db)
+    finally:
+        model.compute_dtype = "f32"
+    assert int(n16) == int(n32) == int(g["n_tok"])
+    assert abs(l16 - l32) / l32 < 1e-2 and abs(l16 - float(g["loss_sum"])) / float(g["loss_sum"]) < 1e-2
+    assert l16 != l32                                         # the bf16 kernels really ran
+    valid = db.tar_label.view(ids16.shape)[:, 1:] != 0        # positions that carry a label
+    agree = (ids16[:, :-1] == ids32[:, :-1])[valid].float().mean()
+    assert float(agree) >= 0.99, float(agree)
+    # gradient: direction and size agree with fp32 (bf16 input rounding: ~1e-2 relative on the whole vector)
+    live = model.layout.live
+    cos = torch.nn.functional.cosine_similarity(g16[:live].double(), g32[:live].double(), dim=0)
+    assert float(cos) > 0.999, float(cos)
+    assert abs(float(g16[:live].norm() / g32[:live].norm()) - 1) < 2e-2
+
+
+def test_bf16_loss_curve_batch32_tracks_reference_fp32_curve():
+    """20 Adam steps at batch 32, dropout off, against the reference's own fp32 curve."""
+    from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict
+    from fira_icse_amd.train import Trainer
+    gold = json.load(open(os.path.join(util.GOLDEN, "large_ref.json")))
+    cfg = FiraConfig()
+    store = data.process_raw(cfg, synth.generate_dataset(util.LARGE_N, seed=util.LARGE_SEED))
+    idx = data.split_index(*util.LARGE_SPLIT, seed=0)["train"]
+    torch.manual_seed(0)
+    model = TransModel(cfg, init=False)
+    model.load_state_dict(util.perturb_state_dict(reference_init_state_dict(cfg), seed=1))
+    model.eval()
+    model.compute_dtype = "bf16"
+    trainer = Trainer(model)
+    batches = [DeviceBatch(store.batch(idx[i * 32:(i + 1) * 32]), cfg) for i in range(4)]
+    curve = []
+    for it in range(20):
+        trainer.step(batches[it % 4])
+        curve.append(trainer.last_loss())
+    ref = np.array(gold["loss_curve"])
+    dev = np.abs(np.array(curve) - ref) / ref
+    assert dev.max() < 2e-2, (dev.max(), curve, gold["loss_curve"])
+    assert curve[-1] < curve[0] - 0.5                         # it learns

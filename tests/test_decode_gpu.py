@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import search_ref
 import util
 from fira_icse_amd import data, text
 from fira_icse_amd.config import FiraConfig
@@ -106,7 +107,7 @@ def test_device_beam_bookkeeping_equals_torch_statement(setup, beam):
     store = data.process_raw(cfg, raw)
     for sel in (None, list(range(7))):                       # the fixture batch, and 7 other commits (odd batch)
         d = db if sel is None else DeviceBatch(store.batch(sel), cfg)
-        gen_t, len_t, p_t = search.beam_torch(d, beam)
+        gen_t, len_t, p_t = search_ref.beam_torch(search, d, beam)
         gen_e, len_e, p_e = search.beam(d, beam, use_graphs=False)
         gen_g, len_g, p_g = search.beam(d, beam)
         gen_r, len_r, p_r = search.beam(d, beam)

@@ -34,9 +34,11 @@ def _run(rank, world, port, out):
     trainer = Trainer(model, distributed=world > 1)
     losses = []
     for step in range(3):
-        gidx = idx[4 * step:4 * step + 4]
+        # the last global batch holds ONE commit: with two ranks, rank 1's shard is empty (DataParallel.scatter chunking)
+        # and it must still join the collectives and apply the same Adam update (deadlock / divergence)
+        gidx = idx[4 * step:4 * step + 4] if step < 2 else idx[8:9]
         mine = shard_indices(gidx, rank, world)
-        trainer.step(DeviceBatch(store.batch(mine), cfg))
+        trainer.step(DeviceBatch(store.batch(mine), cfg) if mine else None)
         losses.append(trainer.last_loss())
     torch.cuda.synchronize()
     if rank == 0:
@@ -61,3 +63,19 @@ def test_two_rank_training_equals_single_process(tmp_path):
     diff = (a["flat"] - b["flat"]).abs()
     assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
     assert float(diff.mean()) < 1e-3 * cfg.lr
+
+
+def test_bench_self_launches_under_torchrun():
+    """`python bench.py --gpus 2` (what the driver runs) re-launches itself with one process per rank and prints exactly
+    one JSON line; on a one-GPU box both ranks share cuda:0 over gloo."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(util.REPO, "bench.py"), "--gpus", "2", "--dp-same-device", "--steps", "3",
+           "--warmup", "1", "--no-decode", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["process_group"]["rccl_world_size"] == 2
+    assert line["config"]["global_batch"] == 64 and line["value"] > 0

@@ -72,6 +72,53 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _worker_empty(rank, world, port, tmp):
+    """Rank 1 holds an EMPTY shard (global batch of one commit over two ranks): it contributes a zero gradient and
+    zero (loss_sum, n_tok) to the same collectives, as Trainer.step(None) does on the GPU."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, util.REPO)
+    torch.set_num_threads(4)
+    from oracle import fira_oracle as O
+    from fira_icse_amd.model import ParamLayout, reference_init_state_dict
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = FiraConfig()
+    store = data.process_raw(cfg, util.load_golden_raw())
+    idx = data.split_index(*util.GOLDEN_SPLIT, seed=0)["train"][:1]
+    torch.manual_seed(0)
+    sd = reference_init_state_dict(cfg)
+    layout = ParamLayout(cfg)
+    mine = shard_indices(idx, rank, world)
+    assert (len(mine) == 1) == (rank == 0)
+    if mine:
+        tb = util.to_torch_batch(store.batch(mine), cfg)
+        P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ls, nt = O.forward(P, cfg, tb["sou"], tb["tar"], tb["mark"], tb["ast_change"], tb["edge"], tb["tar_label"],
+                           tb["sub_token"], "train")
+        ls.backward()
+        g, stats = _flat_grad(P, layout), torch.tensor([float(ls.detach()), float(nt)])
+    else:
+        g, stats = torch.zeros(layout.total), torch.zeros(2)
+    ref = g.clone()
+    red = GradReducer(layout.split, layout.live)
+    red.start_early_bucket(g, None)
+    red.finish(g, stats)
+    out = [None, None]
+    dist.all_gather_object(out, (g[:layout.live].clone(), stats.clone()))
+    if rank == 0:
+        torch.save(dict(g0=out[0][0], g1=out[1][0], s0=out[0][1], s1=out[1][1], ref=ref[:layout.live]), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_with_empty_shard_joins_the_collectives(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = 29300 + (os.getpid() % 200)
+    mp.spawn(_worker_empty, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert torch.equal(r["g0"], r["g1"]) and torch.equal(r["g0"], r["ref"])      # both hold rank 0's gradient
+    assert torch.equal(r["s0"], r["s1"]) and float(r["s0"][1]) > 0               # and the global token count
+
+
 def test_two_rank_gradient_equals_single_rank(tmp_path):
     out = str(tmp_path / "res.pt")
     port = 29600 + (os.getpid() % 200)

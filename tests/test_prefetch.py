@@ -34,3 +34,21 @@ def test_errors_surface_at_the_consumer():
     assert next(it) == 0 and next(it) == 1
     with pytest.raises(ValueError):
         next(it)
+
+
+def test_close_stops_the_worker_after_an_early_break():
+    made = []
+
+    def prepare(i):
+        made.append(i)
+        return i
+
+    it = prefetch(range(1000), prepare, depth=2)
+    for v in it:
+        if v == 3:
+            break
+    it.close()
+    n = len(made)
+    time.sleep(0.2)
+    assert len(made) == n and n < 20          # nothing is prepared after close(); the worker is not blocked on put()
+    assert not it._th.is_alive()

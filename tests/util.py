@@ -20,6 +20,10 @@ for p in (REPO,):
 GOLDEN_N = 24                 # commits in the golden synthetic DataSet
 GOLDEN_SPLIT = (16, 4, 4)     # train / valid / test
 GOLDEN_B = 4                  # batch the golden model run uses (first commits of the split)
+# fixtures at BASELINE batch sizes (tests/golden/make_golden_large.py): 128 train / 4 valid / 64 test commits
+LARGE_SEED = 11
+LARGE_SPLIT = (128, 4, 64)
+LARGE_N = sum(LARGE_SPLIT)
 
 GRAD_SAMPLE_KEYS = [
     "encoder.embedding.weight", "encoder.mark_embedding.weight", "encoder.ast_change_embedding.weight",

@@ -19,6 +19,11 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
 int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                  const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
+int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                              float* C, int ldc, float* colsum);
+int gemm_bf16_group_flush(hipStream_t s);
+bool gemm_bf16_takes(int M, int N, int K);     // false: the product is too small for the bf16 tiles (runs in fp32)
+void gemm_bf16_group_reset();
 // grouped weight gradients (one launch for many small dW += dY^T X problems; see gemm_f32.hip)
 int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                          int ldc, float* colsum);

@@ -259,14 +259,18 @@ static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* 
 static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X,
                                        int ldx, float* dW, float* db) {
     SideStream& sd = side();
-    if (!(sd.stream && sd.enabled) || g_dtype == 1) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    if (!(sd.stream && sd.enabled)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    if (g_dtype == 1) {
+        if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);   // e.g. the 2-column gate
+        return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
+    }
     return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
 }
 static inline int flush_grouped_wgrads(hipStream_t s) {
     SideStream& sd = side();
     if (!(sd.stream && sd.enabled)) return 0;
     TRY(side_fork(s));
-    return gemm_group_flush(sd.stream);
+    return g_dtype == 1 ? gemm_bf16_group_flush(sd.stream) : gemm_group_flush(sd.stream);
 }
 
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
@@ -435,6 +439,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     float* G = c.G;
 
     gemm_group_reset();
+    gemm_bf16_group_reset();
     // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
     // The vocabulary dgrad ([R, V] x [V, 256], the head's largest product) and the copy branch are independent until
     // both land in ddec: the former runs on the side stream under the latter.

@@ -138,34 +138,18 @@ struct StageSel { using type = StageR<ROWS, SLOT>; };
 template <int ROWS, int SLOT>
 struct StageSel<ROWS, true, SLOT> { using type = StageK<ROWS>; };
 
+// One BM x BN output tile (tm, tn) over the K range of split z, by the 256 threads of a workgroup.
 template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ B, int ldb, float* __restrict__ C,
-                                                        int ldc, const float* __restrict__ bias, int flags,
-                                                        int tiles_m, int tiles_n, int splitk, int k_chunk, int spread_n,
-                                                        float* __restrict__ colsum, const int32_t* __restrict__ c_rows,
-                                                        const float* __restrict__ relu_mask) {
+__device__ __forceinline__ void gemm_bf16_tile(int M, int N, int K, const float* __restrict__ A, int lda,
+                                               const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                               const float* __restrict__ bias, int flags, int splitk, int k_chunk,
+                                               float* __restrict__ colsum, const int32_t* __restrict__ c_rows,
+                                               const float* __restrict__ relu_mask, int tm, int tn, int z) {
     using SA = typename StageSel<BM, !TA, 0>::type;       // A stored [M,K] (k contiguous) unless TA
     using SB = typename StageSel<BN, TB, 1>::type;        // B stored [N,K] (k contiguous) when TB
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) char sm[2 * (BM + BN) * 128];
 
-    // ---- tile of this workgroup (XCD-aware order, see the header) ----
-    int tm, tn, z;
-    {
-        const int xcd = blockIdx.x & 7;
-        int j = blockIdx.x >> 3;
-        if (!spread_n) {                 // A panels are spread over the XCDs; one XCD walks the N tiles of its panel
-            tn = j % tiles_n; j /= tiles_n;
-            z = j % splitk; j /= splitk;
-            tm = j * 8 + xcd;
-        } else {                         // B panels (weights / wide outputs) are spread; one XCD walks the M tiles
-            tm = j % tiles_m; j /= tiles_m;
-            z = j % splitk; j /= splitk;
-            tn = j * 8 + xcd;
-        }
-        if (tm >= tiles_m || tn >= tiles_n) return;
-    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = z * k_chunk, kend = min(K, kbeg + k_chunk);
     const bool atomic = splitk > 1, first = z == 0;
@@ -294,19 +278,81 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, con
     }
 }
 
+// Workgroup -> tile order.  Hardware places workgroup b on XCD b % 8 (each XCD has a private 4 MiB L2), so logical work
+// item i = (b % 8) * chunk + b / 8 gives every XCD one CONTIGUOUS range of items; the items are ordered so that
+// neighbours share operand panels:  z (K split) slowest -- with splitk >= 8 an XCD owns whole K slabs of both operands
+// (weight gradients: every tile of a slab re-reads it from that XCD's L2, not from HBM) -- then the tiles of the
+// operand with the larger footprint, then the other dimension fastest.
+__device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int splitk, int spread_n, int chunk, int& tm, int& tn,
+                                              int& z) {
+    const int i = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (i >= tiles_m * tiles_n * splitk) return false;
+    const int per = tiles_m * tiles_n;
+    z = i / per;
+    const int r = i - z * per;
+    if (!spread_n) { tm = r / tiles_n; tn = r - tm * tiles_n; }
+    else { tn = r / tiles_m; tm = r - tn * tiles_m; }
+    return true;
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                        int ldc, const float* __restrict__ bias, int flags,
+                                                        int tiles_m, int tiles_n, int splitk, int k_chunk, int spread_n,
+                                                        int chunk, float* __restrict__ colsum,
+                                                        const int32_t* __restrict__ c_rows,
+                                                        const float* __restrict__ relu_mask) {
+    int tm, tn, z;
+    if (!tile_of_block(tiles_m, tiles_n, splitk, spread_n, chunk, tm, tn, z)) return;
+    gemm_bf16_tile<BM, BN, TA, TB>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, k_chunk, colsum, c_rows, relu_mask,
+                                   tm, tn, z);
+}
+
+// Grouped weight gradients: dW_i += dY_i^T X_i (+ db_i) for up to GROUP_MAX independent problems in ONE launch -- the
+// decoder's and the head's small reductions over the B*30 target rows, which launched one by one are a fill and a
+// drain each.  The table travels in the kernel arguments; workgroups are ordered problem-major with the same
+// contiguous-range-per-XCD rule, so one XCD works on a few whole problems.
+struct GroupProblem16 {
+    const float* A;      // dY  [K, M] (transA layout)
+    const float* B;      // X   [K, N]
+    float* C;            // dW  [M, N], accumulated
+    float* colsum;       // db  [M] or nullptr
+    int M, N, K, lda, ldb, ldc, tiles_m, tiles_n, splitk, k_chunk;
+};
+constexpr int GROUP16_MAX = 40;
+struct GroupTable16 {
+    int n, chunk;
+    int wg_start[GROUP16_MAX + 1];
+    GroupProblem16 p[GROUP16_MAX];
+};
+__global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(GroupTable16 g) {
+    const int w = (blockIdx.x & 7) * g.chunk + (blockIdx.x >> 3);
+    if (w >= g.wg_start[g.n]) return;
+    int i = 0;
+    while (i + 1 < g.n && w >= g.wg_start[i + 1]) ++i;               // uniform scan of <= 40 entries
+    const GroupProblem16& q = g.p[i];
+    const int r = w - g.wg_start[i];
+    const int per = q.tiles_m * q.tiles_n;
+    const int z = r / per, tile = r - z * per;
+    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+    gemm_bf16_tile<64, 64, true, false>(q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, nullptr, FIRA_GEMM_ACCUM,
+                                        q.splitk, q.k_chunk, q.colsum, nullptr, nullptr, tm, tn, z);
+}
+
 template <int BM, int BN>
 static int launch_bf16(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B,
                        int ldb, float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                        const int32_t* c_rows, const float* relu_mask) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     const int k_chunk = cdiv(cdiv(K, splitk), HK) * HK;
-    // spread the operand with the larger footprint over the XCDs (its panels are then read from HBM once)
-    const int spread_n = (!colsum && (long)N * K > (long)M * K) ? 1 : 0;
-    const int groups = spread_n ? cdiv(tiles_n, 8) * tiles_m : cdiv(tiles_m, 8) * tiles_n;
-    dim3 grid(8 * groups * splitk);
+    // walk the tiles of the operand with the larger footprint slowest (its panels are then read from HBM once)
+    const int spread_n = (long)N > (long)M ? 1 : 0;
+    const int chunk = cdiv(tiles_m * tiles_n * splitk, 8);
+    dim3 grid(8 * chunk);
 #define FIRA_GO(TA, TB)                                                                                           \
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
-                       bias, flags, tiles_m, tiles_n, splitk, k_chunk, spread_n, colsum, c_rows, relu_mask)
+                       bias, flags, tiles_m, tiles_n, splitk, k_chunk, spread_n, chunk, colsum, c_rows, relu_mask)
     if (!tA && tB) FIRA_GO(false, true);
     else if (!tA && !tB) FIRA_GO(false, false);
     else if (tA && !tB) FIRA_GO(true, false);
@@ -318,6 +364,7 @@ static int launch_bf16(hipStream_t s, int tA, int tB, int M, int N, int K, const
 
 // Products this kernel does not take (handled by the fp32 kernels, i.e. computed more precisely, never less):
 // unaligned operands, and the tiny ones (4-row mark table, 2-column gate) where a 64-wide tile is mostly padding.
+bool gemm_bf16_takes(int M, int N, int K) { return M >= 32 && N >= 32 && K >= 32; }
 static bool bf16_shape_ok(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
     if (M < 32 || N < 32 || K < 32) return false;
     if (((uintptr_t)A % 16) || ((uintptr_t)B % 16) || (lda % 4) || (ldb % 4)) return false;
@@ -337,21 +384,72 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic; 0: 128x128; 1, 2: 64x64
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
-    if (tile < 0) tile = (t128 >= 512 && !tA) ? 0 : 2;          // big tiles only when they still give every CU two
+    // 128x128 (one workgroup per CU, 2x fewer operand re-reads) only pays on long reductions with plenty of tiles
+    // (measured: K = 3072 dgrad / wgrad of the cross K|V projection 1.4x faster, every K = 256 shape 1.5-1.9x slower)
+    if (tile < 0) tile = (t128 >= 256 && K >= 2048) ? 0 : 2;
     if (splitk == 0) {
         // memory-bound: aim at ~2 workgroups per CU; every split re-reads nothing (disjoint K ranges) but adds one
         // atomic per output element, so split only reductions that are long compared with the tile
         splitk = 1;
         const long tiles = tile == 0 ? t128 : t64;
-        if (can_split && tiles < 512 && K >= 1024) {
-            const long want = (512 + tiles - 1) / tiles;
-            splitk = (int)std::max(1L, std::min(want, (long)K / 512));
+        if (can_split && tiles < 512 && K >= 512) {
+            // ~3 workgroups per CU; at least 4 K tiles per split; multiples of 8 so that every XCD owns whole K slabs
+            long want = std::min((768 + tiles - 1) / tiles, (long)K / 256);
+            if (want >= 8) want = want / 8 * 8;
+            splitk = (int)std::max(1L, want);
         }
     }
     FIRA_REQUIRE(!(splitk > 1 && !can_split), "gemm_bf16: split-K needs accumulate semantics and no relu");
     flags &= 3;
     if (tile == 0) return launch_bf16<128, 128>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
     return launch_bf16<64, 64>(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+}
+
+// ---- grouped weight gradients (host side): problems are collected, then launched together
+struct GroupBuilder16 {
+    GroupTable16 t;
+    GroupBuilder16() { t.n = 0; t.wg_start[0] = 0; }
+};
+static GroupBuilder16& group16() { static thread_local GroupBuilder16 g; return g; }
+
+void gemm_bf16_group_reset() { group16().t.n = 0; }
+int gemm_bf16_group_flush(hipStream_t s) {
+    GroupTable16& t = group16().t;
+    if (t.n == 0) return 0;
+    double flop = 0, bytes = 0;
+    for (int i = 0; i < t.n; ++i) {
+        const double M = t.p[i].M, N = t.p[i].N, K = t.p[i].K;
+        flop += 2.0 * M * N * K;
+        bytes += 4.0 * (M * K + N * K + M * N);
+    }
+    ProfScope prof(s, PROF_GEMM, flop, bytes);
+    t.chunk = cdiv(t.wg_start[t.n], 8);
+    hipLaunchKernelGGL(gemm_bf16_grouped_wgrad_kernel, dim3(8 * t.chunk), dim3(256), 0, s, t);
+    t.n = 0;
+    FIRA_CHECK_LAUNCH("gemm_bf16_grouped_wgrad");
+    return 0;
+}
+// dW[M,N] += A^T B with A = dY [K,M], B = X [K,N]; db[M] += column sums of dY.  Queued; runs at the next flush on `s`.
+int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                              float* C, int ldc, float* colsum) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    FIRA_REQUIRE(bf16_shape_ok(1, 0, M, N, K, A, lda, B, ldb), "gemm_bf16_group_add_wgrad: unsupported shape %dx%dx%d", M, N, K);
+    GroupTable16& t = group16().t;
+    if (t.n == GROUP16_MAX) {
+        int rc = gemm_bf16_group_flush(s);
+        if (rc) return rc;
+    }
+    GroupProblem16& q = t.p[t.n];
+    q.A = A; q.B = B; q.C = C; q.colsum = colsum;
+    q.M = M; q.N = N; q.K = K; q.lda = lda; q.ldb = ldb; q.ldc = ldc;
+    q.tiles_m = cdiv(M, 64); q.tiles_n = cdiv(N, 64);
+    // the group shares the chip (a few thousand workgroups in all): short K chains (<= 8 tiles) matter more than the
+    // extra atomics of a split
+    q.splitk = std::max(1, std::min(8, K / 512));
+    q.k_chunk = cdiv(cdiv(K, q.splitk), HK) * HK;
+    t.wg_start[t.n + 1] = t.wg_start[t.n] + q.tiles_m * q.tiles_n * q.splitk;
+    ++t.n;
+    return 0;
 }
 
 }  // namespace fira

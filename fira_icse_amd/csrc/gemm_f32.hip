@@ -266,11 +266,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
                                                        int ldc, const float* __restrict__ bias, int flags,
                                                        int k_chunk, int vecA, int vecB, float* __restrict__ colsum,
                                                        const int32_t* __restrict__ c_rows,
-                                                       const float* __restrict__ relu_mask) {
-    const int kbeg = blockIdx.z * k_chunk;
+                                                       const float* __restrict__ relu_mask, int tiles_m, int tiles_n,
+                                                       int splitk, int spread_n, int chunk) {
+    // Workgroup -> tile order (same rule as gemm_bf16.hip): workgroup b runs on XCD b % 8; logical item
+    // i = (b % 8) * chunk + b / 8 gives every XCD a contiguous range of items ordered K split (slowest), tiles of the
+    // larger operand, other dimension (fastest): weight-gradient K slabs and activation row panels are fetched from HBM
+    // once per XCD and re-read from its private L2 by the neighbouring tiles.
+    const int i = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (i >= tiles_m * tiles_n * splitk) return;
+    const int per = tiles_m * tiles_n;
+    const int z = i / per, r = i - z * per;
+    int tm, tn;
+    if (!spread_n) { tm = r / tiles_n; tn = r - tm * tiles_n; }
+    else { tn = r / tiles_m; tm = r - tn * tiles_m; }
+    const int kbeg = z * k_chunk;
     gemm_tile<BM, BN, TA, TB>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, vecA, vecB, colsum, c_rows, relu_mask,
-                              blockIdx.y * BM, blockIdx.x * BN, kbeg, min(K, kbeg + k_chunk), gridDim.z > 1,
-                              blockIdx.z == 0, blockIdx.x == 0);
+                              tm * BM, tn * BN, kbeg, min(K, kbeg + k_chunk), splitk > 1, z == 0, tn == 0);
 }
 
 // Grouped weight gradients: dW_i (+)= dY_i^T X_i for up to GROUP_MAX independent problems in ONE launch.  The decoder's
@@ -308,13 +319,17 @@ template <int BM, int BN>
 static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   float* C, int ldc, const float* bias, int flags, int splitk, float* colsum, const int32_t* c_rows,
                   const float* relu_mask) {
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), splitk);
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    const int spread_n = (long)N > (long)M ? 1 : 0;
+    const int chunk = cdiv(tiles_m * tiles_n * splitk, 8);
+    dim3 grid(8 * chunk);
     int k_chunk = cdiv(cdiv(K, splitk), BK) * BK;
     const int vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     const int vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
 #define FIRA_GEMM_GO(TA, TB)                                                                                     \
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
-                       bias, flags, k_chunk, vecA, vecB, colsum, c_rows, relu_mask)
+                       bias, flags, k_chunk, vecA, vecB, colsum, c_rows, relu_mask, tiles_m, tiles_n, splitk, spread_n, \
+                       chunk)
     if (!tA && tB) FIRA_GEMM_GO(false, true);
     else if (!tA && !tB) FIRA_GEMM_GO(false, false);
     else if (tA && !tB) FIRA_GEMM_GO(true, false);

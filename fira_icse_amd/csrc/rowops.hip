@@ -699,9 +699,25 @@ int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, 
     return 0;
 }
 
+// keep/scale factors of one dropout site, as every kernel derives them (test surface: lets the CPU oracle apply the
+// SAME masks, so training-mode loss and gradients are compared, not just their statistics)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, float* __restrict__ out, float p, float inv_keep,
+                                                           uint64_t seed, uint32_t site) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = p > 0.f ? dropout_scale(seed, site, (uint32_t)i, p, inv_keep) : 1.f;
+}
+
 }  // namespace fira
 
 extern "C" {
+int fira_dropout_mask(void* stream, uint64_t seed, uint32_t site, int64_t n, float p, float* out) {
+    FIRA_REQUIRE(out && n >= 0 && p >= 0.f && p < 1.f, "fira_dropout_mask: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fira::dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       out, p, 1.0f / (1.0f - p), seed, site);
+    FIRA_CHECK_LAUNCH("dropout_mask");
+    return 0;
+}
 int fira_embed_gather_fwd(void* stream, int B, int L, const int32_t* idx, const float* table, const float* pos,
                           float* out, int out_bstride, int out_off) {
     return fira::embed_gather_fwd((hipStream_t)stream, B, L, idx, table, pos, out, out_bstride, out_off);

@@ -107,6 +107,13 @@ def add_layernorm_bwd(dy, s, stats, gamma, dropout=0.0, seed=0, site=0, want_dx_
     return ds, dxd, dg, db
 
 
+def dropout_mask(seed, site, n, p, device="cuda"):
+    """Scale factors (0 or 1/(1-p)) of dropout site ``site`` for element indices 0..n-1 under ``seed``."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.lib().fira_dropout_mask(cur_stream(), seed, site, n, p, ptr(out)), "fira_dropout_mask")
+    return out
+
+
 def colsum(X):
     out = torch.zeros(X.shape[1], dtype=torch.float32, device=X.device)
     check(_lib.lib().fira_colsum_f32(cur_stream(), X.shape[0], X.shape[1], ptr(_f32(X)), X.stride(0), ptr(out)),

@@ -175,6 +175,23 @@ int fira_add_layernorm_bwd(void* stream, int M, const float* dy, const float* su
                            const float* gamma, float* ds, float* dx_drop, float* dgamma, float* dbeta,
                            float dropout, uint64_t seed, uint32_t stream_id);
 
+/* Dropout is counter-based: the keep/scale factor of element `idx` of a dropout site is a pure function of
+ * (seed, site, idx), re-derived in the backward kernels (no mask tensors).  Sites of the model-level entry points:
+ * FIRA_SITE(layer, kind); idx = row * 256 + column with `row` the kernel's own row index: the position in
+ * fira_batch.code_rows for the two Combination sites, the compact node id for the GCN site, b*tar_len + t for the
+ * decoder sites.  fira_dropout_mask writes out[i] = 0 or 1/(1-p) for idx = 0..n-1 (all 1 when p == 0): the hook that
+ * lets a CPU restatement of the model run with the SAME masks (tests/test_dropout_gpu.py).
+ * Reference sites: combination_layer.py:15-16, gnn_transformer.py:205 (Combination), :83 (GCN), :161 (both
+ * attentions), :174 (FeedForward).                                                                               */
+#define FIRA_SITE_GATE 0      /* dropout on the gated mix inside the Combination      */
+#define FIRA_SITE_COMB_OUT 1  /* on the Combination's output projection               */
+#define FIRA_SITE_GCN 2       /* on the GCN's fc2 output (p = gcn_dropout)            */
+#define FIRA_SITE_SELF 3      /* on the self-attention output projection              */
+#define FIRA_SITE_CROSS 4     /* on the cross-attention output projection             */
+#define FIRA_SITE_FFN 5       /* on the feed-forward output                           */
+#define FIRA_SITE(layer, kind) ((uint32_t)((layer) * 8 + (kind) + 1))
+int fira_dropout_mask(void* stream, uint64_t seed, uint32_t site, int64_t n, float p, float* out);
+
 /* colsum[n] += sum_m X[m,n]  (bias gradients) */
 int fira_colsum_f32(void* stream, int M, int N, const float* X, int ldx, float* out);
 

@@ -14,7 +14,11 @@ checks this restatement against those fixtures (and, when the reference tree is
 present, against the live reference).
 
 Parameters are a flat ``dict[str, Tensor]`` with the reference's state-dict
-keys.  Dropout is not modelled: parity runs use p = 0 / eval().
+keys.  Dropout: the reference draws its masks from torch's global RNG, which no other implementation
+can reproduce; the functions below take an optional ``drop(kind, layer, x)`` callable applied at the reference's six
+dropout sites (combination_layer.py:15-16; gnn_transformer.py:205, :83, :161 twice, :174) so that a test can feed the
+engine's own counter-based masks (``fira_dropout_mask``) and compare training-mode losses and gradients exactly.
+``drop=None`` = eval() / p = 0.
 """
 from __future__ import annotations
 
@@ -50,7 +54,14 @@ def _ln(P: Params, name: str, x: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- encoder
-def combination(P: Params, pre: str, x: torch.Tensor, mark_em: torch.Tensor, d_k: int) -> torch.Tensor:
+GATE, COMB_OUT, GCN, SELF, CROSS, FFN = range(6)      # dropout site kinds (include/fira_hip.h FIRA_SITE_*)
+
+
+def _drop(drop, kind, layer, x):
+    return x if drop is None else drop(kind, layer, x)
+
+
+def combination(P: Params, pre: str, x: torch.Tensor, mark_em: torch.Tensor, d_k: int, drop=None, layer=0) -> torch.Tensor:
     """Element-wise 2-way gated fusion of (q, k, v) + output projection + post-LN
     (reference gnn_transformer.py:192-205, combination_layer.py:7-17).
     The head split / transposes of the reference cancel: the op is element-wise."""
@@ -59,18 +70,18 @@ def combination(P: Params, pre: str, x: torch.Tensor, mark_em: torch.Tensor, d_k
     v = _lin(P, pre + ".linear_layers.2", mark_em)
     s = math.sqrt(d_k)
     w = torch.softmax(torch.stack([q * k / s, q * v / s], -1), dim=-1)
-    mixed = (w * torch.stack([k, v], -1)).sum(-1)
-    return _ln(P, pre + ".layernorm", _lin(P, pre + ".output_linear", mixed) + x)
+    mixed = _drop(drop, GATE, layer, (w * torch.stack([k, v], -1)).sum(-1))
+    return _ln(P, pre + ".layernorm", _drop(drop, COMB_OUT, layer, _lin(P, pre + ".output_linear", mixed)) + x)
 
 
-def gcn(P: Params, pre: str, x: torch.Tensor, adj32: torch.Tensor) -> torch.Tensor:
+def gcn(P: Params, pre: str, x: torch.Tensor, adj32: torch.Tensor, drop=None, layer=0) -> torch.Tensor:
     """LN(fc2(A_hat @ fc1(x)) + x) (reference gnn_transformer.py:74-86)."""
     h = _lin(P, pre + ".fc1", x)
     z = torch.bmm(adj32, h)
-    return _ln(P, pre + ".layernorm", _lin(P, pre + ".fc2", z) + x)
+    return _ln(P, pre + ".layernorm", _drop(drop, GCN, layer, _lin(P, pre + ".fc2", z)) + x)
 
 
-def encoder(P: Params, cfg, sou, mark, ast_change, edge, sub_token) -> Tuple[torch.Tensor, torch.Tensor]:
+def encoder(P: Params, cfg, sou, mark, ast_change, edge, sub_token, drop=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Reference gnn_transformer.py:45-62. ``edge`` is the [B,N,N] adjacency (any float dtype)."""
     L, S = cfg.sou_len, cfg.sub_token_len
     # padding_idx=0 on the three encoder tables (gnn_transformer.py:32-39): row 0 never receives a gradient, which is
@@ -82,14 +93,14 @@ def encoder(P: Params, cfg, sou, mark, ast_change, edge, sub_token) -> Tuple[tor
     sub_em = F.embedding(sub_token, emb, padding_idx=0)
     adj32 = edge.float()
     for i in range(cfg.num_layers):
-        x = combination(P, "encoder.combination_list2.%d" % i, x, mark_em, cfg.d_head)
-        g = gcn(P, "encoder.gcn_list.%d" % i, torch.cat([x, sub_em, ast_em], 1), adj32)
+        x = combination(P, "encoder.combination_list2.%d" % i, x, mark_em, cfg.d_head, drop, i)
+        g = gcn(P, "encoder.gcn_list.%d" % i, torch.cat([x, sub_em, ast_em], 1), adj32, drop, i)
         x, sub_em, ast_em = g[:, :L], g[:, L:L + S], g[:, L + S:]
     return x, sub_em
 
 
 # ----------------------------------------------------------------------------- decoder
-def attention(P: Params, pre: str, q_in, kv_in, mask, heads: int) -> torch.Tensor:
+def attention(P: Params, pre: str, q_in, kv_in, mask, heads: int, drop=None, kind=SELF, layer=0) -> torch.Tensor:
     """Multi-head attention, -1e9 masking, post-LN residual (reference gnn_transformer.py:137-161).
     ``mask``: [B,Tk] (key padding) or [B,1,Tq,Tk]."""
     B, Tq, d = q_in.shape
@@ -103,24 +114,25 @@ def attention(P: Params, pre: str, q_in, kv_in, mask, heads: int) -> torch.Tenso
         mask = mask[:, None, None, :]
     w = torch.softmax(w.masked_fill(mask == 0, -1e9), dim=-1)
     o = torch.matmul(w, v).transpose(1, 2).contiguous().view(B, Tq, d)
-    return _ln(P, pre + ".layernorm", _lin(P, pre + ".fc_o", o) + q_in)
+    return _ln(P, pre + ".layernorm", _drop(drop, kind, layer, _lin(P, pre + ".fc_o", o)) + q_in)
 
 
-def feed_forward(P: Params, pre: str, x) -> torch.Tensor:
+def feed_forward(P: Params, pre: str, x, drop=None, layer=0) -> torch.Tensor:
     """Reference gnn_transformer.py:170-174."""
-    return _ln(P, pre + ".layernorm", _lin(P, pre + ".fc2", torch.relu(_lin(P, pre + ".fc1", x))) + x)
+    h = _lin(P, pre + ".fc2", torch.relu(_lin(P, pre + ".fc1", x)))
+    return _ln(P, pre + ".layernorm", _drop(drop, FFN, layer, h) + x)
 
 
-def decoder(P: Params, cfg, tar, memory, mem_mask, tar_pad_mask) -> torch.Tensor:
+def decoder(P: Params, cfg, tar, memory, mem_mask, tar_pad_mask, drop=None) -> torch.Tensor:
     """Reference gnn_transformer.py:108-122: key-pad AND causal mask on self-attention."""
     T = cfg.tar_len
     x = P["decoder.embedding.weight"][tar] + position_table(T, cfg.embedding_dim)
     causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
     self_mask = tar_pad_mask[:, None, None, :] & causal[None, None]
     for i in range(cfg.num_layers):
-        x = attention(P, "decoder.attention_list.%d" % i, x, x, self_mask, cfg.num_head)
-        x = attention(P, "decoder.cross_attention_list.%d" % i, x, memory, mem_mask, cfg.num_head)
-        x = feed_forward(P, "decoder.feed_forward_list.%d" % i, x)
+        x = attention(P, "decoder.attention_list.%d" % i, x, x, self_mask, cfg.num_head, drop, SELF, i)
+        x = attention(P, "decoder.cross_attention_list.%d" % i, x, memory, mem_mask, cfg.num_head, drop, CROSS, i)
+        x = feed_forward(P, "decoder.feed_forward_list.%d" % i, x, drop, i)
     return x
 
 
@@ -142,15 +154,15 @@ def output_distribution(P: Params, memory, mem_mask, dec) -> torch.Tensor:
     return torch.cat([gate[..., 0:1] * p_gen, gate[..., 1:2] * p_copy], -1)
 
 
-def encode_memory(P: Params, cfg, sou, mark, ast_change, edge, sub_token):
-    code, sub = encoder(P, cfg, sou, mark, ast_change, edge, sub_token)
+def encode_memory(P: Params, cfg, sou, mark, ast_change, edge, sub_token, drop=None):
+    code, sub = encoder(P, cfg, sou, mark, ast_change, edge, sub_token, drop)
     return torch.cat([code, sub], 1), torch.cat([sou != 0, sub_token != 0], 1)
 
 
-def forward(P: Params, cfg, sou, tar, mark, ast_change, edge, tar_label, sub_token, stage="train"):
+def forward(P: Params, cfg, sou, tar, mark, ast_change, edge, tar_label, sub_token, stage="train", drop=None):
     """Whole model (reference Model.py:38-86): 'train' -> (loss_sum, n_tok); 'dev'/'test' -> argmax ids [B,T]."""
-    memory, mem_mask = encode_memory(P, cfg, sou, mark, ast_change, edge, sub_token)
-    dec = decoder(P, cfg, tar, memory, mem_mask, tar != 0)
+    memory, mem_mask = encode_memory(P, cfg, sou, mark, ast_change, edge, sub_token, drop)
+    dec = decoder(P, cfg, tar, memory, mem_mask, tar != 0, drop)
     logp = torch.log(output_distribution(P, memory, mem_mask, dec).clamp(min=1e-10, max=1))
     label = torch.cat([tar_label[:, 1:], torch.zeros_like(tar_label[:, :1])], 1)     # shift left, pad with 0
     keep = label != 0

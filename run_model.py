@@ -190,6 +190,8 @@ class Run:
                 break
         if best_bleu < 0 and self.rank == 0:            # never reached a dev point (short runs): keep the last weights
             torch.save(self.model.state_dict(), os.path.join(self.root, "best_model.pt"))
+            if a.save_optimizer:                         # ... and the optimizer state that belongs to them (--resume)
+                torch.save(trainer.state_dict(), state_path)
         return best_bleu
 
     # ------------------------------------------------------------------------------ test (run_model.py:187-380,401-415)

@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fira_icse_amd import ops
 from scripts.bench_kernels import timeit
 
-Nc, Cc, Mc, R, TB = 12000, 5000, 8500, 700, 960
+# usage: python scripts/gemm_step_shapes.py [f32|bf16] [batch]   (batch 32: the sizes below; 64: doubled)
+DTYPE = sys.argv[1] if len(sys.argv) > 1 else "f32"
+SCALE = (int(sys.argv[2]) if len(sys.argv) > 2 else 32) // 32
+Nc, Cc, Mc, R, TB = 12000 * SCALE, 5000 * SCALE, 8500 * SCALE, 700 * SCALE, 960 * SCALE
 SHAPES = [  # name, M, N, K, tA, tB, accumulate, launches per step
     ("enc fc fwd", Nc, 256, 256, 0, 1, 0, 12), ("enc qk fwd", Cc, 512, 256, 0, 1, 0, 6), ("enc o fwd", Cc, 256, 256, 0, 1, 0, 6),
     ("kv_all fwd", Mc, 3072, 256, 0, 1, 0, 1), ("src fwd", Mc, 256, 256, 0, 1, 0, 1),
@@ -34,14 +37,16 @@ def main():
         res = {}
         for label, tile in (("auto", 0), ("t128", 1), ("t64x128", 2), ("t64", 3)):
             t = timeit(lambda: ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=C, accumulate=bool(acc), splitk=0,
-                                        tile=tile), iters=30)
+                                        tile=tile, dtype=DTYPE), iters=30)
             res[label] = t * 1e6
         best = min(res, key=res.get)
         total["auto"] += cnt * res["auto"]
         total["best"] += cnt * res[best]
-        rows.append("%-16s %6d %6d %6d  x%-2d  auto %7.1f us %6.1f TF | t128 %7.1f  t64x128 %7.1f  t64 %7.1f | best %s" % (
-            name, M, N, K, cnt, res["auto"], 2.0 * M * N * K / res["auto"] / 1e6, res["t128"], res["t64x128"], res["t64"],
-            best))
+        by = 4.0 * (M * K + N * K + M * N)
+        rows.append("%-16s %6d %6d %6d  x%-2d  auto %7.1f us %6.1f TF %5.2f TB/s | t128 %7.1f  t64x128 %7.1f  t64 %7.1f | best %s" % (
+            name, M, N, K, cnt, res["auto"], 2.0 * M * N * K / res["auto"] / 1e6, by / res["auto"] / 1e6, res["t128"],
+            res["t64x128"], res["t64"], best))
+    print("dtype %s, batch %d" % (DTYPE, 32 * SCALE))
     print("\n".join(rows))
     print("sum over the step: auto %.0f us, best-of-forced %.0f us" % (total["auto"], total["best"]))
 

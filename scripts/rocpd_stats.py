@@ -18,6 +18,13 @@ def main():
     sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
     rows = cur.execute("select s.kernel_name, d.start, d.end, s.arch_vgpr_count, s.accum_vgpr_count, s.group_segment_size "
                        "from %s d join %s s on d.kernel_id = s.id" % (disp, sym)).fetchall()
+    try:        # busy time per HIP stream / hardware queue: which chain is the critical path of the step
+        cols = [r[1] for r in cur.execute("pragma table_info(%s)" % disp)]
+        qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else None)
+        per_q = cur.execute("select %s, count(*), sum(end - start) / 1e3, min(start), max(end) from %s group by %s"
+                            % (qcol, disp, qcol)).fetchall() if qcol else []
+    except Exception:
+        per_q = []
     agg = collections.OrderedDict()
     for name, st, en, vg, ag, lds in rows:
         short = re.sub(r"\(.*", "", name).replace(".kd", "")
@@ -31,6 +38,11 @@ def main():
         print("| `%s` | %d | %.1f | %.1f | %.2f | %.1f | %.1f | %.1f | %s | %s | %s |" %
               (k[:120], v[0], v[0] / steps, v[1] / steps, 100 * v[1] / tot, v[1] / v[0], v[2], v[3], v[4], v[5], v[6]))
     print("\ntotal kernel time: %.1f us over %d dispatches (%.1f us/step over %d steps)" % (tot, len(rows), tot / steps, steps))
+    if per_q:
+        print("\n| stream / queue | dispatches | busy us/step | span ms |")
+        print("|---|---|---|---|")
+        for q, n, busy, t0, t1 in per_q:
+            print("| %s | %d | %.1f | %.1f |" % (q, n, busy / steps, (t1 - t0) / 1e6))
 
 
 if __name__ == "__main__":

@@ -43,8 +43,6 @@ def test_gemm_bf16_layouts(M, N, K, layout):
     from fira_icse_amd import ops
     tile = int(layout[-1]) if "-t" in layout else 0          # 1: 128x128, 3: 64x64, 0: automatic
     tA, tB = {"nt": (False, True), "nn": (False, False), "tn": (True, False), "tt": (True, True)}[layout[:2]]
-    if (K * M if tA else M * K) % 4 or M % 4 and tA or N % 4 and not tB:
-        pass                                               # unaligned leading dimensions fall back to fp32 inside
     A = randn(*((K, M) if tA else (M, K)), seed=1)
     B = randn(*((N, K) if tB else (K, N)), seed=2)           # asymmetric operands: a swapped tile cannot pass
     bias = randn(N, seed=3)
@@ -113,9 +111,12 @@ def test_model_bf16_loss_grad_and_ids_vs_fp32(small):
     assert int(n16) == int(n32) == int(g["n_tok"])
     assert abs(l16 - l32) / l32 < 1e-2 and abs(l16 - float(g["loss_sum"])) / float(g["loss_sum"]) < 1e-2
     assert l16 != l32                                         # the bf16 kernels really ran
-    valid = db.tar_label.view(ids16.shape)[:, 1:] != 0        # positions that carry a label
+    # teacher-forced argmax on the 71 labelled positions of this 4-commit batch: with freshly initialised weights the
+    # 25 020-way distribution is nearly flat (top-2 margins ~1e-3 relative), so a position or two may flip under bf16
+    # rounding; the >= 99 % gate is applied where it is meaningful, on trained weights (the curve test below)
+    valid = db.tar_label.view(ids16.shape)[:, 1:] != 0
     agree = (ids16[:, :-1] == ids32[:, :-1])[valid].float().mean()
-    assert float(agree) >= 0.99, float(agree)
+    assert float(agree) >= 0.95, float(agree)
     # gradient: direction and size agree with fp32 (bf16 input rounding: ~1e-2 relative on the whole vector)
     live = model.layout.live
     cos = torch.nn.functional.cosine_similarity(g16[:live].double(), g32[:live].double(), dim=0)
@@ -146,3 +147,15 @@ def test_bf16_loss_curve_batch32_tracks_reference_fp32_curve():
     dev = np.abs(np.array(curve) - ref) / ref
     assert dev.max() < 2e-2, (dev.max(), curve, gold["loss_curve"])
     assert curve[-1] < curve[0] - 0.5                         # it learns
+    # teacher-forced argmax ids of the trained weights: bf16 forward vs fp32 forward, >= 99 % identical
+    model.eval()
+    agree, total = 0, 0
+    for db in batches:
+        model.compute_dtype = "bf16"
+        ids16 = model.forward_dev(db)
+        model.compute_dtype = "f32"
+        ids32 = model.forward_dev(db)
+        valid = db.tar_label.view(ids16.shape)[:, 1:] != 0
+        agree += int((ids16[:, :-1] == ids32[:, :-1])[valid].sum())
+        total += int(valid.sum())
+    assert total > 1000 and agree / total >= 0.99, (agree, total)

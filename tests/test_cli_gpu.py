@@ -38,3 +38,34 @@ def test_train_then_test_roundtrip(tmp_path):
         run(["test", "--splits", "16,4,4", "--test-batch-size", "3", "--beam", beam], root)
         lines = open(os.path.join(root, "OUTPUT", "output_fira")).read().split("\n")
         assert len(lines) == 5 and lines[-1] == ""                  # one line per test commit, in all_index order
+
+
+def test_resume_continues_from_the_saved_adam_state(tmp_path):
+    """--resume (run_model.py:410-414 loads only the weights; here also fira_train_state.pt: Adam moments, step count,
+    dropout step): 2 steps + resume + 2 steps must land on the weights of 4 uninterrupted steps.  One batch per epoch
+    (batch = the whole train split) makes the batches of both schedules identical whatever the shuffle."""
+    common = ["--splits", "16,4,4", "--batch-size", "16", "--dev-from-epoch", "99", "--no-dropout", "--save-optimizer"]
+    roots = {}
+    for name in ("full", "split", "cold"):
+        roots[name] = str(tmp_path / name)
+        os.makedirs(roots[name])
+        synth.write_dataset(roots[name], util.load_golden_raw())
+    run(["train", "--max-steps", "4"] + common, roots["full"])
+    run(["train", "--max-steps", "2"] + common, roots["split"])
+    st = torch.load(os.path.join(roots["split"], "fira_train_state.pt"), map_location="cpu")
+    assert int(st["t"]) == 2 and float(st["v"].abs().sum()) > 0
+    run(["train", "--max-steps", "2", "--resume"] + common, roots["split"])
+    st = torch.load(os.path.join(roots["split"], "fira_train_state.pt"), map_location="cpu")
+    assert int(st["t"]) == 4
+    # control: weights resumed WITHOUT the optimizer state restart Adam's bias correction and drift visibly
+    run(["train", "--max-steps", "2"] + common, roots["cold"])
+    os.remove(os.path.join(roots["cold"], "fira_train_state.pt"))
+    run(["train", "--max-steps", "2", "--resume"] + common, roots["cold"])
+    w = {k: torch.load(os.path.join(r, "best_model.pt"), map_location="cpu") for k, r in roots.items()}
+    key = "decoder.feed_forward_list.0.fc1.weight"
+    # mean |difference| (Adam turns an entry whose gradient is rounding noise into a +-lr step, so a handful of entries
+    # may differ by 2e-4 between any two runs; the mean separates "same trajectory" from "restarted optimizer" by 100x)
+    d_split = float((w["split"][key] - w["full"][key]).abs().mean())
+    d_cold = float((w["cold"][key] - w["full"][key]).abs().mean())
+    assert d_split < 2e-7, d_split
+    assert d_cold > 50 * max(d_split, 1e-9), (d_cold, d_split)

@@ -63,7 +63,7 @@ int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, con
 // 3 out[dst[r]]=in[src[r]]
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
          int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
-         int32_t* compact_row, int32_t* iota);
+         int32_t* compact_row, int32_t* iota, float* loss_sum = nullptr, int32_t* n_tok = nullptr);   // the two scalars are zeroed
 int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
                   const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
                   float* X);

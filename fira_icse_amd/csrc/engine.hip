@@ -58,6 +58,7 @@ struct Plan {
     float *inv_ntok;
     // backward temporaries (training only)
     float *dXa, *dXb, *dNB2, *dCB_a, *dvtab_all;
+    float *zero_beg = nullptr, *zero_end = nullptr;
     float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
@@ -107,12 +108,17 @@ struct Plan {
         if (training) {
             dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
             dCB_a = a.f((size_t)CB * D);
+            // buffers that must start a backward pass at zero, contiguous: ONE fill per step (zero_beg .. zero_end)
+            zero_beg = (float*)a.get<char>(0);
             dvtab_all = a.f((size_t)4 * nl * D);
             dW21 = a.f((size_t)nl * D * D + (size_t)nl * D); dc21 = dW21 + (size_t)nl * D * D;
+            dtgt = a.f((size_t)TB * D);
+            ddec_c = a.f((size_t)TB * D);
+            zero_end = (float*)a.get<char>(0);
             dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
-            dkv_c = a.f((size_t)MB * nl * 2 * D); dtgt = a.f((size_t)TB * D);
+            dkv_c = a.f((size_t)MB * nl * 2 * D);
             dkv_all = a.f((size_t)MB * nl * 2 * D);
-            ddec = a.f((size_t)TB * D); ddec_c = a.f((size_t)TB * D);
+            ddec = a.f((size_t)TB * D);
             dT_a = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
             encg.resize(nl);
             decg.resize(nl);
@@ -290,6 +296,8 @@ struct Ctx {
     int R = 0;
     const int32_t* rows = nullptr;
     bool deferred = false;
+    float* loss_sum = nullptr;      // zeroed by the prep launch (head_loss accumulates into them)
+    int32_t* n_tok = nullptr;
     hipEvent_t ev_kv[16] = {};
     hipEvent_t ev_src = nullptr;
 };
@@ -306,7 +314,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     const int D = FIRA_D, Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem, KV = p.nl * 2 * D;
     // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
     TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
-             p.pos_tar, c.R, c.rows, bt.tar ? p.compact_row : nullptr, c.rows ? nullptr : p.iota));
+             p.pos_tar, c.R, c.rows, bt.tar ? p.compact_row : nullptr, c.rows ? nullptr : p.iota, c.loss_sum, c.n_tok));
     TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
                       p.pos_code, p.X[0]));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
@@ -420,8 +428,6 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid,
                           argmax_out ? nullptr : c.bt->tar_label, p.V));
     TRY(linear(s, p.TB, 2, D, dec, D, c.P + L.wp, c.P + L.bp, p.gate, 2));
-    if (loss_sum) TRY(zero(s, loss_sum, sizeof(float)));
-    if (n_tok) TRY(zero(s, n_tok, sizeof(int32_t)));
     TRY(head_loss(s, p.TB, p.T, p.V, Sm, p.compact_row, p.logits, p.ldl, p.score, p.mem_valid, p.gate,
                   c.bt->tar_label, loss_sum, n_tok, argmax_out, want_grad));
     return 0;
@@ -446,9 +452,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     const bool so = side_on();
     hipStream_t ss = so ? side().aux : s;
     hipEvent_t ev_dfc = nullptr;
+    // dvtab_all, dW21|dc21, dtgt, ddec_c: accumulated into below, one fill for all of them
+    TRY(zero(s, p.zero_beg, (size_t)((char*)p.zero_end - (char*)p.zero_beg)));
     if (R > 0) {
         if (so) TRY(aux_fork(s));
-        TRY(zero(ss, p.ddec_c, (size_t)R * D * sizeof(float)));
         // ddec_rows = dlogits W_out, split over the vocabulary axis
         TRY(gemm_any(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
                         nullptr));
@@ -457,7 +464,6 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     }
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad_grouped(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
-    TRY(zero(s, p.dtgt, (size_t)p.TB * D * sizeof(float)));
     TRY(copy_score_bwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres,
                           p.mem_valid));
     TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
@@ -543,8 +549,6 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));            // AST/edit rows of the last layer feed nothing
     if (ev_dmem) TRY(main_wait(s, ev_dmem));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
-    TRY(zero(s, p.dvtab_all, (size_t)4 * p.nl * D * sizeof(float)));
-    TRY(zero(s, p.dW21, ((size_t)p.nl * D * D + (size_t)p.nl * D) * sizeof(float)));
     for (int l = p.nl - 1; l >= 0; --l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
@@ -688,6 +692,8 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
         c.R = R;
         c.rows = rows;
     }
+    c.loss_sum = loss_sum;
+    c.n_tok = n_tok;
     TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
@@ -708,6 +714,8 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
     FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     TRY(check_counts(batch, p));
     Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
+    c.loss_sum = loss_sum;
+    c.n_tok = n_tok;
     TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
     TRY(head_forward(c, p.TB, p.iota, loss_sum, n_tok, ids_out, 0));

@@ -25,6 +25,7 @@
 //     re-reads hit its private 4 MiB L2.
 #include "engine.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace fira {
 
@@ -48,12 +49,15 @@ template <int ROWS>
 struct StageK {
     static constexpr int NV = ROWS / 32;                         // 8-element chunks per thread per tile
     f32x4 v[NV][2];
+    // wave-uniform base pointer + 32-bit per-lane offset: lets the loads use the scalar-base addressing form, so the
+    // K loop computes no per-lane 64-bit addresses (and needs no fresh address registers while loads are in flight)
     __device__ __forceinline__ void load_fast(const float* __restrict__ src, int ld, int r0, int k0, int t) {
-        const float* p = src + (size_t)(r0 + (t >> 3)) * ld + k0 + (t & 7) * 8;
+        const float* base = src + (size_t)r0 * ld + k0;
+        const unsigned o = (unsigned)(t >> 3) * (unsigned)ld + (unsigned)(t & 7) * 8u;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            v[i][0] = *reinterpret_cast<const f32x4*>(p + (size_t)32 * i * ld);
-            v[i][1] = *reinterpret_cast<const f32x4*>(p + (size_t)32 * i * ld + 4);
+            v[i][0] = *reinterpret_cast<const f32x4*>(base + (o + 32u * i * (unsigned)ld));
+            v[i][1] = *reinterpret_cast<const f32x4*>(base + (o + 32u * i * (unsigned)ld + 4u));
         }
     }
     // edge tiles (branch-free): rows past the end are clamped to the last row -- their products land in output rows /
@@ -94,9 +98,10 @@ struct StageR {
     __device__ __forceinline__ void load_fast(const float* __restrict__ src, int ld, int r0, int k0, int t) {
         if (!active(t)) return;
         const int idx = t % TP, rb = idx % (ROWS / 4), kb = idx / (ROWS / 4);
-        const float* p = src + (size_t)(k0 + kb * 8) * ld + r0 + rb * 4;
+        const float* base = src + (size_t)k0 * ld + r0;
+        const unsigned o = (unsigned)(kb * 8) * (unsigned)ld + (unsigned)rb * 4u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (size_t)j * ld);
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(base + (o + (unsigned)j * (unsigned)ld));
     }
     __device__ __forceinline__ void load(const float* __restrict__ src, int ld, int r0, int r_end, int k0, int k_end, int t) {
         if (!active(t)) return;
@@ -171,31 +176,8 @@ __device__ __forceinline__ void gemm_bf16_tile(int M, int N, int K, const float*
     const bool do_cs = TA && colsum != nullptr && tn == 0;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const bool a_in = m0 + BM <= M, b_in = n0 + BN <= N;                // block-uniform
-    SA ra0, ra1;
-    SB rb0, rb1;
-    auto fetch = [&](int k0, SA& ra, SB& rb) __attribute__((always_inline)) {
-        const bool k_in = k0 + HK <= kend;
-        if (a_in && k_in) ra.load_fast(A, lda, m0, k0, t);
-        else ra.load(A, lda, m0, M, k0, kend, t);
-        if (b_in && k_in) rb.load_fast(B, ldb, n0, k0, t);
-        else rb.load(B, ldb, n0, N, k0, kend, t);
-    };
     char* const smA = sm;
     char* const smB = sm + 2 * BM * 128;
-    // every fetched tile is stored exactly once; the column sums are taken there, when the registers are needed anyway
-    auto put = [&](const SA& ra, const SB& rb, int buf) __attribute__((always_inline)) {
-        if (do_cs) ra.colsum_add(cs);
-        ra.store(smA + buf * BM * 128, t);
-        rb.store(smB + buf * BN * 128, t);
-    };
-    if (ntile > 0) {
-        fetch(kbeg, ra0, rb0);
-        put(ra0, rb0, 0);
-        if (ntile > 1) fetch(kbeg + HK, ra0, rb0);
-    }
-    __syncthreads();
-
     // per-lane operand rows of the MFMA fetch: row offset and swizzle key
     int offA[TM], keyA[TM], offB[TN], keyB[TN];
 #pragma unroll
@@ -203,11 +185,9 @@ __device__ __forceinline__ void gemm_bf16_tile(int M, int N, int K, const float*
 #pragma unroll
     for (int j = 0; j < TN; ++j) { const int r = wn * WN + j * 32 + l31; offB[j] = r * 128; keyB[j] = lds_swz(r); }
 
-    int cur = 0;
-    auto step = [&](int it, SA& pa, SB& pb, SA& qa, SB& qb) __attribute__((always_inline)) {
-        if (it + 2 < ntile) fetch(kbeg + (it + 2) * HK, qa, qb);
-        const char* sa = smA + cur * BM * 128;
-        const char* sb = smB + cur * BN * 128;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* sa = smA + buf * BM * 128;
+        const char* sb = smB + buf * BN * 128;
 #pragma unroll
         for (int s = 0; s < HK / 16; ++s) {
             bf16x8 a[TM], b[TN];
@@ -223,14 +203,79 @@ __device__ __forceinline__ void gemm_bf16_tile(int M, int N, int K, const float*
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < ntile) put(pa, pb, cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     };
-    for (int it = 0; it < ntile; it += 2) {
-        step(it, ra0, rb0, ra1, rb1);
-        if (it + 1 < ntile) step(it + 1, ra1, rb1, ra0, rb0);
+    // every fetched tile is stored exactly once; the column sums are taken there, when the registers are needed anyway
+    auto put = [&](const SA& ra, const SB& rb, int buf) __attribute__((always_inline)) {
+        if (do_cs) ra.colsum_add(cs);
+        ra.store(smA + buf * BM * 128, t);
+        rb.store(smB + buf * BN * 128, t);
+    };
+
+    // Interior workgroups (every row, column and K tile in range -- block-uniform, decided once) run a software
+    // pipeline of straight 16-byte loads with two register stages.  Tile t is fetched into stage t & 1 and stored to
+    // LDS buffer t & 1 one step before it is consumed:
+    //     step(t):  fetch(t + 2) -> stage t & 1 | MFMAs on LDS[t & 1] | store stage (t + 1) & 1 -> LDS[(t + 1) & 1]
+    // Both sub-steps of the steady-state loop are unconditional and the last <= 3 tiles are straight-line code per
+    // remaining count, so that no load sits behind a branch: the compiler's s_waitcnt insertion merges the pending-load
+    // state of both sides of every join, and a conditional prefetch (or a per-tile fast/edge choice) made it drain the
+    // tiles in flight at the head of every iteration -- the loop then ran at one memory latency per K tile.
+    if (m0 + BM <= M && n0 + BN <= N && (kend - kbeg) % HK == 0 && ntile > 0) {
+        SA ra0, ra1;
+        SB rb0, rb1;
+        auto fetch = [&](int k0, SA& ra, SB& rb) __attribute__((always_inline)) {
+            ra.load_fast(A, lda, m0, k0, t);
+            rb.load_fast(B, ldb, n0, k0, t);
+        };
+        fetch(kbeg, ra0, rb0);
+        put(ra0, rb0, 0);
+        if (ntile == 1) {
+            __syncthreads();
+            compute(0);
+        } else {
+            fetch(kbeg + HK, ra1, rb1);
+            __syncthreads();
+            int it = 0;
+            for (; it + 3 < ntile; it += 2) {                 // `it` stays even: stage / buffer roles are static
+                fetch(kbeg + (it + 2) * HK, ra0, rb0);
+                compute(0);
+                put(ra1, rb1, 1);
+                __syncthreads();
+                fetch(kbeg + (it + 3) * HK, ra1, rb1);
+                compute(1);
+                put(ra0, rb0, 0);
+                __syncthreads();
+            }
+            if (ntile - it == 3) {                            // tile it in LDS[0], tile it + 1 in flight (stage 1)
+                fetch(kbeg + (it + 2) * HK, ra0, rb0);
+                compute(0);
+                put(ra1, rb1, 1);
+                __syncthreads();
+                compute(1);
+                put(ra0, rb0, 0);
+                __syncthreads();
+                compute(0);
+            } else {
+                compute(0);
+                put(ra1, rb1, 1);
+                __syncthreads();
+                compute(1);
+            }
+        }
+    } else {
+        // edge workgroups (last row / column of tiles, the split that holds a partial K tile): clamped branch-free loads,
+        // one register stage, no overlap -- a few per cent of the workgroups at most
+        SA ra;
+        SB rb;
+        for (int it = 0; it < ntile; ++it) {
+            ra.load(A, lda, m0, M, kbeg + it * HK, kend, t);
+            rb.load(B, ldb, n0, N, kbeg + it * HK, kend, t);
+            put(ra, rb, 0);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
     }
+    __syncthreads();
 
     if constexpr (TA) {
         if (do_cs) {                               // block-level combine of the column sums, one atomic per column

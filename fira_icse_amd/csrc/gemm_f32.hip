@@ -17,17 +17,20 @@
 namespace fira {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native 4-vector for the register stages (HIP's f32x4 is a union-based struct: conditionally written arrays of it are
+// kept in scratch memory instead of registers)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 
 template <int ROWS, bool CONTIG_K>
 struct TileLoader {
     // ROWS = BM or BN (extent along the non-reduction axis)
-    static constexpr int NV = ROWS / 32;            // float4 per thread per tile
+    static constexpr int NV = ROWS / 32;            // f32x4 per thread per tile
     static constexpr int LD = CONTIG_K ? ROWS + 1 : ROWS + 4;
 
     // source element (r, k): CONTIG_K ? src[r*ld + k] : src[k*ld + r]
-    __device__ __forceinline__ static void load(float4 (&v)[NV], const float* __restrict__ src, int ld,
+    __device__ __forceinline__ static void load(f32x4 (&v)[NV], const float* __restrict__ src, int ld,
                                                 int r0, int r_end, int k0, int k_end, bool vec_ok, int t) {
         if constexpr (CONTIG_K) {
             const int kq = (t & 7) * 4;
@@ -35,11 +38,11 @@ struct TileLoader {
             for (int i = 0; i < NV; ++i) {
                 const int r = r0 + (t >> 3) + 32 * i;
                 const int k = k0 + kq;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (r < r_end) {
                     const float* p = src + (size_t)r * ld + k;
                     if (vec_ok && k + 3 < k_end) {
-                        x = *reinterpret_cast<const float4*>(p);
+                        x = *reinterpret_cast<const f32x4*>(p);
                     } else {
                         if (k + 0 < k_end) x.x = p[0];
                         if (k + 1 < k_end) x.y = p[1];
@@ -50,18 +53,18 @@ struct TileLoader {
                 v[i] = x;
             }
         } else {
-            constexpr int CPR = ROWS / 4;           // float4 columns per k-row (32 or 16)
+            constexpr int CPR = ROWS / 4;           // f32x4 columns per k-row (32 or 16)
             constexpr int KSTEP = 256 / CPR;        // k-rows covered per pass (8 or 16)
             const int c = (t % CPR) * 4;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int k = k0 + (t / CPR) + KSTEP * i;
                 const int r = r0 + c;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (k < k_end) {
                     const float* p = src + (size_t)k * ld + r;
                     if (vec_ok && r + 3 < r_end) {
-                        x = *reinterpret_cast<const float4*>(p);
+                        x = *reinterpret_cast<const f32x4*>(p);
                     } else {
                         if (r + 0 < r_end) x.x = p[0];
                         if (r + 1 < r_end) x.y = p[1];
@@ -76,22 +79,22 @@ struct TileLoader {
 
     // interior tile (every row and k in range, 16-byte aligned rows): straight-line loads, no exec-mask branches, so
     // all NV 16-byte loads of a thread are in flight together
-    __device__ __forceinline__ static void load_fast(float4 (&v)[NV], const float* __restrict__ src, int ld, int r0,
+    __device__ __forceinline__ static void load_fast(f32x4 (&v)[NV], const float* __restrict__ src, int ld, int r0,
                                                      int k0, int t) {
         if constexpr (CONTIG_K) {
             const float* p = src + (size_t)(r0 + (t >> 3)) * ld + k0 + (t & 7) * 4;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(p + (size_t)32 * i * ld);
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)32 * i * ld);
         } else {
             constexpr int CPR = ROWS / 4;
             constexpr int KSTEP = 256 / CPR;
             const float* p = src + (size_t)(k0 + t / CPR) * ld + r0 + (t % CPR) * 4;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(p + (size_t)KSTEP * i * ld);
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)KSTEP * i * ld);
         }
     }
 
-    __device__ __forceinline__ static void store(const float4 (&v)[NV], float* __restrict__ lds, int t) {
+    __device__ __forceinline__ static void store(const f32x4 (&v)[NV], float* __restrict__ lds, int t) {
         if constexpr (CONTIG_K) {
             const int kq = (t & 7) * 4;
 #pragma unroll
@@ -109,7 +112,7 @@ struct TileLoader {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int k = (t / CPR) + KSTEP * i;
-                *reinterpret_cast<float4*>(&lds[k * LD + c]) = v[i];
+                *reinterpret_cast<f32x4*>(&lds[k * LD + c]) = v[i];
             }
         }
     }
@@ -148,39 +151,15 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __re
     // fused bias gradient (wgrad layout only): colsum[m] += sum_k A[k][m] over this block's K range, taken from the
     // A-tile registers on their way to LDS (thread t always carries the same 4 columns of the tile)
     const bool do_cs = TA && colsum != nullptr && cs_tile;
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto cs_add = [&](const float4 (&v)[LA::NV]) {
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto cs_add = [&](const f32x4 (&v)[LA::NV]) {
 #pragma unroll
         for (int i = 0; i < LA::NV; ++i) { cs.x += v[i].x; cs.y += v[i].y; cs.z += v[i].z; cs.w += v[i].w; }
     };
 
-    // Two register stages: while tile `it` is consumed from LDS, tile it+1 waits in one register set (loaded during the
-    // previous iteration) and tile it+2 is being fetched into the other.  With K = 256 a 64x64 workgroup runs only
-    // 8 iterations of 16 MFMAs (~0.4 us) each, far less than a global-load latency: one tile of look-ahead left the
-    // loop latency-bound, two tiles cover it together with the co-resident workgroups.
-    float4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
-    const bool a_in = vecA && m0 + BM <= M, b_in = vecB && n0 + BN <= N;       // block-uniform
-    auto fetch = [&](int k0, float4 (&ra)[LA::NV], float4 (&rb)[LB::NV]) {
-        if (a_in && k0 + BK <= kend) LA::load_fast(ra, A, lda, m0, k0, t);
-        else LA::load(ra, A, lda, m0, M, k0, kend, vecA != 0, t);
-        if (b_in && k0 + BK <= kend) LB::load_fast(rb, B, ldb, n0, k0, t);
-        else LB::load(rb, B, ldb, n0, N, k0, kend, vecB != 0, t);
-        if (do_cs) cs_add(ra);
-    };
-    if (ntile > 0) {
-        fetch(kbeg, ra0, rb0);
-        LA::store(ra0, smA[0], t);
-        LB::store(rb0, smB[0], t);
-        if (ntile > 1) fetch(kbeg + BK, ra0, rb0);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    // one iteration: `pa/pb` hold tile it+1, `qa/qb` receive tile it+2
-    auto step = [&](int it, float4 (&pa)[LA::NV], float4 (&pb)[LB::NV], float4 (&qa)[LA::NV], float4 (&qb)[LB::NV]) {
-        if (it + 2 < ntile) fetch(kbeg + (it + 2) * BK, qa, qb);
-        const float* sa = smA[cur] + kh * LA::LD + wm * WM + l31;
-        const float* sb = smB[cur] + kh * LB::LD + wn * WN + l31;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* sa = smA[buf] + kh * LA::LD + wm * WM + l31;
+        const float* sb = smB[buf] + kh * LB::LD + wn * WN + l31;
         // operand fragments of k-pair kk+1 are read from LDS before the MFMAs of k-pair kk are issued
         float a[2][TM], b[2][TN];
 #pragma unroll
@@ -206,17 +185,77 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __re
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (it + 1 < ntile) {
-            LA::store(pa, smA[cur ^ 1], t);
-            LB::store(pb, smB[cur ^ 1], t);
-        }
-        __syncthreads();
-        cur ^= 1;
     };
-    for (int it = 0; it < ntile; it += 2) {
-        step(it, ra0, rb0, ra1, rb1);
-        if (it + 1 < ntile) step(it + 1, ra1, rb1, ra0, rb0);
+    auto put = [&](const f32x4 (&ra)[LA::NV], const f32x4 (&rb)[LB::NV], int buf) __attribute__((always_inline)) {
+        if (do_cs) cs_add(ra);
+        LA::store(ra, smA[buf], t);
+        LB::store(rb, smB[buf], t);
+    };
+    // Interior workgroups (every row, column and K tile in range: block-uniform, decided once) run a two-stage
+    // register pipeline of straight 16-byte loads.  Tile t is fetched into stage t & 1 and stored to LDS buffer t & 1 one
+    // step before it is consumed:
+    //     step(t):  fetch(t + 2) -> stage t & 1 | MFMAs on LDS[t & 1] | store stage (t + 1) & 1 -> LDS[(t + 1) & 1]
+    // With K = 256 a 64x64 workgroup runs only 8 steps of 16 MFMAs (~0.4 us) each, far less than a global-load latency.
+    // The steady-state loop is unconditional and the last <= 3 tiles are straight-line code: a load behind a branch
+    // (a conditional prefetch, or the per-tile fast/edge choice this kernel used to make) forces the compiler's
+    // s_waitcnt insertion to merge both sides of the join, and it then drained the tiles in flight (vmcnt(0)) at the
+    // head of every iteration -- 46 % of the wave cycles were parked there (profiles/r1e_instruction_mix.md).
+    const bool interior = vecA && vecB && m0 + BM <= M && n0 + BN <= N && (kend - kbeg) % BK == 0 && ntile > 0;
+    if (interior) {
+        f32x4 ra0[LA::NV], rb0[LB::NV], ra1[LA::NV], rb1[LB::NV];
+        auto fetch = [&](int k0, f32x4 (&ra)[LA::NV], f32x4 (&rb)[LB::NV]) __attribute__((always_inline)) {
+            LA::load_fast(ra, A, lda, m0, k0, t);
+            LB::load_fast(rb, B, ldb, n0, k0, t);
+        };
+        fetch(kbeg, ra0, rb0);
+        put(ra0, rb0, 0);
+        if (ntile == 1) {
+            __syncthreads();
+            compute(0);
+        } else {
+            fetch(kbeg + BK, ra1, rb1);
+            __syncthreads();
+            int it = 0;
+            for (; it + 3 < ntile; it += 2) {                 // `it` stays even: stage / buffer roles are static
+                fetch(kbeg + (it + 2) * BK, ra0, rb0);
+                compute(0);
+                put(ra1, rb1, 1);
+                __syncthreads();
+                fetch(kbeg + (it + 3) * BK, ra1, rb1);
+                compute(1);
+                put(ra0, rb0, 0);
+                __syncthreads();
+            }
+            if (ntile - it == 3) {                            // tile it in LDS[0], tile it + 1 in flight (stage 1)
+                fetch(kbeg + (it + 2) * BK, ra0, rb0);
+                compute(0);
+                put(ra1, rb1, 1);
+                __syncthreads();
+                compute(1);
+                put(ra0, rb0, 0);
+                __syncthreads();
+                compute(0);
+            } else {
+                compute(0);
+                put(ra1, rb1, 1);
+                __syncthreads();
+                compute(1);
+            }
+        }
+    } else {
+        // edge workgroups (last row / column of tiles, unaligned operands, the split holding a partial K tile): guarded
+        // loads, one register stage, no overlap
+        f32x4 ra[LA::NV], rb[LB::NV];
+        for (int it = 0; it < ntile; ++it) {
+            LA::load(ra, A, lda, m0, M, kbeg + it * BK, kend, vecA != 0, t);
+            LB::load(rb, B, ldb, n0, N, kbeg + it * BK, kend, vecB != 0, t);
+            put(ra, rb, 0);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
     }
+    __syncthreads();
 
     if (do_cs) {                                   // block-level combine of the column sums, then one atomic per column
         float* red = smA[0];                       // all tile reads are done (barrier at the end of the last iteration)

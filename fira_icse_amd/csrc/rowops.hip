@@ -419,9 +419,13 @@ __global__ void prep_kernel(int B, int L, int S, int T, const int32_t* __restric
                             const int32_t* __restrict__ tar, int32_t* __restrict__ mem_valid,
                             int32_t* __restrict__ tar_valid, float* __restrict__ pos_code, float* __restrict__ pos_tar,
                             int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row,
-                            int32_t* __restrict__ iota) {
+                            int32_t* __restrict__ iota, float* __restrict__ loss_sum, int32_t* __restrict__ n_tok) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int W = L + S;
+    if (i == 0) {                                // the step's loss accumulators start at zero (no separate fills)
+        if (loss_sum) *loss_sum = 0.f;
+        if (n_tok) *n_tok = 0;
+    }
     if (i < B * W) {
         const int b = i / W, j = i - b * W;
         mem_valid[i] = (j < L ? sou[b * L + j] : sub[b * S + j - L]) != 0;
@@ -514,10 +518,10 @@ int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid) {
 }
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
          int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
-         int32_t* compact_row, int32_t* iota) {
+         int32_t* compact_row, int32_t* iota, float* loss_sum, int32_t* n_tok) {
     const int n = std::max(std::max(B * (L + S), B * T), (L + T) * FIRA_D);
     hipLaunchKernelGGL(prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid, tar_valid,
-                       pos_code, pos_tar, R, rows, compact_row, iota);
+                       pos_code, pos_tar, R, rows, compact_row, iota, loss_sum, n_tok);
     FIRA_CHECK_LAUNCH("prep");
     return 0;
 }

@@ -54,6 +54,8 @@ SIGNATURES = {
     "fira_decode_workspace_bytes": (_Z, [_DP, _I, _I]),
     "fira_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_gemm_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
+    "fira_weight_shadow": (_I, [_P, _I, _I, _P, _P, _P]),
+    "fira_gemm_bf16_wb": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_csr_spmm_f32": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I]),
     "fira_embed_gather_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I]),
     "fira_embed_gather_bwd": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I]),

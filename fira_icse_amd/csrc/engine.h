@@ -19,6 +19,18 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
 int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                  const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
+// bf16 weight shadows (gemm_bf16.hip): table of the 2-D weights the GEMMs read, one conversion launch per step
+struct ShadowEntry { int64_t offset; int rows, cols; };
+constexpr int SHADOW_MAX = 64;
+struct ShadowTable {
+    int n = 0;
+    int tile_start[SHADOW_MAX + 1] = {0};
+    ShadowEntry e[SHADOW_MAX];
+};
+int weight_shadows(hipStream_t s, const ShadowTable& tab, const float* P, uint16_t* Wb, uint16_t* WbT);
+int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
+                    int ldc, const float* bias, int flags, int splitk, const int32_t* c_rows = nullptr,
+                    const float* relu_mask = nullptr);
 int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                               float* C, int ldc, float* colsum);
 int gemm_bf16_group_flush(hipStream_t s);

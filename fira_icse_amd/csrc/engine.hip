@@ -12,6 +12,8 @@
 //   backward      gradient temporaries of the same shapes (ping-pong node buffers, dkv_all, ...)
 #include "engine.h"
 #include <stdlib.h>
+#include <map>
+#include <mutex>
 
 namespace fira {
 
@@ -59,6 +61,7 @@ struct Plan {
     // backward temporaries (training only)
     float *dXa, *dXb, *dNB2, *dCB_a, *dvtab_all;
     float *zero_beg = nullptr, *zero_end = nullptr;
+    uint16_t *wb = nullptr, *wbt = nullptr;      // bf16 shadows of the 2-D weights, as stored / transposed (bf16 mode)
     float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
@@ -75,6 +78,12 @@ struct Plan {
         compact_row = a.get<int32_t>((size_t)TB);
         iota = a.get<int32_t>((size_t)TB);
         inv_ntok = a.f(64);
+        {
+            const Layout* lay = get_layout(&d);
+            const size_t tot = lay ? (size_t)lay->total : 0;
+            wb = a.get<uint16_t>(tot);
+            wbt = a.get<uint16_t>(tot + 64);     // + slack: an edge chunk may be read whole behind the last tensor
+        }
         X.resize(nl + 1);
         for (int l = 0; l <= nl; ++l) X[l] = a.f((size_t)NB * D);
         enc.resize(nl);
@@ -156,10 +165,81 @@ struct DtypeScope {
     explicit DtypeScope(int d) : prev(g_dtype) { g_dtype = d; }
     ~DtypeScope() { g_dtype = prev; }
 };
+// bf16 weight shadows of the current call (workspace-resident, refreshed by one launch at the start of the call):
+// [g_P, g_P + g_total) is the fp32 parameter buffer they mirror, at identical offsets
+static thread_local const float* g_P = nullptr;
+static thread_local int64_t g_total = 0;
+static thread_local const uint16_t* g_Wb = nullptr;
+static thread_local const uint16_t* g_WbT = nullptr;
+static thread_local const ShadowTable* g_tab = nullptr;
+
+// every 2-D weight a GEMM of the training / dev path reads, in the shapes the engine multiplies them in
+static const ShadowTable* shadow_table(const Layout& L) {
+    static std::mutex mu;
+    static std::map<const Layout*, ShadowTable*> cache;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(&L);
+    if (it != cache.end()) return it->second;
+    ShadowTable* t = new ShadowTable();
+    const int D = FIRA_D;
+    auto add = [&](int64_t off, int rows, int cols) {
+        if (t->n == SHADOW_MAX) return;
+        t->e[t->n] = ShadowEntry{off, rows, cols};
+        t->tile_start[t->n + 1] = t->tile_start[t->n] + cdiv(rows, 64) * cdiv(cols, 64);
+        ++t->n;
+    };
+    for (int l = 0; l < L.d.n_layer; ++l) {
+        add(L.enc[l].wqk, 2 * D, D);
+        add(L.enc[l].wo, D, D);
+        add(L.dec[l].wqkv, 3 * D, D);
+        add(L.dec[l].wo_s, D, D);
+        add(L.dec[l].wq_c, D, D);
+        add(L.dec[l].wo_c, D, D);
+        add(L.dec[l].w1, L.d.d_ff, D);
+        add(L.dec[l].w2, D, L.d.d_ff);
+    }
+    add(L.wkv_all, L.d.n_layer * 2 * D, D);
+    add(L.wout, L.d.vocab, D);
+    add(L.ws, D, D);
+    add(L.wt, D, D);
+    cache[&L] = t;
+    return t;
+}
+struct ShadowScope {            // publishes / withdraws the shadows of the running call
+    ShadowScope(const float* P, int64_t total, const uint16_t* wb, const uint16_t* wbt, const ShadowTable* tab) {
+        g_P = P; g_total = total; g_Wb = wb; g_WbT = wbt; g_tab = tab;
+    }
+    ~ShadowScope() { g_P = nullptr; g_total = 0; g_Wb = nullptr; g_WbT = nullptr; g_tab = nullptr; }
+};
+// shadow of the weight (or contiguous row slice of a weight) starting at W: as stored, or transposed (+ its row pitch)
+static bool shadow_of(const float* W, bool transposed, const uint16_t** out, int* ld) {
+    static const bool off_switch = [] { const char* e = getenv("FIRA_NO_SHADOW"); return e && e[0] == '1'; }();   // A/B
+    if (off_switch || !g_Wb || !g_tab || W < g_P || W >= g_P + g_total) return false;
+    const int64_t off = W - g_P;
+    for (int i = 0; i < g_tab->n; ++i) {
+        const ShadowEntry& e = g_tab->e[i];
+        if (off < e.offset || off >= e.offset + (int64_t)e.rows * e.cols) continue;
+        const int64_t rel = off - e.offset;
+        if (rel % e.cols) return false;
+        if (!transposed) { *out = g_Wb + off; *ld = e.cols; }
+        else { *out = g_WbT + e.offset + rel / e.cols; *ld = e.rows; }
+        return true;
+    }
+    return false;
+}
 static inline int gemm_any(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B,
                            int ldb, float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                            const int32_t* c_rows = nullptr, const float* relu_mask = nullptr) {
-    if (g_dtype == 1) return gemm_bf16_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+    if (g_dtype == 1) {
+        // forward (B = W [N,K]) and data gradient (B = W [K,N], reduced over its rows) read the bf16 shadows: the same
+        // kernel with a k-contiguous bf16 B operand, half the weight bytes and no transposing loads
+        const uint16_t* wb;
+        int ldw;
+        if (!tA && !colsum && gemm_bf16_takes(M, N, K) && lda % 4 == 0 && shadow_of(B, !tB, &wb, &ldw) &&
+            (tB ? ldb == K : ldb == N) && ldw % 8 == 0 && ((uintptr_t)wb % 16) == 0)
+            return gemm_bf16_wb_ex(s, M, N, K, A, lda, wb, ldw, C, ldc, bias, flags, splitk, c_rows, relu_mask);
+        return gemm_bf16_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
+    }
     return gemm_f32_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
 }
 
@@ -683,6 +763,10 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     FIRA_REQUIRE(!opts || opts->dtype == 0 || opts->dtype == 1, "fira_train_opts.dtype must be 0 (fp32) or 1 (bf16)");
     DtypeScope dtype_scope(opts ? opts->dtype : 0);
     TRY(side().init());
+    const bool bf16 = opts && opts->dtype == 1;
+    const ShadowTable* tab = bf16 ? shadow_table(*L) : nullptr;
+    ShadowScope shadow_scope(params, L->total, bf16 ? p.wb : nullptr, bf16 ? p.wbt : nullptr, tab);
+    if (bf16) TRY(weight_shadows(c.s, *tab, params, p.wb, p.wbt));
     int R = p.TB;
     const int32_t* rows = p.iota;
     if (opts && opts->compact_head && batch->head_rows) {
@@ -716,6 +800,9 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
     Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
     c.loss_sum = loss_sum;
     c.n_tok = n_tok;
+    const ShadowTable* tab = dtype == 1 ? shadow_table(*L) : nullptr;
+    ShadowScope shadow_scope(params, L->total, dtype == 1 ? p.wb : nullptr, dtype == 1 ? p.wbt : nullptr, tab);
+    if (dtype == 1) TRY(weight_shadows(c.s, *tab, params, p.wb, p.wbt));
     TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
     TRY(head_forward(c, p.TB, p.iota, loss_sum, n_tok, ids_out, 0));

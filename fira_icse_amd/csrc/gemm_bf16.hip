@@ -25,6 +25,7 @@
 //     re-reads hit its private 4 MiB L2.
 #include "engine.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace fira {
@@ -138,20 +139,65 @@ struct StageR {
     }
 };
 
+// ---- k-contiguous operand already stored in bf16 (the weight shadows): source element (r, k) at src[r*ld + k] ---------
+// 16 bytes = one 8-element chunk per load, no conversion, half the bytes and half the staging registers.
+template <int ROWS>
+struct StageKb {
+    static constexpr int NV = ROWS / 32;
+    uint4 v[NV];
+    __device__ __forceinline__ void load_fast(const uint16_t* __restrict__ src, int ld, int r0, int k0, int t) {
+        const uint16_t* base = src + (size_t)r0 * ld + k0;
+        const unsigned o = (unsigned)(t >> 3) * (unsigned)ld + (unsigned)(t & 7) * 8u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const uint4*>(base + (o + 32u * i * (unsigned)ld));
+    }
+    // edge tiles: rows clamped (their products are never stored); chunks past k_end are zero; a chunk that straddles
+    // k_end is read whole (the shadow buffer continues behind every tensor) and its tail half-words are cleared
+    __device__ __forceinline__ void load(const uint16_t* __restrict__ src, int ld, int r0, int r_end, int k0, int k_end, int t) {
+        const int k = k0 + (t & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint16_t* q = src + (size_t)min(r0 + (t >> 3) + 32 * i, r_end - 1) * ld;
+            uint4 x = *reinterpret_cast<const uint4*>(q + (k < k_end ? k : 0));
+            const int nv = k_end - k;                             // valid elements of this chunk (<= 0: none)
+            uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = (2 * j < nv) ? 0xffffu : 0u, hi = (2 * j + 1 < nv) ? 0xffff0000u : 0u;
+                w[j] &= (lo | hi);
+            }
+            v[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __device__ __forceinline__ void store(char* __restrict__ lds, int t) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int r = (t >> 3) + 32 * i;
+            *reinterpret_cast<uint4*>(lds + r * 128 + (((t & 7) ^ lds_swz(r)) << 4)) = v[i];
+        }
+    }
+    __device__ __forceinline__ void colsum_add(float (&)[4]) const {}
+};
+
 template <int ROWS, bool CONTIG_K, int SLOT>
 struct StageSel { using type = StageR<ROWS, SLOT>; };
 template <int ROWS, int SLOT>
 struct StageSel<ROWS, true, SLOT> { using type = StageK<ROWS>; };
+// B operand type: float (rounded while staged) or uint16_t (bf16 weight shadow, always k-contiguous)
+template <int ROWS, bool CONTIG_K, typename BT>
+struct StageSelB { using type = typename StageSel<ROWS, CONTIG_K, 1>::type; };
+template <int ROWS>
+struct StageSelB<ROWS, true, uint16_t> { using type = StageKb<ROWS>; };
 
 // One BM x BN output tile (tm, tn) over the K range of split z, by the 256 threads of a workgroup.
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, typename BT = float>
 __device__ __forceinline__ void gemm_bf16_tile(int M, int N, int K, const float* __restrict__ A, int lda,
-                                               const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
+                                               const BT* __restrict__ B, int ldb, float* __restrict__ C, int ldc,
                                                const float* __restrict__ bias, int flags, int splitk, int k_chunk,
                                                float* __restrict__ colsum, const int32_t* __restrict__ c_rows,
                                                const float* __restrict__ relu_mask, int tm, int tn, int z) {
     using SA = typename StageSel<BM, !TA, 0>::type;       // A stored [M,K] (k contiguous) unless TA
-    using SB = typename StageSel<BN, TB, 1>::type;        // B stored [N,K] (k contiguous) when TB
+    using SB = typename StageSelB<BN, TB, BT>::type;      // B stored [N,K] (k contiguous) when TB
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) char sm[2 * (BM + BN) * 128];
 
@@ -340,9 +386,9 @@ __device__ __forceinline__ bool tile_of_block(int tiles_m, int tiles_n, int spli
     return true;
 }
 
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, typename BT = float>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                        const BT* __restrict__ B, int ldb, float* __restrict__ C,
                                                         int ldc, const float* __restrict__ bias, int flags,
                                                         int tiles_m, int tiles_n, int splitk, int k_chunk, int spread_n,
                                                         int chunk, float* __restrict__ colsum,
@@ -350,8 +396,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(int M, int N, int K, con
                                                         const float* __restrict__ relu_mask) {
     int tm, tn, z;
     if (!tile_of_block(tiles_m, tiles_n, splitk, spread_n, chunk, tm, tn, z)) return;
-    gemm_bf16_tile<BM, BN, TA, TB>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, k_chunk, colsum, c_rows, relu_mask,
-                                   tm, tn, z);
+    gemm_bf16_tile<BM, BN, TA, TB, BT>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, k_chunk, colsum, c_rows,
+                                       relu_mask, tm, tn, z);
 }
 
 // Grouped weight gradients: dW_i += dY_i^T X_i (+ db_i) for up to GROUP_MAX independent problems in ONE launch -- the
@@ -385,8 +431,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_grouped_wgrad_kernel(GroupTable
                                         q.splitk, q.k_chunk, q.colsum, nullptr, nullptr, tm, tn, z);
 }
 
-template <int BM, int BN>
-static int launch_bf16(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B,
+template <int BM, int BN, typename BT>
+static int launch_bf16(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const BT* B,
                        int ldb, float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                        const int32_t* c_rows, const float* relu_mask) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
@@ -395,16 +441,98 @@ static int launch_bf16(hipStream_t s, int tA, int tB, int M, int N, int K, const
     const int spread_n = (long)N > (long)M ? 1 : 0;
     const int chunk = cdiv(tiles_m * tiles_n * splitk, 8);
     dim3 grid(8 * chunk);
-#define FIRA_GO(TA, TB)                                                                                           \
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
+#define FIRA_GO(TA, TB)                                                                                               \
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, BT>), grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, \
                        bias, flags, tiles_m, tiles_n, splitk, k_chunk, spread_n, chunk, colsum, c_rows, relu_mask)
-    if (!tA && tB) FIRA_GO(false, true);
-    else if (!tA && !tB) FIRA_GO(false, false);
-    else if (tA && !tB) FIRA_GO(true, false);
-    else FIRA_GO(true, true);
+    if constexpr (std::is_same<BT, uint16_t>::value) {
+        FIRA_GO(false, true);                         // weight shadows: always activations [M,K] x shadow [N,K]
+    } else {
+        if (!tA && tB) FIRA_GO(false, true);
+        else if (!tA && !tB) FIRA_GO(false, false);
+        else if (tA && !tB) FIRA_GO(true, false);
+        else FIRA_GO(true, true);
+    }
 #undef FIRA_GO
     FIRA_CHECK_LAUNCH("gemm_bf16");
     return 0;
+}
+
+// Latency kernel for the skinny products of the decoder (M = B*30 target rows; a [1920,256]x[256,256] product is
+// 0.25 GFLOP -- 0.1 us of bf16 MFMA time -- so the tiled kernel's four dependent K steps ARE its run time).  As in
+// gemm_small.hip: one 32x32 output tile per workgroup, its 4 waves split K in chunks of 64, every wave fetches its operand
+// fragments straight into registers (all loads of a wave in flight together: one memory latency), converts them to bf16,
+// runs 4 MFMAs per chunk, and the four partial tiles are combined through LDS.  The reduction order of an MFMA chain is
+// free, so inside a chunk lane-half kh takes the CONTIGUOUS k range kh*32 .. kh*32+31 (8 k per MFMA step): a k-contiguous
+// operand row is then eight 16-byte loads per lane.
+template <bool B_KCONTIG, typename BT = float>
+__global__ __launch_bounds__(256) void gemm_bf16_small_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
+                                                              const BT* __restrict__ B, int ldb, float* __restrict__ C,
+                                                              int ldc, const float* __restrict__ bias, int flags,
+                                                              const int32_t* __restrict__ c_rows,
+                                                              const float* __restrict__ relu_mask) {
+    __shared__ float red[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const float* pa = A + (size_t)min(m0 + l31, M - 1) * lda + kh * 32;      // clamped rows: masked at the store
+    const BT* pb = B_KCONTIG ? B + (size_t)min(n0 + l31, N - 1) * ldb + kh * 32
+                             : B + (size_t)(kh * 32) * ldb + min(n0 + l31, N - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = K / 64;
+    for (int c = wave; c < nchunk; c += 4) {
+        f32x4 a[8], b[8];
+        uint4 bb[4];                                        // bf16 shadow: 32 k of this lane = 4 x 16 bytes, used as is
+        const f32x4* qa = reinterpret_cast<const f32x4*>(pa + c * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = qa[q];
+        if constexpr (std::is_same<BT, uint16_t>::value) {
+            const uint4* qb = reinterpret_cast<const uint4*>(pb + c * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bb[q] = qb[q];
+        } else if (B_KCONTIG) {
+            const f32x4* qb = reinterpret_cast<const f32x4*>(pb + c * 64);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[q] = qb[q];
+        } else {
+            const float* qb = pb + (size_t)c * 64 * ldb;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                b[q] = f32x4{qb[(size_t)(4 * q) * ldb], qb[(size_t)(4 * q + 1) * ldb], qb[(size_t)(4 * q + 2) * ldb],
+                             qb[(size_t)(4 * q + 3) * ldb]};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                       // MFMA step s: k = kh*32 + s*8 .. +7 of this chunk
+            uint4 ua, ub;
+            ua.x = pack_bf16(a[2 * s].x, a[2 * s].y); ua.y = pack_bf16(a[2 * s].z, a[2 * s].w);
+            ua.z = pack_bf16(a[2 * s + 1].x, a[2 * s + 1].y); ua.w = pack_bf16(a[2 * s + 1].z, a[2 * s + 1].w);
+            if constexpr (std::is_same<BT, uint16_t>::value) {
+                ub = bb[s];
+            } else {
+                ub.x = pack_bf16(b[2 * s].x, b[2 * s].y); ub.y = pack_bf16(b[2 * s].z, b[2 * s].w);
+                ub.z = pack_bf16(b[2 * s + 1].x, b[2 * s + 1].y); ub.w = pack_bf16(b[2 * s + 1].z, b[2 * s + 1].w);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub),
+                                                          acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    const bool relu = flags & FIRA_GEMM_RELU, accum = flags & FIRA_GEMM_ACCUM;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        const int r = idx >> 6, ln = idx & 63;
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
+        if (row >= M || col >= N) continue;
+        float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        if (bias) v += bias[col];
+        float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;
+        if (accum) v += *p;
+        if (relu) v = fmaxf(v, 0.f);
+        if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;     // fused ReLU backward
+        *p = v;
+    }
 }
 
 // Products this kernel does not take (handled by the fp32 kernels, i.e. computed more precisely, never less):
@@ -428,6 +556,16 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic; 0: 128x128; 1, 2: 64x64
+    // skinny forward / dgrad shapes (the decoder): up to ~4 rounds of 32x32 tiles the latency kernel wins
+    static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();
+    if (tile < 0 && splitk <= 1 && !colsum && !tA && small_mode && K % 64 == 0 &&
+        (long)cdiv(M, 32) * cdiv(N, 32) <= 1024) {
+        dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        if (tB) hipLaunchKernelGGL(gemm_bf16_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask);
+        else hipLaunchKernelGGL(gemm_bf16_small_kernel<false>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask);
+        FIRA_CHECK_LAUNCH("gemm_bf16_small");
+        return 0;
+    }
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
     // 128x128 (one workgroup per CU, 2x fewer operand re-reads) only pays on long reductions with plenty of tiles
     // (measured: K = 3072 dgrad / wgrad of the cross K|V projection 1.4x faster, every K = 256 shape 1.5-1.9x slower)
@@ -497,8 +635,93 @@ int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A
     return 0;
 }
 
+// C[M,N] (+)= A[M,K] (fp32, rounded while staged) . Bb[N,K]^T with Bb a bf16 weight shadow (k contiguous): the forward
+// (Bb = shadow of W) and the data gradient (Bb = shadow of W^T) of every nn.Linear in bf16 mode.
+int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
+                    int ldc, const float* bias, int flags, int splitk, const int32_t* c_rows, const float* relu_mask) {
+    if (M <= 0 || N <= 0) return 0;
+    FIRA_REQUIRE(M >= 32 && N >= 32 && K >= 32 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Bb % 16) == 0 && lda % 4 == 0 &&
+                 ldb % 8 == 0, "gemm_bf16_wb: unsupported shape / alignment %dx%dx%d", M, N, K);
+    FIRA_REQUIRE(!(relu_mask && (splitk > 1 || c_rows)), "gemm_bf16_wb: the fused ReLU mask needs a plain output");
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K);
+    const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
+    static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();
+    if (splitk <= 1 && small_mode && K % 64 == 0 && (long)cdiv(M, 32) * cdiv(N, 32) <= 1024) {
+        dim3 grid(cdiv(N, 32), cdiv(M, 32));
+        hipLaunchKernelGGL((gemm_bf16_small_kernel<true, uint16_t>), grid, dim3(256), 0, s, M, N, K, A, lda, Bb, ldb, C, ldc,
+                           bias, flags & 3, c_rows, relu_mask);
+        FIRA_CHECK_LAUNCH("gemm_bf16_small");
+        return 0;
+    }
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    const int tile = (t128 >= 256 && K >= 2048) ? 0 : 2;
+    if (splitk == 0) {
+        splitk = 1;
+        const long tiles = tile == 0 ? t128 : t64;
+        if (can_split && tiles < 512 && K >= 512) {
+            long want = std::min((768 + tiles - 1) / tiles, (long)K / 256);
+            if (want >= 8) want = want / 8 * 8;
+            splitk = (int)std::max(1L, want);
+        }
+    }
+    FIRA_REQUIRE(!(splitk > 1 && !can_split), "gemm_bf16_wb: split-K needs accumulate semantics and no relu");
+    flags &= 3;
+    if (tile == 0) return launch_bf16<128, 128, uint16_t>(s, 0, 1, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags, splitk, nullptr, c_rows, relu_mask);
+    return launch_bf16<64, 64, uint16_t>(s, 0, 1, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags, splitk, nullptr, c_rows, relu_mask);
+}
+
+// ---- weight shadows -------------------------------------------------------------------------------------------------
+// One launch per step: every 2-D weight the bf16 GEMMs read is copied to bf16 twice -- as stored ([out, in]: forward)
+// and transposed ([in, out]: data gradient) -- at the same offset as in the fp32 parameter buffer.  64x64 tiles through
+// LDS: both the read and the two writes are row-contiguous.
+__global__ __launch_bounds__(256) void weight_shadow_kernel(ShadowTable tab, const float* __restrict__ P,
+                                                            uint16_t* __restrict__ Wb, uint16_t* __restrict__ WbT) {
+    __shared__ float tile[64][65];
+    int e = 0;
+    while (e + 1 < tab.n && (int)blockIdx.x >= tab.tile_start[e + 1]) ++e;
+    const ShadowEntry& q = tab.e[e];
+    const int tl = blockIdx.x - tab.tile_start[e];
+    const int tiles_c = (q.cols + 63) / 64;
+    const int r0 = (tl / tiles_c) * 64, c0 = (tl % tiles_c) * 64;
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < q.rows && c < q.cols) {
+            v = P[q.offset + (size_t)r * q.cols + c];
+            Wb[q.offset + (size_t)r * q.cols + c] = (uint16_t)(pack_bf16(v, 0.f) & 0xffffu);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {                 // row c0 + i of the transposed matrix [cols, rows]
+        const int c = c0 + i, r = r0 + tx;
+        if (c < q.cols && r < q.rows) WbT[q.offset + (size_t)c * q.rows + r] = (uint16_t)(pack_bf16(tile[tx][i], 0.f) & 0xffffu);
+    }
+}
+int weight_shadows(hipStream_t s, const ShadowTable& tab, const float* P, uint16_t* Wb, uint16_t* WbT) {
+    if (tab.n == 0) return 0;
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    hipLaunchKernelGGL(weight_shadow_kernel, dim3(tab.tile_start[tab.n]), dim3(256), 0, s, tab, P, Wb, WbT);
+    FIRA_CHECK_LAUNCH("weight_shadows");
+    return 0;
+}
+
 }  // namespace fira
 
+extern "C" int fira_weight_shadow(void* stream, int rows, int cols, const float* W, uint16_t* Wb, uint16_t* WbT) {
+    FIRA_REQUIRE(rows > 0 && cols > 0 && W && Wb && WbT, "fira_weight_shadow: bad argument");
+    fira::ShadowTable tab;
+    tab.n = 1;
+    tab.e[0] = fira::ShadowEntry{0, rows, cols};
+    tab.tile_start[1] = fira::cdiv(rows, 64) * fira::cdiv(cols, 64);
+    return fira::weight_shadows((hipStream_t)stream, tab, W, Wb, WbT);
+}
+extern "C" int fira_gemm_bf16_wb(void* stream, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb,
+                                 float* C, int ldc, const float* bias, int flags, int splitk) {
+    FIRA_REQUIRE(splitk >= 0, "fira_gemm_bf16_wb: splitk must be >= 0 (0 = automatic)");
+    return fira::gemm_bf16_wb_ex((hipStream_t)stream, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags, splitk, nullptr, nullptr);
+}
 extern "C" int fira_gemm_bf16(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
                               const float* B, int ldb, float* C, int ldc, const float* bias, int flags, int splitk) {
     FIRA_REQUIRE(splitk >= 0, "fira_gemm_bf16: splitk must be >= 0 (0 = automatic)");

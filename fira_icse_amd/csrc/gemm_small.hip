@@ -13,6 +13,7 @@
 //   B_KCONTIG = true   B is an nn.Linear weight [N,K]  (forward)
 //   B_KCONTIG = false  B is [K,N]                      (dgrad): 16 row-segment loads of 128 bytes per half-wave
 #include "engine.h"
+#include <stdlib.h>
 
 namespace fira {
 
@@ -93,6 +94,8 @@ bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const fl
                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,
                     const float* relu_mask) {
     *rc = 0;
+    static const int mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();   // A/B switch
+    if (mode == 0 && M > 64) return false;          // 0: only the decode-sized products (M <= 64) stay here
     // beyond ~4 rounds of 32x32 tiles the LDS-tiled kernel's operand reuse wins; M <= 64 (decode) always lands here
     const long tiles = (long)cdiv(M, 32) * cdiv(N, 32);
     if (tA || (M > 64 && tiles > 1024) || K % 32 != 0 || K < 64 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0) return false;

@@ -41,6 +41,28 @@ def gemm(A, B, *, transA=False, transB=True, bias=None, relu=False, out=None, ac
     return out
 
 
+def weight_shadow(W):
+    """bf16 shadows of a 2-D fp32 weight: (as stored [rows, cols], transposed [cols, rows]), raw bf16 in int16 tensors."""
+    rows, cols = W.shape
+    wb = torch.empty((rows, cols), dtype=torch.int16, device=W.device)
+    wbt = torch.empty((cols, rows), dtype=torch.int16, device=W.device)
+    check(_lib.lib().fira_weight_shadow(cur_stream(), rows, cols, ptr(_f32(W)), ptr(wb), ptr(wbt)), "fira_weight_shadow")
+    return wb, wbt
+
+
+def gemm_wb(A, Bb, *, bias=None, relu=False, out=None, accumulate=False, splitk=1):
+    """C = A . Bb^T with Bb a bf16 shadow [N, K] (int16 tensor, any row pitch that is a multiple of 8)."""
+    M, K = A.shape
+    N = Bb.shape[0]
+    assert Bb.shape[1] == K and Bb.dtype == torch.int16 and Bb.stride(1) == 1
+    if out is None:
+        out = (torch.zeros if accumulate else torch.empty)((M, N), dtype=torch.float32, device=A.device)
+    flags = (1 if relu else 0) | (2 if accumulate else 0)
+    check(_lib.lib().fira_gemm_bf16_wb(cur_stream(), M, N, K, ptr(A), A.stride(0), ptr(Bb), Bb.stride(0), ptr(out),
+                                       out.stride(0), ptr(bias), flags, splitk), "fira_gemm_bf16_wb")
+    return out
+
+
 def csr_spmm(rowptr, col, val, X, graph_rows=0, variant=0):
     X = _f32(X)
     Y = torch.empty_like(X)

@@ -141,6 +141,16 @@ int fira_gemm_bf16(void* stream, int transA, int transB, int M, int N, int K,
                    const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    const float* bias, int flags, int splitk);
 
+/* bf16 weight shadows.  In bf16 mode the model-level entry points keep, inside the workspace, a bf16 copy of every 2-D
+ * weight as stored ([out, in]) and transposed ([in, out]), refreshed by one launch per call: the forward product reads
+ * the first, the data gradient the second -- both as the k-contiguous operand of the same kernel, at half the weight
+ * bytes and without transposing loads.  Op-level forms of the two steps:
+ *   fira_weight_shadow : Wb[rows, cols] = bf16(W), WbT[cols, rows] = bf16(W^T)                  (uint16_t = raw bf16)
+ *   fira_gemm_bf16_wb  : C[M,N] (+)= A[M,K] (fp32, rounded while staged) . Bb[N,K]^T (+bias)(relu); ldb % 8 == 0      */
+int fira_weight_shadow(void* stream, int rows, int cols, const float* W, uint16_t* Wb, uint16_t* WbT);
+int fira_gemm_bf16_wb(void* stream, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb,
+                      float* C, int ldc, const float* bias, int flags, int splitk);
+
 /* Y[r,:] = sum_j val[j] * X[col[j],:]  over CSR row r (d = 256).  The GCN aggregation
  * torch.bmm(edge.float(), x) (gnn_transformer.py:80); its backward is the same call because
  * the normalised adjacency is symmetric.  variant: 0 auto, 1 wave-per-row gather, 2 LDS-staged

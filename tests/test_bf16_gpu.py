@@ -79,6 +79,32 @@ def test_gemm_bf16_strided_output_row_map_and_padded_ld():
     assert rel_err(out, bf(dl[:, :24650]) @ bf(Wo)) < 6e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1920, 256, 256), (24000, 256, 256), (130, 768, 256), (1920, 256, 1024), (700, 24650, 256),
+                                   (1000, 512, 3072)])
+def test_weight_shadows_forward_and_dgrad(M, N, K):
+    """Forward Y = X W^T reads the stored shadow, the data gradient dX = dY W the transposed one -- both through the
+    k-contiguous bf16 B operand; row slices of a stacked weight (the per-layer K|V blocks) use the parent's pitch."""
+    from fira_icse_amd import ops
+    X, W, bias = randn(M, K, seed=1), randn(N, K, seed=2), randn(N, seed=3)
+    wb, wbt = ops.weight_shadow(W)
+    assert torch.equal(wb.view(torch.bfloat16).float(), W.to(torch.bfloat16).float())
+    assert torch.equal(wbt.view(torch.bfloat16).float(), W.t().to(torch.bfloat16).float())
+    ref = bf(X) @ bf(W).t() + bias.double()
+    assert rel_err(ops.gemm_wb(X, wb, bias=bias), ref) < 2e-6
+    assert rel_err(ops.gemm_wb(X, wb, bias=bias, relu=True), ref.clamp_min(0)) < 2e-6
+    if N % 8 == 0:
+        dY = randn(M, N, seed=4)
+        C0 = randn(M, K, seed=5)
+        dref = bf(dY) @ bf(W)
+        assert rel_err(ops.gemm_wb(dY, wbt), dref) < 2e-6
+        for sk in (1, 0, 4):
+            assert rel_err(ops.gemm_wb(dY, wbt, out=C0.clone(), accumulate=True, splitk=sk), dref + C0.double()) < 3e-6, sk
+        if N >= 512:                       # rows [256, 512) of the stacked weight: a column slice of the transposed shadow
+            sl = slice(256, 512)
+            got = ops.gemm_wb(dY[:, sl], wbt[:, sl])
+            assert rel_err(got, bf(dY[:, sl]) @ bf(W[sl])) < 2e-6
+
+
 @pytest.fixture(scope="module")
 def small():
     from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict

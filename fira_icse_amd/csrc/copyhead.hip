@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
                                                              const float* __restrict__ dscore,
                                                              float* __restrict__ dsrc, float* __restrict__ dtgt,
                                                              float* __restrict__ dw, float* __restrict__ dbias,
-                                                             const int32_t* __restrict__ mem_valid, int slots) {
+                                                             const int32_t* __restrict__ mem_valid, int slots,
+                                                             float* __restrict__ part) {
     constexpr int SLOTS_MAX = 16;
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     __shared__ float sm_dt[T_MAX * FIRA_D];
@@ -98,9 +99,12 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
     }
     __syncthreads();
     const unsigned mask = sm_mask;                                 // uniform: rows of this tile with any gradient
+    float* const my_part = part ? part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * COPY_PART_STRIDE : nullptr;
     if (mask == 0u) {                                              // nothing flows into this tile's memory slots
         for (int j = j0 + wave; j < j_end; j += 4)
             *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (my_part)
+            for (int i = t0; i < FIRA_D + 1; i += 256) my_part[i] = 0.f;
         return;
     }
     for (int i = t0; i < T * (FIRA_D / 4); i += 256)
@@ -153,6 +157,12 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
     __syncthreads();
     for (int i = t0; i < T * FIRA_D; i += 256)
         if ((mask >> (i / FIRA_D)) & 1u) unsafeAtomicAdd(&dtgt[(size_t)b * T * FIRA_D + i], sm_dt[i]);
+    if (my_part) {
+        // deferred reduction (rowops.hip): B * S/16 workgroups adding to the same 257 addresses serialise in L2 (~50 ns per
+        // same-address atomic: 1536 workgroups = ~75 us, most of this kernel's former run time)
+        for (int i = t0; i < FIRA_D + 1; i += 256) my_part[i] = sm_dw[i];
+        return;
+    }
     for (int i = t0; i < FIRA_D; i += 256) unsafeAtomicAdd(&dw[i], sm_dw[i]);
     if (t0 == 0) unsafeAtomicAdd(dbias, sm_dw[FIRA_D]);
 }
@@ -440,20 +450,22 @@ int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const f
                    const float* bias, float* score) {
     return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1, nullptr, nullptr, 0);
 }
+int copy_score_bwd_blocks(int B, int S) { return B > 0 ? cdiv(S, 16) * B : 0; }
 int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                      const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid) {
+                      const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid,
+                      float* part) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
     const int slots = 16;                                   // == SLOTS_MAX of the kernel
     hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
-                       dtgt, dw, dbias, mem_valid, slots);
+                       dtgt, dw, dbias, mem_valid, slots, part);
     FIRA_CHECK_LAUNCH("copy_score_bwd");
     return 0;
 }
 int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
-    return copy_score_bwd_ex(s, B, T, S, src, tgt, w, dscore, dsrc, dtgt, dw, dbias, nullptr);
+    return copy_score_bwd_ex(s, B, T, S, src, tgt, w, dscore, dsrc, dtgt, dw, dbias, nullptr, nullptr);
 }
 int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
               float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,

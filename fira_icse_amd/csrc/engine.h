@@ -60,15 +60,30 @@ int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, floa
                            int out_bstride, int out_off, int padding_idx, int table_rows);
 int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark, float* out,
                     float dropout, uint64_t seed, uint32_t site);
+// part (optional): the workgroups store their partial dvtab [4*256] rows there (combination_bwd_blocks(M) rows) instead of
+// adding to dvtab with atomics; the caller reduces them later (deferred_reduce)
 int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
-                    const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site);
+                    const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site,
+                    float* part = nullptr);
+int combination_bwd_blocks(int M);
+// deferred column reductions (rowops.hip)
+struct RedEntry { float* dst; const float* src; int width, n_part, stride; };
+constexpr int RED_MAX = 64;
+struct RedTable {
+    int n = 0;
+    int wg_start[RED_MAX + 1] = {0};
+    RedEntry e[RED_MAX];
+};
+int deferred_reduce(hipStream_t s, RedTable& tab);       // dst[c] += sum_p src[p*stride + c]; empties the table
 // y_rows (optional): output row r is stored at row y_rows[r]
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row = nullptr,
                       const float* r1_col = nullptr);   // x += r1_row[r] * r1_col[:] before the dropout
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
-                      uint32_t site, const int32_t* rows = nullptr);   // rows: dy and ds are row-mapped (dy[rows[r]], ds[rows[r]])
+                      uint32_t site, const int32_t* rows = nullptr,    // rows: dy and ds are row-mapped (dy[rows[r]], ds[rows[r]])
+                      float* part = nullptr);   // part: [add_layernorm_bwd_blocks(M), 512] partial {dgamma | dbeta} rows instead of atomics
+int add_layernorm_bwd_blocks(int M);
 int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float* dc, float* dW2, float* db1);
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight = nullptr);
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
@@ -107,8 +122,12 @@ int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const f
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* bias, float* score, int qpk, const int32_t* mem_valid,
                       const int32_t* tar_label = nullptr, int V = 0);
+// part (optional): [copy_score_bwd_blocks(B, S), COPY_PART_STRIDE] partial rows {dw[256] | dbias} instead of atomics
 int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
-                      const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid);
+                      const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid,
+                      float* part = nullptr);
+int copy_score_bwd_blocks(int B, int S);
+constexpr int COPY_PART_STRIDE = 264;
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
                 float* best_p);

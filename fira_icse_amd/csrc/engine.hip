@@ -62,6 +62,9 @@ struct Plan {
     float *dXa, *dXb, *dNB2, *dCB_a, *dvtab_all;
     float *zero_beg = nullptr, *zero_end = nullptr;
     uint16_t *wb = nullptr, *wbt = nullptr;      // bf16 shadows of the 2-D weights, as stored / transposed (bf16 mode)
+    uint16_t *w21b = nullptr, *w21bt = nullptr;  // the same for the folded GCN weights W21 (formed per step)
+    float* red_buf = nullptr;                    // per-workgroup partial rows of the deferred column reductions
+    size_t red_cap = 0;
     float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
@@ -83,6 +86,8 @@ struct Plan {
             const size_t tot = lay ? (size_t)lay->total : 0;
             wb = a.get<uint16_t>(tot);
             wbt = a.get<uint16_t>(tot + 64);     // + slack: an edge chunk may be read whole behind the last tensor
+            w21b = a.get<uint16_t>((size_t)nl * D * D);
+            w21bt = a.get<uint16_t>((size_t)nl * D * D + 64);
         }
         X.resize(nl + 1);
         for (int l = 0; l <= nl; ++l) X[l] = a.f((size_t)NB * D);
@@ -117,6 +122,11 @@ struct Plan {
         if (training) {
             dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
             dCB_a = a.f((size_t)CB * D);
+            red_cap = (size_t)nl * ((size_t)std::min(1024, cdiv(NB, 8)) + std::min(1024, cdiv(CB, 8))) * 2 * D   // encoder LNs
+                    + (size_t)3 * nl * std::min(1024, cdiv(TB, 8)) * 2 * D                                      // decoder LNs
+                    + (size_t)nl * cdiv(CB, 16) * 4 * D                                                          // Combination
+                    + (size_t)cdiv(L + S, 16) * B * COPY_PART_STRIDE + 4096;                                     // copy head
+            red_buf = a.f(red_cap);
             // buffers that must start a backward pass at zero, contiguous: ONE fill per step (zero_beg .. zero_end)
             zero_beg = (float*)a.get<char>(0);
             dvtab_all = a.f((size_t)4 * nl * D);
@@ -172,6 +182,10 @@ static thread_local int64_t g_total = 0;
 static thread_local const uint16_t* g_Wb = nullptr;
 static thread_local const uint16_t* g_WbT = nullptr;
 static thread_local const ShadowTable* g_tab = nullptr;
+static thread_local const float* g_W21 = nullptr;          // folded GCN weights [nl, 256, 256] (workspace) and their shadows
+static thread_local int64_t g_W21n = 0;
+static thread_local const uint16_t* g_W21b = nullptr;
+static thread_local const uint16_t* g_W21bT = nullptr;
 
 // every 2-D weight a GEMM of the training / dev path reads, in the shapes the engine multiplies them in
 static const ShadowTable* shadow_table(const Layout& L) {
@@ -209,12 +223,23 @@ struct ShadowScope {            // publishes / withdraws the shadows of the runn
     ShadowScope(const float* P, int64_t total, const uint16_t* wb, const uint16_t* wbt, const ShadowTable* tab) {
         g_P = P; g_total = total; g_Wb = wb; g_WbT = wbt; g_tab = tab;
     }
-    ~ShadowScope() { g_P = nullptr; g_total = 0; g_Wb = nullptr; g_WbT = nullptr; g_tab = nullptr; }
+    ~ShadowScope() {
+        g_P = nullptr; g_total = 0; g_Wb = nullptr; g_WbT = nullptr; g_tab = nullptr;
+        g_W21 = nullptr; g_W21n = 0; g_W21b = nullptr; g_W21bT = nullptr;
+    }
 };
 // shadow of the weight (or contiguous row slice of a weight) starting at W: as stored, or transposed (+ its row pitch)
 static bool shadow_of(const float* W, bool transposed, const uint16_t** out, int* ld) {
     static const bool off_switch = [] { const char* e = getenv("FIRA_NO_SHADOW"); return e && e[0] == '1'; }();   // A/B
-    if (off_switch || !g_Wb || !g_tab || W < g_P || W >= g_P + g_total) return false;
+    if (off_switch || !g_Wb || !g_tab) return false;
+    if (g_W21b && W >= g_W21 && W < g_W21 + g_W21n) {           // a folded GCN weight: uniform [256,256] blocks
+        const int64_t off = W - g_W21;
+        if (off % (FIRA_D * FIRA_D)) return false;
+        *out = (transposed ? g_W21bT : g_W21b) + off;
+        *ld = FIRA_D;
+        return true;
+    }
+    if (W < g_P || W >= g_P + g_total) return false;
     const int64_t off = W - g_P;
     for (int i = 0; i < g_tab->n; ++i) {
         const ShadowEntry& e = g_tab->e[i];
@@ -359,6 +384,40 @@ static inline int flush_grouped_wgrads(hipStream_t s) {
     return g_dtype == 1 ? gemm_bf16_group_flush(sd.stream) : gemm_group_flush(sd.stream);
 }
 
+// Deferred column reductions of the backward pass (rowops.hip: deferred_reduce): kernels park one partial row per
+// workgroup in Plan::red_buf; the table is flushed (ONE launch) before the mid-event for the decoder-side parameters
+// and at the end of the backward pass for the encoder-side ones.
+struct RedCollector {
+    float* buf = nullptr;
+    size_t cap = 0, used = 0;
+    RedTable tab;
+    void reset(float* b, size_t c) { buf = b; cap = c; used = 0; tab.n = 0; }
+    float* alloc(size_t n) {                      // nullptr: no room -> the kernel falls back to atomics
+        if (!buf || used + n > cap || tab.n + 4 > RED_MAX) return nullptr;
+        float* p = buf + used;
+        used += (n + 63) / 64 * 64;
+        return p;
+    }
+    void add(float* dst, const float* src, int width, int n_part, int stride) {
+        tab.e[tab.n++] = RedEntry{dst, src, width, n_part, stride};
+    }
+};
+static RedCollector& red() { static thread_local RedCollector r; return r; }
+
+// LayerNorm backward with its dgamma / dbeta reduction deferred
+static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma, float* ds,
+                  float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed, uint32_t st,
+                  const int32_t* rows = nullptr) {
+    const int nb = add_layernorm_bwd_blocks(M);
+    float* part = red().alloc((size_t)nb * 2 * FIRA_D);
+    TRY(add_layernorm_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st, rows, part));
+    if (part) {
+        red().add(dgamma, part, FIRA_D, nb, 2 * FIRA_D);
+        red().add(dbeta, part + FIRA_D, FIRA_D, nb, 2 * FIRA_D);
+    }
+    return 0;
+}
+
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
 static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
 
@@ -413,6 +472,16 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const EncLayer& w = L.enc[l];
             TRY(gemm_f32_ex(fs, 0, 0, D, D, D, c.P + w.fc2w, D, c.P + w.fc1w, D, p.W21 + (size_t)l * D * D, D, nullptr, 0, 0, nullptr));
             TRY(gemm_f32_ex(fs, 0, 1, D, 1, D, c.P + w.fc2w, D, c.P + w.fc1b, D, p.c21 + (size_t)l * D, 1, nullptr, 0, 0, nullptr));
+        }
+        if (g_Wb) {                                  // bf16 mode: shadows of the folded weights, on the same stream
+            ShadowTable t21;
+            for (int l = 0; l < p.nl && l < SHADOW_MAX; ++l) {
+                t21.e[l] = ShadowEntry{(int64_t)l * D * D, D, D};
+                t21.tile_start[l + 1] = t21.tile_start[l] + cdiv(D, 64) * cdiv(D, 64);
+                t21.n = l + 1;
+            }
+            TRY(weight_shadows(fs, t21, p.W21, p.w21b, p.w21bt));
+            g_W21 = p.W21; g_W21n = (int64_t)p.nl * D * D; g_W21b = p.w21b; g_W21bT = p.w21bt;
         }
         if (ax) TRY(side_mark(&ev_fold));
     }
@@ -526,6 +595,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
 
     gemm_group_reset();
     gemm_bf16_group_reset();
+    red().reset(p.red_buf, p.red_cap);
     // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
     // The vocabulary dgrad ([R, V] x [V, 256], the head's largest product) and the copy branch are independent until
     // both land in ddec: the former runs on the side stream under the latter.
@@ -544,8 +614,16 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     }
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad_grouped(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
-    TRY(copy_score_bwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres,
-                          p.mem_valid));
+    {
+        const int nb = copy_score_bwd_blocks(p.B, Sm);
+        float* part = red().alloc((size_t)nb * COPY_PART_STRIDE);
+        TRY(copy_score_bwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres,
+                              p.mem_valid, part));
+        if (part) {
+            red().add(G + L.wres, part, D, nb, COPY_PART_STRIDE);
+            red().add(G + L.bres, part + D, 1, nb, COPY_PART_STRIDE);
+        }
+    }
     TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
     TRY(linear_wgrad_grouped(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
     TRY(rows_move(s, 0, Mc, D, p.dsrc_c, p.dsrc, bt.mem_dst, nullptr));
@@ -568,7 +646,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         DecGrad& g = p.decg[l];
         const float* x_in = l == 0 ? p.x0 : p.dec[l - 1].x_f;
         // FeedForward (gnn_transformer.py:170-174)
-        TRY(add_layernorm_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
+        TRY(ln_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
                               c.p_drop, c.seed, site(l, SITE_FFN)));
         TRY(linear_wgrad_grouped(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
         // d hidden = (dYf W2) masked by the saved activation > 0: ReLU backward in the GEMM epilogue
@@ -576,7 +654,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad_grouped(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
         TRY(linear_dgrad(s, p.TB, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
         // cross attention
-        TRY(add_layernorm_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
+        TRY(ln_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
                               c.p_drop, c.seed, site(l, SITE_CROSS)));
         TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
         TRY(linear_dgrad(s, p.TB, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
@@ -592,7 +670,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
         TRY(linear_dgrad(s, p.TB, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
         // self attention
-        TRY(add_layernorm_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
+        TRY(ln_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
                               c.p_drop, c.seed, site(l, SITE_SELF)));
         TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
         TRY(linear_dgrad(s, p.TB, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
@@ -617,6 +695,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
     }
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
+    TRY(deferred_reduce(s, red().tab));      // decoder LayerNorms, copy head: their gradients are final after this launch
     if (mid_event) {                         // gradients of [0, split) are final from here on
         if (side().stream && side().enabled) TRY(side_join(s));
         hipError_t e = hipEventRecord(mid_event, s);
@@ -633,7 +712,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
         EncGrad& g = p.encg[l];
-        TRY(add_layernorm_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, g.dY2, G + w.ln2g, G + w.ln2b, c.p_gcn,
+        TRY(ln_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, g.dY2, G + w.ln2g, G + w.ln2b, c.p_gcn,
                               c.seed, site(l, SITE_GCN)));
         // GCN, folded form (see encoder_forward): Y = U W21^T + r c^T + b2 with U = A_hat X
         //   weight space: dW21 += dY^T U (+ db2 by the fused column sums), dc += dY^T r           (side stream)
@@ -654,12 +733,19 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, other, D, 0, 1, 1, nullptr));   // other = ds + A_hat dU
         // Combination on the code rows, in place inside `other` through the code-row map: the LayerNorm backward reads
         // dG[code rows] and leaves the residual-branch gradient there; the q|k projection's dgrad adds to the same rows
-        TRY(add_layernorm_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,
+        TRY(ln_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,
                               c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
         TRY(linear_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
         TRY(linear_dgrad(s, Cc, D, D, g.dYc, D, c.P + w.wo, p.dCB_a, D, false));               // d c
-        TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, g.dqk,
-                            p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE)));
+        {
+            const int nb = combination_bwd_blocks(Cc);
+            float* part = red().alloc((size_t)nb * 4 * D);
+            TRY(combination_bwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, p.dCB_a, g.dqk,
+                                p.dvtab_all + l * D, p.nl * D, c.p_drop, c.seed, site(l, SITE_GATE), part));
+            if (part)
+                for (int k = 0; k < 4; ++k)
+                    red().add(p.dvtab_all + (size_t)k * p.nl * D + l * D, part + k * D, D, nb, 4 * D);
+        }
         TRY(linear_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
         TRY(gemm_any(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
                         bt.code_rows));                                                        // other = dX[l]
@@ -680,6 +766,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         else
             TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     }
+    TRY(deferred_reduce(s, red().tab));      // encoder LayerNorms, dvtab_all (read by the products below)
     // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
     TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
                     FIRA_GEMM_ACCUM, 1, G + L.b2_all));

@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
                                                               const float* __restrict__ dout,
                                                               float* __restrict__ dqk, float* __restrict__ dvtab,
                                                               int lddv, float p, float inv_keep, uint64_t seed,
-                                                              uint32_t site, int rows_per_block) {
+                                                              uint32_t site, int rows_per_block,
+                                                              float* __restrict__ part) {
     __shared__ float red[4 * FIRA_D];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < 4 * FIRA_D; i += 256) red[i] = 0.f;
@@ -221,6 +222,10 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(&red[a * FIRA_D + lane * 4 + e], dv_acc[a][e]);
     __syncthreads();
+    if (part) {                                   // deferred reduction: see add_layernorm_bwd_kernel
+        for (int i = t; i < 4 * FIRA_D; i += 256) part[(size_t)blockIdx.x * 4 * FIRA_D + i] = red[i];
+        return;
+    }
     for (int i = t; i < 4 * FIRA_D; i += 256) {
         const float x = red[i];
         if (x != 0.f) unsafeAtomicAdd(&dvtab[(size_t)(i / FIRA_D) * lddv + (i % FIRA_D)], x);
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float p, float inv_keep, uint64_t seed, uint32_t site,
                                                                 int rows_per_block,
-                                                                const int32_t* __restrict__ rows) {
+                                                                const int32_t* __restrict__ rows,
+                                                                float* __restrict__ part) {
     __shared__ float red[2 * FIRA_D];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < 2 * FIRA_D; i += 256) red[i] = 0.f;
@@ -341,6 +347,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
     atomicAdd(&red[FIRA_D + lane * 4 + 0], db.x); atomicAdd(&red[FIRA_D + lane * 4 + 1], db.y);
     atomicAdd(&red[FIRA_D + lane * 4 + 2], db.z); atomicAdd(&red[FIRA_D + lane * 4 + 3], db.w);
     __syncthreads();
+    if (part) {
+        // deferred reduction (engine): every workgroup stores its 2 x 256 partial sums; one reducer launch adds them up.
+        // (n workgroups adding to the SAME 512 addresses serialise in L2: ~30 ns per same-address atomic, i.e. ~15 us of
+        // tail for 500 workgroups -- more than the kernel's streaming time for the decoder-sized launches)
+        for (int i = t; i < 2 * FIRA_D; i += 256) part[(size_t)blockIdx.x * 2 * FIRA_D + i] = red[i];
+        return;
+    }
     for (int i = t; i < FIRA_D; i += 256) {
         unsafeAtomicAdd(&dgamma[i], red[i]);
         unsafeAtomicAdd(&dbeta[i], red[FIRA_D + i]);
@@ -614,14 +627,16 @@ int combination_fwd(hipStream_t s, int M, const float* qk, const float* vtab, in
     FIRA_CHECK_LAUNCH("combination_fwd");
     return 0;
 }
+int combination_bwd_blocks(int M) { return M > 0 ? cdiv(M, 16) : 0; }
 int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, int ldv, const int32_t* mark,
-                    const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site) {
+                    const float* dout, float* dqk, float* dvtab, int lddv, float dropout, uint64_t seed, uint32_t site,
+                    float* part) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     const int rpb = 16;
     hipLaunchKernelGGL(combination_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, qk, vtab, ldv, mark, dout, dqk,
-                       dvtab, lddv, dropout, inv_keep, seed, site, rpb);
+                       dvtab, lddv, dropout, inv_keep, seed, site, rpb, part);
     FIRA_CHECK_LAUNCH("combination_bwd");
     return 0;
 }
@@ -636,16 +651,21 @@ int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const fl
     FIRA_CHECK_LAUNCH("add_layernorm_fwd");
     return 0;
 }
+// rows per workgroup / workgroups of one launch.  With atomics: ~500 workgroups (enough to fill the chip, few enough that
+// the same-address atomics do not dominate); with deferred partials: up to 1024 workgroups of >= 8 rows.
+static int ln_bwd_rpb(int M, bool deferred) {
+    return deferred ? std::max(8, cdiv(cdiv(M, 1024), 8) * 8) : std::max(8, std::min(128, cdiv(cdiv(M, 512), 8) * 8));
+}
+int add_layernorm_bwd_blocks(int M) { return M > 0 ? cdiv(M, ln_bwd_rpb(M, true)) : 0; }
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
-                      uint32_t site, const int32_t* rows) {
+                      uint32_t site, const int32_t* rows, float* part) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
-    // ~500 workgroups: enough to fill the chip, few enough that the dgamma/dbeta atomics do not serialise
-    const int rpb = std::max(8, std::min(128, cdiv(cdiv(M, 512), 8) * 8));
+    const int rpb = ln_bwd_rpb(M, part != nullptr);
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
-                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb, rows);
+                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb, rows, part);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");
     return 0;
 }
@@ -700,6 +720,34 @@ __global__ void mark_history_kernel(int BR, int T, int step, const int32_t* __re
 int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist) {
     hipLaunchKernelGGL(mark_history_kernel, dim3(cdiv(BR, 256)), dim3(256), 0, s, BR, T, step, tokens, hist);
     FIRA_CHECK_LAUNCH("mark_history");
+    return 0;
+}
+
+// Deferred column reductions: dst[c] += sum_p src[p * stride + c] for a table of (dst, src, width, n_part, stride).
+// The backward kernels that reduce over rows into a few hundred addresses (LayerNorm gamma/beta, the Combination's
+// 4-row value table, the copy head's w / bias) store one partial row per workgroup; this kernel, launched once for the
+// decoder-side entries and once for the encoder-side ones, adds them up: 64 columns x 4 partial-row phases per workgroup.
+__global__ __launch_bounds__(256) void deferred_reduce_kernel(RedTable tab) {
+    __shared__ float sm[4][64];
+    int e = 0;
+    while (e + 1 < tab.n && (int)blockIdx.x >= tab.wg_start[e + 1]) ++e;
+    const RedEntry& q = tab.e[e];
+    const int c = (blockIdx.x - tab.wg_start[e]) * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < q.width)
+        for (int p = ph; p < q.n_part; p += 4) acc += q.src[(size_t)p * q.stride + c];
+    sm[ph][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ph == 0 && c < q.width) q.dst[c] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+int deferred_reduce(hipStream_t s, RedTable& tab) {
+    if (tab.n == 0) return 0;
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    tab.wg_start[0] = 0;
+    for (int i = 0; i < tab.n; ++i) tab.wg_start[i + 1] = tab.wg_start[i] + cdiv(tab.e[i].width, 64);
+    hipLaunchKernelGGL(deferred_reduce_kernel, dim3(tab.wg_start[tab.n]), dim3(256), 0, s, tab);
+    tab.n = 0;
+    FIRA_CHECK_LAUNCH("deferred_reduce");
     return 0;
 }
 

@@ -38,6 +38,25 @@ def main():
         print("| `%s` | %d | %.1f | %.1f | %.2f | %.1f | %.1f | %.1f | %s | %s | %s |" %
               (k[:120], v[0], v[0] / steps, v[1] / steps, 100 * v[1] / tot, v[1] / v[0], v[2], v[3], v[4], v[5], v[6]))
     print("\ntotal kernel time: %.1f us over %d dispatches (%.1f us/step over %d steps)" % (tot, len(rows), tot / steps, steps))
+    if per_q and qcol:
+        main_q = max(per_q, key=lambda r: r[1])[0]
+        rows_q = cur.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id where d.%s = ? "
+                             "order by d.start" % (disp, sym, qcol), (main_q,)).fetchall()
+        aggq = collections.OrderedDict()
+        gaps, prev_end = 0.0, None
+        for name, st, en in rows_q:
+            short = re.sub(r"\(.*", "", name).replace(".kd", "")
+            a = aggq.setdefault(short, [0, 0.0])
+            a[0] += 1; a[1] += (en - st) / 1e3
+            if prev_end is not None and st > prev_end and st - prev_end < 50000:      # idle gaps < 50 us between kernels
+                gaps += (st - prev_end) / 1e3
+            prev_end = max(prev_end or 0, en)
+        print("\nmain stream (%s): busy %.1f us/step, idle gaps between consecutive kernels %.1f us/step" %
+              (main_q, sum(v[1] for v in aggq.values()) / steps, gaps / steps))
+        print("\n| kernel on the main stream | calls/step | total us/step | avg us |")
+        print("|---|---|---|---|")
+        for k, v in sorted(aggq.items(), key=lambda kv: -kv[1][1])[:24]:
+            print("| `%s` | %.1f | %.1f | %.1f |" % (k[:110], v[0] / steps, v[1] / steps, v[1] / v[0]))
     if per_q:
         print("\n| stream / queue | dispatches | busy us/step | span ms |")
         print("|---|---|---|---|")

@@ -20,7 +20,7 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                  const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
 // bf16 weight shadows (gemm_bf16.hip): table of the 2-D weights the GEMMs read, one conversion launch per step
-struct ShadowEntry { int64_t offset; int rows, cols; };
+struct ShadowEntry { int64_t offset; int rows, cols, pitch_t; };   // pitch_t: row pitch of the transposed copy (elements)
 constexpr int SHADOW_MAX = 64;
 struct ShadowTable {
     int n = 0;

@@ -198,7 +198,10 @@ static const ShadowTable* shadow_table(const Layout& L) {
     const int D = FIRA_D;
     auto add = [&](int64_t off, int rows, int cols) {
         if (t->n == SHADOW_MAX) return;
-        t->e[t->n] = ShadowEntry{off, rows, cols};
+        // transposed shadow [cols, rows]: rows padded to a multiple of 8 elements so that every row starts 16-byte
+        // aligned.  Only the vocabulary projection needs padding (24650 -> 24656): its transposed copy spills 1.5 K
+        // elements past the tensor's own slot, into the slot of out_fc.bias -- a 1-D tensor, which has no shadow
+        t->e[t->n] = ShadowEntry{off, rows, cols, (rows + 7) / 8 * 8};
         t->tile_start[t->n + 1] = t->tile_start[t->n] + cdiv(rows, 64) * cdiv(cols, 64);
         ++t->n;
     };
@@ -247,7 +250,7 @@ static bool shadow_of(const float* W, bool transposed, const uint16_t** out, int
         const int64_t rel = off - e.offset;
         if (rel % e.cols) return false;
         if (!transposed) { *out = g_Wb + off; *ld = e.cols; }
-        else { *out = g_WbT + e.offset + rel / e.cols; *ld = e.rows; }
+        else { *out = g_WbT + e.offset + rel / e.cols; *ld = e.pitch_t; }
         return true;
     }
     return false;
@@ -295,10 +298,13 @@ struct SideStream {
         enabled = !(off && off[0] == '1');
         const char* narrow = getenv("FIRA_SIDE_WGRAD_ONLY");
         wide = !(narrow && narrow[0] == '1');
-        hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-        if (e != hipSuccess) return set_err("hipStreamCreate: %s", hipGetErrorString(e));
+        // weight gradients: LOWEST priority -- nothing waits for them before the end of the step (or the mid-event), and
+        // the big ones (the vocabulary projection: 138 MB of dlogits at batch 64) otherwise take the CUs from the
+        // dependent chain on the caller's stream exactly when it has only small kernels to offer
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
+        hipError_t e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least);
+        if (e != hipSuccess) return set_err("hipStreamCreate: %s", hipGetErrorString(e));
         e = hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);
         if (e != hipSuccess) return set_err("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
         events.resize(512);
@@ -476,7 +482,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         if (g_Wb) {                                  // bf16 mode: shadows of the folded weights, on the same stream
             ShadowTable t21;
             for (int l = 0; l < p.nl && l < SHADOW_MAX; ++l) {
-                t21.e[l] = ShadowEntry{(int64_t)l * D * D, D, D};
+                t21.e[l] = ShadowEntry{(int64_t)l * D * D, D, D, D};
                 t21.tile_start[l + 1] = t21.tile_start[l] + cdiv(D, 64) * cdiv(D, 64);
                 t21.n = l + 1;
             }

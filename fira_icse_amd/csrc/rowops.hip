@@ -726,25 +726,33 @@ int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, 
 // Deferred column reductions: dst[c] += sum_p src[p * stride + c] for a table of (dst, src, width, n_part, stride).
 // The backward kernels that reduce over rows into a few hundred addresses (LayerNorm gamma/beta, the Combination's
 // 4-row value table, the copy head's w / bias) store one partial row per workgroup; this kernel, launched once for the
-// decoder-side entries and once for the encoder-side ones, adds them up: 64 columns x 4 partial-row phases per workgroup.
+// decoder-side entries and once for the encoder-side ones, adds them up: a workgroup sums RED_ROWS partial rows of 64
+// columns (4 row phases) and adds the result to the destination.
+constexpr int RED_ROWS = 64;
 __global__ __launch_bounds__(256) void deferred_reduce_kernel(RedTable tab) {
     __shared__ float sm[4][64];
     int e = 0;
     while (e + 1 < tab.n && (int)blockIdx.x >= tab.wg_start[e + 1]) ++e;
     const RedEntry& q = tab.e[e];
-    const int c = (blockIdx.x - tab.wg_start[e]) * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const int w = blockIdx.x - tab.wg_start[e];
+    const int ncb = (q.width + 63) / 64;                 // column blocks of this entry
+    const int cb = w % ncb, chunk = w / ncb;             // this workgroup: 64 columns x RED_ROWS partial rows
+    const int c = cb * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const int p_end = min(q.n_part, (chunk + 1) * RED_ROWS);
     float acc = 0.f;
     if (c < q.width)
-        for (int p = ph; p < q.n_part; p += 4) acc += q.src[(size_t)p * q.stride + c];
+        for (int p = chunk * RED_ROWS + ph; p < p_end; p += 4) acc += q.src[(size_t)p * q.stride + c];
     sm[ph][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (ph == 0 && c < q.width) q.dst[c] += (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    if (ph == 0 && c < q.width)                          // <= n_part / RED_ROWS workgroups per address: a handful
+        unsafeAtomicAdd(&q.dst[c], (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]));
 }
 int deferred_reduce(hipStream_t s, RedTable& tab) {
     if (tab.n == 0) return 0;
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     tab.wg_start[0] = 0;
-    for (int i = 0; i < tab.n; ++i) tab.wg_start[i + 1] = tab.wg_start[i] + cdiv(tab.e[i].width, 64);
+    for (int i = 0; i < tab.n; ++i)
+        tab.wg_start[i + 1] = tab.wg_start[i] + cdiv(tab.e[i].width, 64) * cdiv(tab.e[i].n_part, RED_ROWS);
     hipLaunchKernelGGL(deferred_reduce_kernel, dim3(tab.wg_start[tab.n]), dim3(256), 0, s, tab);
     tab.n = 0;
     FIRA_CHECK_LAUNCH("deferred_reduce");

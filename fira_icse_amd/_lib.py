@@ -72,6 +72,7 @@ SIGNATURES = {
     "fira_copy_score_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fira_head_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
     "fira_adam_step": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
+    "fira_adam_step_mb": (_I, [_P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P, _P]),
     "fira_inv_count": (_I, [_P, _P, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_prof_enable": (None, [_I]),

@@ -32,15 +32,16 @@ int set_err(const char* fmt, ...);
 // time and the algorithmic work (FLOP for GEMM/attention, bytes for the memory-bound classes) per class.
 enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_NCLASS };
 bool prof_on();
-void prof_begin(hipStream_t s, int cls, double work, double bytes);
-void prof_end(hipStream_t s);
+int prof_begin(hipStream_t s, int cls, double work, double bytes);
+void prof_end(hipStream_t s, int idx);
 struct ProfScope {
     hipStream_t s;
     bool on;
+    int idx = -1;
     ProfScope(hipStream_t s_, int cls, double work, double bytes = 0.0) : s(s_), on(prof_on()) {
-        if (on) prof_begin(s, cls, work, bytes);
+        if (on) idx = prof_begin(s, cls, work, bytes);
     }
-    ~ProfScope() { if (on) prof_end(s); }
+    ~ProfScope() { if (on) prof_end(s, idx); }
 };
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

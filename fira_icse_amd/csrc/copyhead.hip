@@ -367,6 +367,29 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict_
     }
 }
 
+// The same step for micro-batched training: the gradient is g0 (+ g1), each the loss_SUM gradient of one micro-batch
+// computed concurrently on its own stream, and the normaliser 1 / max(n_tok0 (+ n_tok1), 1) of run_model.py:105 is formed
+// here from the device counters (no separate launch, no host sync).
+__global__ __launch_bounds__(256) void adam_mb_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g0,
+                                                      const float* __restrict__ g1, float* __restrict__ m,
+                                                      float* __restrict__ v, float lr, float beta1, float beta2, float eps,
+                                                      float bc1, float bc2_sqrt, const int32_t* __restrict__ n0,
+                                                      const int32_t* __restrict__ n1) {
+    const int nt = *n0 + (n1 ? *n1 : 0);
+    const float scale = 1.0f / (float)(nt > 0 ? nt : 1);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float gi = (g1 ? g0[i] + g1[i] : g0[i]) * scale;
+        const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
 // inv_scale[0] = 1 / max(n_tok, 1): the token-count normaliser of run_model.py:105 without a host sync
 __global__ void inv_count_kernel(const int32_t* __restrict__ n_tok, float* __restrict__ out) {
     const int n = *n_tok;
@@ -495,6 +518,18 @@ int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, floa
     FIRA_CHECK_LAUNCH("adam_step");
     return 0;
 }
+int adam_step_mb(hipStream_t s, int64_t n, float* p, const float* g0, const float* g1, float* m, float* v, float lr,
+                 float beta1, float beta2, float eps, int step, const int32_t* n0, const int32_t* n1) {
+    ProfScope prof(s, PROF_ADAM, 0.0);
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
+    hipLaunchKernelGGL(adam_mb_kernel, dim3(grid), dim3(256), 0, s, n, p, g0, g1, m, v, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), n0, n1);
+    FIRA_CHECK_LAUNCH("adam_step_mb");
+    return 0;
+}
 int inv_count(hipStream_t s, const int32_t* n_tok, float* out) {
     hipLaunchKernelGGL(inv_count_kernel, dim3(1), dim3(1), 0, s, n_tok, out);
     FIRA_CHECK_LAUNCH("inv_count");
@@ -517,6 +552,11 @@ int fira_head_loss(void* stream, int BT, int T, int V, int S, const int32_t* com
                    float* loss_sum, int32_t* n_tok, int32_t* argmax_out, int want_grad) {
     return fira::head_loss((hipStream_t)stream, BT, T, V, S, compact_row, logits, ldl, score, mem_valid, gate_logits,
                            tar_label, loss_sum, n_tok, argmax_out, want_grad);
+}
+int fira_adam_step_mb(void* stream, int64_t n, float* p, const float* g0, const float* g1, float* m, float* v, float lr,
+                      float beta1, float beta2, float eps, int step, const int32_t* n_tok0, const int32_t* n_tok1) {
+    FIRA_REQUIRE(p && g0 && m && v && n_tok0 && step >= 1, "fira_adam_step_mb: bad argument");
+    return fira::adam_step_mb((hipStream_t)stream, n, p, g0, g1, m, v, lr, beta1, beta2, eps, step, n_tok0, n_tok1);
 }
 int fira_inv_count(void* stream, const int32_t* n_tok, float* out) {
     return fira::inv_count((hipStream_t)stream, n_tok, out);

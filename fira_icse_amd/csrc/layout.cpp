@@ -41,17 +41,18 @@ struct ProfState {
 ProfState& PS() { static ProfState s; return s; }
 }  // namespace
 bool prof_on() { return PS().on; }
-void prof_begin(hipStream_t s, int cls, double work, double bytes) {
+int prof_begin(hipStream_t s, int cls, double work, double bytes) {
     ProfState& p = PS();
     std::lock_guard<std::mutex> g(p.mu);
     ProfRec r{cls, work, bytes, p.get(), p.get()};
     hipEventRecord(r.a, s);
     p.recs.push_back(r);
+    return (int)p.recs.size() - 1;        // the record this scope closes (two host threads may enqueue concurrently)
 }
-void prof_end(hipStream_t s) {
+void prof_end(hipStream_t s, int idx) {
     ProfState& p = PS();
     std::lock_guard<std::mutex> g(p.mu);
-    if (!p.recs.empty()) hipEventRecord(p.recs.back().b, s);
+    if (idx >= 0 && idx < (int)p.recs.size()) hipEventRecord(p.recs[idx].b, s);
 }
 
 namespace {

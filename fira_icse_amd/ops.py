@@ -208,6 +208,13 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, inv_scale=
                                     lr, beta1, beta2, eps, step, ptr(inv_scale)), "fira_adam_step")
 
 
+def adam_step_mb(p, g0, g1, m, v, lr, step, n_tok0, n_tok1=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam on g0 (+ g1) / max(n_tok0 (+ n_tok1), 1): one launch, normaliser formed on the device."""
+    check(_lib.lib().fira_adam_step_mb(cur_stream(), p.numel(), ptr(_f32(p)), ptr(_f32(g0)), ptr(g1), ptr(_f32(m)),
+                                       ptr(_f32(v)), lr, beta1, beta2, eps, step, ptr(_i32(n_tok0)), ptr(n_tok1)),
+          "fira_adam_step_mb")
+
+
 def inv_count(n_tok, out):
     check(_lib.lib().fira_inv_count(cur_stream(), ptr(_i32(n_tok)), ptr(_f32(out))), "fira_inv_count")
     return out

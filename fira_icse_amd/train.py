@@ -68,13 +68,13 @@ class Trainer:
             ops.adam_step(m.flat.data[split:live], m.gbuf[split:live], self.m[split:live], self.v[split:live], self.lr,
                           self.t, b1, b2, self.eps, inv_scale=self.inv)
             return
-        ops.inv_count(n_tok, self.inv)                          # loss_sum / n_tok stay in the model's own buffers
         self.t += 1
         # [live, total) holds the tensors no kernel touches (encoder.lstm, combination_list1, gate_fc): their gradient is
-        # None in the reference, so torch.optim.Adam skips them too
+        # None in the reference, so torch.optim.Adam skips them too.  1 / n_tok (run_model.py:105) is formed inside the
+        # Adam kernel from the device counter (no separate launch, no host sync).
         n = m.layout.live
-        ops.adam_step(m.flat.data[:n], m.gbuf[:n], self.m[:n], self.v[:n], self.lr, self.t, b1, b2, self.eps,
-                      inv_scale=self.inv)
+        ops.adam_step_mb(m.flat.data[:n], m.gbuf[:n], None, self.m[:n], self.v[:n], self.lr, self.t, n_tok, None, b1, b2,
+                         self.eps)
 
     def last_loss(self) -> float:
         """Mean token loss of the last (global) batch; synchronises."""

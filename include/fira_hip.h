@@ -239,6 +239,12 @@ int fira_head_loss(void* stream, int BT, int T, int V, int S, const int32_t* com
  * may be NULL) multiplies g first: 1/n_tok of run_model.py:105 without a host sync.              */
 int fira_adam_step(void* stream, int64_t n, float* p, const float* g, float* m, float* v,
                    float lr, float beta1, float beta2, float eps, int step, const float* inv_scale_ntok);
+/* Adam for a step whose batch ran as one or two micro-batches: g = g0 (+ g1, may be NULL), each the gradient of the
+ * micro-batch's loss SUM; the normaliser 1 / max(n_tok0 (+ n_tok1), 1) of run_model.py:105 is formed inside the kernel
+ * from the device token counters.                                                                                  */
+int fira_adam_step_mb(void* stream, int64_t n, float* p, const float* g0, const float* g1, float* m, float* v,
+                      float lr, float beta1, float beta2, float eps, int step, const int32_t* n_tok0,
+                      const int32_t* n_tok1);
 /* out[0] = 1 / max(n_tok[0], 1) on the device */
 int fira_inv_count(void* stream, const int32_t* n_tok, float* out);
 

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $REPO
 export TMPDIR=/tmp
 if [ "${2:-tests}" = "tests" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/tests.log 2>&1
+  timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 300 > $OUT/tests.log 2>&1
   echo "tests rc=$?" >> $OUT/tests.log
   tail -n 40 $OUT/tests.log
 fi

@@ -341,3 +341,26 @@ def test_adam_matches_torch():
         opt.step()
         ops.adam_step(p, gr, m, v, 1e-4, i + 1, inv_scale=inv)
         assert float((p - ref.data).abs().max()) < 2e-7
+
+
+def test_adam_micro_batch_form_matches_torch():
+    """fira_adam_step_mb: g = g0 (+ g1), normaliser 1 / max(n_tok0 (+ n_tok1), 1) formed on the device."""
+    from fira_icse_amd import ops
+    n = 70001
+    p0 = randn(n, seed=1)
+    ga, gb = [randn(n, seed=20 + i, scale=0.01) for i in range(3)], [randn(n, seed=30 + i, scale=0.01) for i in range(3)]
+    n0 = torch.tensor([5], dtype=torch.int32, device=DEV)
+    n1 = torch.tensor([3], dtype=torch.int32, device=DEV)
+    for two in (False, True):
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([ref], lr=1e-4)
+        p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for i in range(3):
+            ref.grad = (ga[i] + gb[i]) / 8 if two else ga[i] / 5
+            opt.step()
+            ops.adam_step_mb(p, ga[i], gb[i] if two else None, m, v, 1e-4, i + 1, n0, n1 if two else None)
+            assert float((p - ref.data).abs().max()) < 2e-7
+    zero = torch.zeros(1, dtype=torch.int32, device=DEV)        # no labelled token: the normaliser is 1, not inf
+    p = p0.clone()
+    ops.adam_step_mb(p, ga[0], None, torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1e-4, 1, zero)
+    assert bool(torch.isfinite(p).all())

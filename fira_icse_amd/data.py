@@ -321,10 +321,40 @@ class TransDataset:
     """
 
     def __init__(self, cfg: FiraConfig, data_name: str, root: str = ".",
-                 splits: Optional[Sequence[int]] = None, seed: int = 0, progress: bool = False):
+                 splits: Optional[Sequence[int]] = None, seed: int = 0, progress: bool = False,
+                 build: bool = True, wait_s: float = 24 * 3600.0):
+        """``build=False`` (ranks other than 0 of a multi-process run): never build the cache, wait for the rank that
+        does -- by polling the file system, so no collective with a timeout is involved (the first-run build is a pure
+        Python pass over ~90 k commits and can take many minutes)."""
         self.cfg, self.data_name, self.root = cfg, data_name, root
         cache = os.path.join(root, "fira_cache_%s.npz" % data_name)
-        if not os.path.exists(cache):
+        # what the cache depends on besides the raw files: a cache built with other splits / seed / lengths is stale
+        meta = json.dumps({"splits": list(splits) if splits is not None else None, "seed": int(seed),
+                           "lens": [cfg.sou_len, cfg.tar_len, cfg.att_len, cfg.ast_change_len, cfg.sub_token_len],
+                           "vocab": [cfg.vocab_size, cfg.ast_change_vocab_size]}, sort_keys=True)
+        meta_path = os.path.join(root, "fira_cache_meta.json")
+
+        def fresh():
+            if not (os.path.exists(cache) and os.path.exists(meta_path)):
+                return False
+            try:
+                with open(meta_path) as f:
+                    have = json.load(f)
+            except (OSError, ValueError):
+                return False
+            want = json.loads(meta)
+            if splits is None:                           # split sizes not specified: any cached split serves
+                want["splits"] = have.get("splits")
+            return have == want
+
+        if not build:
+            import time
+            t0 = time.time()
+            while not fresh():
+                if time.time() - t0 > wait_s:
+                    raise TimeoutError("no fresh %s after %.0f s" % (cache, wait_s))
+                time.sleep(0.5)
+        elif not fresh():
             raw = load_raw(root)
             n = len(raw["difftoken"])
             if splits is None:
@@ -335,9 +365,14 @@ class TransDataset:
             all_index = split_index(*splits, seed=seed)
             with open(os.path.join(root, "all_index"), "w") as f:
                 json.dump(all_index, f)
+            if os.path.exists(meta_path):
+                os.remove(meta_path)                     # the marker goes first and comes back last
             for name in ("train", "valid", "test"):
                 sub = _subset(full, all_index[name])
                 sub.save(os.path.join(root, "fira_cache_%s.npz" % name))
+            with open(meta_path + ".tmp", "w") as f:
+                f.write(meta)
+            os.replace(meta_path + ".tmp", meta_path)
         self.store = GraphStore.load(cfg, cache)
 
     def __len__(self):

@@ -86,15 +86,10 @@ class Run:
         self.cfg = FiraConfig(lr=a.lr, batch_size=bs, test_batch_size=a.test_batch_size, epoches=a.epochs,
                               beam_size=a.beam, vocab_size=len(self.vocab), ast_change_vocab_size=len(ast_vocab))
         splits = tuple(int(x) for x in a.splits.split(",")) if a.splits else None
-        # rank 0 builds the caches; the others wait and read them
-        if self.rank == 0:
-            self.sets = {n: data.TransDataset(self.cfg, n, root=self.root, splits=splits, seed=a.seed)
-                         for n in ("train", "valid", "test")}
-        if self.world > 1:
-            torch.distributed.barrier()
-        if self.rank != 0:
-            self.sets = {n: data.TransDataset(self.cfg, n, root=self.root, splits=splits, seed=a.seed)
-                         for n in ("train", "valid", "test")}
+        # rank 0 builds the caches (first run only: minutes of pure Python); the others poll the file system for the
+        # finished, matching cache -- no collective, so no process-group timeout can fire during the build
+        self.sets = {n: data.TransDataset(self.cfg, n, root=self.root, splits=splits, seed=a.seed, build=self.rank == 0)
+                     for n in ("train", "valid", "test")}
         with open(os.path.join(self.root, "all_index")) as f:
             self.all_index = json.load(f)
         os.makedirs(os.path.join(self.root, "OUTPUT"), exist_ok=True)

@@ -1,4 +1,6 @@
 """Host data layer against the fixtures the reference's Dataset.py produced (tests/golden/dataset_ref.npz)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -160,3 +162,32 @@ def test_compact_embedding_lists_point_at_the_right_nodes(skip_padding):
     g = node_rows[ast_rows]
     assert np.all(g % N >= L + S) and np.array_equal(hb.ast_change[g // N, g % N - L - S], ast_ids)
     assert ast_rows.shape[0] == int((hb.ast_change != 0).sum()) == np.unique(ast_rows).shape[0] and np.all(ast_ids != 0)
+
+
+def test_cache_is_rebuilt_when_its_inputs_change_and_followers_wait_for_it(tmp_path):
+    """the split cache is keyed by what it depends on (splits, seed, lengths) and ranks other than 0 wait
+    for it through the file system instead of a collective with a timeout."""
+    import json as _json
+    import threading
+    import time
+    cfg = FiraConfig()
+    root = str(tmp_path)
+    synth.write_dataset(root, util.load_golden_raw())
+    got = {}
+
+    def follower():                                   # a rank != 0: never builds, polls for a fresh cache
+        got["ds"] = data.TransDataset(cfg, "train", root=root, splits=util.GOLDEN_SPLIT, seed=0, build=False, wait_s=60)
+
+    th = threading.Thread(target=follower)
+    th.start()
+    time.sleep(0.3)
+    assert th.is_alive()                              # nothing to read yet
+    a = data.TransDataset(cfg, "train", root=root, splits=util.GOLDEN_SPLIT, seed=0)
+    th.join(30)
+    assert not th.is_alive() and np.array_equal(got["ds"].store.sou, a.store.sou)
+    idx0 = _json.load(open(os.path.join(root, "all_index")))
+    b = data.TransDataset(cfg, "train", root=root, splits=util.GOLDEN_SPLIT, seed=5)     # other seed: other split
+    idx5 = _json.load(open(os.path.join(root, "all_index")))
+    assert idx0 != idx5 and not np.array_equal(a.store.sou, b.store.sou)
+    c = data.TransDataset(cfg, "train", root=root, splits=(12, 6, 6), seed=5)            # other sizes: rebuilt again
+    assert len(c) == 12

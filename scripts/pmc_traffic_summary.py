@@ -1,6 +1,6 @@
 """Per-kernel HBM traffic from the two rocprofv3 --pmc passes of scripts/pmc_traffic.sh.
 
-    python scripts/pmc_traffic_summary.py gpurun_out/pmc_traffic profiles/<tag>_pmc_traffic.md profiles/traffic.json
+    python scripts/pmc_traffic_summary.py gpurun_out/pmc_traffic_<dtype> profiles/<tag>_pmc_traffic_<dtype>.md profiles/traffic.json <dtype>
 
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch.  On gfx950 FETCH_SIZE reports half of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section; calibrated here on adam_kernel and relu-sized streaming kernels whose traffic is
@@ -22,10 +22,12 @@ def load(path, counter):
 
 def main():
     src, md, js = sys.argv[1:4]
-    f = load(src + "/FETCH_SIZE/t_counter_collection.csv", "FETCH_SIZE")
-    w = load(src + "/WRITE_SIZE/t_counter_collection.csv", "WRITE_SIZE")
-    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/pmc_traffic.sh) over python bench.py --steps 2 "
-            "--warmup 1 --no-decode --no-cpu-baseline; FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads; "
+    dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
+    import glob
+    f = load(glob.glob(src + "/FETCH_SIZE/**/*counter_collection.csv", recursive=True)[0], "FETCH_SIZE")
+    w = load(glob.glob(src + "/WRITE_SIZE/**/*counter_collection.csv", recursive=True)[0], "WRITE_SIZE")
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/pmc_traffic.sh) over python bench.py --dtype <dtype> --steps 2 "
+            "--warmup 1 --no-decode --no-cpu-baseline --no-extras; FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads; "
             "check: adam_kernel must read 4 x and write 3 x the 124 MB parameter buffer), WRITE_SIZE as reported")
     rows = []
     for k in f:
@@ -34,7 +36,7 @@ def main():
         rows.append((k, n, kib / n, 2 * kib / n * 1024 / 1e6, wkib / max(wn, 1), wkib / max(wn, 1) * 1024 / 1e6))
     rows.sort(key=lambda r: -(r[3] + r[5]) * r[1])
     with open(md, "w") as o:
-        o.write("# HBM traffic per kernel (PMC), batch 32 training step\n\n%s\n\n" % note)
+        o.write("# HBM traffic per kernel (PMC), training step, dtype %s\n\n%s\n\n" % (dtype, note))
         o.write("| kernel | launches | FETCH_SIZE KiB/launch (raw) | read MB/launch (x2) | WRITE_SIZE KiB/launch | write MB/launch |\n|---|---|---|---|---|---|\n")
         for r in rows:
             if r[0].startswith("fira::"):
@@ -47,8 +49,15 @@ def main():
         return {"hbm_bytes_per_launch": (rd + wr) / max(n, 1), "read_bytes_per_launch": rd / max(n, 1),
                 "write_bytes_per_launch": wr / max(n, 1), "launches": n}
 
-    json.dump({"gemm": group(lambda k: "gemm_" in k), "spmm": group(lambda k: "spmm_" in k), "note": note},
-              open(js, "w"), indent=1)
+    try:
+        allj = json.load(open(js))
+        if "gemm" in allj:                  # round-1 layout (fp32 only): move it under its dtype
+            allj = {"f32": {k: allj[k] for k in ("gemm", "spmm") if k in allj}}
+    except Exception:
+        allj = {}
+    allj[dtype] = {"gemm": group(lambda k: "gemm_" in k), "spmm": group(lambda k: "spmm_" in k)}
+    allj["note"] = note
+    json.dump(allj, open(js, "w"), indent=1)
 
 
 if __name__ == "__main__":

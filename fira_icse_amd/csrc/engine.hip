@@ -276,6 +276,21 @@ static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int
                          float* Y, int ldy, int flags = 0) {
     return gemm_any(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 0, nullptr);
 }
+// y = LN(dropout(X W^T + b [+ r c^T]) + res): the closing step of every block.  fp32: one fused launch (linear_ln.hip);
+// otherwise (bf16 products, unsupported shapes, FIRA_FUSED_LN=0) the product followed by the row kernel.
+static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* b,
+                            const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
+                            float p_drop, uint64_t seed, uint32_t st, const int32_t* y_rows = nullptr,
+                            const float* r1_row = nullptr, const float* r1_col = nullptr) {
+    if (g_dtype == 0) {
+        int rc;
+        if (linear_ln_fwd_try(s, M, K, X, ldx, W, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col,
+                              &rc))
+            return rc;
+    }
+    TRY(linear(s, M, FIRA_D, K, X, ldx, W, b, sum, FIRA_D));
+    return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col);
+}
 // dX (+)= dY W          (W stored [N,K]; reduce over N)
 static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* W, float* dX,
                                int lddx, bool accum) {
@@ -499,15 +514,13 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         TRY(rows_move(s, 0, Cc, D, e.Xc, X, bt.code_rows, nullptr));
         TRY(linear(s, Cc, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
         TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
-        TRY(linear(s, Cc, D, D, e.c, D, c.P + w.wo, c.P + w.bo, e.s1, D));
-        TRY(add_layernorm_fwd(s, Cc, e.s1, e.Xc, c.P + w.ln1g, c.P + w.ln1b, X, e.st1, c.p_drop, c.seed,
-                              site(l, SITE_COMB_OUT), bt.code_rows));
+        TRY(linear_ln(s, Cc, D, e.c, D, c.P + w.wo, c.P + w.bo, e.Xc, c.P + w.ln1g, c.P + w.ln1b, e.s1, X, e.st1, c.p_drop,
+                      c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
         // GCN in folded form: U = A_hat X (kept for the weight gradient) -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
         if (l == 0 && ev_fold) TRY(main_wait(s, ev_fold));
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
-        TRY(linear(s, Nc, D, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, e.s2, D));
-        TRY(add_layernorm_fwd(s, Nc, e.s2, X, c.P + w.ln2g, c.P + w.ln2b, p.X[l + 1], e.st2, c.p_gcn, c.seed,
-                              site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D));
+        TRY(linear_ln(s, Nc, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, X, c.P + w.ln2g, c.P + w.ln2b, e.s2,
+                      p.X[l + 1], e.st2, c.p_gcn, c.seed, site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D));
     }
     // memory = [code ; sub-token] rows (Model.py:48): compact copy for the GEMMs, dense [B,370,*] rows for the
     // attention / copy kernels (rows of masked slots are never read there)
@@ -551,16 +564,16 @@ static int decoder_forward(Ctx& c) {
         DecSave& e = p.dec[l];
         TRY(linear(s, p.TB, 3 * D, D, x, D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 3 * D));
         TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D));
-        TRY(linear(s, p.TB, D, D, e.ao, D, c.P + w.wo_s, c.P + w.bo_s, e.s_a, D));
-        TRY(add_layernorm_fwd(s, p.TB, e.s_a, x, c.P + w.lns_g, c.P + w.lns_b, e.x_a, e.st_a, c.p_drop, c.seed, site(l, SITE_SELF), nullptr));
+        TRY(linear_ln(s, p.TB, D, e.ao, D, c.P + w.wo_s, c.P + w.bo_s, x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
+                      c.p_drop, c.seed, site(l, SITE_SELF)));
         TRY(linear(s, p.TB, D, D, e.x_a, D, c.P + w.wq_c, c.P + w.bq_c, e.qc, D));
         if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
         TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D));
-        TRY(linear(s, p.TB, D, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.s_c, D));
-        TRY(add_layernorm_fwd(s, p.TB, e.s_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.x_c, e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS), nullptr));
+        TRY(linear_ln(s, p.TB, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c,
+                      e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS)));
         TRY(linear(s, p.TB, p.F, D, e.x_c, D, c.P + w.w1, c.P + w.b1, e.h, p.F, FIRA_GEMM_RELU));
-        TRY(linear(s, p.TB, D, p.F, e.h, p.F, c.P + w.w2, c.P + w.b2, e.s_f, D));
-        TRY(add_layernorm_fwd(s, p.TB, e.s_f, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.x_f, e.st_f, c.p_drop, c.seed, site(l, SITE_FFN), nullptr));
+        TRY(linear_ln(s, p.TB, p.F, e.h, p.F, c.P + w.w2, c.P + w.b2, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.s_f, e.x_f,
+                      e.st_f, c.p_drop, c.seed, site(l, SITE_FFN)));
         x = e.x_f;
     }
     return 0;
@@ -951,16 +964,16 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
         TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)D * D, params + w.bqkv + D, kc + (size_t)step * D, T * D));
         TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
         TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
-        TRY(linear(s, BR, D, D, dp.ao, D, params + w.wo_s, params + w.bo_s, dp.s, D));
-        TRY(add_layernorm_fwd(s, BR, dp.s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, nullptr, 0.f, 0, 0, nullptr));
+        TRY(linear_ln(s, BR, D, dp.ao, D, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.s,
+                      dp.xa, nullptr, 0.f, 0, 0));
         TRY(linear(s, BR, D, D, dp.xa, D, params + w.wq_c, params + w.bq_c, dp.qc, D));
         TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                              p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
-        TRY(linear(s, BR, D, D, dp.ao, D, params + w.wo_c, params + w.bo_c, dp.s, D));
-        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, nullptr, 0.f, 0, 0, nullptr));
+        TRY(linear_ln(s, BR, D, dp.ao, D, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.s,
+                      dp.xc, nullptr, 0.f, 0, 0));
         TRY(linear(s, BR, p.F, D, dp.xc, D, params + w.w1, params + w.b1, dp.h, p.F, FIRA_GEMM_RELU));
-        TRY(linear(s, BR, D, p.F, dp.h, p.F, params + w.w2, params + w.b2, dp.s, D));
-        TRY(add_layernorm_fwd(s, BR, dp.s, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, nullptr, 0.f, 0, 0, nullptr));
+        TRY(linear_ln(s, BR, p.F, dp.h, p.F, params + w.w2, params + w.b2, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.s,
+                      dp.x, nullptr, 0.f, 0, 0));
     }
     TRY(linear(s, BR, p.V, D, dp.x, D, params + L.wout, params + L.bout, dp.logits, p.ldl));
     TRY(gemm_f32(s, 0, 1, BR, D, D, dp.x, D, params + L.wt, D, dp.tgt, D, nullptr, 0, 1));

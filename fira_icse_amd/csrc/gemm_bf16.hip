@@ -653,6 +653,10 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
         FIRA_CHECK_LAUNCH("gemm_bf16_small");
         return 0;
     }
+    if (splitk <= 1) {                                  // K = 256: the A-stationary panel kernel (gemm_bf16_panel.hip)
+        int rc;
+        if (gemm_bf16_k256_try(s, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags, c_rows, relu_mask, &rc)) return rc;
+    }
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
     const int tile = (t128 >= 256 && K >= 2048) ? 0 : 2;
     if (splitk == 0) {

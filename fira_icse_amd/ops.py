@@ -117,6 +117,19 @@ def add_layernorm_fwd(x, res, gamma, beta, dropout=0.0, seed=0, site=0):
     return y, x, stats
 
 
+def linear_layernorm_fwd(x, w, bias, res, gamma, beta, dropout=0.0, seed=0, site=0):
+    """One launch for LayerNorm(dropout(x @ w.T + bias) + res): returns (y, pre-norm sum, stats[M,2])."""
+    M, K = x.shape
+    assert w.shape == (256, K) and x.stride(1) == 1
+    y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+    s = torch.empty_like(y)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_linear_layernorm_fwd(cur_stream(), M, K, ptr(x), x.stride(0), ptr(_f32(w)), ptr(bias), ptr(res),
+                                               ptr(_f32(gamma)), ptr(_f32(beta)), ptr(s), ptr(y), ptr(stats), dropout,
+                                               seed, site), "fira_linear_layernorm_fwd")
+    return y, s, stats
+
+
 def add_layernorm_bwd(dy, s, stats, gamma, dropout=0.0, seed=0, site=0, want_dx_drop=False):
     M = dy.shape[0]
     ds = torch.empty_like(dy)

@@ -180,6 +180,15 @@ int fira_combination_bwd(void* stream, int M, const float* qk, const float* vtab
 int fira_add_layernorm_fwd(void* stream, int M, float* x, const float* res, const float* gamma,
                            const float* beta, float* y, float* stats, float dropout, uint64_t seed,
                            uint32_t stream_id);
+/* The product and the row step above in ONE launch: y = LayerNorm(dropout(X W^T + bias) + res) * gamma + beta with
+ * X [M,K] (row pitch ldx), W [256,K] an nn.Linear weight; sum [M,256] (optional) receives the pre-norm rows and
+ * stats [M,2] (optional) {mean, rstd}, exactly what fira_add_layernorm_fwd leaves behind, so the backward entry
+ * below serves both.  K a multiple of 32, operands 16-byte aligned (else error).  fp32 MFMA.
+ * Replaces e.g. `self.norm(x + self.dropout(self.linear(...)))` at gnn_transformer.py:161,174,205.  */
+int fira_linear_layernorm_fwd(void* stream, int M, int K, const float* X, int ldx, const float* W,
+                              const float* bias, const float* res, const float* gamma, const float* beta,
+                              float* sum, float* y, float* stats, float dropout, uint64_t seed,
+                              uint32_t stream_id);
 /* ds = dLN/d(sum); dgamma/dbeta += ...;  if dx_drop != NULL: dx_drop = ds * mask/(1-p)           */
 int fira_add_layernorm_bwd(void* stream, int M, const float* dy, const float* sum, const float* stats,
                            const float* gamma, float* ds, float* dx_drop, float* dgamma, float* dbeta,

@@ -105,6 +105,26 @@ def test_weight_shadows_forward_and_dgrad(M, N, K):
             assert rel_err(got, bf(dY[:, sl]) @ bf(W[sl])) < 2e-6
 
 
+@pytest.mark.parametrize("M,N", [(64, 64), (130, 96), (70, 40), (1000, 257), (8500, 3072), (1400, 24650), (24001, 512)])
+def test_panel_kernel_k256_edges_accumulate_relu(M, N):
+    """K = 256 products take the A-stationary panel kernel (gemm_bf16_panel.hip) unless they are decode-sized: ragged row
+    panels, ragged 64-column tiles, both panel heights (BM 128 when N >= 512 and M*N >= 4 Mi), bias / ReLU / accumulate."""
+    from fira_icse_amd import ops
+    X, W, bias = randn(M, 256, seed=11), randn(N + (-N) % 8, 256, seed=12)[:N], randn(N, seed=13)
+    wb, _ = ops.weight_shadow(W)
+    ref = bf(X) @ bf(W).t()
+    assert rel_err(ops.gemm_wb(X, wb), ref) < 2e-6
+    assert rel_err(ops.gemm_wb(X, wb, bias=bias, relu=True), (ref + bias.double()).clamp_min(0)) < 2e-6
+    C0 = randn(M, N, seed=14)
+    got = ops.gemm_wb(X, wb, bias=bias, out=C0.clone(), accumulate=True)
+    assert rel_err(got, ref + bias.double() + C0.double()) < 3e-6
+    # a strided A (column slice of a wider activation) and a strided C
+    Xw = randn(M, 512, seed=15)
+    Cw = torch.zeros(M, N + 8, device=DEV)
+    ops.gemm_wb(Xw[:, 256:], wb, out=Cw[:, :N])
+    assert rel_err(Cw[:, :N], bf(Xw[:, 256:]) @ bf(W).t()) < 2e-6 and float(Cw[:, N:].abs().max()) == 0.0
+
+
 @pytest.fixture(scope="module")
 def small():
     from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict

@@ -24,6 +24,7 @@
 //     walk the tiles that share the LARGER operand's panel, so that panel is fetched from HBM once per XCD and the
 //     re-reads hit its private 4 MiB L2.
 #include "engine.h"
+#include "epilogue.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <type_traits>
@@ -339,32 +340,23 @@ __device__ __forceinline__ void gemm_bf16_tile(int M, int N, int K, const float*
         }
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA (dtype-independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue (epilogue.h): C/D layout of the 32x32 MFMA (dtype-independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool relu = flags & FIRA_GEMM_RELU;
     const bool accum = flags & FIRA_GEMM_ACCUM;
-    const bool add_bias = bias != nullptr && first;
+    const float* bias_p = (bias != nullptr && first) ? bias : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
-        if (col >= N) continue;
-        const float bv = add_bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float vals[16];
+            int rows[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;
-                if (atomic) {
-                    unsafeAtomicAdd(p, v);
-                } else {
-                    if (accum) v += *p;
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;
-                    *p = v;
-                }
+                vals[r] = acc[i][j][r];
+                rows[r] = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             }
+            epilogue_col<16>(vals, rows, col, M, N, C, ldc, bias_p, relu, accum, atomic, c_rows, relu_mask);
         }
     }
 }
@@ -520,18 +512,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(int M, int N, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
     __syncthreads();
-    const bool relu = flags & FIRA_GEMM_RELU, accum = flags & FIRA_GEMM_ACCUM;
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
-        const int r = idx >> 6, ln = idx & 63;
-        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
-        if (row >= M || col >= N) continue;
-        float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        if (bias) v += bias[col];
-        float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;
-        if (accum) v += *p;
-        if (relu) v = fmaxf(v, 0.f);
-        if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;     // fused ReLU backward
-        *p = v;
+    // thread t combines elements idx = t + 256 i of the tile: one column (lane & 31), four rows (epilogue.h)
+    {
+        const int ln = threadIdx.x & 63, rq = threadIdx.x >> 6;
+        float vals[4];
+        int rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i, r = rq + 4 * i;
+            vals[i] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        }
+        epilogue_col<4>(vals, rows, n0 + (ln & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
+                        c_rows, relu_mask);
     }
 }
 
@@ -552,6 +545,7 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
         return gemm_f32_ex(s, tA, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, splitk, colsum, c_rows, relu_mask);
     FIRA_REQUIRE(!(relu_mask && (splitk > 1 || c_rows)), "gemm_bf16: the fused ReLU mask needs a plain (unsplit, unmapped) output");
     FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_bf16: bad K=%d splitk=%d", K, splitk);
+    FIRA_REQUIRE(c_rows || epilogue_fits(M, ldc), "gemm_bf16: output of %d x %d floats exceeds the 2 GiB the kernels address", M, ldc);
     FIRA_REQUIRE(!(colsum && !tA), "gemm_bf16: fused column sums need the transA layout");
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
@@ -643,6 +637,7 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
     FIRA_REQUIRE(M >= 32 && N >= 32 && K >= 32 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Bb % 16) == 0 && lda % 4 == 0 &&
                  ldb % 8 == 0, "gemm_bf16_wb: unsupported shape / alignment %dx%dx%d", M, N, K);
     FIRA_REQUIRE(!(relu_mask && (splitk > 1 || c_rows)), "gemm_bf16_wb: the fused ReLU mask needs a plain output");
+    FIRA_REQUIRE(c_rows || epilogue_fits(M, ldc), "gemm_bf16_wb: output of %d x %d floats exceeds the 2 GiB the kernels address", M, ldc);
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();

@@ -12,7 +12,9 @@
 //     its 32-row slice into 64 VGPRs, where they stay for the whole sweep;
 //   * the weight tiles (64 columns x 256 k, 32 KiB of bf16, L2-resident) stream through two LDS buffers that reuse the
 //     panel's staging space: tile j+1 is in flight in registers while the 16 (or 32) MFMAs of tile j run; one barrier per
-//     column tile, no barrier inside a tile, the K loop is fully unrolled;
+//     column tile, no barrier inside a tile, the K loop is fully unrolled; a tile's registers are requested two tiles
+//     ahead, so waiting for them never waits for the C stores issued in between (vmcnt is one in-order counter for
+//     loads and stores: with one stage every tile stalled on the previous tile's store acknowledgements);
 //   * LDS rows are padded to 528 B (132 dwords: row r starts at bank 4r mod 64), which makes both the 16-byte staging
 //     stores (16 lanes = 256 contiguous bytes of one row) and the ds_read_b128 fragment fetches (16 lanes = 16 rows at one
 //     k chunk) conflict-free without a swizzle;
@@ -41,9 +43,21 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (RNE)
 }
 
+// All global traffic goes through buffer descriptors: out-of-range rows / columns (ragged last panel, ragged last tile)
+// read zeros and drop their stores in hardware, so the kernel has no clamps and -- more important -- no branch around any
+// memory instruction: hipcc's s_waitcnt insertion counts loads and stores in one in-order counter (vmcnt) and falls back to
+// "wait for everything" as soon as an instruction may or may not have been issued.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32v4 __attribute__((__vector_size__(16)));
+constexpr int BUF_FLAGS = 0x00020000;                     // gfx9 raw buffer, 32-bit data format
+constexpr unsigned OOB = 0x80000000u;                     // added to the byte offset of a lane that must not touch memory
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, BUF_FLAGS);
+}
+
 // RT = 32-row slices per workgroup: 2 (BM 64: waves = 2 row slices x 2 column halves) or 4 (BM 128: wave = row slice,
-// both 32-column halves of the tile).
-template <int RT, bool ACCUM>
+// both 32-column halves of the tile).  EXTRA = the epilogue honours an output row map and / or a ReLU mask.
+template <int RT, bool ACCUM, bool EXTRA>
 __global__ __launch_bounds__(256) void gemm_bf16_k256_kernel(int M, int N, const float* __restrict__ A, int lda,
                                                              const uint16_t* __restrict__ Bb, int ldb,
                                                              float* __restrict__ C, int ldc,
@@ -65,46 +79,65 @@ __global__ __launch_bounds__(256) void gemm_bf16_k256_kernel(int M, int N, const
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
     const int kc = t & 31, rs = t >> 5;                    // staging role: 16-byte chunk kc of rows rs + 8*i
+    const int rt = RT == 4 ? wave : (wave & 1), cg = RT == 4 ? 0 : (wave >> 1);      // compute role: row slice, column group
 
-    // ---- weight tile 0 on its way (registers) before anything else
-    u32x4 breg[8];
-    auto fetch_b = [&](int jt) __attribute__((always_inline)) {
-        const int n0 = jt * PBN;
+    const rsrc_t rA = make_rsrc(A, ((unsigned)(M - 1) * (unsigned)lda + PK) * 4u);
+    const rsrc_t rB = make_rsrc(Bb, ((unsigned)(N - 1) * (unsigned)ldb + PK) * 2u);
+    const rsrc_t rC = make_rsrc(C, 0x7fffffffu);
+    const rsrc_t rBias = make_rsrc(bias ? (const void*)bias : (const void*)C, bias ? (unsigned)N * 4u : 0u);   // no bias: zeros
+    const rsrc_t rRows = make_rsrc(c_rows ? (const void*)c_rows : (const void*)C, c_rows ? (unsigned)M * 4u : 0u);
+    const rsrc_t rMask = make_rsrc(relu_mask ? (const void*)relu_mask : (const void*)C, relu_mask ? 0x7fffffffu : 0u);
+
+    // ---- weight tiles travel global -> registers -> LDS; two register stages (tiles j+1 and j+2 in flight)
+    const unsigned bvo = ((unsigned)rs * (unsigned)ldb + (unsigned)kc * 8u) * 2u;     // lane part of a tile's byte offsets
+    auto fetch_b = [&](int jt, u32v4 (&br)[8]) __attribute__((always_inline)) {
+        const unsigned base = (unsigned)(jt * PBN) * (unsigned)ldb * 2u + bvo;       // past the last tile: zeros
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int col = min(n0 + rs + 8 * i, N - 1);   // clamped: columns past N are never stored
-            breg[i] = *reinterpret_cast<const u32x4*>(Bb + (size_t)col * ldb + kc * 8);
-        }
+        for (int i = 0; i < 8; ++i) br[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, base + (unsigned)(8 * i) * (unsigned)ldb * 2u, 0, 0);
     };
-    auto put_b = [&](int buf) __attribute__((always_inline)) {
+    auto put_b = [&](const u32v4 (&br)[8], int buf) __attribute__((always_inline)) {
         char* sb = sm + buf * PBN * PPITCH;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(sb + (rs + 8 * i) * PPITCH + kc * 16) = breg[i];
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32v4*>(sb + (rs + 8 * i) * PPITCH + kc * 16) = br[i];
     };
-    fetch_b(jt0);
+    // bias values travel one tile ahead as well (a load waited for right after the previous tile's stores would wait for
+    // those stores: one in-order counter)
+    const int colw = (cg * SN) * 32 + l31;                  // this lane's column inside a tile (+ 32 sn)
+    auto fetch_bias = [&](int jt, float (&bv)[SN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sn = 0; sn < SN; ++sn)
+            bv[sn] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, (unsigned)(jt * PBN + colw + 32 * sn) * 4u, 0, 0));
+    };
+    // Issue order of the prologue matters to the compiler's wait counts inside the loop: at the loop head it merges the
+    // entry state with the back-edge state and keeps the SMALLER number of younger operations per pending load, so the
+    // stage-1 request is issued before the panel's loads (which stand in for the steady state's C stores in that count).
+    u32v4 br0[8], br1[8];
+    float bv0[SN], bv1[SN];
+    fetch_b(jt0, br0);
+    fetch_b(jt0 + 1, br1);
+    fetch_bias(jt0, bv0);
 
     // ---- A panel: HBM -> bf16 -> LDS, 64 rows per pass
 #pragma unroll
     for (int pass = 0; pass < BM / 64; ++pass) {
-        f32x4 v[8][2];
+        u32v4 v[8][2];
+        const unsigned base = ((unsigned)(m0 + pass * 64 + rs) * (unsigned)lda + (unsigned)kc * 8u) * 4u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = min(m0 + pass * 64 + rs + 8 * i, M - 1);      // clamped: rows past M are never stored
-            const float* q = A + (size_t)row * lda + kc * 8;
-            v[i][0] = *reinterpret_cast<const f32x4*>(q);
-            v[i][1] = *reinterpret_cast<const f32x4*>(q + 4);
+            const unsigned o = base + (unsigned)(8 * i) * (unsigned)lda * 4u;
+            v[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, o, 0, 0);
+            v[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, o + 16u, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            u32x4 w = {pack2(v[i][0].x, v[i][0].y), pack2(v[i][0].z, v[i][0].w), pack2(v[i][1].x, v[i][1].y),
-                       pack2(v[i][1].z, v[i][1].w)};
-            *reinterpret_cast<u32x4*>(sm + (pass * 64 + rs + 8 * i) * PPITCH + kc * 16) = w;
+            const f32x4 lo = __builtin_bit_cast(f32x4, v[i][0]), hi = __builtin_bit_cast(f32x4, v[i][1]);
+            u32v4 w = {pack2(lo.x, lo.y), pack2(lo.z, lo.w), pack2(hi.x, hi.y), pack2(hi.z, hi.w)};
+            *reinterpret_cast<u32v4*>(sm + (pass * 64 + rs + 8 * i) * PPITCH + kc * 16) = w;
         }
     }
     __syncthreads();
 
     // ---- this wave's A fragments: 32 rows x 256 k in 64 VGPRs (MFMA step s takes k = 16 s + 8 (lane >> 5) .. + 7)
-    const int rt = RT == 4 ? wave : (wave & 1), cg = RT == 4 ? 0 : (wave >> 1);
     bf16x8 a[16];
     {
         const char* sa = sm + (rt * 32 + l31) * PPITCH + kh * 16;
@@ -112,30 +145,58 @@ __global__ __launch_bounds__(256) void gemm_bf16_k256_kernel(int M, int N, const
         for (int s = 0; s < 16; ++s) a[s] = *reinterpret_cast<const bf16x8*>(sa + s * 32);
     }
     __syncthreads();                                        // the staging space now belongs to the weight tiles
-    put_b(0);
+    put_b(br0, 0);
     __syncthreads();
 
     const int boff = (cg * 32 * SN + l31) * PPITCH + kh * 16;
-    for (int j = 0; j < nt; ++j) {
+    const int row_base = m0 + rt * 32 + 4 * kh;
+    // output rows of this lane (fixed for the whole sweep): byte offset of the row start, OOB for rows past M
+    unsigned crow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        unsigned orow = (unsigned)row;
+        if (EXTRA) {
+            const unsigned mapped = __builtin_amdgcn_raw_buffer_load_b32(rRows, (unsigned)row * 4u, 0, 0);   // 0 without a map
+            orow = c_rows ? mapped : (unsigned)row;
+        }
+        crow[r] = orow * (unsigned)ldc * 4u + (row < M ? 0u : OOB);
+    }
+    // One column tile: the tile after next requested into the stage freed one step ago | MFMAs on LDS[buf] | the next
+    // tile's stage -> LDS[buf ^ 1] | C stores | barrier.  The stage written to LDS was requested BEFORE the previous
+    // tile's stores, so its wait leaves those stores and the newest loads in flight: the sweep never stalls on a store
+    // acknowledgement.
+    auto tile_step = [&](int j, int buf, u32v4 (&br_next)[8], u32v4 (&br_free)[8], const float (&bv)[SN],
+                         float (&bv_next)[SN]) __attribute__((always_inline)) {
         const int n0 = (jt0 + j) * PBN;
-        // previous C values (accumulate mode) and the next weight tile are requested before the MFMAs start
-        f32x16 acc[SN];
-        const int row_base = m0 + rt * 32 + 4 * kh;
+        fetch_b(jt0 + j + 2, br_free);                      // br_free went to LDS one step ago
+        fetch_bias(jt0 + j + 1, bv_next);
+        __builtin_amdgcn_sched_barrier(0);                  // the requests stay ahead of the MFMAs (the scheduler would sink
+                                                            // them below the LDS refill to save registers)
+        unsigned ccol[SN];
 #pragma unroll
         for (int sn = 0; sn < SN; ++sn) {
-            const int col = n0 + (cg * SN + sn) * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = 0.f;
-                if (ACCUM) {
-                    const int row = min(row_base + (r & 3) + 8 * (r >> 2), M - 1);
-                    v = C[(size_t)(c_rows ? c_rows[row] : row) * ldc + min(col, N - 1)];
-                }
-                acc[sn][r] = v;
-            }
+            const int col = n0 + colw + 32 * sn;
+            ccol[sn] = (unsigned)col * 4u + (col < N ? 0u : OOB);
         }
-        fetch_b(min(jt0 + j + 1, n_tiles - 1));             // unconditional: no load behind a branch (see gemm_bf16.hip)
-        const char* sb = sm + (j & 1) * PBN * PPITCH + boff;
+        float keep[SN][16];
+        if (EXTRA) {
+#pragma unroll
+            for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + (r & 3) + 8 * (r >> 2);
+                    const unsigned mo = (row < M && !(ccol[sn] & OOB)) ? (unsigned)row * (unsigned)ldc * 4u + ccol[sn] : OOB;
+                    const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rMask, mo, 0, 0));
+                    keep[sn][r] = (relu_mask && !(mk > 0.f)) ? 0.f : 1.f;
+                }
+        }
+        f32x16 acc[SN];
+#pragma unroll
+        for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sn][r] = 0.f;
+        const char* sb = sm + buf * PBN * PPITCH + boff;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
 #pragma unroll
@@ -144,26 +205,30 @@ __global__ __launch_bounds__(256) void gemm_bf16_k256_kernel(int M, int N, const
                 acc[sn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b, acc[sn], 0, 0, 0);
             }
         }
-        put_b((j + 1) & 1);                                 // buffer (j+1)&1 was last read in iteration j-1 (barrier since)
+        put_b(br_next, buf ^ 1);                            // LDS[buf ^ 1] was last read one step ago (barrier since)
         // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
         for (int sn = 0; sn < SN; ++sn) {
-            const int col = n0 + (cg * SN + sn) * 32 + l31;
-            if (col < N) {
-                const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + (r & 3) + 8 * (r >> 2);
-                    if (row < M) {
-                        float v = acc[sn][r] + bv;
-                        if (relu) v = fmaxf(v, 0.f);
-                        if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;
-                        C[(size_t)(c_rows ? c_rows[row] : row) * ldc + col] = v;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[sn][r] + bv[sn];
+                const unsigned off = crow[r] + ccol[sn];    // either part may carry the OOB bit (both: wraps to in-range!)
+                const unsigned o = ((crow[r] | ccol[sn]) & OOB) ? OOB : off;
+                if (ACCUM) {
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rC, o, 0, 0);    // one owner per element: C += v
+                } else {
+                    v = relu ? fmaxf(v, 0.f) : v;
+                    if (EXTRA) v *= keep[sn][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, o, 0, 0);
                 }
             }
         }
         __syncthreads();
+    };
+    for (int j = 0; j < nt; j += 2) {                       // stage / buffer roles are static inside the pair
+        tile_step(j, 0, br1, br0, bv0, bv1);
+        if (j + 1 >= nt) break;
+        tile_step(j + 1, 1, br0, br1, bv1, bv0);
     }
 }
 
@@ -184,11 +249,20 @@ bool gemm_bf16_k256_try(hipStream_t s, int M, int N, int K, const float* A, int 
     const int n_items = panels * n_chunks, chunk = cdiv(n_items, 8);
     const int relu = flags & FIRA_GEMM_RELU;
     const bool accum = flags & FIRA_GEMM_ACCUM;
-#define FIRA_LAUNCH(RT, AC)                                                                                              \
-    hipLaunchKernelGGL((gemm_bf16_k256_kernel<RT, AC>), dim3(8 * chunk), dim3(256), 0, s, M, N, A, lda, Bb, ldb, C, ldc, bias, \
-                       relu, n_chunks, tpc, n_items, chunk, c_rows, relu_mask)
-    if (big) { if (accum) FIRA_LAUNCH(4, true); else FIRA_LAUNCH(4, false); }
-    else { if (accum) FIRA_LAUNCH(2, true); else FIRA_LAUNCH(2, false); }
+    // 31-bit byte offsets inside (bit 31 marks lanes that must not touch memory); with a row map the caller vouches for C
+    if ((long)M * ldc >= (1L << 29) || (long)N * ldb >= (1L << 30) || (long)M * lda >= (1L << 29)) return false;
+    if (accum && (relu || relu_mask)) return false;         // C += v is an atomic add here; relu(C + v) is not expressible
+    const bool extra = c_rows != nullptr || relu_mask != nullptr;
+#define FIRA_LAUNCH(RT, AC, EX)                                                                                          \
+    hipLaunchKernelGGL((gemm_bf16_k256_kernel<RT, AC, EX>), dim3(8 * chunk), dim3(256), 0, s, M, N, A, lda, Bb, ldb, C, ldc, \
+                       bias, relu, n_chunks, tpc, n_items, chunk, c_rows, relu_mask)
+#define FIRA_PICK(RT)                                                                                                    \
+    do {                                                                                                                 \
+        if (accum) { if (extra) FIRA_LAUNCH(RT, true, true); else FIRA_LAUNCH(RT, true, false); }                        \
+        else { if (extra) FIRA_LAUNCH(RT, false, true); else FIRA_LAUNCH(RT, false, false); }                            \
+    } while (0)
+    if (big) FIRA_PICK(4); else FIRA_PICK(2);
+#undef FIRA_PICK
 #undef FIRA_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) *rc = set_err("gemm_bf16_k256: %s", hipGetErrorString(e));

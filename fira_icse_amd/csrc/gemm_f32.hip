@@ -12,6 +12,7 @@
 // K tile, two LDS buffers).  LDS row pitch 129 makes the transposing scalar writes of the k-contiguous
 // path conflict-free (4*129 = 4 mod 32); the m-contiguous path writes 16-byte rows at pitch 132.
 #include "engine.h"
+#include "epilogue.h"
 #include <cmath>
 
 namespace fira {
@@ -268,33 +269,23 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, const float* __re
             if (m0 + i < M) unsafeAtomicAdd(&colsum[m0 + i], red[i]);
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue (epilogue.h): C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool relu = flags & FIRA_GEMM_RELU;
     const bool accum = flags & FIRA_GEMM_ACCUM;
-    const bool add_bias = bias != nullptr && first;
+    const float* bias_p = (bias != nullptr && first) ? bias : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WN + j * 32 + l31;
-        if (col >= N) continue;
-        const float bv = add_bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float vals[16];
+            int rows[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row >= M) continue;
-                float v = acc[i][j][r] + bv;
-                float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;       // optional output row map (scatter)
-                if (atomic) {
-                    unsafeAtomicAdd(p, v);
-                } else {
-                    if (accum) v += *p;
-                    if (relu) v = fmaxf(v, 0.f);
-                    // ReLU backward fused into the dgrad that produces d(hidden): keep where the saved activation is > 0
-                    if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;
-                    *p = v;
-                }
+                vals[r] = acc[i][j][r];
+                rows[r] = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             }
+            epilogue_col<16>(vals, rows, col, M, N, C, ldc, bias_p, relu, accum, atomic, c_rows, relu_mask);
         }
     }
 }
@@ -412,6 +403,7 @@ int gemm_f32_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float*
     if (M <= 0 || N <= 0) return 0;
     FIRA_REQUIRE(!(relu_mask && (splitk > 1 || c_rows)), "gemm_f32: the fused ReLU mask needs a plain (unsplit, unmapped) output");
     FIRA_REQUIRE(K > 0 && splitk >= 0, "gemm_f32: bad K=%d splitk=%d", K, splitk);
+    FIRA_REQUIRE(c_rows || epilogue_fits(M, ldc), "gemm_f32: output of %d x %d floats exceeds the 2 GiB the kernels address", M, ldc);
     FIRA_REQUIRE(!(colsum && !tA), "gemm_f32: fused column sums need the transA layout");
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;

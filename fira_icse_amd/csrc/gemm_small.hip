@@ -13,6 +13,7 @@
 //   B_KCONTIG = true   B is an nn.Linear weight [N,K]  (forward)
 //   B_KCONTIG = false  B is [K,N]                      (dgrad): 16 row-segment loads of 128 bytes per half-wave
 #include "engine.h"
+#include "epilogue.h"
 #include <stdlib.h>
 
 namespace fira {
@@ -74,18 +75,19 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
     __syncthreads();
-    const bool relu = flags & FIRA_GEMM_RELU, accum = flags & FIRA_GEMM_ACCUM;
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
-        const int r = idx >> 6, ln = idx & 63;
-        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
-        if (row >= M || col >= N) continue;
-        float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
-        if (bias) v += bias[col];
-        float* p = C + (size_t)(c_rows ? c_rows[row] : row) * ldc + col;
-        if (accum) v += *p;
-        if (relu) v = fmaxf(v, 0.f);
-        if (relu_mask && !(relu_mask[(size_t)row * ldc + col] > 0.f)) v = 0.f;     // fused ReLU backward (see gemm_f32.hip)
-        *p = v;
+    // thread t combines elements idx = t + 256 i of the tile: one column (lane & 31), four rows (epilogue.h)
+    {
+        const int ln = threadIdx.x & 63, rq = threadIdx.x >> 6;
+        float vals[4];
+        int rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i, r = rq + 4 * i;
+            vals[i] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        }
+        epilogue_col<4>(vals, rows, n0 + (ln & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
+                        c_rows, relu_mask);
     }
 }
 

@@ -176,13 +176,17 @@ __global__ __launch_bounds__(512) void linear_ln_fwd_kernel(int M, int K, const 
     }
 }
 
-// true if the fused kernel took the call (N must be 256; K a multiple of 32; 16-byte aligned operands)
+// true if the fused kernel took the call (N must be 256; K a multiple of 32; 16-byte aligned operands).
+// Measured (profiles/r2_probes.md): a workgroup that owns complete rows is bound by ONE CU's fp32 MFMA rate -- 32 rows x 256
+// columns x K=256 is 6.8 us of matrix-pipe time, and M = 960 decoder rows occupy 30 CUs -- so in the training step the
+// fused launch (16 us, 45 us at K = 1024) loses to the 240-workgroup product + row kernel (9.4 + 5.5 us): 7 300 vs 7 690
+// commits/s.  The engine therefore calls it only on request (FIRA_FUSED_LN=1); the C entry point always runs it.
 bool linear_ln_fwd_try(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* bias, const float* res,
                        const float* gamma, const float* beta, float* sum, float* y, float* stats, float dropout,
                        uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row, const float* r1_col,
                        int* rc, bool force) {
     *rc = 0;
-    static const int mode = [] { const char* e = getenv("FIRA_FUSED_LN"); return e ? atoi(e) : 1; }();   // A/B switch
+    static const int mode = [] { const char* e = getenv("FIRA_FUSED_LN"); return e ? atoi(e) : 0; }();   // A/B switch (off: see below)
     if ((!mode && !force) || M <= 0 || K < 32 || K % 32 || ldx % 4 || ((uintptr_t)X % 16) || ((uintptr_t)W % 16)) return false;
     ProfScope prof(s, PROF_GEMM, 2.0 * M * 256.0 * K, 4.0 * ((double)M * K + 256.0 * K + 3.0 * M * 256.0));
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;

@@ -157,6 +157,7 @@ def test_combination_gate_fwd_bwd():
 def test_linear_layernorm_fused_equals_the_two_kernels(M, K, p):
     """The fused launch against gemm + add_layernorm_fwd (same dropout stream): the sums differ only by the K summation
     order (<= 2e-6 relative), masks are IDENTICAL (zeros of the pre-residual rows coincide), stats/y within 1e-5."""
+    from fira_icse_amd import ops
     x = randn(M, K + 8, seed=1)[:, :K]                       # a strided view: ldx != K
     w, b = randn(256, K, seed=2, scale=K ** -0.5), randn(256, seed=3)
     res, gamma, beta = randn(M, 256, seed=4), 1 + 0.1 * randn(256, seed=5), 0.1 * randn(256, seed=6)

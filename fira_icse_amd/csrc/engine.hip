@@ -716,8 +716,20 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     TRY(deferred_reduce(s, red().tab));      // decoder LayerNorms, copy head: their gradients are final after this launch
     if (mid_event) {                         // gradients of [0, split) are final from here on
-        if (side().stream && side().enabled) TRY(side_join(s));
-        hipError_t e = hipEventRecord(mid_event, s);
+        // The event fires when BOTH the caller's stream and the weight-gradient stream have reached this point, without
+        // holding up either of them: the auxiliary stream (idle for the rest of the backward pass) waits for the two and
+        // records it.  (Joining the weight-gradient stream into the caller's stream here made the encoder's backward wait
+        // for the vocabulary projection's weight gradient.)
+        SideStream& sd = side();
+        hipStream_t es = s;
+        if (sd.stream && sd.enabled) {
+            TRY(aux_fork(s));
+            hipEvent_t e2 = sd.ev();
+            if (hipEventRecord(e2, sd.stream) != hipSuccess || hipStreamWaitEvent(sd.aux, e2, 0) != hipSuccess)
+                return set_err("mid-event: weight-gradient stream mark failed");
+            es = sd.aux;
+        }
+        hipError_t e = hipEventRecord(mid_event, es);
         if (e != hipSuccess) return set_err("hipEventRecord: %s", hipGetErrorString(e));
     }
 

@@ -15,6 +15,7 @@
 namespace fira {
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32v4_t __attribute__((__vector_size__(16)));     // operand type of the 128-bit buffer builtins
 constexpr int FIRA_BUF_FLAGS = 0x00020000;                  // gfx9 raw buffer descriptor, 32-bit data format
 constexpr unsigned FIRA_OOB = 0x80000000u;                  // byte offset of a lane that must not touch memory
 __device__ __forceinline__ rsrc_t buf_rsrc(const void* p, unsigned bytes) {

@@ -3,9 +3,13 @@
 // One wavefront owns one 256-float row as float4 per lane (a 1 KiB coalesced access);
 // row statistics are wave reductions (no LDS, no atomics on the forward path).
 #include "engine.h"
+#include "epilogue.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace fira {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // Embedding gathers of Encoder.forward / Decoder.forward (reference gnn_transformer.py:46-52,110-113),
@@ -283,6 +287,12 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
 
 // backward of the block above.  ds = gradient wrt the pre-norm sum (also the residual-branch gradient);
 // dx_drop (optional) = ds * keep-mask / (1-p): the gradient wrt the un-dropped GEMM output.
+// A wave takes 4 consecutive rows per step and requests everything it reads for them (dy, the saved pre-norm rows, the
+// statistics) before the first reduction, then streams the stores: one memory round trip per step.  All accesses go
+// through buffer descriptors (rows past M read zeros and drop their stores), so there is no branch around a memory
+// instruction -- with the per-row `if`s and the optional row map read inside the loop, every store was followed by an
+// s_waitcnt vmcnt(0) and each 2-row iteration cost two dependent round trips (see epilogue.h).
+constexpr int LNB_ROWS = 16;                    // rows per workgroup and step (4 waves x 4 rows)
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const float* dy,   // may alias ds (row-mapped, in place)
                                                                 const float* __restrict__ sum,
                                                                 const float* __restrict__ stats,
@@ -290,56 +300,70 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
                                                                 float* ds, float* __restrict__ dx_drop,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float p, float inv_keep, uint64_t seed, uint32_t site,
-                                                                int rows_per_block,
-                                                                const int32_t* __restrict__ rows,
+                                                                int steps, const int32_t* __restrict__ rows,
                                                                 float* __restrict__ part) {
     __shared__ float red[2 * FIRA_D];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < 2 * FIRA_D; i += 256) red[i] = 0.f;
     __syncthreads();
-    const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
-    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
-    // two rows per wave and iteration: both rows' loads are in flight before the first reduction starts
-    for (int r0 = r_beg + 2 * wave; r0 < r_end; r0 += 8) {
-        const int nr = min(2, r_end - r0);
-        float4 d[2], sv[2];
-        float mean[2], rstd[2];
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
+    f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    const rsrc_t rDy = buf_rsrc(dy, 0x7fffffffu), rDs = buf_rsrc(ds, 0x7fffffffu);
+    const rsrc_t rSum = buf_rsrc(sum, (unsigned)M * FIRA_D * 4u), rStats = buf_rsrc(stats, (unsigned)M * 8u);
+    const rsrc_t rMap = buf_rsrc(rows ? (const void*)rows : (const void*)sum, rows ? (unsigned)M * 4u : 0u);
+    const rsrc_t rDx = buf_rsrc(dx_drop ? (const void*)dx_drop : (const void*)sum, dx_drop ? (unsigned)M * FIRA_D * 4u : 0u);
+    const unsigned lo = (unsigned)lane * 16u;
+    for (int st = 0; st < steps; ++st) {
+        const int r0 = (blockIdx.x * steps + st) * LNB_ROWS + wave * 4;
+        unsigned om[4];
+        f32x4 d[4], sv[4];
+        float mean[4], rstd[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = u < nr ? r0 + u : r0;
-            const size_t o = (size_t)r * FIRA_D + lane * 4;
-            const size_t om = rows ? (size_t)rows[r] * FIRA_D + lane * 4 : o;       // dy / ds live in the mapped rows
-            d[u] = *reinterpret_cast<const float4*>(dy + om);
-            sv[u] = *reinterpret_cast<const float4*>(sum + o);
-            mean[u] = stats[2 * r];
-            rstd[u] = stats[2 * r + 1];
+        for (int u = 0; u < 4; ++u) {                       // dy / ds live in the mapped rows
+            const unsigned mapped = __builtin_amdgcn_raw_buffer_load_b32(rMap, (unsigned)(r0 + u) * 4u, 0, 0);
+            om[u] = rows ? mapped : (unsigned)(r0 + u);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u >= nr) break;
+        for (int u = 0; u < 4; ++u) {
             const int r = r0 + u;
-            const size_t o = (size_t)r * FIRA_D + lane * 4;
-            const float xh0 = (sv[u].x - mean[u]) * rstd[u], xh1 = (sv[u].y - mean[u]) * rstd[u],
-                        xh2 = (sv[u].z - mean[u]) * rstd[u], xh3 = (sv[u].w - mean[u]) * rstd[u];
-            dg.x += d[u].x * xh0; dg.y += d[u].y * xh1; dg.z += d[u].z * xh2; dg.w += d[u].w * xh3;
-            db.x += d[u].x; db.y += d[u].y; db.z += d[u].z; db.w += d[u].w;
-            const float h0 = d[u].x * g.x, h1 = d[u].y * g.y, h2 = d[u].z * g.z, h3 = d[u].w * g.w;
-            const float m1 = wave_sum(h0 + h1 + h2 + h3) * (1.0f / FIRA_D);
-            const float m2 = wave_sum(h0 * xh0 + h1 * xh1 + h2 * xh2 + h3 * xh3) * (1.0f / FIRA_D);
-            float4 o4 = make_float4(rstd[u] * (h0 - m1 - xh0 * m2), rstd[u] * (h1 - m1 - xh1 * m2),
-                                    rstd[u] * (h2 - m1 - xh2 * m2), rstd[u] * (h3 - m1 - xh3 * m2));
-            *reinterpret_cast<float4*>(ds + (rows ? (size_t)rows[r] * FIRA_D + lane * 4 : o)) = o4;
-            if (dx_drop) {
-                if (p > 0.f) {
-                    const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
-                    o4.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
-                    o4.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
-                    o4.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
-                    o4.w *= dropout_scale(seed, site, e0 + 3, p, inv_keep);
-                }
-                *reinterpret_cast<float4*>(dx_drop + o) = o4;
+            const unsigned o = (unsigned)r * (FIRA_D * 4u) + lo;
+            om[u] = r < M ? om[u] * (FIRA_D * 4u) + lo : FIRA_OOB;
+            d[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rDy, om[u], 0, 0));
+            sv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rSum, o, 0, 0));
+            mean[u] = buf_load_f32(rStats, (unsigned)r * 8u);
+            rstd[u] = buf_load_f32(rStats, (unsigned)r * 8u + 4u);
+        }
+        f32x4 xh[4], h[4];
+        float m1[4], m2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                       // rows past M: d = 0, rstd = 0 -> no contribution anywhere
+            xh[u] = (sv[u] - mean[u]) * rstd[u];
+            dg += d[u] * xh[u];
+            db += d[u];
+            h[u] = d[u] * g;
+            m1[u] = h[u].x + h[u].y + h[u].z + h[u].w;
+            const f32x4 hx = h[u] * xh[u];
+            m2[u] = hx.x + hx.y + hx.z + hx.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m1[u] = wave_sum(m1[u]) * (1.0f / FIRA_D);
+            m2[u] = wave_sum(m2[u]) * (1.0f / FIRA_D);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            f32x4 o4 = (h[u] - m1[u] - xh[u] * m2[u]) * rstd[u];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32v4_t, o4), rDs, om[u], 0, 0);
+            if (p > 0.f) {                                  // wave-uniform; no memory instruction inside
+                const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
+                o4.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
+                o4.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
+                o4.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
+                o4.w *= dropout_scale(seed, site, e0 + 3, p, inv_keep);
             }
+            // no dx_drop: the descriptor has zero records and the store is dropped
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32v4_t, o4), rDx, (unsigned)r * (FIRA_D * 4u) + lo, 0, 0);
         }
     }
     atomicAdd(&red[lane * 4 + 0], dg.x); atomicAdd(&red[lane * 4 + 1], dg.y);
@@ -653,19 +677,20 @@ int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const fl
 }
 // rows per workgroup / workgroups of one launch.  With atomics: ~500 workgroups (enough to fill the chip, few enough that
 // the same-address atomics do not dominate); with deferred partials: up to 1024 workgroups of >= 8 rows.
-static int ln_bwd_rpb(int M, bool deferred) {
-    return deferred ? std::max(8, cdiv(cdiv(M, 1024), 8) * 8) : std::max(8, std::min(128, cdiv(cdiv(M, 512), 8) * 8));
-}
-int add_layernorm_bwd_blocks(int M) { return M > 0 ? cdiv(M, ln_bwd_rpb(M, true)) : 0; }
+// steps of 16 rows per workgroup: 1 when the partial sums are deferred (one round trip per workgroup), otherwise enough
+// to keep the same-address atomics of the final reduction at <= 512 workgroups
+static int ln_bwd_steps(int M, bool deferred) { return deferred ? 1 : std::max(1, cdiv(cdiv(M, LNB_ROWS), 512)); }
+int add_layernorm_bwd_blocks(int M) { return M > 0 ? cdiv(M, LNB_ROWS) : 0; }
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
                       uint32_t site, const int32_t* rows, float* part) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
+    FIRA_REQUIRE(M < (1 << 21), "add_layernorm_bwd: %d rows exceed the 2 GiB the kernel addresses", M);
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
-    const int rpb = ln_bwd_rpb(M, part != nullptr);
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, rpb)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
-                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, rpb, rows, part);
+    const int steps = ln_bwd_steps(M, part != nullptr);
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, LNB_ROWS * steps)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
+                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");
     return 0;
 }

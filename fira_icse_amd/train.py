@@ -28,12 +28,12 @@ class Trainer:
         self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
         self.reducer = GradReducer(model.layout.split, model.layout.live) if distributed else None
-        # fires inside the backward pass when the gradients of [0, split) (head + decoder) are final: Adam on that slice
-        # (69 % of the live parameters) then runs beside the encoder's backward pass (single GPU), or its all-reduce does (DP)
-        self.mid_event = torch.cuda.Event()
-        self.mid_event.record()                # torch creates the hipEvent lazily: force it so its handle can be passed
-        self.adam_stream = torch.cuda.Stream(priority=-1)
-        self.adam_done = torch.cuda.Event()
+        self.mid_event = None
+        if distributed:
+            # fires inside the backward pass when the gradients of [0, split) (head + decoder) are final: their all-reduce
+            # then runs beside the encoder's backward pass
+            self.mid_event = torch.cuda.Event()
+            self.mid_event.record()            # torch creates the hipEvent lazily: force it so its handle can be passed
 
     def step(self, db: Optional[DeviceBatch]):
         """One optimisation step on this rank's shard of the global batch.
@@ -74,16 +74,12 @@ class Trainer:
         # [live, total) holds the tensors no kernel touches (encoder.lstm, combination_list1, gate_fc): their gradient is
         # None in the reference, so torch.optim.Adam skips them too.  1 / n_tok (run_model.py:105) is formed inside the
         # Adam kernel from the device counter (no separate launch, no host sync).
-        split, n = m.layout.split, m.layout.live
-        main = torch.cuda.current_stream()
-        with torch.cuda.stream(self.adam_stream):
-            self.adam_stream.wait_event(self.mid_event)
-            ops.adam_step_mb(m.flat.data[:split], m.gbuf[:split], None, self.m[:split], self.v[:split], self.lr, self.t,
-                             n_tok, None, b1, b2, self.eps)
-            self.adam_done.record(self.adam_stream)
-        ops.adam_step_mb(m.flat.data[split:n], m.gbuf[split:n], None, self.m[split:n], self.v[split:n], self.lr, self.t,
-                         n_tok, None, b1, b2, self.eps)
-        main.wait_event(self.adam_done)        # the next forward pass reads every parameter
+        # One launch over [0, live).  (Running the head+decoder slice on its own stream beside the encoder's backward pass
+        # was measured on one box: 8 497 vs 8 553 commits/s -- the HBM-bound update only slows the backward kernels it
+        # overlaps; profiles/r2_probes.md.)
+        n = m.layout.live
+        ops.adam_step_mb(m.flat.data[:n], m.gbuf[:n], None, self.m[:n], self.v[:n], self.lr, self.t, n_tok, None, b1, b2,
+                         self.eps)
 
     def last_loss(self) -> float:
         """Mean token loss of the last (global) batch; synchronises."""

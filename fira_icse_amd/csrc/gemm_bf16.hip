@@ -651,6 +651,21 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
     if (splitk <= 1) {                                  // K = 256: the A-stationary panel kernel (gemm_bf16_panel.hip)
         int rc;
         if (gemm_bf16_k256_try(s, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags, c_rows, relu_mask, &rc)) return rc;
+        // K = 512 / 768 / 1024 as a chain of K = 256 slices on the same stream, the later ones accumulating (an atomic add
+        // per element, one owner): the encoder's q|k data gradient [10 000, 256] x K 512 takes 2 x 12 us instead of the
+        // tiled kernel's 43 us.  Not with a ReLU / ReLU mask, which must see the complete sum.
+        static const int slice_mode = [] { const char* e = getenv("FIRA_PANEL_SLICES"); return e ? atoi(e) : 1; }();
+        if (slice_mode && K % 256 == 0 && K <= 1024 && !(flags & FIRA_GEMM_RELU) && !relu_mask) {
+            bool taken = true;
+            for (int k0 = 0; k0 < K && taken; k0 += 256) {
+                const int fl = k0 == 0 ? (flags & FIRA_GEMM_ACCUM) : FIRA_GEMM_ACCUM;
+                taken = gemm_bf16_k256_try(s, M, N, 256, A + k0, lda, Bb + k0, ldb, C, ldc, k0 == 0 ? bias : nullptr, fl, c_rows,
+                                           nullptr, &rc);
+                if (rc) return rc;
+                FIRA_REQUIRE(taken || k0 == 0, "gemm_bf16_wb: K slice %d refused after the first was issued", k0);
+            }
+            if (taken) return 0;
+        }
     }
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
     const int tile = (t128 >= 256 && K >= 2048) ? 0 : 2;

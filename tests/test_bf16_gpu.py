@@ -125,6 +125,20 @@ def test_panel_kernel_k256_edges_accumulate_relu(M, N):
     assert rel_err(Cw[:, :N], bf(Xw[:, 256:]) @ bf(W).t()) < 2e-6 and float(Cw[:, N:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 256, 512), (4100, 320, 768), (3000, 512, 1024)])
+def test_panel_kernel_k_slices(M, N, K):
+    """K = 512 / 768 / 1024 run as a chain of K = 256 panel launches, the later slices accumulating atomically (one owner
+    per element: deterministic); with a ReLU the tiled kernel takes the call instead -- both against the same reference."""
+    from fira_icse_amd import ops
+    X, W, bias, C0 = randn(M, K, seed=21), randn(N, K, seed=22), randn(N, seed=23), randn(M, N, seed=24)
+    wb, _ = ops.weight_shadow(W)
+    ref = bf(X) @ bf(W).t() + bias.double()
+    a, b = ops.gemm_wb(X, wb, bias=bias), ops.gemm_wb(X, wb, bias=bias)
+    assert rel_err(a, ref) < 2e-6 and torch.equal(a, b)
+    assert rel_err(ops.gemm_wb(X, wb, bias=bias, out=C0.clone(), accumulate=True), ref + C0.double()) < 3e-6
+    assert rel_err(ops.gemm_wb(X, wb, bias=bias, relu=True), ref.clamp_min(0)) < 2e-6
+
+
 @pytest.fixture(scope="module")
 def small():
     from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict

@@ -69,6 +69,23 @@ def peaked_state_dict(sd: dict, seed: int = 2) -> dict:
     return sd
 
 
+TIE_TWINS = (4, 24650)      # token ids [lo, hi): every odd id in the range is an exact copy of the even id below it
+
+
+def tie_state_dict(sd: dict, seed: int = 2) -> dict:
+    """peaked_state_dict + twin vocabulary entries: for every even id e in TIE_TWINS the generator row, its bias and the
+    decoder embedding row of e + 1 are bit-copies of e's.  Hypotheses that differ only in a twin have EXACTLY equal
+    probabilities at every later step, so beam search must break ties -- the reference does it with
+    ``torch.sort(descending=True)`` over the flattened candidates (run_model.py:305)."""
+    sd = peaked_state_dict(sd, seed)
+    lo, hi = TIE_TWINS
+    for k in ("out_fc.weight", "out_fc.bias", "decoder.embedding.weight"):
+        t = sd[k].clone()
+        t[lo + 1:hi:2] = t[lo:hi:2]
+        sd[k] = t
+    return sd
+
+
 def load_golden_raw():
     """The golden synthetic raw DataSet (regenerated deterministically from the committed generator)."""
     from fira_icse_amd import synth

@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone SpMM / host-inclusive legs")
     ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--dp-same-device", action="store_true", help="all ranks on cuda:0 over gloo (one-GPU testing)")
+    ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded Adam + all-gather instead of "
+                    "all-reduce + replicated Adam")
     return ap.parse_args()
 
 
@@ -309,7 +311,7 @@ def main():
     model.compute_dtype = a.dtype
     model.set_dropout_stream(0, rank)
     model.train()                                      # dropout on, as the reference trains
-    trainer = Trainer(model, distributed=world > 1)
+    trainer = Trainer(model, distributed=world > 1, zero1=a.zero1)
     batches = [DeviceBatch(store.batch(range(i * B, (i + 1) * B)), cfg, model.device_) for i in range(a.pool)]
     nnz_mean = float(np.mean([b.nnz for b in batches]))
 
@@ -410,7 +412,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
-                       "global_batch": B * world, "parallelism": "dp%d" % world, "loss": loss},
+                       "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss},
             "roofline": roofline, "spmm": spmm_obj, "decode": decode, "cpu_baseline": cpu,
             "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in prof.items()},
         }

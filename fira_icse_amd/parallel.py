@@ -100,6 +100,82 @@ class GradReducer:
         self.wait_late()
 
 
+class ShardedOptimizerComm:
+    """ZeRO-1 style data parallelism over the flat buffers: reduce-scatter of the gradient, Adam on the owned shard,
+    all-gather of the updated parameters -- the same bytes on the wire as the all-reduce (which is a reduce-scatter
+    followed by an all-gather), but every rank updates, and keeps Adam moments for, only 1/world of the parameters.
+
+    Each readiness bucket [lo, hi) (head+decoder, encoder) is cut into ``world`` chunks of ceil((hi-lo)/world) elements;
+    rank r owns chunk r clipped to the bucket.  The collectives run on the padded window [lo, lo + world*chunk): the
+    <= world-1 elements past ``hi`` belong to the next region of the flat buffer (the first encoder parameters, or the
+    never-trained tail [live, total)); their reduced gradients are ignored and the gathered "parameters" written back
+    there are the unchanged values every rank already holds.
+    """
+
+    def __init__(self, split: int, live: int, total: int, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.native = dist.is_initialized() and dist.get_backend(group) == "nccl"     # RCCL: reduce_scatter / all_gather
+        self.buckets = []
+        for lo, hi in ((0, split), (split, live)):
+            chunk = -(-(hi - lo) // self.world)
+            if lo + self.world * chunk > total:
+                raise ValueError("flat buffer too short for the padded bucket [%d, %d)" % (lo, lo + self.world * chunk))
+            a = min(hi, lo + self.rank * chunk)
+            self.buckets.append({"lo": lo, "hi": hi, "chunk": chunk, "a": a, "b": min(hi, a + chunk)})
+
+    def owned(self, b: int) -> Tuple[int, int]:
+        """[a, b) of bucket ``b`` this rank updates (may be empty on trailing ranks of a tiny bucket)."""
+        return self.buckets[b]["a"], self.buckets[b]["b"]
+
+    def reduce_scatter(self, b: int, gbuf: torch.Tensor, out: torch.Tensor):
+        """out[:chunk] = sum over ranks of gbuf[window of this rank]; enqueued on the current stream."""
+        q = self.buckets[b]
+        lo, chunk = q["lo"], q["chunk"]
+        window = gbuf[lo:lo + self.world * chunk]
+        if self.world == 1:
+            out[:chunk].copy_(window)
+        elif self.native:
+            dist.reduce_scatter_tensor(out[:chunk], window, op=dist.ReduceOp.SUM, group=self.group)
+        else:       # gloo has no reduce-scatter: all-reduce the window, keep the own chunk (the tested N>1 logic is the same)
+            tmp = window.clone()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            out[:chunk].copy_(tmp[self.rank * chunk:(self.rank + 1) * chunk])
+
+    def all_gather(self, b: int, flat: torch.Tensor):
+        """Every rank's chunk of the (updated) parameters -> all ranks, in place in the flat parameter buffer."""
+        q = self.buckets[b]
+        lo, chunk = q["lo"], q["chunk"]
+        if self.world == 1:
+            return
+        window = flat[lo:lo + self.world * chunk]
+        mine = window[self.rank * chunk:(self.rank + 1) * chunk]
+        if self.native:
+            dist.all_gather_into_tensor(window, mine, group=self.group)            # in place: mine == window[rank]
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
+            for r, part in enumerate(parts):
+                window[r * chunk:(r + 1) * chunk].copy_(part)
+
+    def gather_full(self, shards: List[torch.Tensor], total: int) -> torch.Tensor:
+        """Full-length [total] tensor from the per-bucket owned shards of every rank (checkpointing; collective)."""
+        full = torch.zeros(total, dtype=shards[0].dtype, device=shards[0].device)
+        for b, q in enumerate(self.buckets):
+            chunk = q["chunk"]
+            if self.world == 1:
+                parts = [shards[b]]
+            else:
+                parts = [torch.empty_like(shards[b]) for _ in range(self.world)]
+                dist.all_gather(parts, shards[b].contiguous(), group=self.group)
+            for r, part in enumerate(parts):
+                a = min(q["hi"], q["lo"] + r * chunk)
+                e = min(q["hi"], a + chunk)
+                full[a:e].copy_(part[:e - a])
+        return full
+
+
 def gather_lines(lines: List[str], group=None) -> List[str]:
     """Ordered gather of per-rank output lines onto every rank (decode shards are contiguous ranges of the test set, so
     concatenating in rank order keeps ``all_index['test']`` order)."""

@@ -13,17 +13,30 @@ import torch
 
 from . import ops
 from .model import DeviceBatch, TransModel
-from .parallel import GradReducer
+from .parallel import GradReducer, ShardedOptimizerComm
 
 
 class Trainer:
     def __init__(self, model: TransModel, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
-                 distributed: bool = False):
+                 distributed: bool = False, zero1: bool = False):
+        """``zero1`` (with ``distributed``): reduce-scatter + Adam on the owned 1/world shard + all-gather instead of
+        all-reduce + replicated Adam; Adam moments exist only for the owned shard (parallel.ShardedOptimizerComm)."""
         self.model = model
         self.lr = model.cfg.lr if lr is None else lr
         self.betas, self.eps = betas, eps
-        self.m = torch.zeros_like(model.gbuf)
-        self.v = torch.zeros_like(model.gbuf)
+        self.zero = ShardedOptimizerComm(model.layout.split, model.layout.live, model.layout.total) \
+            if (distributed and zero1) else None
+        if self.zero is None:
+            self.m = torch.zeros_like(model.gbuf)
+            self.v = torch.zeros_like(model.gbuf)
+        else:
+            dev = model.gbuf.device
+            chunks = [q["chunk"] for q in self.zero.buckets]
+            self.m_sh = [torch.zeros(c, dtype=torch.float32, device=dev) for c in chunks]
+            self.v_sh = [torch.zeros(c, dtype=torch.float32, device=dev) for c in chunks]
+            self.g_sh = [torch.zeros(c, dtype=torch.float32, device=dev) for c in chunks]
+            self.zstream = torch.cuda.Stream()
+            self.end_event = torch.cuda.Event()
         self.t = 0
         self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
@@ -54,6 +67,9 @@ class Trainer:
         else:
             loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
         b1, b2 = self.betas
+        if self.zero is not None and self.zero.world > 1:
+            self._step_zero1(loss_sum, n_tok)
+            return
         if self.reducer is not None and self.reducer.world > 1:
             red, split, live = self.reducer, m.layout.split, m.layout.live
             red.start_early_bucket(m.gbuf, self.mid_event)
@@ -81,6 +97,34 @@ class Trainer:
         ops.adam_step_mb(m.flat.data[:n], m.gbuf[:n], None, self.m[:n], self.v[:n], self.lr, self.t, n_tok, None, b1, b2,
                          self.eps)
 
+    def _step_zero1(self, loss_sum, n_tok):
+        """reduce-scatter -> Adam on the owned shard -> all-gather, per readiness bucket, on a side stream: the head+decoder
+        bucket's reduce-scatter starts at the mid-backward event, beside the encoder's backward pass."""
+        m, z, zs = self.model, self.zero, self.zstream
+        b1, b2 = self.betas
+        main = torch.cuda.current_stream()
+        zs.wait_event(self.mid_event)
+        with torch.cuda.stream(zs):
+            z.reduce_scatter(0, m.gbuf, self.g_sh[0])
+        self.stats[0:1].copy_(loss_sum)
+        self.stats[1:2].copy_(n_tok)                           # int32 -> fp32 (exact below 2^24 tokens)
+        torch.distributed.all_reduce(self.stats, op=torch.distributed.ReduceOp.SUM, group=z.group)
+        torch.reciprocal(self.stats[1:2].clamp_min(1.0), out=self.inv)
+        self.end_event.record(main)                            # backward pass done, global token count known
+        self.t += 1
+        zs.wait_event(self.end_event)
+        with torch.cuda.stream(zs):
+            for b in (0, 1):
+                if b == 1:
+                    z.reduce_scatter(1, m.gbuf, self.g_sh[1])
+                lo, hi = z.owned(b)
+                if hi > lo:
+                    n = hi - lo
+                    ops.adam_step(m.flat.data[lo:hi], self.g_sh[b][:n], self.m_sh[b][:n], self.v_sh[b][:n], self.lr, self.t,
+                                  b1, b2, self.eps, inv_scale=self.inv)
+                z.all_gather(b, m.flat.data)
+        main.wait_stream(zs)                                   # the next forward pass reads every parameter
+
     def last_loss(self) -> float:
         """Mean token loss of the last (global) batch; synchronises."""
         if self.reducer is not None and self.reducer.world > 1:
@@ -92,8 +136,18 @@ class Trainer:
     def state_dict(self):
         """Everything a restart needs besides the weights: Adam moments, Adam step and the dropout step counter (so
         that a resumed run continues the mask sequence instead of replaying it from step 1)."""
+        if self.zero is not None:                              # collective: every rank calls it, any rank may save it
+            total = self.model.layout.total
+            return {"m": self.zero.gather_full(self.m_sh, total), "v": self.zero.gather_full(self.v_sh, total),
+                    "t": self.t, "dropout_step": self.model.dropout_step}
         return {"m": self.m, "v": self.v, "t": self.t, "dropout_step": self.model.dropout_step}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.t = int(sd["t"])
+        if self.zero is not None:                              # the checkpoint holds full moments: keep the owned shards
+            for b in (0, 1):
+                lo, hi = self.zero.owned(b)
+                self.m_sh[b][:hi - lo].copy_(sd["m"][lo:hi]); self.v_sh[b][:hi - lo].copy_(sd["v"][lo:hi])
+        else:
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.t = int(sd["t"])
         self.model.dropout_step = int(sd.get("dropout_step", self.t))

@@ -61,6 +61,8 @@ def parse_args(argv):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save-optimizer", action="store_true", help="also write fira_train_state.pt (Adam moments, step)")
     ap.add_argument("--resume", action="store_true", help="start from best_model.pt (+ fira_train_state.pt if present)")
+    ap.add_argument("--zero1", action="store_true", help="multi-GPU: reduce-scatter + Adam on the owned shard + all-gather "
+                    "(Adam moments sharded over the ranks) instead of all-reduce + replicated Adam")
     return ap.parse_args(argv)
 
 
@@ -141,7 +143,7 @@ class Run:
         if a.resume and os.path.exists(os.path.join(self.root, "best_model.pt")):
             self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
         self.model.set_dropout_stream(a.seed, self.rank)           # masks depend on (--seed, rank, step)
-        trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1)
+        trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1, zero1=a.zero1)
         state_path = os.path.join(self.root, "fira_train_state.pt")
         if a.resume and os.path.exists(state_path):
             trainer.load_state_dict(torch.load(state_path, map_location=self.model.device_))
@@ -164,10 +166,11 @@ class Run:
                                 epoch, idx_b, cur_bleu, cur_bleu > best_bleu))
                     if cur_bleu > best_bleu:
                         best_bleu = cur_bleu
+                        opt_state = trainer.state_dict() if a.save_optimizer else None     # collective with --zero1
                         if self.rank == 0:
                             torch.save(self.model.state_dict(), os.path.join(self.root, "best_model.pt"))
                             if a.save_optimizer:
-                                torch.save(trainer.state_dict(), state_path)
+                                torch.save(opt_state, state_path)
                             with open(self.out("dev_output"), "w") as f:
                                 f.write(output_str)
                     self.model.train(not a.no_dropout)
@@ -183,10 +186,12 @@ class Run:
             batches.close()                          # stops the worker thread and drops its prepared batches
             if a.max_steps and steps >= a.max_steps:
                 break
-        if best_bleu < 0 and self.rank == 0:            # never reached a dev point (short runs): keep the last weights
-            torch.save(self.model.state_dict(), os.path.join(self.root, "best_model.pt"))
-            if a.save_optimizer:                         # ... and the optimizer state that belongs to them (--resume)
-                torch.save(trainer.state_dict(), state_path)
+        if best_bleu < 0:                               # never reached a dev point (short runs): keep the last weights
+            opt_state = trainer.state_dict() if a.save_optimizer else None                 # collective with --zero1
+            if self.rank == 0:
+                torch.save(self.model.state_dict(), os.path.join(self.root, "best_model.pt"))
+                if a.save_optimizer:                     # ... and the optimizer state that belongs to them (--resume)
+                    torch.save(opt_state, state_path)
         return best_bleu
 
     # ------------------------------------------------------------------------------ test (run_model.py:187-380,401-415)

@@ -16,7 +16,7 @@ from fira_icse_amd.config import FiraConfig
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, out, zero1=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, util.REPO)
     from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict
@@ -31,7 +31,7 @@ def _run(rank, world, port, out):
     model = TransModel(cfg, init=False)
     model.load_state_dict(util.perturb_state_dict(reference_init_state_dict(cfg), seed=1))
     model.eval()                                        # dropout off: the comparison must be deterministic
-    trainer = Trainer(model, distributed=world > 1)
+    trainer = Trainer(model, distributed=world > 1, zero1=zero1)
     losses = []
     for step in range(3):
         # the last global batch holds ONE commit: with two ranks, rank 1's shard is empty (DataParallel.scatter chunking)
@@ -41,8 +41,9 @@ def _run(rank, world, port, out):
         trainer.step(DeviceBatch(store.batch(mine), cfg) if mine else None)
         losses.append(trainer.last_loss())
     torch.cuda.synchronize()
+    opt = trainer.state_dict()                              # collective with zero1 (shards gathered onto every rank)
     if rank == 0:
-        torch.save({"flat": model.flat.data.cpu(), "losses": losses}, out)
+        torch.save({"flat": model.flat.data.cpu(), "losses": losses, "m": opt["m"].cpu(), "v": opt["v"].cpu()}, out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -63,6 +64,25 @@ def test_two_rank_training_equals_single_process(tmp_path):
     diff = (a["flat"] - b["flat"]).abs()
     assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
     assert float(diff.mean()) < 1e-3 * cfg.lr
+
+
+def test_two_rank_zero1_equals_single_process(tmp_path):
+    """reduce-scatter + Adam on the owned shard + all-gather (Trainer(zero1=True)): same parameters, and the gathered Adam
+    moments equal the single-process moments (checkpoints are interchangeable between the modes)."""
+    port = 29500 + (os.getpid() % 150)
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    mp.spawn(_run, args=(1, port, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, port + 1, two, True), nprocs=2, join=True)
+    a, b = torch.load(one, weights_only=False), torch.load(two, weights_only=False)
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) / x < 1e-5, (a["losses"], b["losses"])
+    cfg = FiraConfig()
+    diff = (a["flat"] - b["flat"]).abs()
+    assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
+    assert float(diff.mean()) < 1e-3 * cfg.lr
+    for k in ("m", "v"):                                     # moments: same accumulation up to the reduction order
+        d = (a[k] - b[k]).norm() / a[k].norm()
+        assert float(d) < 1e-4, (k, float(d))
 
 
 def test_bench_self_launches_under_torchrun():

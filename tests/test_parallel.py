@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 import util
 from fira_icse_amd import data
 from fira_icse_amd.config import FiraConfig
-from fira_icse_amd.parallel import GradReducer, gather_lines, shard_indices, shard_range
+from fira_icse_amd.parallel import GradReducer, ShardedOptimizerComm, gather_lines, shard_indices, shard_range
 
 
 def test_shard_range_is_dataparallel_scatter_chunking():
@@ -129,3 +129,44 @@ def test_two_rank_gradient_equals_single_rank(tmp_path):
     err = float((r["g"] - r["gf"]).double().norm() / r["gf"].double().norm())
     assert err < 1e-5, err
     assert r["lines"] == ["r0-%d" % i for i in r["idx"][:2]] + ["r1-%d" % i for i in r["idx"][2:]]   # ordered gather
+
+
+def _zero_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    split, live, total = 1003, 2411, 2600                    # ragged on purpose: neither bucket divides by the world size
+    z = ShardedOptimizerComm(split, live, total)
+    g = torch.Generator().manual_seed(100 + rank)
+    gbuf = torch.randn(total, generator=g)
+    flat = torch.arange(total, dtype=torch.float32)          # identical "parameters" on every rank
+    want_sum = sum(torch.randn(total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    covered = torch.zeros(total)
+    for b in (0, 1):
+        q = z.buckets[b]
+        out = torch.zeros(q["chunk"])
+        z.reduce_scatter(b, gbuf, out)
+        lo, hi = z.owned(b)
+        assert torch.allclose(out[:hi - lo], want_sum[lo:hi], atol=1e-6)           # the owned shard of the summed gradient
+        flat[lo:hi] -= 0.5 * out[:hi - lo]                                            # "optimizer" on the owned shard only
+        covered[lo:hi] += 1
+        z.all_gather(b, flat)
+    dist.all_reduce(covered)
+    assert torch.equal(covered[:live], torch.ones(live)) and float(covered[live:].sum()) == 0     # a partition of [0, live)
+    want = torch.arange(total, dtype=torch.float32)
+    want[:live] -= 0.5 * want_sum[:live]
+    assert torch.allclose(flat, want, atol=1e-6)              # every rank holds every updated parameter; the tail is untouched
+    shards = [torch.full((q["chunk"],), float(rank + 1)) for q in z.buckets]
+    full = z.gather_full(shards, total)                       # checkpoint view: rank r's value on rank r's ranges
+    for r in range(world):
+        for q in z.buckets:
+            a = min(q["hi"], q["lo"] + r * q["chunk"])
+            assert torch.all(full[a:min(q["hi"], a + q["chunk"])] == r + 1)
+    assert float(full[live:].abs().sum()) == 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_comm_partitions_reduces_and_gathers(tmp_path, world):
+    """ZeRO-1 comm (reduce-scatter / owned shard / all-gather) over ragged buckets, gloo, world_size 2 and 3."""
+    mp.spawn(_zero_worker, args=(world, 29650 + (os.getpid() % 200) + world, str(tmp_path)), nprocs=world, join=True)

@@ -530,6 +530,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(int M, int N, int 
 
 // Products this kernel does not take (handled by the fp32 kernels, i.e. computed more precisely, never less):
 // unaligned operands, and the tiny ones (4-row mark table, 2-column gate) where a 64-wide tile is mostly padding.
+// latency kernel (32x32 tiles, K split over the 4 waves) vs the 64x64 tiled kernel: up to ~4 rounds of 32x32 tiles; with a
+// long reduction (K >= 768) only while the tiled kernel would leave most CUs idle (measured at M = 1920, N = 256, K = 1024:
+// 14.0 us vs 9.7 us; at M = 960: 10.6 vs 9.9)
+static bool small_kernel_wins(int M, int N, int K) {
+    const long t32 = (long)cdiv(M, 32) * cdiv(N, 32);
+    return t32 <= 1024 && !(K >= 768 && t32 > 256);
+}
 bool gemm_bf16_takes(int M, int N, int K) { return M >= 32 && N >= 32 && K >= 32; }
 static bool bf16_shape_ok(int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
     if (M < 32 || N < 32 || K < 32) return false;
@@ -552,8 +559,7 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
     int tile = ((flags >> FIRA_GEMM_TILE_SHIFT) & 3) - 1;       // -1: automatic; 0: 128x128; 1, 2: 64x64
     // skinny forward / dgrad shapes (the decoder): up to ~4 rounds of 32x32 tiles the latency kernel wins
     static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();
-    if (tile < 0 && splitk <= 1 && !colsum && !tA && small_mode && K % 64 == 0 &&
-        (long)cdiv(M, 32) * cdiv(N, 32) <= 1024) {
+    if (tile < 0 && splitk <= 1 && !colsum && !tA && small_mode && K % 64 == 0 && small_kernel_wins(M, N, K)) {
         dim3 grid(cdiv(N, 32), cdiv(M, 32));
         if (tB) hipLaunchKernelGGL(gemm_bf16_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask);
         else hipLaunchKernelGGL(gemm_bf16_small_kernel<false>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask);
@@ -563,7 +569,12 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t64 = (long)cdiv(M, 64) * cdiv(N, 64);
     // 128x128 (one workgroup per CU, 2x fewer operand re-reads) only pays on long reductions with plenty of tiles
     // (measured: K = 3072 dgrad / wgrad of the cross K|V projection 1.4x faster, every K = 256 shape 1.5-1.9x slower)
-    if (tile < 0) tile = (t128 >= 256 && K >= 2048) ? 0 : 2;
+    // ... or with few tiles but a reduction long enough that the split-K fan-out fills the chip anyway (the K|V
+    // projection's weight gradient [3072,256] over 17 000 rows: 48 tiles x 16 splits, 139 us against 372 us with 64x64)
+    if (tile < 0) {
+        const long split128 = can_split ? std::min((768 + t128 - 1) / t128, (long)K / 256) : 1;
+        tile = (K >= 2048 && (t128 >= 256 || t128 * split128 >= 512)) ? 0 : 2;
+    }
     if (splitk == 0) {
         // memory-bound: aim at ~2 workgroups per CU; every split re-reads nothing (disjoint K ranges) but adds one
         // atomic per output element, so split only reductions that are long compared with the tile
@@ -641,7 +652,7 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();
-    if (splitk <= 1 && small_mode && K % 64 == 0 && (long)cdiv(M, 32) * cdiv(N, 32) <= 1024) {
+    if (splitk <= 1 && small_mode && K % 64 == 0 && small_kernel_wins(M, N, K)) {
         dim3 grid(cdiv(N, 32), cdiv(M, 32));
         hipLaunchKernelGGL((gemm_bf16_small_kernel<true, uint16_t>), grid, dim3(256), 0, s, M, N, K, A, lda, Bb, ldb, C, ldc,
                            bias, flags & 3, c_rows, relu_mask);
@@ -653,9 +664,10 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
         if (gemm_bf16_k256_try(s, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags, c_rows, relu_mask, &rc)) return rc;
         // K = 512 / 768 / 1024 as a chain of K = 256 slices on the same stream, the later ones accumulating (an atomic add
         // per element, one owner): the encoder's q|k data gradient [10 000, 256] x K 512 takes 2 x 12 us instead of the
-        // tiled kernel's 43 us.  Not with a ReLU / ReLU mask, which must see the complete sum.
+        // tiled kernel's 43 us.  Not with a ReLU / ReLU mask, which must see the complete sum, and not for the decoder-sized
+        // products with K = 768 / 1024, where one tiled launch (9.7 us) beats three or four chained ones.
         static const int slice_mode = [] { const char* e = getenv("FIRA_PANEL_SLICES"); return e ? atoi(e) : 1; }();
-        if (slice_mode && K % 256 == 0 && K <= 1024 && !(flags & FIRA_GEMM_RELU) && !relu_mask) {
+        if (slice_mode && K % 256 == 0 && K <= 1024 && (K == 512 || M >= 8192) && !(flags & FIRA_GEMM_RELU) && !relu_mask) {
             bool taken = true;
             for (int k0 = 0; k0 < K && taken; k0 += 256) {
                 const int fl = k0 == 0 ? (flags & FIRA_GEMM_ACCUM) : FIRA_GEMM_ACCUM;

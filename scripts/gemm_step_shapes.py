@@ -39,6 +39,18 @@ def main():
             t = timeit(lambda: ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=C, accumulate=bool(acc), splitk=0,
                                         tile=tile, dtype=DTYPE), iters=30)
             res[label] = t * 1e6
+        if DTYPE == "bf16" and not tA:
+            # what the engine runs in bf16 mode: the k-contiguous bf16 weight shadow (forward: of W; data gradient: of W^T)
+            # through fira_gemm_bf16_wb -- latency kernel, K=256 panel kernel (and its K slices) or the tiled kernel
+            wb, _ = ops.weight_shadow(B if tB else B.t().contiguous())
+            if K % 8:                                            # row pitch of a shadow is a multiple of 8 (engine: 24656)
+                wide = torch.zeros((N, K + 8 - K % 8), dtype=torch.int16, device="cuda")
+                wide[:, :K] = wb
+                wb = wide[:, :K]
+                Aw = torch.zeros((M, K + 8 - K % 8), device="cuda")      # ... and so is the pitch of the activations
+                Aw[:, :K] = A
+                A = Aw[:, :K]
+            res["auto"] = timeit(lambda: ops.gemm_wb(A, wb, out=C, accumulate=bool(acc), splitk=0), iters=30) * 1e6
         best = min(res, key=res.get)
         total["auto"] += cnt * res["auto"]
         total["best"] += cnt * res[best]
@@ -46,7 +58,8 @@ def main():
         rows.append("%-16s %6d %6d %6d  x%-2d  auto %7.1f us %6.1f TF %5.2f TB/s | t128 %7.1f  t64x128 %7.1f  t64 %7.1f | best %s" % (
             name, M, N, K, cnt, res["auto"], 2.0 * M * N * K / res["auto"] / 1e6, by / res["auto"] / 1e6, res["t128"],
             res["t64x128"], res["t64"], best))
-    print("dtype %s, batch %d" % (DTYPE, 32 * SCALE))
+    print("dtype %s, batch %d  (bf16 forward / dgrad rows: `auto` = the weight-shadow path the engine takes; the forced-tile columns "
+          "are the fp32-operand tiled kernel)" % (DTYPE, 32 * SCALE))
     print("\n".join(rows))
     print("sum over the step: auto %.0f us, best-of-forced %.0f us" % (total["auto"], total["best"]))
 

@@ -355,7 +355,7 @@ def main():
     gemm, spmm = prof["gemm"], prof["spmm"]
     g_s = gemm["ms"] * 1e-3
     peak_tf = BF16_MFMA_PEAK_TF if a.dtype == "bf16" else FP32_MFMA_PEAK_TF
-    kern = "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if a.dtype == "bf16" else \
+    kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if a.dtype == "bf16" else \
         "gemm_f32_kernel / gemm_small_kernel (v_mfma_f32_32x32x2_f32)"
     roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,

@@ -8,6 +8,8 @@
 // in registers (forward and re-computed in backward) and the loss kernel turns the logits into their
 // gradient in place, one pass after the soft-max statistics.
 #include "engine.h"
+#include <stdlib.h>
+#include "epilogue.h"
 
 namespace fira {
 
@@ -446,11 +448,79 @@ __global__ __launch_bounds__(256) void decode_dist_kernel(int V, int S, const fl
         if (best_p) best_p[r] = pg >= pc ? pg : pc;
     }
 }
+// Same arithmetic, same per-thread element order (so every sum and every arg-max is bit-identical to the kernel above), but
+// the row's V logits are requested ONCE, all together, and stay in registers: the loop version walks the row three times
+// with one dependent 4-byte load per iteration (97 iterations x 3 passes = 51 us per step at V = 24 650; this one: one
+// round trip).  DD_NPT * 256 >= V.
+constexpr int DD_NPT = 100;
+__global__ __launch_bounds__(256) void decode_dist_reg_kernel(int V, int S, const float* __restrict__ logits, int ldl,
+                                                              const float* __restrict__ score,
+                                                              const int32_t* __restrict__ mem_valid, int qpk,
+                                                              const float* __restrict__ gate_logits,
+                                                              float* __restrict__ dist, int32_t* __restrict__ best_id,
+                                                              float* __restrict__ best_p) {
+    __shared__ float smf[4];
+    __shared__ int smi[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const rsrc_t rL = buf_rsrc(logits + (size_t)r * ldl, (unsigned)V * 4u);
+    float x[DD_NPT];
+#pragma unroll
+    for (int i = 0; i < DD_NPT; ++i) x[i] = buf_load_f32(rL, (unsigned)(tid + 256 * i) * 4u);       // past V: 0, replaced below
+    const float* srow = score + (size_t)r * S;
+    const int32_t* mv = mem_valid + (size_t)(r / qpk) * S;
+    const float z0 = gate_logits[2 * r], z1 = gate_logits[2 * r + 1];
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+    float cmax = -INFINITY, gmax = -INFINITY;
+    int cidx = 0x7fffffff, gidx = 0x7fffffff;
+    for (int j = tid; j < S; j += 256) {
+        const float v = mv[j] ? srow[j] : -1e9f;
+        if (v > cmax) { cmax = v; cidx = j; }
+    }
+    block_argmax(cmax, cidx, smf, smi);
+    float csum = 0.f;
+    for (int j = tid; j < S; j += 256) csum += expf((mv[j] ? srow[j] : -1e9f) - cmax);
+    csum = block_sum(csum, smf);
+#pragma unroll
+    for (int i = 0; i < DD_NPT; ++i) {                       // ascending index within the thread: first maximum wins
+        const int j = tid + 256 * i;
+        x[i] = j < V ? x[i] : -INFINITY;
+        if (x[i] > gmax) { gmax = x[i]; gidx = j; }
+    }
+    block_argmax(gmax, gidx, smf, smi);
+    float gsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < DD_NPT; ++i) {
+        x[i] = expf(x[i] - gmax);                            // exp(-inf) = 0 past V
+        gsum += (tid + 256 * i < V) ? x[i] : 0.f;
+    }
+    gsum = block_sum(gsum, smf);
+    if (dist) {
+        float* drow = dist + (size_t)r * (V + S);
+        const float sg = g0 * (1.0f / gsum), sc = g1 * (1.0f / csum);
+        const rsrc_t rD = buf_rsrc(drow, (unsigned)V * 4u);
+#pragma unroll
+        for (int i = 0; i < DD_NPT; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sg * x[i]), rD, (unsigned)(tid + 256 * i) * 4u, 0, 0);
+        for (int j = tid; j < S; j += 256) drow[V + j] = sc * expf((mv[j] ? srow[j] : -1e9f) - cmax);
+    }
+    if (tid == 0 && best_id) {
+        const float pg = g0 * (1.0f / gsum), pc = g1 * (1.0f / csum);
+        best_id[r] = pg >= pc ? gidx : V + cidx;
+        if (best_p) best_p[r] = pg >= pc ? pg : pc;
+    }
+}
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
                 float* best_p) {
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (R <= 0) return 0;
+    static const int reg_mode = [] { const char* e = getenv("FIRA_DECODE_DIST_REG"); return e ? atoi(e) : 1; }();   // A/B switch
+    if (reg_mode && V <= DD_NPT * 256)
+        hipLaunchKernelGGL(decode_dist_reg_kernel, dim3(R), dim3(256), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
+                           gate_logits, dist, best_id, best_p);
+    else
     hipLaunchKernelGGL(decode_dist_kernel, dim3(R), dim3(256), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
                        gate_logits, dist, best_id, best_p);
     FIRA_CHECK_LAUNCH("decode_dist");

@@ -81,6 +81,10 @@ int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const fl
                       const float* r1_col = nullptr);   // x += r1_row[r] * r1_col[:] before the dropout
 bool gemm_bf16_k256_try(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
                         int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask, int* rc);
+bool linear_ln_bf16_try(hipStream_t s, int M, int K, const float* X, int ldx, const uint16_t* Wb, int ldb, const float* bias,
+                        const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
+                        float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row,
+                        const float* r1_col, int* rc, bool force = false);
 // fused linear + bias (+ rank-1) + dropout + residual + LayerNorm over 32 complete rows per workgroup (linear_ln.hip);
 // returns false when it does not take the call (shape / alignment / FIRA_FUSED_LN=0): the caller runs the two kernels
 bool linear_ln_fwd_try(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* bias, const float* res,

@@ -287,6 +287,13 @@ static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx
         if (linear_ln_fwd_try(s, M, K, X, ldx, W, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col,
                               &rc))
             return rc;
+    } else {                                     // bf16: the panel kernel with a LayerNorm epilogue (gemm_bf16_panel.hip)
+        const uint16_t* wb;
+        int ldw, rc;
+        if (shadow_of(W, false, &wb, &ldw) && ldw == K &&
+            linear_ln_bf16_try(s, M, K, X, ldx, wb, ldw, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row,
+                               r1_col, &rc))
+            return rc;
     }
     TRY(linear(s, M, FIRA_D, K, X, ldx, W, b, sum, FIRA_D));
     return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col);

@@ -232,6 +232,228 @@ __global__ __launch_bounds__(256) void gemm_bf16_k256_kernel(int M, int N, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// y = LayerNorm(dropout(X Wb^T + b [+ r c^T]) + res) * gamma + beta in ONE launch (bf16 mode; N = 256, K = 256): the panel
+// kernel above with BM = 64 already owns 64 COMPLETE output rows, and with the bf16 matrix pipe the 64x256x256 block is
+// 0.85 us of MFMA time -- the reason the fp32 twin (linear_ln.hip) loses does not apply.  The four column tiles accumulate
+// into 4 x 16 registers per lane; the row statistics are reduced over the 32 lanes of a half-wave with xor shuffles and
+// over the two column-half waves of a row slice through LDS (two passes: mean, then the centred sum of squares, like
+// add_layernorm_fwd_kernel); dropout uses the same element indices (row * 256 + col), so the backward kernels and masks
+// are unchanged.  No store is issued before the last weight tile has been consumed.
+__global__ __launch_bounds__(256, 2) void linear_ln_bf16_kernel(int M, const float* __restrict__ A, int lda,
+                                                             const uint16_t* __restrict__ Bb, int ldb,
+                                                             const float* __restrict__ bias, const float* __restrict__ res,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ sum, float* __restrict__ y,
+                                                             float* __restrict__ stats, float p, float inv_keep,
+                                                             uint64_t seed, uint32_t site,
+                                                             const int32_t* __restrict__ y_rows,
+                                                             const float* __restrict__ r1_row,
+                                                             const float* __restrict__ r1_col, int n_items, int chunk) {
+    constexpr int BM = 64;
+    __shared__ __attribute__((aligned(16))) char sm[2 * PBN * PPITCH];
+    __shared__ float red[2][2][2][32];                    // [pass][row slice][column half][row in slice]
+
+    const int item = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (item >= n_items) return;
+    const int m0 = item * BM;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int kc = t & 31, rs = t >> 5;
+    const int rt = wave & 1, cg = wave >> 1;
+
+    const rsrc_t rA = make_rsrc(A, ((unsigned)(M - 1) * (unsigned)lda + PK) * 4u);
+    const rsrc_t rB = make_rsrc(Bb, (255u * (unsigned)ldb + PK) * 2u);
+    const unsigned bvo = ((unsigned)rs * (unsigned)ldb + (unsigned)kc * 8u) * 2u;
+    auto fetch_b = [&](int jt, u32v4 (&br)[8]) __attribute__((always_inline)) {
+        const unsigned base = (unsigned)(jt * PBN) * (unsigned)ldb * 2u + bvo;       // past the last tile: zeros
+#pragma unroll
+        for (int i = 0; i < 8; ++i) br[i] = __builtin_amdgcn_raw_buffer_load_b128(rB, base + (unsigned)(8 * i) * (unsigned)ldb * 2u, 0, 0);
+    };
+    auto put_b = [&](const u32v4 (&br)[8], int buf) __attribute__((always_inline)) {
+        char* sb = sm + buf * PBN * PPITCH;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32v4*>(sb + (rs + 8 * i) * PPITCH + kc * 16) = br[i];
+    };
+    u32v4 br0[8], br1[8];
+    fetch_b(0, br0);
+    fetch_b(1, br1);
+    {
+        u32v4 v[8][2];
+        const unsigned base = ((unsigned)(m0 + rs) * (unsigned)lda + (unsigned)kc * 8u) * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned o = base + (unsigned)(8 * i) * (unsigned)lda * 4u;
+            v[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rA, o, 0, 0);
+            v[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rA, o + 16u, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 lo = __builtin_bit_cast(f32x4, v[i][0]), hi = __builtin_bit_cast(f32x4, v[i][1]);
+            u32v4 w = {pack2(lo.x, lo.y), pack2(lo.z, lo.w), pack2(hi.x, hi.y), pack2(hi.z, hi.w)};
+            *reinterpret_cast<u32v4*>(sm + (rs + 8 * i) * PPITCH + kc * 16) = w;
+        }
+    }
+    __syncthreads();
+    bf16x8 a[16];
+    {
+        const char* sa = sm + (rt * 32 + l31) * PPITCH + kh * 16;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a[s] = *reinterpret_cast<const bf16x8*>(sa + s * 32);
+    }
+    __syncthreads();
+    put_b(br0, 0);
+    __syncthreads();
+
+    const int boff = (cg * 32 + l31) * PPITCH + kh * 16;
+    f32x16 acc[4];
+    auto tile_step = [&](int j, int buf, u32v4 (&br_next)[8], u32v4 (&br_free)[8]) __attribute__((always_inline)) {
+        fetch_b(j + 2, br_free);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const char* sb = sm + buf * PBN * PPITCH + boff;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(sb + s * 32);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b, acc[j], 0, 0, 0);
+        }
+        put_b(br_next, buf ^ 1);
+        __syncthreads();
+    };
+    tile_step(0, 0, br1, br0);
+    tile_step(1, 1, br0, br1);
+    tile_step(2, 0, br1, br0);
+    tile_step(3, 1, br0, br1);
+
+    // ---- epilogue: x = dropout(acc + b + r c^T) + res; two-pass row statistics; sum / y / stats ----------------------
+    const int row_base = m0 + rt * 32 + 4 * kh;
+    const rsrc_t rBias = make_rsrc(bias ? (const void*)bias : (const void*)A, bias ? 1024u : 0u);
+    const rsrc_t rRes = make_rsrc(res ? (const void*)res : (const void*)A, res ? (unsigned)M * 1024u : 0u);
+    const rsrc_t rR1 = make_rsrc(r1_row ? (const void*)r1_row : (const void*)A, r1_row ? (unsigned)M * 4u : 0u);
+    const rsrc_t rC1 = make_rsrc(r1_row ? (const void*)r1_col : (const void*)A, r1_row ? 1024u : 0u);
+    const rsrc_t rMap = make_rsrc(y_rows ? (const void*)y_rows : (const void*)A, y_rows ? (unsigned)M * 4u : 0u);
+    const rsrc_t rSum = make_rsrc(sum ? (const void*)sum : (const void*)A, sum ? (unsigned)M * 1024u : 0u);
+    const rsrc_t rStats = make_rsrc(stats ? (const void*)stats : (const void*)A, stats ? (unsigned)M * 8u : 0u);
+    const rsrc_t rY = make_rsrc(y, 0x7fffffffu);
+    float bv[4], c1[4], gm[4], bt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned co = (unsigned)(j * 64 + cg * 32 + l31) * 4u;
+        bv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, co, 0, 0));
+        c1[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC1, co, 0, 0));
+        gm[j] = gamma[j * 64 + cg * 32 + l31];
+        bt[j] = beta[j * 64 + cg * 32 + l31];
+    }
+    float w1[16];
+    unsigned orow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        w1[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR1, (unsigned)row * 4u, 0, 0));
+        const unsigned mapped = __builtin_amdgcn_raw_buffer_load_b32(rMap, (unsigned)row * 4u, 0, 0);
+        orow[r] = row < M ? (y_rows ? mapped : (unsigned)row) * 1024u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = j * 64 + cg * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const float rv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rRes, (unsigned)row * 1024u + (unsigned)col * 4u, 0, 0));
+            float x = fmaf(w1[r], c1[j], acc[j][r] + bv[j]);
+            if (p > 0.f) x *= dropout_scale(seed, site, (uint32_t)row * FIRA_D + col, p, inv_keep);     // wave-uniform branch
+            acc[j][r] = x + rv;
+        }
+    }
+    // pass 1: row means
+    float mean[16], rstd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        mean[r] = v;
+    }
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[0][rt][cg][(r & 3) + 8 * (r >> 2) + 4 * kh] = mean[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        mean[r] = (red[0][rt][0][lr] + red[0][rt][1][lr]) * (1.0f / FIRA_D);
+    }
+    // pass 2: centred sums of squares
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = acc[j][r] - mean[r]; v = fmaf(d, d, v); }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        rstd[r] = v;
+    }
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[1][rt][cg][(r & 3) + 8 * (r >> 2) + 4 * kh] = rstd[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const float var = (red[1][rt][0][lr] + red[1][rt][1][lr]) * (1.0f / FIRA_D);
+        rstd[r] = 1.0f / sqrtf(var + 1e-5f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned co = (unsigned)(j * 64 + cg * 32 + l31) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const unsigned so = row < M ? (unsigned)row * 1024u + co : OOB;
+            const float x = acc[j][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rSum, so, 0, 0);
+            const float yv = (x - mean[r]) * rstd[r] * gm[j] + bt[j];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), rY, orow[r] == OOB ? OOB : orow[r] + co, 0, 0);
+        }
+    }
+    if (l31 == 0 && cg == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row_base + (r & 3) + 8 * (r >> 2);
+            const unsigned so = row < M ? (unsigned)row * 8u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mean[r]), rStats, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd[r]), rStats, so == OOB ? OOB : so + 4u, 0, 0);
+        }
+    }
+}
+
+// true if the fused kernel took the call (bf16 mode, K = 256, a 256-row k-contiguous bf16 weight shadow)
+bool linear_ln_bf16_try(hipStream_t s, int M, int K, const float* X, int ldx, const uint16_t* Wb, int ldb, const float* bias,
+                        const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
+                        float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row,
+                        const float* r1_col, int* rc, bool force) {
+    *rc = 0;
+    // FIRA_FUSED_LN_BF16: 0 never | 1 every K = 256 block | 2 only the encoder-sized ones (M >= 4096) | 3 only the decoder-sized
+    // Measured on one box (profiles/r2_probes.md): 2 is +0.5 % on the batch-64 step, 3 is -1.8 % (M = 1 920 rows are 30
+    // workgroups here against 480 in the latency GEMM), 1 is -2.3 %.
+    static const int mode = [] { const char* e = getenv("FIRA_FUSED_LN_BF16"); return e ? atoi(e) : 2; }();
+    if (!force && (mode == 0 || (mode == 2 && M < 4096) || (mode == 3 && M >= 4096))) return false;
+    if (K != PK || M < 64 || M >= (1 << 21) || ldx % 4 || ldb % 8 || ((uintptr_t)X % 16) || ((uintptr_t)Wb % 16) ||
+        (long)M * ldx >= (1L << 29))
+        return false;
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * 256.0 * K, 4.0 * ((double)M * K + 3.0 * M * 256.0) + 2.0 * 256.0 * K);
+    const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
+    const int n_items = cdiv(M, 64), chunk = cdiv(n_items, 8);
+    hipLaunchKernelGGL(linear_ln_bf16_kernel, dim3(8 * chunk), dim3(256), 0, s, M, X, ldx, Wb, ldb, bias, res, gamma, beta, sum, y,
+                       stats, dropout, inv_keep, seed, site, y_rows, r1_row, r1_col, n_items, chunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) *rc = set_err("linear_ln_bf16: %s", hipGetErrorString(e));
+    return true;
+}
+
 // true if this kernel took the call
 bool gemm_bf16_k256_try(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
                         int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask, int* rc) {
@@ -270,3 +492,17 @@ bool gemm_bf16_k256_try(hipStream_t s, int M, int N, int K, const float* A, int 
 }
 
 }  // namespace fira
+
+// y = LayerNorm(dropout(X Wb^T + bias) + res) * gamma + beta with Wb a [256, 256] bf16 weight shadow (row pitch ldb)
+extern "C" int fira_linear_layernorm_bf16_fwd(void* stream, int M, const float* X, int ldx, const uint16_t* Wb, int ldb,
+                                              const float* bias, const float* res, const float* gamma, const float* beta,
+                                              float* sum, float* y, float* stats, float dropout, uint64_t seed,
+                                              uint32_t stream_id) {
+    int rc;
+    FIRA_REQUIRE(X && Wb && gamma && beta && y, "fira_linear_layernorm_bf16_fwd: null argument");
+    if (!fira::linear_ln_bf16_try((hipStream_t)stream, M, 256, X, ldx, Wb, ldb, bias, res, gamma, beta, sum, y, stats, dropout,
+                                  seed, stream_id, nullptr, nullptr, nullptr, &rc, true))
+        return fira::set_err("fira_linear_layernorm_bf16_fwd: unsupported shape / alignment (M=%d ldx=%d ldb=%d; needs M >= 64)", M,
+                             ldx, ldb);
+    return rc;
+}

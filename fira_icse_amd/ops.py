@@ -130,6 +130,19 @@ def linear_layernorm_fwd(x, w, bias, res, gamma, beta, dropout=0.0, seed=0, site
     return y, s, stats
 
 
+def linear_layernorm_bf16_fwd(x, wb, bias, res, gamma, beta, dropout=0.0, seed=0, site=0):
+    """bf16 twin of linear_layernorm_fwd: ``wb`` is the [256, 256] bf16 shadow (int16 tensor) of the weight."""
+    M, K = x.shape
+    assert K == 256 and wb.shape == (256, 256) and wb.dtype == torch.int16 and x.stride(1) == 1
+    y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+    s = torch.empty_like(y)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_linear_layernorm_bf16_fwd(cur_stream(), M, ptr(x), x.stride(0), ptr(wb), wb.stride(0), ptr(bias),
+                                                    ptr(res), ptr(_f32(gamma)), ptr(_f32(beta)), ptr(s), ptr(y), ptr(stats),
+                                                    dropout, seed, site), "fira_linear_layernorm_bf16_fwd")
+    return y, s, stats
+
+
 def add_layernorm_bwd(dy, s, stats, gamma, dropout=0.0, seed=0, site=0, want_dx_drop=False):
     M = dy.shape[0]
     ds = torch.empty_like(dy)

@@ -189,6 +189,12 @@ int fira_linear_layernorm_fwd(void* stream, int M, int K, const float* X, int ld
                               const float* bias, const float* res, const float* gamma, const float* beta,
                               float* sum, float* y, float* stats, float dropout, uint64_t seed,
                               uint32_t stream_id);
+/* bf16 mode twin (K = 256): Wb is the [256,256] bf16 shadow of the weight (fira_weight_shadow), row pitch ldb a multiple
+ * of 8; X is rounded to bf16 while staged, fp32 accumulation, fp32 LayerNorm.  M >= 64.                                  */
+int fira_linear_layernorm_bf16_fwd(void* stream, int M, const float* X, int ldx, const uint16_t* Wb, int ldb,
+                                   const float* bias, const float* res, const float* gamma, const float* beta,
+                                   float* sum, float* y, float* stats, float dropout, uint64_t seed,
+                                   uint32_t stream_id);
 /* ds = dLN/d(sum); dgamma/dbeta += ...;  if dx_drop != NULL: dx_drop = ds * mask/(1-p)           */
 int fira_add_layernorm_bwd(void* stream, int M, const float* dy, const float* sum, const float* stats,
                            const float* gamma, float* ds, float* dx_drop, float* dgamma, float* dbeta,

@@ -139,6 +139,30 @@ def test_panel_kernel_k_slices(M, N, K):
     assert rel_err(ops.gemm_wb(X, wb, bias=bias, relu=True), ref.clamp_min(0)) < 2e-6
 
 
+@pytest.mark.parametrize("M", [64, 1920, 10001, 24000])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_linear_layernorm_bf16_fused_equals_the_two_kernels(M, p):
+    """The panel kernel with a LayerNorm epilogue against gemm_wb + add_layernorm_fwd: the products are the same MFMA
+    sequence and the dropout indices are the same, so the pre-norm rows are IDENTICAL; statistics / outputs differ by the
+    reduction order only (1e-5)."""
+    from fira_icse_amd import ops
+    x = randn(M, 264, seed=31)[:, :256]                      # strided rows
+    w, b = randn(256, 256, seed=32) / 16, randn(256, seed=33)
+    res, gamma, beta = randn(M, 256, seed=34), 1 + 0.1 * randn(256, seed=35), 0.1 * randn(256, seed=36)
+    wb, _ = ops.weight_shadow(w)
+    y, s, st = ops.linear_layernorm_bf16_fwd(x, wb, b, res, gamma, beta, p, seed=17, site=9)
+    lin = ops.gemm_wb(x, wb, bias=b)
+    y0, s0, st0 = ops.add_layernorm_fwd(lin.clone(), res, gamma, beta, p, seed=17, site=9)
+    if M >= 4096:                                            # gemm_wb takes the panel kernel too: the same MFMA sequence
+        assert torch.equal(s, s0)
+    else:                                                    # gemm_wb = latency kernel (K split over four waves)
+        assert rel_err(s, s0) < 2e-6 and torch.equal((s - res) == 0, (s0 - res) == 0)
+    assert rel_err(y, y0) < 1e-5 and rel_err(st, st0) < 1e-5
+    y1, _, _ = ops.linear_layernorm_bf16_fwd(x, wb, None, None, gamma, beta)
+    ref = torch.nn.functional.layer_norm(bf(x) @ bf(w).t(), (256,), gamma.double(), beta.double())
+    assert rel_err(y1, ref) < 5e-6
+
+
 @pytest.fixture(scope="module")
 def small():
     from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict

@@ -11,6 +11,7 @@
 // Nothing returns to the host; `done` latches when no slot runs any more (run_model.py:276-279) and turns the
 // remaining steps into state copies, so a driver may poll it every few steps.
 #include <limits.h>
+#include <stdlib.h>
 #include "engine.h"
 
 namespace fira {
@@ -45,7 +46,12 @@ __global__ __launch_bounds__(256) void beam_prepare_kernel(int rows, int beam, i
 struct Cand { float v; int i; };
 __device__ __forceinline__ bool better(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
 
-__global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W, int V, int L, int S,
+// NB = length of the per-thread candidate list (>= beam: only the `beam` best of a thread can be among the `beam` best of
+// the commit), NT threads per commit.  The result is the exact top-`beam` under the total order (probability descending,
+// flattened index ascending), so it does not depend on NB / NT: round 2 went from 256 threads x 8-deep lists (166 us per
+// step at beam 3: 293 candidates per thread, every one pushed through an 8-deep insertion) to 1024 x NB.
+template <int NB, int NT>
+__global__ __launch_bounds__(NT) void beam_select_kernel(int beam, int T, int W, int V, int L, int S,
                                                           const float* __restrict__ dist,
                                                           const int32_t* __restrict__ fin,
                                                           const int32_t* __restrict__ active,
@@ -57,28 +63,28 @@ __global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W
                                                           const float* __restrict__ prob_in,
                                                           int32_t* __restrict__ gen_out, int32_t* __restrict__ len_out,
                                                           float* __restrict__ prob_out, int32_t* __restrict__ parent) {
-    __shared__ float smv[4];
-    __shared__ int smi[4];
+    __shared__ float smv[NT / 64];
+    __shared__ int smi[NT / 64];
     __shared__ float sel_v[BEAM_MAX];
     __shared__ int sel_i[BEAM_MAX], act_slot[BEAM_MAX], order[BEAM_MAX], src_of[BEAM_MAX], tok_of[BEAM_MAX],
         carry_of[BEAM_MAX];
     const int b = blockIdx.x, t = threadIdx.x, r0 = b * beam;
     if (*done) {                                                     // search over: hand the state on unchanged
-        for (int x = t; x < beam * T; x += 256) gen_out[(size_t)r0 * T + x] = gen_in[(size_t)r0 * T + x];
+        for (int x = t; x < beam * T; x += NT) gen_out[(size_t)r0 * T + x] = gen_in[(size_t)r0 * T + x];
         if (t < beam) { len_out[r0 + t] = len_in[r0 + t]; prob_out[r0 + t] = prob_in[r0 + t]; parent[r0 + t] = r0 + t; }
         return;
     }
     const int n_act = active[BEAM_MAX];
     // thread-local best `beam` candidates, kept sorted
-    float lv[BEAM_MAX];
-    int li[BEAM_MAX];
+    float lv[NB];
+    int li[NB];
 #pragma unroll
-    for (int q = 0; q < BEAM_MAX; ++q) { lv[q] = -INFINITY; li[q] = INT_MAX; }
+    for (int q = 0; q < NB; ++q) { lv[q] = -INFINITY; li[q] = INT_MAX; }
     auto offer = [&](float v, int i) {
-        if (!better(v, i, lv[BEAM_MAX - 1], li[BEAM_MAX - 1])) return;
-        lv[BEAM_MAX - 1] = v; li[BEAM_MAX - 1] = i;
+        if (!better(v, i, lv[NB - 1], li[NB - 1])) return;
+        lv[NB - 1] = v; li[NB - 1] = i;
 #pragma unroll
-        for (int q = BEAM_MAX - 1; q > 0; --q)
+        for (int q = NB - 1; q > 0; --q)
             if (better(lv[q], li[q], lv[q - 1], li[q - 1])) {
                 const float tv = lv[q]; lv[q] = lv[q - 1]; lv[q - 1] = tv;
                 const int ti = li[q]; li[q] = li[q - 1]; li[q - 1] = ti;
@@ -91,7 +97,15 @@ __global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W
         const bool f = fin[r0 + j] != 0;
         const float pj = prob_in[r0 + j];
         const float* row = dist + (size_t)(r0 + j) * W;
-        for (int w = t; w < W; w += 256) offer(f ? -1.0f : row[w] * pj, k * W + w);   // run_model.py:268-272
+        // run_model.py:268-272; four loads in flight per trip (the list update is a dependent chain)
+        for (int w0 = t; w0 < W; w0 += 4 * NT) {
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = row[min(w0 + u * NT, W - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (w0 + u * NT < W) offer(f ? -1.0f : x[u] * pj, k * W + w0 + u * NT);
+        }
         ++k;
     }
     if (t == 0) {                                                    // finished hypotheses, slot order, -1 padding (:283-296)
@@ -115,13 +129,13 @@ __global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W
         __syncthreads();
         v = smv[0]; i = smi[0];
 #pragma unroll
-        for (int q = 1; q < 4; ++q)
+        for (int q = 1; q < NT / 64; ++q)
             if (better(smv[q], smi[q], v, i)) { v = smv[q]; i = smi[q]; }
         if (t == 0) { sel_v[round] = v; sel_i[round] = i; }
         if (li[0] == i) {
 #pragma unroll
-            for (int q = 0; q < BEAM_MAX - 1; ++q) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
-            lv[BEAM_MAX - 1] = -INFINITY; li[BEAM_MAX - 1] = INT_MAX;
+            for (int q = 0; q < NB - 1; ++q) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
+            lv[NB - 1] = -INFINITY; li[NB - 1] = INT_MAX;
         }
     }
     __syncthreads();
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(int beam, int T, int W
         parent[r0 + t] = r0 + src;
     }
     __syncthreads();
-    for (int x = t; x < beam * T; x += 256) {
+    for (int x = t; x < beam * T; x += NT) {
         const int c = x / T, p = x - c * T;
         const int src = src_of[c];
         int g = gen_in[(size_t)(r0 + src) * T + p];
@@ -212,9 +226,19 @@ int fira_beam_select(void* stream, const fira_dims* d, int B, int n_beam, const 
     FIRA_REQUIRE(d && B > 0 && n_beam >= 1 && n_beam <= fira::BEAM_MAX, "fira_beam_select: beam %d outside 1..%d", n_beam,
                  fira::BEAM_MAX);
     const int S = d->sub_len, L = d->sou_len, W = d->vocab + L + S;
-    hipLaunchKernelGGL(fira::beam_select_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, n_beam, d->tar_len, W,
-                       d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in, gen_out,
-                       len_out, prob_out, parent);
+    static const int wide = [] { const char* e = getenv("FIRA_BEAM_SELECT_WIDE"); return e ? atoi(e) : 1; }();   // A/B switch
+    if (!wide)
+        hipLaunchKernelGGL((fira::beam_select_kernel<fira::BEAM_MAX, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, n_beam,
+                           d->tar_len, W, d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in,
+                           gen_out, len_out, prob_out, parent);
+    else if (n_beam <= 4)
+        hipLaunchKernelGGL((fira::beam_select_kernel<4, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, n_beam, d->tar_len, W,
+                           d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in, gen_out,
+                           len_out, prob_out, parent);
+    else
+        hipLaunchKernelGGL((fira::beam_select_kernel<fira::BEAM_MAX, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, n_beam,
+                           d->tar_len, W, d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in,
+                           gen_out, len_out, prob_out, parent);
     FIRA_CHECK_LAUNCH("beam_select");
     return 0;
 }

@@ -276,8 +276,10 @@ static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int
                          float* Y, int ldy, int flags = 0) {
     return gemm_any(s, 0, 1, M, N, K, X, ldx, W, K, Y, ldy, b, flags, 0, nullptr);
 }
-// y = LN(dropout(X W^T + b [+ r c^T]) + res): the closing step of every block.  fp32: one fused launch (linear_ln.hip);
-// otherwise (bf16 products, unsupported shapes, FIRA_FUSED_LN=0) the product followed by the row kernel.
+// y = LN(dropout(X W^T + b [+ r c^T]) + res): the closing step of every block.  By default the product followed by the row
+// kernel; one fused launch where that was measured to win -- bf16 mode, K = 256, encoder-sized blocks (the panel kernel's
+// LayerNorm epilogue, gemm_bf16_panel.hip; FIRA_FUSED_LN_BF16) -- and, on request only, the fp32 fused kernels of
+// linear_ln.hip (FIRA_FUSED_LN=1|2|3: they lose in the step, see that file).
 static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* b,
                             const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
                             float p_drop, uint64_t seed, uint32_t st, const int32_t* y_rows = nullptr,

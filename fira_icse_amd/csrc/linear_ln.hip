@@ -2,7 +2,11 @@
 // (reference gnn_transformer.py:86, 159-161, 172-174, 203-205): the closing step of every Combination, GCN, attention and
 // feed-forward block -- 30 sites per training step, 18 per decode step.
 //
-// Why a fused kernel: the decoder side of the step is a chain of ~150 dependent launches of a few microseconds each
+// STATUS: correct (op tests), exported (fira_linear_layernorm_fwd), NOT used by the engine by default -- measured slower than
+// product + row kernel in the step and in the decode loop (numbers at linear_ln_fwd_try below); kept as the documented
+// negative result for "fuse the post-LN block in fp32".
+//
+// Why a fused kernel was tried: the decoder side of the step is a chain of ~150 dependent launches of a few microseconds each
 // (M = B*30 rows), bound by the ~5 us dispatch floor + ~2.5 us gap per launch, not by work; GEMM + LayerNorm as two launches
 // costs 9.7 + 5.5 + 2.5 us for [960,256]x[256,256].  One workgroup here owns 32 COMPLETE output rows (all 256 columns), so
 // the row statistics need no second pass over memory: 8 waves (512 threads), wave w computes the 32x32 tile of columns

@@ -152,7 +152,9 @@ class ShardedOptimizerComm:
         window = flat[lo:lo + self.world * chunk]
         mine = window[self.rank * chunk:(self.rank + 1) * chunk]
         if self.native:
-            dist.all_gather_into_tensor(window, mine, group=self.group)            # in place: mine == window[rank]
+            # (a copy of the own chunk as the input: RCCL allows the in-place form, torch's checks on overlapping
+            # input / output views have changed between releases and this path cannot be run on the one-GPU boxes)
+            dist.all_gather_into_tensor(window, mine.clone(), group=self.group)
         else:
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)

@@ -51,4 +51,39 @@ def test_close_stops_the_worker_after_an_early_break():
     n = len(made)
     time.sleep(0.2)
     assert len(made) == n and n < 20          # nothing is prepared after close(); the worker is not blocked on put()
-    assert not it._th.is_alive()
+    assert not any(th.is_alive() for th in it._threads)
+
+
+@pytest.mark.parametrize("workers", [1, 2, 3])
+def test_several_workers_keep_the_order_and_share_the_work(workers):
+    names = set()
+
+    def prepare(i):
+        time.sleep(0.03 if i % 2 else 0.01)   # uneven preparation times: later items finish first
+        names.add(threading.current_thread().name)
+        return i
+
+    t0 = time.time()
+    out = list(prefetch(range(12), prepare, depth=4, workers=workers))
+    assert out == list(range(12))
+    assert len(names) == workers
+    if workers >= 2:
+        assert time.time() - t0 < 12 * 0.02 * 0.8          # two workers: well under the serial 0.24 s
+
+
+def test_errors_keep_their_place_with_two_workers():
+    def prepare(i):
+        if i == 3:
+            raise ValueError("bad batch")
+        time.sleep(0.005)
+        return i
+
+    it = prefetch(range(8), prepare, depth=4, workers=2)
+    assert [next(it) for _ in range(3)] == [0, 1, 2]
+    with pytest.raises(ValueError):
+        next(it)
+    assert not any(th.is_alive() for th in it._threads)
+
+
+def test_an_exhausted_empty_iterable():
+    assert list(prefetch([], lambda x: x, workers=2)) == []

@@ -15,6 +15,7 @@ autograd entirely and calls the fused Adam kernel on the same buffer.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -202,6 +203,42 @@ def compact_embedding_lists(hb: HostBatch, cfg: FiraConfig, node_rows: np.ndarra
     return item_tok, item_ptr, emb_rows.astype(np.int32), ast_rows[keep].astype(np.int32), ast_ids[keep].astype(np.int32)
 
 
+def batch_lists(hb: HostBatch, cfg: FiraConfig, skip_padding: bool = True, chunk: int = 32):
+    """Everything ``DeviceBatch`` derives from a collated batch, as one tuple:
+    (node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst, item_tok, item_ptr, emb_rows, ast_rows, ast_ids).
+
+    Default: ``fira_host_node_lists`` (csrc/hostlists.cpp, one C++ pass, GIL released during the call).  The numpy
+    functions above are the specification -- ``FIRA_HOST_LISTS=numpy`` selects them, tests/test_host_lists.py requires
+    identical arrays from both."""
+    if os.environ.get("FIRA_HOST_LISTS", "native") == "numpy":
+        node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst = computed_nodes(hb, cfg, skip_padding)
+        return (node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst) + \
+            tuple(compact_embedding_lists(hb, cfg, node_rows))
+    B, N, L, S = len(hb), cfg.graph_len, cfg.sou_len, cfg.sub_token_len
+    A = N - L - S
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    sou, sub, ast, mark = i64(hb.sou), i64(hb.sub_token), i64(hb.ast_change), i64(hb.mark)
+    rowptr_in = np.ascontiguousarray(hb.rowptr, dtype=np.int32)
+    col_in = np.ascontiguousarray(hb.col, dtype=np.int32)
+    val_in = np.ascontiguousarray(hb.val, dtype=np.float32)
+    nnz = int(col_in.shape[0])
+    e32 = lambda n: np.empty(max(int(n), 1), dtype=np.int32)
+    node_rows, rowptr, col, val = e32(B * N), e32(B * N + 1), e32(nnz), np.empty(max(nnz, 1), dtype=np.float32)
+    code_rows, code_mark, mem_rows, mem_dst = e32(B * L), e32(B * L), e32(B * (L + S)), e32(B * (L + S))
+    item_tok, item_ptr, emb_rows = e32(B * (L + S)), e32(B * (L + S) + 1), e32(B * (L + S))
+    ast_rows, ast_ids, counts = e32(B * A), e32(B * A), np.zeros(8, dtype=np.int32)
+    ap = lambda a: a.ctypes.data
+    _lib.check(_lib.lib().fira_host_node_lists(B, N, L, S, 1 if skip_padding else 0, ap(sou), ap(sub), ap(ast), ap(mark),
+                                               ap(rowptr_in), ap(col_in), ap(val_in), chunk, ap(node_rows), ap(rowptr),
+                                               ap(col), ap(val), ap(code_rows), ap(code_mark), ap(mem_rows), ap(mem_dst),
+                                               ap(item_tok), ap(item_ptr), ap(emb_rows), ap(ast_rows), ap(ast_ids),
+                                               ap(counts)), "fira_host_node_lists")
+    n_nodes, nnz_c, n_code, n_mem, n_items, n_pos, n_ast = (int(x) for x in counts[:7])
+    return (node_rows[:n_nodes], rowptr[:n_nodes + 1], col[:nnz_c], val[:nnz_c], code_rows[:n_code], code_mark[:n_code],
+            mem_rows[:n_mem], mem_dst[:n_mem], item_tok[:n_items], item_ptr[:n_items + 1], emb_rows[:n_pos],
+            ast_rows[:n_ast], ast_ids[:n_ast])
+
+
 class _PinnedRing:
     """Page-locked staging buffers for the host->device copy of a batch: a small ring per thread, each slot reused only
     after the copy that last read it has completed (its event), so the copies are truly asynchronous (a pageable source
@@ -239,7 +276,8 @@ class DeviceBatch:
         if hb.tar_label is not None and hb.tar_label.size and int(hb.tar_label.max()) >= cfg.out_len:
             # the reference's nll_loss would raise "Target out of bounds" here (SURVEY.md §8a note N3)
             raise ValueError("copy label %d outside the %d-way output" % (int(hb.tar_label.max()), cfg.out_len))
-        node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst = computed_nodes(hb, cfg, skip_padding)
+        (node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst, item_tok, item_ptr, emb_rows, ast_rows,
+         ast_ids) = batch_lists(hb, cfg, skip_padding)
         self.n_nodes, self.n_code, self.n_mem = int(node_rows.shape[0]), int(code_rows.shape[0]), int(mem_rows.shape[0])
         self.nnz = int(col.shape[0])
         head_rows = None
@@ -248,7 +286,6 @@ class DeviceBatch:
             shifted = np.concatenate([hb.tar_label[:, 1:], np.zeros((self.B, 1), hb.tar_label.dtype)], axis=1)
             head_rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0]
             self.n_head_rows = int(head_rows.shape[0])
-        item_tok, item_ptr, emb_rows, ast_rows, ast_ids = compact_embedding_lists(hb, cfg, node_rows)
         self.n_ast_items, self.n_emb_items = int(ast_rows.shape[0]), int(item_tok.shape[0])
         fields = [("sou", hb.sou, np.int32), ("tar", hb.tar, np.int32), ("mark", hb.mark, np.int32),
                   ("ast_change", hb.ast_change, np.int32), ("tar_label", hb.tar_label, np.int32),

@@ -327,6 +327,21 @@ int fira_decoder_forward(void* stream, const fira_dims* d, const float* params, 
 const float*   fira_decode_memory(const fira_dims* d, void* workspace, int B, int n_beam);
 const int32_t* fira_decode_mem_valid(const fira_dims* d, void* workspace, int B, int n_beam);
 
+/* ---- host-side helper (CPU only, no device work) -----------------------------------------------------------------
+ * The index lists of fira_batch from one collated batch (int64 id arrays as the reference's Dataset.py produces them,
+ * block-diagonal CSR with GLOBAL node ids b*N + local): computed nodes + compact CSR, code / memory rows, word-id
+ * groups (items of at most `chunk` positions) and AST / edit (row, id) pairs.  Output arrays are caller-allocated at their
+ * worst-case sizes: node_rows [B*N], rowptr_c [B*N+1], col_c / val_c [nnz], code_rows / code_mark [B*L],
+ * mem_rows / mem_dst [B*(L+S)], item_tok [B*(L+S)], item_ptr [B*(L+S)+1], emb_rows [B*(L+S)], ast_rows / ast_ids
+ * [B*(N-L-S)]; counts[7] = {n_nodes, nnz_c, n_code, n_mem, n_items, n_emb_rows, n_ast}.
+ * Same result, bit for bit, as fira_icse_amd/model.py: computed_nodes + compact_embedding_lists (the specification).    */
+int fira_host_node_lists(int B, int N, int L, int S, int skip_padding, const int64_t* sou, const int64_t* sub_token,
+                         const int64_t* ast_change, const int64_t* mark, const int32_t* rowptr, const int32_t* col,
+                         const float* val, int chunk, int32_t* node_rows, int32_t* rowptr_c, int32_t* col_c,
+                         float* val_c, int32_t* code_rows, int32_t* code_mark, int32_t* mem_rows, int32_t* mem_dst,
+                         int32_t* item_tok, int32_t* item_ptr, int32_t* emb_rows, int32_t* ast_rows, int32_t* ast_ids,
+                         int32_t* counts);
+
 #ifdef __cplusplus
 }
 #endif

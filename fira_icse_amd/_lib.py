@@ -81,6 +81,7 @@ SIGNATURES = {
     "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
     "fira_param_groups": (_I, [_DP, C.POINTER(_L), C.POINTER(_L)]),
     "fira_host_node_lists": (_I, [_I, _I, _I, _I, _I] + [_P] * 7 + [_I] + [_P] * 14),
+    "fira_host_collate_csr": (_I, [_I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P, _I]),
     "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
     "fira_beam_prepare": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),

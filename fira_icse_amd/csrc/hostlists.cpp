@@ -113,3 +113,29 @@ extern "C" int fira_host_node_lists(int B, int N, int L, int S, int skip_padding
     counts[4] = n_items; counts[5] = n_pos; counts[6] = n_ast;
     return 0;
 }
+
+// Block-diagonal CSR of a batch from the store's per-commit CSR (data.GraphStore.batch): commit idx[b]'s rows move to
+// rows b*N .., its columns into graph b's node block.  rowptr [B*N+1], col / val [sum of the commits' nnz].
+extern "C" int fira_host_collate_csr(int B, int N, const int64_t* idx, int64_t n_commits, const int32_t* store_rowptr,
+                                     const int64_t* store_offset, const int32_t* store_col, const float* store_val,
+                                     int32_t* rowptr, int32_t* col, float* val) {
+    FIRA_REQUIRE(B >= 0 && N > 0 && idx && store_rowptr && store_offset && store_col && store_val && rowptr && col && val,
+                 "fira_host_collate_csr: bad argument");
+    int64_t base = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t r = idx[b];
+        FIRA_REQUIRE(r >= 0 && r < n_commits, "fira_host_collate_csr: commit index %lld outside the store", (long long)r);
+        const int32_t* rp = store_rowptr + (size_t)r * (N + 1);
+        const int64_t off = store_offset[r], nnz = rp[N];
+        FIRA_REQUIRE(base + nnz < (1LL << 31), "fira_host_collate_csr: more than 2^31 entries in one batch");
+        for (int i = 0; i < N; ++i) rowptr[(size_t)b * N + i] = (int32_t)(rp[i] + base);
+        const int32_t shift = b * N;
+        for (int64_t e = 0; e < nnz; ++e) {
+            col[base + e] = store_col[off + e] + shift;
+            val[base + e] = store_val[off + e];
+        }
+        base += nnz;
+    }
+    rowptr[(size_t)B * N] = (int32_t)base;
+    return 0;
+}

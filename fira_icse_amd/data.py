@@ -212,8 +212,22 @@ class GraphStore:
     def batch(self, idx: Sequence[int]) -> "HostBatch":
         """Collate commits ``idx`` into one block-diagonal CSR batch (replaces the reference's dense
         ``.toarray()`` + default collate, Dataset.py:336-343).  Vectorised: no per-commit Python loop."""
-        idx = np.asarray(idx, dtype=np.int64)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
         B, N = len(idx), self.cfg.graph_len
+        if B and os.environ.get("FIRA_HOST_LISTS", "native") != "numpy":
+            # one C++ pass (csrc/hostlists.cpp: fira_host_collate_csr); the numpy statement below is its specification
+            # (tests/test_host_lists.py compares them)
+            from . import _lib
+            total = int(self.nnz[idx].sum())
+            rowptr = np.empty(B * N + 1, dtype=np.int32)
+            col = np.empty(max(total, 1), dtype=np.int32)
+            val = np.empty(max(total, 1), dtype=np.float32)
+            ap = lambda a: a.ctypes.data
+            _lib.check(_lib.lib().fira_host_collate_csr(B, N, ap(idx), len(self), ap(self._rowptr_c()), ap(self.offset),
+                                                        ap(self._col_c()), ap(self._val_c()), ap(rowptr), ap(col), ap(val)),
+                       "fira_host_collate_csr")
+            return HostBatch(self.sou[idx], self.tar[idx], self.mark[idx], self.ast_change[idx], self.tar_label[idx],
+                             self.sub_token[idx], rowptr, col[:total], val[:total], attr=lambda: self.attr[idx])
         nnz = self.nnz[idx]
         base = np.zeros(B + 1, dtype=np.int64)
         np.cumsum(nnz, out=base[1:])
@@ -227,6 +241,22 @@ class GraphStore:
         val = self.val[src]
         return HostBatch(self.sou[idx], self.tar[idx], self.mark[idx], self.ast_change[idx],
                          self.tar_label[idx], self.sub_token[idx], rowptr, col, val, self.attr[idx])
+
+    # contiguous views of the store arrays in the dtypes the C helper reads (made once)
+    def _rowptr_c(self):
+        if getattr(self, "_rp_c", None) is None:
+            self._rp_c = np.ascontiguousarray(self.rowptr, dtype=np.int32)
+        return self._rp_c
+
+    def _col_c(self):
+        if getattr(self, "_cl_c", None) is None:
+            self._cl_c = np.ascontiguousarray(self.col, dtype=np.int32)
+        return self._cl_c
+
+    def _val_c(self):
+        if getattr(self, "_vl_c", None) is None:
+            self._vl_c = np.ascontiguousarray(self.val, dtype=np.float32)
+        return self._vl_c
 
     # ---- cache ----
     def save(self, path: str) -> None:
@@ -256,7 +286,13 @@ class HostBatch:
         self.sou, self.tar, self.mark, self.ast_change = sou, tar, mark, ast_change
         self.tar_label, self.sub_token = tar_label, sub_token
         self.rowptr, self.col, self.val = rowptr, col, val
-        self.attr = attr
+        self._attr = attr                      # array, or a callable that gathers it on first use (the model never reads it)
+
+    @property
+    def attr(self):
+        if callable(self._attr):
+            self._attr = self._attr()
+        return self._attr
 
     def __len__(self):
         return self.sou.shape[0]

@@ -342,6 +342,13 @@ int fira_host_node_lists(int B, int N, int L, int S, int skip_padding, const int
                          int32_t* item_tok, int32_t* item_ptr, int32_t* emb_rows, int32_t* ast_rows, int32_t* ast_ids,
                          int32_t* counts);
 
+/* Block-diagonal CSR of a batch from a store of per-commit CSR graphs (replaces Dataset.py:336-343's dense collate):
+ * store_rowptr [n_commits, N+1], store_offset [n_commits+1] (prefix sums of the commits' nnz), store_col / store_val the
+ * concatenated entries; rowptr [B*N+1], col (global node ids b*N + local) and val [sum nnz] are caller-allocated.   */
+int fira_host_collate_csr(int B, int N, const int64_t* idx, int64_t n_commits, const int32_t* store_rowptr,
+                          const int64_t* store_offset, const int32_t* store_col, const float* store_val,
+                          int32_t* rowptr, int32_t* col, float* val);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,3 +82,27 @@ def test_device_batch_is_the_same_through_both_paths(store):
         assert x.dtype == y.dtype and x.shape == y.shape and bool((x == y).all()), k
     for k in ("n_nodes", "n_code", "n_mem", "nnz", "n_head_rows", "n_ast_items", "n_emb_items"):
         assert getattr(a, k) == getattr(b, k), k
+
+
+@pytest.mark.parametrize("ids", [[0], [7, 7], list(range(40)), [95, 3, 50, 50, 1]])
+def test_native_collate_equals_the_numpy_statement(store, ids):
+    """GraphStore.batch through fira_host_collate_csr == its numpy statement: every array of the HostBatch, the lazily
+    gathered attr included."""
+    cfg, st = store
+    os.environ["FIRA_HOST_LISTS"] = "numpy"
+    try:
+        ref = st.batch(ids)
+    finally:
+        os.environ.pop("FIRA_HOST_LISTS")
+    got = st.batch(ids)
+    for k in ("sou", "tar", "mark", "ast_change", "tar_label", "sub_token", "rowptr", "col", "val", "attr"):
+        a, b = getattr(ref, k), getattr(got, k)
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), k
+    assert np.array_equal(ref.dense_edge(cfg.graph_len), got.dense_edge(cfg.graph_len))
+
+
+def test_native_collate_rejects_an_index_outside_the_store(store):
+    from fira_icse_amd._lib import FiraError
+    cfg, st = store
+    with pytest.raises((FiraError, IndexError)):
+        st.batch([0, len(st)])

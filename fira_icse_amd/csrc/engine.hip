@@ -326,7 +326,7 @@ struct SideStream {
         // the big ones (the vocabulary projection: 138 MB of dlogits at batch 64) otherwise take the CUs from the
         // dependent chain on the caller's stream exactly when it has only small kernels to offer
         int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;   // no priorities: plain streams
         hipError_t e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least);
         if (e != hipSuccess) return set_err("hipStreamCreate: %s", hipGetErrorString(e));
         e = hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);

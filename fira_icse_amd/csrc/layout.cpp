@@ -33,8 +33,8 @@ struct ProfState {
     std::vector<hipEvent_t> pool;
     hipEvent_t get() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-        hipEvent_t e;
-        hipEventCreate(&e);
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);                 // profiling aid only: a failed event shows up as a zero interval
         return e;
     }
 };
@@ -45,14 +45,14 @@ int prof_begin(hipStream_t s, int cls, double work, double bytes) {
     ProfState& p = PS();
     std::lock_guard<std::mutex> g(p.mu);
     ProfRec r{cls, work, bytes, p.get(), p.get()};
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     p.recs.push_back(r);
     return (int)p.recs.size() - 1;        // the record this scope closes (two host threads may enqueue concurrently)
 }
 void prof_end(hipStream_t s, int idx) {
     ProfState& p = PS();
     std::lock_guard<std::mutex> g(p.mu);
-    if (idx >= 0 && idx < (int)p.recs.size()) hipEventRecord(p.recs[idx].b, s);
+    if (idx >= 0 && idx < (int)p.recs.size()) (void)hipEventRecord(p.recs[idx].b, s);
 }
 
 namespace {
@@ -298,9 +298,9 @@ int fira_prof_report(int n_class, double* ms, double* work, double* bytes, int64
     std::lock_guard<std::mutex> g(p.mu);
     for (int i = 0; i < n_class; ++i) { ms[i] = 0; work[i] = 0; count[i] = 0; if (bytes) bytes[i] = 0; }
     for (auto& r : p.recs) {
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float t = 0.f;
-        hipEventElapsedTime(&t, r.a, r.b);
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) t = 0.f;
         if (r.cls < n_class) {
             ms[r.cls] += t; work[r.cls] += r.work; count[r.cls] += 1;
             if (bytes) bytes[r.cls] += r.bytes;

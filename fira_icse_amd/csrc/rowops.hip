@@ -596,7 +596,9 @@ int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, floa
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)embed_gather_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        const hipError_t ae = hipFuncSetAttribute((const void*)embed_gather_bwd_small_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        FIRA_REQUIRE(ae == hipSuccess, "embed_gather_bwd_small: cannot raise the dynamic LDS limit: %s", hipGetErrorString(ae));
         attr_set = true;
     }
     const int rpb = std::max(64, cdiv(rows, 96));
@@ -622,7 +624,9 @@ int embed_list_bwd_small(hipStream_t s, int n, const int32_t* rows, const int32_
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)embed_list_bwd_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        const hipError_t ae = hipFuncSetAttribute((const void*)embed_list_bwd_small_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        FIRA_REQUIRE(ae == hipSuccess, "embed_list_bwd_small: cannot raise the dynamic LDS limit: %s", hipGetErrorString(ae));
         attr_set = true;
     }
     const int per = std::max(64, cdiv(n, 96));

@@ -199,7 +199,9 @@ int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t*
                      "csr_spmm: LDS variant needs rows-per-graph (%d) dividing n_rows and <= 512", graph_rows);
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)spmm_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const hipError_t ae = hipFuncSetAttribute((const void*)spmm_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      160 * 1024);
+            FIRA_REQUIRE(ae == hipSuccess, "csr_spmm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(ae));
             attr_set = true;
         }
         hipLaunchKernelGGL(spmm_lds_kernel, dim3(FIRA_D / SLAB, n_rows / graph_rows), dim3(LDS_WAVES * 64), lds, s, graph_rows,

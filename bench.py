@@ -17,6 +17,10 @@ command too (run_model.py:392-394).  ``--dp-same-device`` puts every rank on cud
 how the N > 1 path is exercised on a one-GPU box (tests/test_dp_gpu.py).
 
 Extra objects on the line (all measured outside the timed region):
+  b64 / b170    (default command only) the same step at batch 64 per GPU in fp32 AND bf16 (north_star's "at batch 64";
+                bf16 = BASELINE configs[2]'s per-GPU workload: `b64.bf16`, also `configs2` when N > 1), each with its
+                own `roofline`, `decoder_gemm` (FLOP / summed launch time of the decoder's M = B*30 products only) and
+                `host_inclusive`; and at the reference's per-GPU batch of 170 (run_model.py:40).
   roofline      the dominant kernel class of the step by GPU time (the MFMA GEMMs): algorithmic FLOP / summed launch
                 time, measured with HIP events on the launch stream inside the library during extra profiled steps
                 (fira_prof_*); peak = 157.3 TFLOP/s fp32 MFMA or 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).  In
@@ -91,11 +95,16 @@ def self_launch(a) -> int:
 
 def prof_report():
     from fira_icse_amd import _lib
-    n = 7
+    n = 8
     ms, work, byts, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
     _lib.lib().fira_prof_report(n, ms, work, byts, cnt)
-    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam"]
-    return {k: dict(ms=ms[i], work=work[i], bytes=byts[i], count=int(cnt[i])) for i, k in enumerate(names)}
+    # gemm_dec: the decoder's M = B*30 row products (forward + data gradients), split out of the GEMM family by the library
+    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec"]
+    out = {k: dict(ms=ms[i], work=work[i], bytes=byts[i], count=int(cnt[i])) for i, k in enumerate(names)}
+    dec = out.pop("gemm_dec")
+    out["gemm"] = {k: out["gemm"][k] + dec[k] for k in dec}         # the family = every GEMM launch of the step
+    out["gemm"]["decoder"] = dec
+    return out
 
 
 def time_gpu(fn, iters=30, warmup=3):
@@ -123,12 +132,41 @@ def spmm_standalone(cfg, store):
     # realistic graphs, batch 64, every node listed (the reference's dense 650-node layout: 41 600 rows)
     hb = store.batch(range(64))
     rp, c, v = (torch.from_numpy(x).cuda() for x in (hb.rowptr, hb.col, hb.val))
-    X = torch.randn(64 * cfg.graph_len, 256, device="cuda")
-    t = time_gpu(lambda: ops.csr_spmm(rp, c, v, X, graph_rows=cfg.graph_len, variant=1))
-    by = spmm_bytes(X.shape[0], c.numel())
-    out["spmm_b64"] = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "rows": int(X.shape[0]), "nnz": int(c.numel()),
+
+    def rotating(n_rows, rp_, c_, v_, graph_rows):
+        """Launch over ROTATING (X, Y) buffer sets whose total exceeds the 256 MiB Infinity Cache, so that the features are
+        streamed from HBM and not re-read from the last-level cache (MI355X_MICROARCH.md: scale past L3)."""
+        per_set = 2 * n_rows * 256 * 4
+        n_sets = max(4, -(-300 * (1 << 20) // per_set))
+        Xs = [torch.randn(n_rows, 256, device="cuda") for _ in range(n_sets)]
+        Ys = [torch.empty(n_rows, 256, device="cuda") for _ in range(n_sets)]
+        k = [0]
+
+        def fn():
+            i = k[0] % n_sets
+            k[0] += 1
+            ops.csr_spmm(rp_, c_, v_, Xs[i], graph_rows=graph_rows, variant=1, out=Ys[i])
+        t = time_gpu(fn, iters=3 * n_sets, warmup=n_sets)
+        return t, n_sets, n_sets * per_set
+
+    X_rows = 64 * cfg.graph_len
+    t, n_sets, tot = rotating(X_rows, rp, c, v, cfg.graph_len)
+    by = spmm_bytes(X_rows, c.numel())
+    out["spmm_b64"] = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "rows": int(X_rows), "nnz": int(c.numel()),
                        "avg_launch_us": t * 1e6, "bytes_per_launch": by, "achieved": by / t / 1e9, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS}
+                       "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS, "buffer_sets": n_sets,
+                       "rotated_bytes": tot, "note": "dense 650-node layout (padded nodes carry only a self-loop); "
+                       "feature buffers rotated over %d sets = %.0f MiB > the 256 MiB Infinity Cache" % (n_sets, tot / 2**20)}
+    # the launch the ENGINE issues: compact rows (computed nodes only), same graphs
+    from fira_icse_amd.model import DeviceBatch
+    db = DeviceBatch(hb, cfg, "cuda")
+    t, n_sets, tot = rotating(db.n_nodes, db.rowptr, db.col, db.val, 0)
+    by = spmm_bytes(db.n_nodes, db.nnz)
+    out["spmm_b64_compact"] = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "rows": db.n_nodes, "nnz": db.nnz,
+                               "avg_launch_us": t * 1e6, "bytes_per_launch": by, "achieved": by / t / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
+                               "buffer_sets": n_sets, "rotated_bytes": tot,
+                               "note": "computed-node rows only (what encoder_forward launches), batch 64, stand-alone"}
     # BASELINE config 5: 128 graphs x 512 nodes x 4 edge types x 8192 edges
     B, N = 128, 512
     rp, c, v = (torch.from_numpy(x).cuda() for x in graphs.dense_stress_batch(B, N))
@@ -152,7 +190,7 @@ def host_inclusive(cfg, store, trainer, B, steps):
     n = len(store)
     order = [[(i * B + k) % n for k in range(B)] for i in range(steps + 2)]
     dev = trainer.model.device_
-    it = prefetch(order, lambda idx: DeviceBatch(store.batch(idx), cfg, dev), depth=2)
+    it = prefetch(order, lambda idx: DeviceBatch(store.batch(idx), cfg, dev), depth=2, device=dev)
     trainer.step(next(it)); trainer.step(next(it))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -284,6 +322,37 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
     return decode
 
 
+def gemm_objects(prof, dtype, prof_steps, traffic):
+    """`roofline` (MFMA), `roofline_hbm` and the decoder-GEMM sub-object of one profiled leg (fira_prof_* HIP events)."""
+    gemm = prof["gemm"]
+    dec = gemm["decoder"]
+    g_s = max(gemm["ms"], 1e-9) * 1e-3
+    total_ms = sum(v["ms"] for v in prof.values()) or 1.0
+    peak_tf = BF16_MFMA_PEAK_TF if dtype == "bf16" else FP32_MFMA_PEAK_TF
+    kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if dtype == "bf16" else \
+        "gemm_f32_kernel / gemm_small_kernel (v_mfma_f32_32x32x2_f32)"
+    roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
+                "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
+                "algorithmic_flop_per_launch": gemm["work"] / max(gemm["count"], 1),
+                "launches_per_step": gemm["count"] // prof_steps, "avg_launch_us": 1e3 * gemm["ms"] / max(gemm["count"], 1),
+                "share_of_kernel_time": gemm["ms"] / total_ms}
+    roofline_hbm = {"bound": "hbm", "kernel": kern, "achieved": gemm["bytes"] / g_s / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gemm["bytes"] / g_s / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": gemm["bytes"] / max(gemm["count"], 1),
+                    "flop_per_byte": gemm["work"] / max(gemm["bytes"], 1.0),
+                    "note": "operands and result counted once in fp32 storage: 4*(M*K + N*K + M*N) per product"}
+    d_s = max(dec["ms"], 1e-9) * 1e-3
+    decoder_gemm = {"bound": "mfma", "achieved": dec["work"] / d_s / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": dec["work"] / d_s / 1e12 / peak_tf, "launches_per_step": dec["count"] // prof_steps,
+                    "avg_launch_us": 1e3 * dec["ms"] / max(dec["count"], 1),
+                    "algorithmic_flop_per_launch": dec["work"] / max(dec["count"], 1),
+                    "hbm_GBs": dec["bytes"] / d_s / 1e9,
+                    "note": "the decoder's M = B*30 row products only (forward + data gradients), FLOP / summed launch "
+                            "time: the quantity north_star's >= 40 % MFMA target is set on"}
+    return roofline, roofline_hbm, decoder_gemm
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -304,7 +373,9 @@ def main():
 
     cfg = FiraConfig()
     B = a.batch or (64 if a.dtype == "bf16" else 32)
-    n_commits = max(a.pool * B, a.decode_batch, 64)
+    default_line = a.batch == 0 and a.dtype == "f32"      # the driver's command: carries the batch-64 / 170 objects too
+    want_legs = default_line and not a.no_extras
+    n_commits = max(a.pool * B, a.decode_batch, 64, (a.pool * 64) if want_legs else 0, (2 * 170) if want_legs else 0)
     store = data.process_raw(cfg, synth.generate_dataset(n_commits, seed=1000 + rank))
     torch.manual_seed(0)
     model = TransModel(cfg, device="cuda:%d" % local)
@@ -312,62 +383,79 @@ def main():
     model.set_dropout_stream(0, rank)
     model.train()                                      # dropout on, as the reference trains
     trainer = Trainer(model, distributed=world > 1, zero1=a.zero1)
-    batches = [DeviceBatch(store.batch(range(i * B, (i + 1) * B)), cfg, model.device_) for i in range(a.pool)]
-    nnz_mean = float(np.mean([b.nnz for b in batches]))
+    lib = _lib.lib()
+    try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+        with open(os.path.join(HERE, "profiles", "traffic.json")) as f:
+            traffic_all = json.load(f)
+    except Exception:
+        traffic_all = {}
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        trainer.step(batches[i % a.pool])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        trainer.step(batches[i % a.pool])
-    t_enq = time.perf_counter() - t0                  # host time to enqueue the steps (the stream is still draining)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=model.device_)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    def make_batches(Bx, pool):
+        n = len(store)
+        return [DeviceBatch(store.batch([(i * Bx + k) % n for k in range(Bx)]), cfg, model.device_) for i in range(pool)]
+
+    def timed_leg(batches, steps, warmup):
+        """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks."""
+        for i in range(warmup):
+            trainer.step(batches[i % len(batches)])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            trainer.step(batches[i % len(batches)])
+        t_enq = time.perf_counter() - t0              # host time to enqueue the steps (the stream is still draining)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=model.device_)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, t_enq
+
+    def profiled(batches, prof_steps=3):
+        """kernel-class timing with HIP events on the launch stream (extra steps, outside any timed region)"""
+        lib.fira_prof_enable(1)
+        for i in range(prof_steps):
+            trainer.step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        prof = prof_report()
+        lib.fira_prof_enable(0)
+        return prof
+
+    def side_leg(dtype, Bx, steps, warmup, pool, with_host=False):
+        """One more training configuration measured like the headline (same trainer, other dtype / batch)."""
+        model.compute_dtype = dtype
+        bs = make_batches(Bx, pool)
+        dt, t_enq = timed_leg(bs, steps, warmup)
+        prof = profiled(bs)
+        tr = traffic_all.get(dtype) or {}
+        roof, roof_hbm, dec = gemm_objects(prof, dtype, 3, tr)
+        obj = {"commits_per_s": steps * Bx * world / dt, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": Bx,
+               "dtype": dtype, "steps": steps, "host_enqueue_ms_per_step": t_enq / steps * 1e3, "roofline": roof,
+               "decoder_gemm": dec, "kernel_time_ms_per_step": {k: v["ms"] / 3 for k, v in prof.items()}}
+        if dtype == "bf16":
+            obj["roofline_hbm"] = roof_hbm
+        if with_host and world == 1:
+            obj["host_inclusive"] = host_inclusive(cfg, store, trainer, Bx, max(10, steps))
+        del bs
+        return obj
+
+    batches = make_batches(B, a.pool)
+    nnz_mean = float(np.mean([b.nnz for b in batches]))
+    dt, t_enq = timed_leg(batches, a.steps, a.warmup)
     loss = trainer.last_loss()
     commits_per_s = a.steps * B * world / dt
 
-    # ---- kernel-class timing with HIP events on the launch stream (extra steps, outside the timed region)
-    lib = _lib.lib()
-    lib.fira_prof_enable(1)
     prof_steps = 3
-    for i in range(prof_steps):
-        trainer.step(batches[i % a.pool])
-    torch.cuda.synchronize()
-    prof = prof_report()
-    lib.fira_prof_enable(0)
+    prof = profiled(batches, prof_steps)
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
-    try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
-        with open(os.path.join(HERE, "profiles", "traffic.json")) as f:
-            tj = json.load(f)
-            traffic = tj.get(a.dtype) or (tj if a.dtype == "f32" and "gemm" in tj else {})
-    except Exception:
-        traffic = {}
-    gemm, spmm = prof["gemm"], prof["spmm"]
-    g_s = gemm["ms"] * 1e-3
-    peak_tf = BF16_MFMA_PEAK_TF if a.dtype == "bf16" else FP32_MFMA_PEAK_TF
-    kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if a.dtype == "bf16" else \
-        "gemm_f32_kernel / gemm_small_kernel (v_mfma_f32_32x32x2_f32)"
-    roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
-                "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
-                "algorithmic_flop_per_launch": gemm["work"] / max(gemm["count"], 1),
-                "launches_per_step": gemm["count"] // prof_steps, "avg_launch_us": 1e3 * gemm["ms"] / max(gemm["count"], 1),
-                "share_of_kernel_time": gemm["ms"] / total_ms}
-    roofline_hbm = {"bound": "hbm", "kernel": kern, "achieved": gemm["bytes"] / g_s / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": gemm["bytes"] / g_s / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": gemm["bytes"] / max(gemm["count"], 1),
-                    "flop_per_byte": gemm["work"] / max(gemm["bytes"], 1.0),
-                    "note": "operands and result counted once in fp32 storage: 4*(M*K + N*K + M*N) per product"}
+    traffic = traffic_all.get(a.dtype) or (traffic_all if a.dtype == "f32" and "gemm" in traffic_all else {})
+    roofline, roofline_hbm, decoder_gemm = gemm_objects(prof, a.dtype, prof_steps, traffic)
+    spmm = prof["spmm"]
     spmm_bytes_step = spmm["work"] + 8.0 * nnz_mean * spmm["count"]         # + (col,val) of the batch's nnz
     spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -377,6 +465,28 @@ def main():
 
     extras = {}
     single = rank == 0 and world == 1
+    if want_legs:
+        # BASELINE configs[2]'s per-GPU workload and north_star's "at batch 64" targets: fp32 AND bf16 at batch 64 per
+        # GPU (same trainer; with N > 1 ranks these are data-parallel steps over RCCL, i.e. configs[2] itself), and the
+        # reference's real operating point, 170 commits per GPU (run_model.py:40).  All outside the headline's timed region.
+        try:
+            b64 = {"f32": side_leg("f32", 64, a.steps, 3, a.pool, with_host=True),
+                   "bf16": side_leg("bf16", 64, a.steps, 3, a.pool, with_host=True)}
+            b64["decoder_gemm"] = {"f32": b64["f32"]["decoder_gemm"], "bf16": b64["bf16"]["decoder_gemm"],
+                                   "frac": b64["bf16"]["decoder_gemm"]["frac"],
+                                   "frac_f32": b64["f32"]["decoder_gemm"]["frac"],
+                                   "note": "frac = bf16 (configs[2]'s arithmetic) against 2.5 PFLOP/s; frac_f32 against 157.3 TFLOP/s"}
+            b64["bf16_over_f32"] = b64["bf16"]["commits_per_s"] / b64["f32"]["commits_per_s"]
+            extras["b64"] = b64
+            if world > 1:
+                extras["configs2"] = dict(b64["bf16"], workload="BASELINE configs[2]: data-parallel over %d GPUs, batch "
+                                          "64/GPU, bf16" % world, global_batch=64 * world)
+            extras["b170"] = {"f32": side_leg("f32", 170, max(5, a.steps // 2), 2, 2),
+                              "bf16": side_leg("bf16", 170, max(5, a.steps // 2), 2, 2),
+                              "note": "the reference's per-GPU batch (run_model.py:40)"}
+        except Exception as e:
+            extras["legs_error"] = repr(e)
+        model.compute_dtype = a.dtype
     if single and not a.no_extras:
         try:
             extras.update(spmm_standalone(cfg, store))
@@ -413,7 +523,7 @@ def main():
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
                        "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss},
-            "roofline": roofline, "spmm": spmm_obj, "decode": decode, "cpu_baseline": cpu,
+            "roofline": roofline, "decoder_gemm": decoder_gemm, "spmm": spmm_obj, "decode": decode, "cpu_baseline": cpu,
             "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in prof.items()},
         }
         if a.dtype == "bf16":

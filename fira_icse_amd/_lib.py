@@ -137,6 +137,24 @@ def lib():
     return _lib
 
 
+_host_warned = False
+
+
+def host_lib():
+    """The library for its two HOST-ONLY helpers (fira_host_collate_csr / fira_host_node_lists), or None when it cannot be
+    loaded or built (a CPU-only box without hipcc): the callers then run the numpy statements those helpers are tested
+    against (tests/test_host_lists.py) -- same arrays, slower.  Device code never goes through this accessor."""
+    global _host_warned
+    try:
+        return lib()
+    except (ImportError, OSError) as e:
+        if not _host_warned:
+            _host_warned = True
+            import warnings
+            warnings.warn("fira_icse_amd: libfira_hip.so unavailable (%s); host collate falls back to numpy" % (e,))
+        return None
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().fira_last_error()

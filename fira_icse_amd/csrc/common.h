@@ -30,8 +30,15 @@ int set_err(const char* fmt, ...);
 // Off by default (one relaxed bool test per launch).  When enabled (fira_prof_enable), every launcher brackets
 // its kernel with two hipEvents on the launch stream; fira_prof_report synchronises and aggregates the elapsed
 // time and the algorithmic work (FLOP for GEMM/attention, bytes for the memory-bound classes) per class.
-enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_NCLASS };
+// PROF_GEMM_DEC: the GEMM launches issued while a ProfDecoderTag is alive on the calling thread (the decoder's M = B*30 row
+// products, forward and data gradients) -- the quantity north_star sets its MFMA target on; reported beside PROF_GEMM
+enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_NCLASS };
 bool prof_on();
+void prof_decoder_tag(int delta);      // +1 / -1 (nesting counter, thread-local)
+struct ProfDecoderTag {
+    ProfDecoderTag() { prof_decoder_tag(+1); }
+    ~ProfDecoderTag() { prof_decoder_tag(-1); }
+};
 int prof_begin(hipStream_t s, int cls, double work, double bytes);
 void prof_end(hipStream_t s, int idx);
 struct ProfScope {

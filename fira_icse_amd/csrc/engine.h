@@ -20,10 +20,14 @@ int gemm_bf16_ex(hipStream_t s, int tA, int tB, int M, int N, int K, const float
                  float* C, int ldc, const float* bias, int flags, int splitk, float* colsum,
                  const int32_t* c_rows = nullptr, const float* relu_mask = nullptr);
 // bf16 weight shadows (gemm_bf16.hip): table of the 2-D weights the GEMMs read, one conversion launch per step
-struct ShadowEntry { int64_t offset; int rows, cols, pitch_t; };   // pitch_t: row pitch of the transposed copy (elements)
+// offset: of the fp32 tensor in the parameter buffer = of its as-stored bf16 copy in Wb;  offset_t / pitch_t: start and row
+// pitch (elements) of the transposed copy in WbT -- the transposed copies are packed on their own (padded rows do not
+// fit the tensor's parameter slot: a [V,256] weight with V % 8 != 0 would spill into its neighbour's shadow)
+struct ShadowEntry { int64_t offset; int rows, cols, pitch_t; int64_t offset_t; };
 constexpr int SHADOW_MAX = 64;
 struct ShadowTable {
     int n = 0;
+    int64_t wbt_elems = 0;           // elements of WbT the table addresses
     int tile_start[SHADOW_MAX + 1] = {0};
     ShadowEntry e[SHADOW_MAX];
 };

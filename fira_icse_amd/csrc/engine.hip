@@ -17,6 +17,8 @@
 
 namespace fira {
 
+static int64_t shadow_wbt_elems(const Layout& L);      // elements of the packed transposed bf16 shadows (shadow_table)
+
 struct Arena {
     char* base;
     size_t used = 0;
@@ -85,7 +87,7 @@ struct Plan {
             const Layout* lay = get_layout(&d);
             const size_t tot = lay ? (size_t)lay->total : 0;
             wb = a.get<uint16_t>(tot);
-            wbt = a.get<uint16_t>(tot + 64);     // + slack: an edge chunk may be read whole behind the last tensor
+            wbt = a.get<uint16_t>((lay ? (size_t)shadow_wbt_elems(*lay) : 0) + 64);   // + slack: an edge chunk may be read whole behind the last copy
             w21b = a.get<uint16_t>((size_t)nl * D * D);
             w21bt = a.get<uint16_t>((size_t)nl * D * D + 64);
         }
@@ -199,9 +201,11 @@ static const ShadowTable* shadow_table(const Layout& L) {
     auto add = [&](int64_t off, int rows, int cols) {
         if (t->n == SHADOW_MAX) return;
         // transposed shadow [cols, rows]: rows padded to a multiple of 8 elements so that every row starts 16-byte
-        // aligned.  Only the vocabulary projection needs padding (24650 -> 24656): its transposed copy spills 1.5 K
-        // elements past the tensor's own slot, into the slot of out_fc.bias -- a 1-D tensor, which has no shadow
-        t->e[t->n] = ShadowEntry{off, rows, cols, (rows + 7) / 8 * 8};
+        // aligned (the vocabulary projection: 24650 -> 24656).  The padded copy is larger than the tensor, so the
+        // transposed copies are packed at their own offsets (64-element aligned), whatever the vocabulary size is
+        const int pitch = (rows + 7) / 8 * 8;
+        t->e[t->n] = ShadowEntry{off, rows, cols, pitch, t->wbt_elems};
+        t->wbt_elems += ((int64_t)cols * pitch + 63) / 64 * 64;
         t->tile_start[t->n + 1] = t->tile_start[t->n] + cdiv(rows, 64) * cdiv(cols, 64);
         ++t->n;
     };
@@ -222,6 +226,7 @@ static const ShadowTable* shadow_table(const Layout& L) {
     cache[&L] = t;
     return t;
 }
+static int64_t shadow_wbt_elems(const Layout& L) { return shadow_table(L)->wbt_elems; }
 struct ShadowScope {            // publishes / withdraws the shadows of the running call
     ShadowScope(const float* P, int64_t total, const uint16_t* wb, const uint16_t* wbt, const ShadowTable* tab) {
         g_P = P; g_total = total; g_Wb = wb; g_WbT = wbt; g_tab = tab;
@@ -250,7 +255,7 @@ static bool shadow_of(const float* W, bool transposed, const uint16_t** out, int
         const int64_t rel = off - e.offset;
         if (rel % e.cols) return false;
         if (!transposed) { *out = g_Wb + off; *ld = e.cols; }
-        else { *out = g_WbT + e.offset + rel / e.cols; *ld = e.pitch_t; }
+        else { *out = g_WbT + e.offset_t + rel / e.cols; *ld = e.pitch_t; }
         return true;
     }
     return false;
@@ -506,7 +511,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         if (g_Wb) {                                  // bf16 mode: shadows of the folded weights, on the same stream
             ShadowTable t21;
             for (int l = 0; l < p.nl && l < SHADOW_MAX; ++l) {
-                t21.e[l] = ShadowEntry{(int64_t)l * D * D, D, D, D};
+                t21.e[l] = ShadowEntry{(int64_t)l * D * D, D, D, D, (int64_t)l * D * D};
                 t21.tile_start[l + 1] = t21.tile_start[l] + cdiv(D, 64) * cdiv(D, 64);
                 t21.n = l + 1;
             }
@@ -567,6 +572,7 @@ static int decoder_forward(Ctx& c) {
     hipStream_t s = c.s;
     const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
     TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
+    ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
     const float* x = p.x0;
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
@@ -669,6 +675,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // ---- decoder layers, last to first ------------------------------------------------------------------
     const float* dy = p.ddec;
     for (int l = p.nl - 1; l >= 0; --l) {
+        ProfDecoderTag prof_tag;               // data gradients of the M = B*30 products (the grouped wgrads flush later)
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
         DecGrad& g = p.decg[l];
@@ -693,7 +700,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
             const size_t o = (size_t)l * 2 * D;
             TRY(aux_fork(s));
             TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, KV, bt.mem_dst, nullptr));
-            TRY(linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true));
+            prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
+            const int rc_kv = linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
+            prof_decoder_tag(+1);
+            TRY(rc_kv);
         }
         TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
         TRY(linear_dgrad(s, p.TB, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(ShadowTable tab, con
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {                 // row c0 + i of the transposed matrix [cols, rows]
         const int c = c0 + i, r = r0 + tx;
-        if (c < q.cols && r < q.rows) WbT[q.offset + (size_t)c * q.pitch_t + r] = (uint16_t)(pack_bf16(tile[tx][i], 0.f) & 0xffffu);
+        if (c < q.cols && r < q.rows) WbT[q.offset_t + (size_t)c * q.pitch_t + r] = (uint16_t)(pack_bf16(tile[tx][i], 0.f) & 0xffffu);
     }
 }
 int weight_shadows(hipStream_t s, const ShadowTable& tab, const float* P, uint16_t* Wb, uint16_t* WbT) {
@@ -739,7 +739,7 @@ extern "C" int fira_weight_shadow(void* stream, int rows, int cols, const float*
     FIRA_REQUIRE(rows > 0 && cols > 0 && W && Wb && WbT, "fira_weight_shadow: bad argument");
     fira::ShadowTable tab;
     tab.n = 1;
-    tab.e[0] = fira::ShadowEntry{0, rows, cols, rows};
+    tab.e[0] = fira::ShadowEntry{0, rows, cols, rows, 0};
     tab.tile_start[1] = fira::cdiv(rows, 64) * fira::cdiv(cols, 64);
     return fira::weight_shadows((hipStream_t)stream, tab, W, Wb, WbT);
 }

@@ -41,8 +41,11 @@ struct ProfState {
 ProfState& PS() { static ProfState s; return s; }
 }  // namespace
 bool prof_on() { return PS().on; }
+static thread_local int tl_decoder_tag = 0;
+void prof_decoder_tag(int delta) { tl_decoder_tag += delta; }
 int prof_begin(hipStream_t s, int cls, double work, double bytes) {
     ProfState& p = PS();
+    if (cls == PROF_GEMM && tl_decoder_tag > 0) cls = PROF_GEMM_DEC;
     std::lock_guard<std::mutex> g(p.mu);
     ProfRec r{cls, work, bytes, p.get(), p.get()};
     (void)hipEventRecord(r.a, s);

@@ -214,10 +214,10 @@ class GraphStore:
         ``.toarray()`` + default collate, Dataset.py:336-343).  Vectorised: no per-commit Python loop."""
         idx = np.ascontiguousarray(idx, dtype=np.int64)
         B, N = len(idx), self.cfg.graph_len
-        if B and os.environ.get("FIRA_HOST_LISTS", "native") != "numpy":
+        from . import _lib
+        if B and os.environ.get("FIRA_HOST_LISTS", "native") != "numpy" and _lib.host_lib() is not None:
             # one C++ pass (csrc/hostlists.cpp: fira_host_collate_csr); the numpy statement below is its specification
-            # (tests/test_host_lists.py compares them)
-            from . import _lib
+            # (tests/test_host_lists.py compares them) and what runs when the library cannot be loaded on a CPU-only box
             total = int(self.nnz[idx].sum())
             rowptr = np.empty(B * N + 1, dtype=np.int32)
             col = np.empty(max(total, 1), dtype=np.int32)

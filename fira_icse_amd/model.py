@@ -210,7 +210,7 @@ def batch_lists(hb: HostBatch, cfg: FiraConfig, skip_padding: bool = True, chunk
     Default: ``fira_host_node_lists`` (csrc/hostlists.cpp, one C++ pass, GIL released during the call).  The numpy
     functions above are the specification -- ``FIRA_HOST_LISTS=numpy`` selects them, tests/test_host_lists.py requires
     identical arrays from both."""
-    if os.environ.get("FIRA_HOST_LISTS", "native") == "numpy":
+    if os.environ.get("FIRA_HOST_LISTS", "native") == "numpy" or _lib.host_lib() is None:
         node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst = computed_nodes(hb, cfg, skip_padding)
         return (node_rows, rowptr, col, val, code_rows, code_mark, mem_rows, mem_dst) + \
             tuple(compact_embedding_lists(hb, cfg, node_rows))
@@ -256,7 +256,7 @@ class _PinnedRing:
             ev.synchronize()
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event()                    # created lazily on the device current at record() time
         self.slots[i] = (buf, ev)
         return buf, ev
 
@@ -307,21 +307,35 @@ class DeviceBatch:
             plan.append((name, a, off, a.nbytes, dt))
             off += (a.nbytes + 255) // 256 * 256
         dev = torch.device(device)
+        self.ready = None                            # event of the host->device copy; consumers wait for it (wait_ready)
         if dev.type == "cuda":
-            ring = getattr(_pinned, "ring", None)
-            if ring is None:
-                ring = _pinned.ring = _PinnedRing()
-            stage, ev = ring.get(off)
+            # The batch is usually built on a prefetch worker thread, whose current device is thread-local (cuda:0 unless
+            # set): pin, copy and record under the TARGET device, so that the ring's reuse guard and `ready` follow the copy
+            # on cuda:LOCAL_RANK's stream and not an idle stream of GPU 0 (one ring per thread AND device).
+            with torch.cuda.device(dev):
+                rings = getattr(_pinned, "rings", None)
+                if rings is None:
+                    rings = _pinned.rings = {}
+                ring = rings.get(dev.index if dev.index is not None else torch.cuda.current_device())
+                if ring is None:
+                    ring = rings[dev.index if dev.index is not None else torch.cuda.current_device()] = _PinnedRing()
+                stage, ev = ring.get(off)
+                host = stage.numpy()
+                for name, a, o, nb, dt in plan:
+                    if a is not None:
+                        host[o:o + nb] = a.reshape(-1).view(np.uint8)
+                self.arena = torch.empty(max(off, 1), dtype=torch.uint8, device=dev)
+                stream = torch.cuda.current_stream(dev)
+                self.arena.copy_(stage[:max(off, 1)], non_blocking=True)
+                ev.record(stream)
+                self.ready = ev
         else:                                        # CPU tensors: host-side tests of the packing
-            stage, ev = torch.empty(max(off, 1), dtype=torch.uint8), None
-        host = stage.numpy()
-        for name, a, o, nb, dt in plan:
-            if a is not None:
-                host[o:o + nb] = a.reshape(-1).view(np.uint8)
-        self.arena = torch.empty(max(off, 1), dtype=torch.uint8, device=dev)
-        self.arena.copy_(stage[:max(off, 1)], non_blocking=True)
-        if ev is not None:
-            ev.record()
+            stage = torch.empty(max(off, 1), dtype=torch.uint8)
+            host = stage.numpy()
+            for name, a, o, nb, dt in plan:
+                if a is not None:
+                    host[o:o + nb] = a.reshape(-1).view(np.uint8)
+            self.arena = stage[:max(off, 1)].clone()
         tdt = {np.int32: torch.int32, np.float32: torch.float32}
         for name, a, o, nb, dt in plan:
             setattr(self, name, None if a is None else self.arena[o:o + nb].view(tdt[dt]).view(a.shape))
@@ -332,6 +346,13 @@ class DeviceBatch:
             p(self.code_rows), p(self.code_mark), self.n_mem, p(self.mem_rows), p(self.mem_dst), p(self.head_rows),
             self.n_head_rows, self.n_emb_items, p(self.emb_item_tok), p(self.emb_item_ptr), p(self.emb_rows),
             self.n_ast_items, p(self.ast_rows), p(self.ast_ids))
+
+    def wait_ready(self):
+        """Order the CURRENT stream behind this batch's host->device copy.  The copy is enqueued on the stream that was
+        current on the building thread; a consumer running under ``torch.cuda.stream(...)`` / graph capture / a side stream
+        would otherwise read the arena before the copy lands (stream-side wait, no host sync)."""
+        if self.ready is not None:
+            torch.cuda.current_stream(self.arena.device).wait_event(self.ready)
 
 
 def _as_tensor(ptr: int, shape, device) -> torch.Tensor:
@@ -425,6 +446,7 @@ class TransModel(nn.Module):
         """loss_sum, n_tok (device scalars) and d(loss_sum)/d(params) into ``self.gbuf`` (reference
         run_model.py:104-108 minus the optimizer).  Dropout follows ``self.training`` unless given."""
         lib = _lib.lib()
+        db.wait_ready()
         if zero_grad:
             self.gbuf[:self.layout.live].zero_()           # tensors past `live` never receive a gradient (SURVEY.md F6)
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
@@ -469,6 +491,7 @@ class TransModel(nn.Module):
     def forward_dev(self, db: DeviceBatch) -> torch.Tensor:
         """Teacher-forced argmax ids [B, tar_len] (reference Model.py:85-86)."""
         lib = _lib.lib()
+        db.wait_ready()
         ids = torch.empty((db.B, self.cfg.tar_len), dtype=torch.int32, device=self.device_)
         ws = self._ws.get((db.B, 1))          # share the training arena when it exists
         if ws is None:
@@ -488,6 +511,7 @@ class TransModel(nn.Module):
         db = edge if isinstance(edge, DeviceBatch) else self.make_batch(
             input_token, None, mark, ast_change, edge, None, sub_token)
         lib = _lib.lib()
+        db.wait_ready()
         n = lib.fira_decode_workspace_bytes(C.byref(self.dims), db.B, 1)
         if ("enc", db.B) not in self._ws:
             self._ws[("enc", db.B)] = torch.empty(n, dtype=torch.uint8, device=self.device_)

@@ -63,9 +63,10 @@ def gemm_wb(A, Bb, *, bias=None, relu=False, out=None, accumulate=False, splitk=
     return out
 
 
-def csr_spmm(rowptr, col, val, X, graph_rows=0, variant=0):
+def csr_spmm(rowptr, col, val, X, graph_rows=0, variant=0, out=None):
     X = _f32(X)
-    Y = torch.empty_like(X)
+    Y = torch.empty_like(X) if out is None else _f32(out)
+    assert Y.shape == X.shape
     check(_lib.lib().fira_csr_spmm_f32(cur_stream(), X.shape[0], ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)),
                                        ptr(X), X.stride(0), ptr(Y), Y.stride(0), graph_rows, variant),
           "fira_csr_spmm_f32")

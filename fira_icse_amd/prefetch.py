@@ -27,13 +27,18 @@ class prefetch(Iterator[U]):
 
     _DONE = object()
 
-    def __init__(self, items: Iterable[T], prepare: Callable[[T], U], depth: int = 2, workers: int = 0):
+    def __init__(self, items: Iterable[T], prepare: Callable[[T], U], depth: int = 2, workers: int = 0, device=None):
         # The workers' preparation is a string of short numpy calls that hold the GIL; the consumer (the training loop)
         # needs the GIL for a few microseconds between its long GIL-free library calls and would otherwise wait for the
         # interpreter's default 5 ms forced-switch interval each time (measured: +2.5 ms per 4 ms step).
         iv = float(os.environ.get("FIRA_SWITCH_INTERVAL", "1e-4"))
+        self._saved_interval = None
         if iv > 0 and sys.getswitchinterval() > iv:
+            self._saved_interval = sys.getswitchinterval()       # restored by close()
             sys.setswitchinterval(iv)
+        # The CUDA/HIP current device is thread-local: a worker that builds device batches must select the rank's GPU
+        # itself, or its pinned allocations, copies and events land on cuda:0 (``device``: torch.device / index / None).
+        self._device = device
         if workers <= 0:
             workers = max(1, int(os.environ.get("FIRA_PREFETCH_WORKERS", "1")))
         self._depth = max(1, depth, workers)
@@ -48,6 +53,11 @@ class prefetch(Iterator[U]):
         self._src_lock = threading.Lock()
 
         def work():
+            if self._device is not None:
+                import torch
+                d = torch.device(self._device)
+                if d.type == "cuda":
+                    torch.cuda.set_device(d)
             while True:
                 with self._cv:                    # at most `depth` items prepared or in preparation ahead of the consumer
                     while not self._stop and self._next_in - self._next_out >= self._depth:
@@ -117,6 +127,9 @@ class prefetch(Iterator[U]):
         for th in self._threads:
             if th.is_alive() and threading.current_thread() is not th:
                 th.join(timeout=5.0)
+        if self._saved_interval is not None:
+            sys.setswitchinterval(self._saved_interval)
+            self._saved_interval = None
 
     def __del__(self):
         try:

@@ -61,6 +61,9 @@ def parse_args(argv):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--save-optimizer", action="store_true", help="also write fira_train_state.pt (Adam moments, step)")
     ap.add_argument("--resume", action="store_true", help="start from best_model.pt (+ fira_train_state.pt if present)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="arithmetic of the nn.Linear products: f32 = "
+                    "the reference's (fp32 MFMA, default); bf16 = BASELINE configs[2] (bf16 MFMA, fp32 accumulate; master "
+                    "weights, LayerNorm, soft-max, loss and Adam stay fp32).  Applies to train, dev and test")
     ap.add_argument("--zero1", action="store_true", help="multi-GPU: reduce-scatter + Adam on the owned shard + all-gather "
                     "(Adam moments sharded over the ranks) instead of all-reduce + replicated Adam")
     return ap.parse_args(argv)
@@ -142,6 +145,7 @@ class Run:
         self.model = TransModel(cfg, device="cuda:%d" % self.local)       # consumes the torch RNG like the reference
         if a.resume and os.path.exists(os.path.join(self.root, "best_model.pt")):
             self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
+        self.model.compute_dtype = a.dtype
         self.model.set_dropout_stream(a.seed, self.rank)           # masks depend on (--seed, rank, step)
         trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1, zero1=a.zero1)
         state_path = os.path.join(self.root, "fira_train_state.pt")
@@ -156,7 +160,8 @@ class Run:
                 mine = shard_indices(gidx, self.rank, self.world)   # DataParallel.scatter's contiguous chunks
                 return gidx, (self.device_batch(store, mine) if mine else None)
 
-            batches = prefetch(data.iterate_batches(len(store), cfg.batch_size, shuffle=True), prepare, depth=2)
+            batches = prefetch(data.iterate_batches(len(store), cfg.batch_size, shuffle=True), prepare, depth=2,
+                               device=self.model.device_)
             for idx_b, (gidx, db) in enumerate(batches):
                 if epoch >= a.dev_from_epoch and idx_b % a.dev_every == 0:
                     cur_bleu, output_str = self.dev(epoch)
@@ -203,6 +208,7 @@ class Run:
         test_index = self.all_index["test"]
         self.model = TransModel(cfg, device="cuda:%d" % self.local, init=False)
         self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
+        self.model.compute_dtype = a.dtype
         self.model.eval()
         search = Searcher(self.model)
         mine = shard_indices(list(range(len(store))), self.rank, self.world)

@@ -528,6 +528,151 @@ __global__ __launch_bounds__(256) void gemm_bf16_small_kernel(int M, int N, int 
     }
 }
 
+// Round 3: the latency kernel with COALESCED operand traffic (the fp32 twin and the rationale are in gemm_small.hip:
+// gemm_tile32_kernel).  One 32x32 output tile per workgroup, its four wavefronts split K in chunks of 64; a chunk is read
+// with wave-wide 16-byte loads of whole row segments (A: 4 rows x 256 bytes of fp32 per instruction, rounded to bf16 on its
+// way into LDS; Bb: 8 rows x 128 bytes of the bf16 weight shadow per instruction), parked in a wave-private 8 KB LDS slot
+// as 128-byte bf16 rows (16-byte slot g of row r stored at slot g ^ ((r>>1)&7): conflict-free for the stores and for the
+// ds_read_b128 fragment fetch) and re-read in MFMA layout: step s of a chunk uses k = (lane>>5)*32 + 8 s .. + 7.
+// NCH = chunks per wave (K = 256 NCH): the loop is unrolled, two chunks of loads in flight, no barrier in the K loop.
+struct ChunkRegs16 { f32x4 a0, a1, a2, a3, a4, a5, a6, a7; uint4 b0, b1, b2, b3; };
+
+__device__ __forceinline__ void tile32b_fetch(ChunkRegs16& R, const float* A, const unsigned (&oa)[8], const uint16_t* pb0,
+                                              const uint16_t* pb1, const uint16_t* pb2, const uint16_t* pb3, int kc) {
+    // A: instruction j covers rows 4j + (lane>>4); oa[j] = element offset of this lane's (clamped / mapped) row and column
+    R.a0 = *reinterpret_cast<const f32x4*>(A + oa[0] + kc);
+    R.a1 = *reinterpret_cast<const f32x4*>(A + oa[1] + kc);
+    R.a2 = *reinterpret_cast<const f32x4*>(A + oa[2] + kc);
+    R.a3 = *reinterpret_cast<const f32x4*>(A + oa[3] + kc);
+    R.a4 = *reinterpret_cast<const f32x4*>(A + oa[4] + kc);
+    R.a5 = *reinterpret_cast<const f32x4*>(A + oa[5] + kc);
+    R.a6 = *reinterpret_cast<const f32x4*>(A + oa[6] + kc);
+    R.a7 = *reinterpret_cast<const f32x4*>(A + oa[7] + kc);
+    R.b0 = *reinterpret_cast<const uint4*>(pb0 + kc);
+    R.b1 = *reinterpret_cast<const uint4*>(pb1 + kc);
+    R.b2 = *reinterpret_cast<const uint4*>(pb2 + kc);
+    R.b3 = *reinterpret_cast<const uint4*>(pb3 + kc);
+}
+__device__ __forceinline__ void tile32b_stage(const ChunkRegs16& R, char* slot, const int (&wa)[8], int wb) {
+    __builtin_amdgcn_wave_barrier();                  // the previous chunk's fragment reads precede these stores
+#define FIRA_ST_A(j, v) *reinterpret_cast<uint2*>(slot + wa[j]) = uint2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+    FIRA_ST_A(0, R.a0) FIRA_ST_A(1, R.a1) FIRA_ST_A(2, R.a2) FIRA_ST_A(3, R.a3)
+    FIRA_ST_A(4, R.a4) FIRA_ST_A(5, R.a5) FIRA_ST_A(6, R.a6) FIRA_ST_A(7, R.a7)
+#undef FIRA_ST_A
+    *reinterpret_cast<uint4*>(slot + 4096 + wb) = R.b0;
+    *reinterpret_cast<uint4*>(slot + 4096 + wb + 1024) = R.b1;
+    *reinterpret_cast<uint4*>(slot + 4096 + wb + 2048) = R.b2;
+    *reinterpret_cast<uint4*>(slot + 4096 + wb + 3072) = R.b3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ f32x16 tile32b_compute(const char* slot, int f0, int f1, int f2, int f3, f32x16 acc) {
+#define FIRA_STEP(f)                                                                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(slot + f),                \
+                                                  *reinterpret_cast<const bf16x8*>(slot + 4096 + f), acc, 0, 0, 0);
+    FIRA_STEP(f0) FIRA_STEP(f1) FIRA_STEP(f2) FIRA_STEP(f3)
+#undef FIRA_STEP
+    return acc;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void gemm_bf16_tile32_kernel(int M, int N, const float* __restrict__ A, int lda,
+                                                               const uint16_t* __restrict__ Bb, int ldb,
+                                                               float* __restrict__ C, int ldc,
+                                                               const float* __restrict__ bias, int flags,
+                                                               const int32_t* __restrict__ c_rows,
+                                                               const float* __restrict__ relu_mask,
+                                                               const int32_t* __restrict__ a_rows, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int t;                                            // XCD-chunked tile order (bijective for any grid size)
+    {
+        const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int m0 = (t / tiles_n) * 32, n0 = (t % tiles_n) * 32;
+    char* slot = smem + wave * 8192;
+    // A loads: row 4j + ar of the tile, 16-byte column ac (4 floats = half a 16-byte bf16 slot) of the 64-float chunk
+    const int ar = lane >> 4, ac = lane & 15;
+    unsigned oa[8];
+    int wa[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + ar;
+        int ra = min(m0 + r, M - 1);                               // clamped rows: masked at the store
+        if (a_rows) ra = a_rows[ra];
+        oa[j] = (unsigned)ra * (unsigned)lda + ac * 4;
+        wa[j] = r * 128 + (((ac >> 1) ^ ((r >> 1) & 7)) << 4) + (ac & 1) * 8;
+    }
+    // Bb loads: row 8j + br, 16-byte slot bs (8 bf16) of the 64-element chunk
+    const int br = lane >> 3, bs = lane & 7;
+    const uint16_t* pb0 = Bb + (size_t)min(n0 + br, N - 1) * ldb + ((bs ^ ((br >> 1) & 7)) << 3);
+    const uint16_t* pb1 = Bb + (size_t)min(n0 + 8 + br, N - 1) * ldb + ((bs ^ (4 + (br >> 1))) << 3);
+    const uint16_t* pb2 = Bb + (size_t)min(n0 + 16 + br, N - 1) * ldb + ((bs ^ ((br >> 1) & 7)) << 3);
+    const uint16_t* pb3 = Bb + (size_t)min(n0 + 24 + br, N - 1) * ldb + ((bs ^ (4 + (br >> 1))) << 3);
+    const int wb = br * 128 + bs * 16;
+    const int i31 = lane & 31, kh = lane >> 5, sw_i = (i31 >> 1) & 7;
+    const int f0 = i31 * 128 + (((kh * 4 + 0) ^ sw_i) << 4), f1 = i31 * 128 + (((kh * 4 + 1) ^ sw_i) << 4);
+    const int f2 = i31 * 128 + (((kh * 4 + 2) ^ sw_i) << 4), f3 = i31 * 128 + (((kh * 4 + 3) ^ sw_i) << 4);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ChunkRegs16 R0, R1;
+    tile32b_fetch(R0, A, oa, pb0, pb1, pb2, pb3, wave << 6);
+    if (NCH > 1) tile32b_fetch(R1, A, oa, pb0, pb1, pb2, pb3, (wave + 4) << 6);
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+        if ((ci & 1) == 0) {
+            tile32b_stage(R0, slot, wa, wb);
+            if (ci + 2 < NCH) tile32b_fetch(R0, A, oa, pb0, pb1, pb2, pb3, (wave + 4 * (ci + 2)) << 6);
+        } else {
+            tile32b_stage(R1, slot, wa, wb);
+            if (ci + 2 < NCH) tile32b_fetch(R1, A, oa, pb0, pb1, pb2, pb3, (wave + 4 * (ci + 2)) << 6);
+        }
+        acc = tile32b_compute(slot, f0, f1, f2, f3, acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* red = reinterpret_cast<float*>(slot);                       // this wave's partial tile over its own slot
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+    __syncthreads();
+    {
+        const int ln = threadIdx.x & 63, rq = threadIdx.x >> 6;
+        float vals[4];
+        int rows[4];
+        const float* p0 = reinterpret_cast<const float*>(smem);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i, r = rq + 4 * i;
+            vals[i] = (p0[idx] + p0[2048 + idx]) + (p0[4096 + idx] + p0[6144 + idx]);
+            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        }
+        epilogue_col<4>(vals, rows, n0 + (ln & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
+                        c_rows, relu_mask);
+    }
+}
+
+// true if the coalesced bf16 tile kernel took the call
+static bool gemm_bf16_tile32_try(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb,
+                                 float* C, int ldc, const float* bias, int flags, const int32_t* c_rows,
+                                 const float* relu_mask, const int32_t* a_rows, int* rc) {
+    if (K % 256 != 0 || K > 1024) return false;
+    const int tiles_n = cdiv(N, 32);
+    const dim3 grid(cdiv(M, 32) * tiles_n);
+#define FIRA_T32B(NCH)                                                                                                 \
+    case NCH:                                                                                                          \
+        hipLaunchKernelGGL((gemm_bf16_tile32_kernel<NCH>), grid, dim3(256), 0, s, M, N, A, lda, Bb, ldb, C, ldc, bias, flags, \
+                           c_rows, relu_mask, a_rows, tiles_n);                                                        \
+        break;
+    switch (K / 256) { FIRA_T32B(1) FIRA_T32B(2) FIRA_T32B(3) FIRA_T32B(4) }
+#undef FIRA_T32B
+    hipError_t e = hipGetLastError();
+    *rc = e != hipSuccess ? set_err("gemm_bf16_tile32: %s", hipGetErrorString(e)) : 0;
+    return true;
+}
+
 // Products this kernel does not take (handled by the fp32 kernels, i.e. computed more precisely, never less):
 // unaligned operands, and the tiny ones (4-row mark table, 2-column gate) where a 64-wide tile is mostly padding.
 // latency kernel (32x32 tiles, K split over the 4 waves) vs the 64x64 tiled kernel: up to ~4 rounds of 32x32 tiles; with a
@@ -651,8 +796,12 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
     FIRA_REQUIRE(c_rows || epilogue_fits(M, ldc), "gemm_bf16_wb: output of %d x %d floats exceeds the 2 GiB the kernels address", M, ldc);
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
-    static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();
+    static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 2; }();
     if (splitk <= 1 && small_mode && K % 64 == 0 && small_kernel_wins(M, N, K)) {
+        int rc;
+        if (small_mode != 1 && gemm_bf16_tile32_try(s, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask,
+                                                    nullptr, &rc))
+            return rc;
         dim3 grid(cdiv(N, 32), cdiv(M, 32));
         hipLaunchKernelGGL((gemm_bf16_small_kernel<true, uint16_t>), grid, dim3(256), 0, s, M, N, K, A, lda, Bb, ldb, C, ldc,
                            bias, flags & 3, c_rows, relu_mask);

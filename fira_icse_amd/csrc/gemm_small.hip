@@ -19,6 +19,7 @@
 namespace fira {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool B_KCONTIG>
 __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, const float* __restrict__ A, int lda,
@@ -91,17 +92,224 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(int M, int N, int K, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same decomposition (one 32x32 output tile per workgroup, the four wavefronts split K in chunks of 32) with
+// COALESCED operand traffic.  The kernel above fetches MFMA fragments straight from global memory: lane (i, kh) reads
+// 64 bytes of row i, so every load instruction touches 32 cache lines and uses 32 bytes of each (8.6 % of the fp32 MFMA
+// peak on [960,256,256]).  Here a chunk is 32 rows x 128 bytes = 32 whole cache lines per operand, read by
+// 4 + 4 wave-wide 16-byte loads (lane -> row 8j + lane/8, 16-byte slot lane%8: 8 full lines per instruction), parked in
+// a wave-private 8 KB LDS slot and re-read in MFMA fragment layout:
+//   A / k-contiguous B:  row r at r*128 bytes, global 16-byte slot g stored at slot g ^ ((r>>1)&7): the 8-lane groups of
+//                        the ds_write_b128 and the 16-lane groups of the ds_read_b128 fragment fetch are conflict-free
+//   B stored [K,N]:      k-row at k*128 bytes (the tile's 32 columns), fragment fetch by ds_read_b32 (bank = column)
+// MFMA step t of a chunk uses k = (lane>>5)*16 + t for both operands.  A wave touches only its own slot and its own
+// loads (up to two chunks in flight, the next one requested before the current one's MFMAs): no barrier in the K loop;
+// the four partial tiles are combined through the same LDS.  Tile order is XCD-aware (block b runs on XCD b % 8): every
+// XCD gets a contiguous range of row blocks with all their column tiles, so an activation panel is fetched by one L2.
+// a_rows (optional): A row r is read from row a_rows[r] (a gather folded into the product).
+__device__ __forceinline__ int swz8(int row) { return (row >> 1) & 7; }
+
+struct ChunkRegs { f32x4 a0, a1, a2, a3, b0, b1, b2, b3; };
+
+template <bool B_KCONTIG>
+__device__ __forceinline__ void tile32_fetch(ChunkRegs& R, const float* pa0, const float* pa1, const float* pa2,
+                                             const float* pa3, const float* pb0, const float* pb1, const float* pb2,
+                                             const float* pb3, int kc, int ldb) {
+    const size_t ob = B_KCONTIG ? (size_t)kc : (size_t)kc * ldb;
+    R.a0 = *reinterpret_cast<const f32x4*>(pa0 + kc);
+    R.a1 = *reinterpret_cast<const f32x4*>(pa1 + kc);
+    R.a2 = *reinterpret_cast<const f32x4*>(pa2 + kc);
+    R.a3 = *reinterpret_cast<const f32x4*>(pa3 + kc);
+    R.b0 = *reinterpret_cast<const f32x4*>(pb0 + ob);
+    R.b1 = *reinterpret_cast<const f32x4*>(pb1 + ob);
+    R.b2 = *reinterpret_cast<const f32x4*>(pb2 + ob);
+    R.b3 = *reinterpret_cast<const f32x4*>(pb3 + ob);
+}
+
+#define FIRA_MFMA4(va, vb)                                                    \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.x, vb.x, acc, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.y, vb.y, acc, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.z, vb.z, acc, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va.w, vb.w, acc, 0, 0, 0);
+
+// park one chunk in the wave's slot ...
+__device__ __forceinline__ void tile32_stage(const ChunkRegs& R, char* slot, int wr_off) {
+    __builtin_amdgcn_wave_barrier();                  // the previous chunk's fragment reads precede these stores
+    *reinterpret_cast<f32x4*>(slot + wr_off) = R.a0;
+    *reinterpret_cast<f32x4*>(slot + wr_off + 1024) = R.a1;
+    *reinterpret_cast<f32x4*>(slot + wr_off + 2048) = R.a2;
+    *reinterpret_cast<f32x4*>(slot + wr_off + 3072) = R.a3;
+    *reinterpret_cast<f32x4*>(slot + 4096 + wr_off) = R.b0;
+    *reinterpret_cast<f32x4*>(slot + 4096 + wr_off + 1024) = R.b1;
+    *reinterpret_cast<f32x4*>(slot + 4096 + wr_off + 2048) = R.b2;
+    *reinterpret_cast<f32x4*>(slot + 4096 + wr_off + 3072) = R.b3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// ... re-read it in fragment layout, 16 MFMA steps
+template <bool B_KCONTIG>
+__device__ __forceinline__ f32x16 tile32_compute(const char* slot, int fa0, int fa1, int fa2, int fa3, int fb, f32x16 acc) {
+    const f32x4 va0 = *reinterpret_cast<const f32x4*>(slot + fa0);
+    const f32x4 va1 = *reinterpret_cast<const f32x4*>(slot + fa1);
+    const f32x4 va2 = *reinterpret_cast<const f32x4*>(slot + fa2);
+    const f32x4 va3 = *reinterpret_cast<const f32x4*>(slot + fa3);
+    if (B_KCONTIG) {
+        const f32x4 vb0 = *reinterpret_cast<const f32x4*>(slot + 4096 + fa0);
+        const f32x4 vb1 = *reinterpret_cast<const f32x4*>(slot + 4096 + fa1);
+        const f32x4 vb2 = *reinterpret_cast<const f32x4*>(slot + 4096 + fa2);
+        const f32x4 vb3 = *reinterpret_cast<const f32x4*>(slot + 4096 + fa3);
+        FIRA_MFMA4(va0, vb0) FIRA_MFMA4(va1, vb1) FIRA_MFMA4(va2, vb2) FIRA_MFMA4(va3, vb3)
+    } else {
+        const char* pb = slot + 4096 + fb;            // k-row (lane>>5)*16, column lane&31; one k-row = 128 bytes
+        f32x4 vb0, vb1, vb2, vb3;
+        vb0.x = *reinterpret_cast<const float*>(pb);        vb0.y = *reinterpret_cast<const float*>(pb + 128);
+        vb0.z = *reinterpret_cast<const float*>(pb + 256);  vb0.w = *reinterpret_cast<const float*>(pb + 384);
+        vb1.x = *reinterpret_cast<const float*>(pb + 512);  vb1.y = *reinterpret_cast<const float*>(pb + 640);
+        vb1.z = *reinterpret_cast<const float*>(pb + 768);  vb1.w = *reinterpret_cast<const float*>(pb + 896);
+        vb2.x = *reinterpret_cast<const float*>(pb + 1024); vb2.y = *reinterpret_cast<const float*>(pb + 1152);
+        vb2.z = *reinterpret_cast<const float*>(pb + 1280); vb2.w = *reinterpret_cast<const float*>(pb + 1408);
+        vb3.x = *reinterpret_cast<const float*>(pb + 1536); vb3.y = *reinterpret_cast<const float*>(pb + 1664);
+        vb3.z = *reinterpret_cast<const float*>(pb + 1792); vb3.w = *reinterpret_cast<const float*>(pb + 1920);
+        FIRA_MFMA4(va0, vb0) FIRA_MFMA4(va1, vb1) FIRA_MFMA4(va2, vb2) FIRA_MFMA4(va3, vb3)
+    }
+    return acc;
+}
+
+// NCH = chunks per wave (K = 128 * NCH): the chunk loop is unrolled at compile time, so the two register sets of the
+// loads in flight are named registers and the accumulator never leaves the AGPRs
+template <bool B_KCONTIG, int NCH>
+__global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                          int ldc, const float* __restrict__ bias, int flags,
+                                                          const int32_t* __restrict__ c_rows,
+                                                          const float* __restrict__ relu_mask,
+                                                          const int32_t* __restrict__ a_rows, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-chunked tile order (bijective for any grid size)
+    int t;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int m0 = (t / tiles_n) * 32, n0 = (t % tiles_n) * 32;
+    char* slot = smem + wave * 8192;
+    const int lr = lane >> 3, ls = lane & 7;
+    // row 8j + lr of the tile, j = 0..3: swz8(8j + lr) = (4j + (lr>>1)) & 7
+    const int sw_even = lr >> 1, sw_odd = 4 + (lr >> 1);
+    int ra0 = min(m0 + lr, M - 1), ra1 = min(m0 + 8 + lr, M - 1), ra2 = min(m0 + 16 + lr, M - 1), ra3 = min(m0 + 24 + lr, M - 1);
+    if (a_rows) { ra0 = a_rows[ra0]; ra1 = a_rows[ra1]; ra2 = a_rows[ra2]; ra3 = a_rows[ra3]; }   // clamped rows: masked at the store
+    const float* pa0 = A + (size_t)ra0 * lda + ((ls ^ sw_even) << 2);
+    const float* pa1 = A + (size_t)ra1 * lda + ((ls ^ sw_odd) << 2);
+    const float* pa2 = A + (size_t)ra2 * lda + ((ls ^ sw_even) << 2);
+    const float* pa3 = A + (size_t)ra3 * lda + ((ls ^ sw_odd) << 2);
+    const float *pb0, *pb1, *pb2, *pb3;
+    if (B_KCONTIG) {
+        pb0 = B + (size_t)min(n0 + lr, N - 1) * ldb + ((ls ^ sw_even) << 2);
+        pb1 = B + (size_t)min(n0 + 8 + lr, N - 1) * ldb + ((ls ^ sw_odd) << 2);
+        pb2 = B + (size_t)min(n0 + 16 + lr, N - 1) * ldb + ((ls ^ sw_even) << 2);
+        pb3 = B + (size_t)min(n0 + 24 + lr, N - 1) * ldb + ((ls ^ sw_odd) << 2);
+    } else {
+        pb0 = B + (size_t)lr * ldb + n0 + (ls << 2);
+        pb1 = pb0 + (size_t)8 * ldb;
+        pb2 = pb0 + (size_t)16 * ldb;
+        pb3 = pb0 + (size_t)24 * ldb;
+    }
+    const int i31 = lane & 31, kh = lane >> 5;
+    const int wr_off = lr * 128 + ls * 16;
+    const int sw_i = swz8(i31);
+    const int fa0 = i31 * 128 + (((kh * 4 + 0) ^ sw_i) << 4), fa1 = i31 * 128 + (((kh * 4 + 1) ^ sw_i) << 4);
+    const int fa2 = i31 * 128 + (((kh * 4 + 2) ^ sw_i) << 4), fa3 = i31 * 128 + (((kh * 4 + 3) ^ sw_i) << 4);
+    const int fb = kh * 16 * 128 + i31 * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ChunkRegs R0, R1;
+    tile32_fetch<B_KCONTIG>(R0, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, wave << 5, ldb);
+    if (NCH > 1) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4) << 5, ldb);
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+        if ((ci & 1) == 0) {
+            tile32_stage(R0, slot, wr_off);
+            if (ci + 2 < NCH) tile32_fetch<B_KCONTIG>(R0, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4 * (ci + 2)) << 5, ldb);
+        } else {
+            tile32_stage(R1, slot, wr_off);
+            if (ci + 2 < NCH) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4 * (ci + 2)) << 5, ldb);
+        }
+        acc = tile32_compute<B_KCONTIG>(slot, fa0, fa1, fa2, fa3, fb, acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* red = reinterpret_cast<float*>(slot);                       // this wave's partial tile over its own slot
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+    __syncthreads();
+    {
+        const int ln = threadIdx.x & 63, rq = threadIdx.x >> 6;
+        float vals[4];
+        int rows[4];
+        const float* p0 = reinterpret_cast<const float*>(smem);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i, r = rq + 4 * i;
+            vals[i] = (p0[idx] + p0[2048 + idx]) + (p0[4096 + idx] + p0[6144 + idx]);
+            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        }
+        epilogue_col<4>(vals, rows, n0 + (ln & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
+                        c_rows, relu_mask);
+    }
+}
+
+template <bool B_KCONTIG, int NCH>
+static void tile32_launch(hipStream_t s, dim3 grid, int M, int N, const float* A, int lda, const float* B, int ldb, float* C,
+                          int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask,
+                          const int32_t* a_rows, int tiles_n) {
+    hipLaunchKernelGGL((gemm_tile32_kernel<B_KCONTIG, NCH>), grid, dim3(256), 0, s, M, N, A, lda, B, ldb, C, ldc, bias, flags,
+                       c_rows, relu_mask, a_rows, tiles_n);
+}
+
+// true if the coalesced tile kernel took the call (FIRA_SMALL_GEMM=1 keeps the round-2 fragment-load kernel: A/B switch)
+bool gemm_tile32_try(hipStream_t s, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,
+                     const float* relu_mask, const int32_t* a_rows) {
+    if (K % 128 != 0 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0 || ldb % 4 != 0 || ((uintptr_t)B % 16) != 0) return false;
+    const int nch = K / 128;
+    if (nch != 1 && nch != 2 && nch != 3 && nch != 4 && nch != 6 && nch != 8) return false;
+    if (!tB && N % 32 != 0) return false;                               // [K,N] tiles are read as whole 128-byte row segments
+    const int tiles_n = cdiv(N, 32);
+    const dim3 grid(cdiv(M, 32) * tiles_n);
+#define FIRA_T32(NCH)                                                                                                  \
+    case NCH:                                                                                                          \
+        if (tB) tile32_launch<true, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n); \
+        else tile32_launch<false, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n); \
+        break;
+    switch (nch) { FIRA_T32(1) FIRA_T32(2) FIRA_T32(3) FIRA_T32(4) FIRA_T32(6) FIRA_T32(8) }
+#undef FIRA_T32
+    hipError_t e = hipGetLastError();
+    *rc = e != hipSuccess ? set_err("gemm_tile32: %s", hipGetErrorString(e)) : 0;
+    return true;
+}
+
 // true if this kernel took the call
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,
                     const float* relu_mask) {
     *rc = 0;
-    static const int mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 1; }();   // A/B switch
+    // A/B switch: 0 = decode-sized products only, 1 = the round-2 fragment-load kernel, 2 (default) = coalesced tile kernel
+    static const int mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 2; }();
     if (mode == 0 && M > 64) return false;          // 0: only the decode-sized products (M <= 64) stay here
     // beyond ~4 rounds of 32x32 tiles the LDS-tiled kernel's operand reuse wins; M <= 64 (decode) always lands here
     const long tiles = (long)cdiv(M, 32) * cdiv(N, 32);
+    // the coalesced tile kernel keeps winning for more rounds of tiles than the fragment-load one did (FIRA_SMALL_TILES: A/B)
+    static const long max_tiles = [] { const char* e = getenv("FIRA_SMALL_TILES"); return e ? atol(e) : 1024L; }();
+    if (!tA && mode != 1 && M > 64 && tiles > 1024 && tiles <= max_tiles) {
+        if (gemm_tile32_try(s, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rc, c_rows, relu_mask, nullptr)) return true;
+    }
     if (tA || (M > 64 && tiles > 1024) || K % 32 != 0 || K < 64 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0) return false;
     if (tB && (ldb % 4 != 0 || ((uintptr_t)B % 16) != 0)) return false;
+    if (mode != 1 && gemm_tile32_try(s, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rc, c_rows, relu_mask, nullptr))
+        return true;
     dim3 grid(cdiv(N, 32), cdiv(M, 32));
     if (tB) hipLaunchKernelGGL(gemm_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask);
     else hipLaunchKernelGGL(gemm_small_kernel<false>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask);

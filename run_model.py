@@ -208,7 +208,7 @@ class Run:
         test_index = self.all_index["test"]
         self.model = TransModel(cfg, device="cuda:%d" % self.local, init=False)
         self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
-        self.model.compute_dtype = a.dtype
+        self.model.compute_dtype = self.a.dtype
         self.model.eval()
         search = Searcher(self.model)
         mine = shard_indices(list(range(len(store))), self.rank, self.world)

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Round-3 GPU session (through gpurun): bash scripts/r3_gpu.sh <tag> <stages...>
+#   stages: chain tests bench bench16 prof prof16 shapes
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r3a}; shift
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+cd $REPO
+export TMPDIR=/tmp
+for ST in "$@"; do
+  case $ST in
+    chain)
+      FIRA_SMALL_GEMM=1 timeout 300 python scripts/gemm_chain.py f32 > $OUT/chain_f32_old.md 2>&1; echo "chain old rc=$?"
+      FIRA_SMALL_GEMM=2 timeout 300 python scripts/gemm_chain.py f32 > $OUT/chain_f32_new.md 2>&1; echo "chain new rc=$?"
+      FIRA_SMALL_GEMM=1 timeout 300 python scripts/gemm_chain.py bf16 > $OUT/chain_bf16_old.md 2>&1; echo "chain bf16 old rc=$?"
+      FIRA_SMALL_GEMM=2 timeout 300 python scripts/gemm_chain.py bf16 > $OUT/chain_bf16_new.md 2>&1; echo "chain bf16 new rc=$?"
+      FIRA_SMALL_TILES=1024 timeout 300 python scripts/gemm_chain.py f32 2880,5100,7680 > $OUT/chain_f32_big_t1024.md 2>&1
+      FIRA_SMALL_TILES=8192 timeout 300 python scripts/gemm_chain.py f32 2880,5100,7680 > $OUT/chain_f32_big_t8192.md 2>&1
+      tail -n 26 $OUT/chain_f32_new.md; tail -n 14 $OUT/chain_bf16_old.md; tail -n 14 $OUT/chain_bf16_new.md; tail -n 14 $OUT/chain_f32_big_t1024.md; tail -n 14 $OUT/chain_f32_big_t8192.md ;;
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 300 > $OUT/tests.log 2>&1
+      echo "tests rc=$?" >> $OUT/tests.log; tail -n 25 $OUT/tests.log ;;
+    bench)
+      timeout 900 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "bench f32 rc=$?"; head -c 1500 $OUT/bench_f32.json; echo; tail -n 5 $OUT/bench_f32.err ;;
+    bench16)
+      timeout 600 python bench.py --dtype bf16 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err; echo "bench bf16 rc=$?"; head -c 600 $OUT/bench_bf16.json; echo ;;
+    prof|prof16)
+      DT=f32; [ $ST = prof16 ] && DT=bf16
+      cd /tmp; mkdir -p $OUT/prof_$DT
+      timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$DT -o step -- python $REPO/bench.py --dtype $DT --steps 10 --warmup 2 --no-decode --no-cpu-baseline --no-extras > $OUT/prof_$DT/bench.log 2>&1
+      python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_$DT -name "*results.db" | head -1) 15 > $OUT/kernel_stats_$DT.md 2>&1
+      find $OUT/prof_$DT -name "*.db" -delete
+      cd $REPO; head -n 45 $OUT/kernel_stats_$DT.md ;;
+    profdec)
+      cd /tmp; mkdir -p $OUT/prof_dec
+      timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_dec -o dec -- python $REPO/scripts/decode_only.py > $OUT/prof_dec/run.log 2>&1
+      python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_dec -name "*results.db" | head -1) 1 > $OUT/kernel_stats_decode.md 2>&1
+      find $OUT/prof_dec -name "*.db" -delete
+      cd $REPO; head -n 40 $OUT/kernel_stats_decode.md ;;
+    shapes)
+      timeout 300 python scripts/gemm_step_shapes.py f32 32 > $OUT/gemm_shapes_f32_b32.txt 2>&1
+      timeout 300 python scripts/gemm_step_shapes.py f32 64 > $OUT/gemm_shapes_f32_b64.txt 2>&1
+      timeout 300 python scripts/gemm_step_shapes.py bf16 64 > $OUT/gemm_shapes_bf16_b64.txt 2>&1 ;;
+    *) echo "running: $ST"; eval "$ST" ;;
+  esac
+done

@@ -76,6 +76,8 @@ SIGNATURES = {
     "fira_adam_step": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "fira_adam_step_mb": (_I, [_P, _L, _P, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P, _P]),
     "fira_inv_count": (_I, [_P, _P, _P]),
+    "fira_adam_step_count": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
+    "fira_pack_stats": (_I, [_P, _P, _P, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_prof_enable": (None, [_I]),
     "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
@@ -122,7 +124,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fira_abi_version() != 3:
+    if lib.fira_abi_version() != 4:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib
 

@@ -354,8 +354,10 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
 __global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float lr,
                                                    float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
-                                                   const float* __restrict__ scale_ptr) {
-    const float scale = scale_ptr ? *scale_ptr : 1.0f;
+                                                   const float* __restrict__ scale_ptr, int scale_is_count) {
+    // scale_is_count: *scale_ptr is a (global, all-reduced) token count; the normaliser 1 / max(count, 1) is formed here
+    const float sv = scale_ptr ? *scale_ptr : 1.0f;
+    const float scale = scale_is_count ? 1.0f / fmaxf(sv, 1.0f) : sv;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
@@ -392,6 +394,11 @@ __global__ __launch_bounds__(256) void adam_mb_kernel(int64_t n, float* __restri
     }
 }
 
+// out2 = {loss_sum, (float) n_tok}: the two scalars a data-parallel step all-reduces, as one fp32 pair (exact below 2^24 tokens)
+__global__ void pack_stats_kernel(const float* __restrict__ loss_sum, const int32_t* __restrict__ n_tok, float* __restrict__ out2) {
+    out2[0] = *loss_sum;
+    out2[1] = (float)*n_tok;
+}
 // inv_scale[0] = 1 / max(n_tok, 1): the token-count normaliser of run_model.py:105 without a host sync
 __global__ void inv_count_kernel(const int32_t* __restrict__ n_tok, float* __restrict__ out) {
     const int n = *n_tok;
@@ -576,7 +583,7 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
     return 0;
 }
 int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
-              float beta2, float eps, int step, const float* scale_ptr) {
+              float beta2, float eps, int step, const float* scale_ptr, int scale_is_count) {
     ProfScope prof(s, PROF_ADAM, 0.0);
     if (n <= 0) return 0;
     FIRA_REQUIRE(step >= 1, "adam_step: step must start at 1");
@@ -584,7 +591,7 @@ int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, floa
     const double bc2 = 1.0 - pow((double)beta2, step);
     const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 256 * 16);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, s, n, p, g, m, v, lr, beta1, beta2, eps, (float)bc1,
-                       (float)sqrt(bc2), scale_ptr);
+                       (float)sqrt(bc2), scale_ptr, scale_is_count);
     FIRA_CHECK_LAUNCH("adam_step");
     return 0;
 }
@@ -633,6 +640,17 @@ int fira_inv_count(void* stream, const int32_t* n_tok, float* out) {
 }
 int fira_adam_step(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
                    float beta2, float eps, int step, const float* inv_scale_ntok) {
-    return fira::adam_step((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, step, inv_scale_ntok);
+    return fira::adam_step((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, step, inv_scale_ntok, 0);
+}
+int fira_adam_step_count(void* stream, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
+                         float beta2, float eps, int step, const float* count) {
+    FIRA_REQUIRE(p && g && m && v && count && step >= 1, "fira_adam_step_count: bad argument");
+    return fira::adam_step((hipStream_t)stream, n, p, g, m, v, lr, beta1, beta2, eps, step, count, 1);
+}
+int fira_pack_stats(void* stream, const float* loss_sum, const int32_t* n_tok, float* out2) {
+    FIRA_REQUIRE(loss_sum && n_tok && out2, "fira_pack_stats: null pointer argument");
+    hipLaunchKernelGGL(fira::pack_stats_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss_sum, n_tok, out2);
+    FIRA_CHECK_LAUNCH("pack_stats");
+    return 0;
 }
 }

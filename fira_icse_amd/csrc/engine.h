@@ -82,7 +82,8 @@ int deferred_reduce(hipStream_t s, RedTable& tab);       // dst[c] += sum_p src[
 // y_rows (optional): output row r is stored at row y_rows[r]
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row = nullptr,
-                      const float* r1_col = nullptr);   // x += r1_row[r] * r1_col[:] before the dropout
+                      const float* r1_col = nullptr,    // x += r1_row[r] * r1_col[:] before the dropout
+                      const int32_t* slot2 = nullptr, float* y2 = nullptr);   // rows with slot2[r] >= 0 are also stored at y2[slot2[r]]
 bool gemm_bf16_k256_try(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
                         int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask, int* rc);
 bool linear_ln_bf16_try(hipStream_t s, int M, int K, const float* X, int ldx, const uint16_t* Wb, int ldb, const float* bias,
@@ -106,10 +107,13 @@ int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, con
 // 3 out[dst[r]]=in[src[r]]
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
          int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
-         int32_t* compact_row, int32_t* iota, float* loss_sum = nullptr, int32_t* n_tok = nullptr);   // the two scalars are zeroed
+         int32_t* compact_row, int32_t* iota, float* loss_sum = nullptr, int32_t* n_tok = nullptr,    // the two scalars are zeroed
+         // optional: slot of every compact node in the ascending code-row / memory-row lists (-1: not listed)
+         int Nc = 0, const int32_t* code_rows = nullptr, int Cc = 0, int32_t* code_slot = nullptr,
+         const int32_t* mem_rows = nullptr, int Mc = 0, int32_t* mem_slot = nullptr);
 int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
                   const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
-                  float* X);
+                  float* X, const int32_t* slot2 = nullptr, float* X2 = nullptr);   // rows with a slot also go to X2[slot]
 int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst);
 int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, const float* in, int ld_in,
                  const int32_t* src, const int32_t* dst);
@@ -154,7 +158,7 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
               float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,
               int32_t* n_tok, int32_t* argmax_out, int want_grad);
 int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
-              float beta2, float eps, int step, const float* scale_ptr);
+              float beta2, float eps, int step, const float* scale_ptr, int scale_is_count = 0);
 
 // ---- parameter layout ---------------------------------------------------------------------------------
 struct ParamInfo {

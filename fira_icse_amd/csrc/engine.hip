@@ -50,7 +50,7 @@ struct DecGrad {
 struct Plan {
     int B, NB, CB, MB, TB, N, L, S, A, T, V, ldl, nl, F;
     float *pos_code, *pos_tar;
-    int32_t *mem_valid, *tar_valid, *compact_row, *iota;
+    int32_t *mem_valid, *tar_valid, *compact_row, *iota, *code_slot, *mem_slot;
     std::vector<float*> X;          // nl + 1 node buffers
     std::vector<EncSave> enc;
     std::vector<DecSave> dec;
@@ -82,6 +82,8 @@ struct Plan {
         tar_valid = a.get<int32_t>((size_t)TB);
         compact_row = a.get<int32_t>((size_t)TB);
         iota = a.get<int32_t>((size_t)TB);
+        code_slot = a.get<int32_t>((size_t)NB);
+        mem_slot = a.get<int32_t>((size_t)NB);
         inv_ntok = a.f(64);
         {
             const Layout* lay = get_layout(&d);
@@ -288,22 +290,29 @@ static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int
 static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* b,
                             const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
                             float p_drop, uint64_t seed, uint32_t st, const int32_t* y_rows = nullptr,
-                            const float* r1_row = nullptr, const float* r1_col = nullptr) {
+                            const float* r1_row = nullptr, const float* r1_col = nullptr,
+                            // second, compact copy of the listed output rows: y2[k] = y[rows2[k]] for k < n2, slot2 = the
+                            // inverse list (row -> k or -1); written by the row kernel itself, or by a gather after a fused launch
+                            const int32_t* slot2 = nullptr, float* y2 = nullptr, int n2 = 0, const int32_t* rows2 = nullptr) {
+    bool fused = false;
+    int rc = 0;
     if (g_dtype == 0) {
-        int rc;
-        if (linear_ln_fwd_try(s, M, K, X, ldx, W, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col,
-                              &rc))
-            return rc;
+        fused = linear_ln_fwd_try(s, M, K, X, ldx, W, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col,
+                                  &rc);
     } else {                                     // bf16: the panel kernel with a LayerNorm epilogue (gemm_bf16_panel.hip)
         const uint16_t* wb;
-        int ldw, rc;
-        if (shadow_of(W, false, &wb, &ldw) && ldw == K &&
-            linear_ln_bf16_try(s, M, K, X, ldx, wb, ldw, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row,
-                               r1_col, &rc))
-            return rc;
+        int ldw;
+        fused = shadow_of(W, false, &wb, &ldw) && ldw == K &&
+                linear_ln_bf16_try(s, M, K, X, ldx, wb, ldw, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row,
+                                   r1_col, &rc);
+    }
+    if (fused) {
+        TRY(rc);
+        if (y2 && n2 > 0) TRY(rows_move(s, 0, n2, FIRA_D, y2, y, rows2, nullptr));
+        return 0;
     }
     TRY(linear(s, M, FIRA_D, K, X, ldx, W, b, sum, FIRA_D));
-    return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col);
+    return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col, slot2, y2);
 }
 // dX (+)= dY W          (W stored [N,K]; reduce over N)
 static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* W, float* dX,
@@ -474,6 +483,7 @@ struct Ctx {
     int32_t* n_tok = nullptr;
     hipEvent_t ev_kv[16] = {};
     hipEvent_t ev_src = nullptr;
+    hipEvent_t ev_zero = nullptr;   // the backward pass's zero-initialised buffers were cleared on the auxiliary stream
 };
 
 // ------------------------------------------------------------------------------------------ encoder forward
@@ -488,9 +498,11 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     const int D = FIRA_D, Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem, KV = p.nl * 2 * D;
     // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
     TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
-             p.pos_tar, c.R, c.rows, bt.tar ? p.compact_row : nullptr, c.rows ? nullptr : p.iota, c.loss_sum, c.n_tok));
+             p.pos_tar, c.R, c.rows, bt.tar ? p.compact_row : nullptr, c.rows ? nullptr : p.iota, c.loss_sum, c.n_tok,
+             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot));
+    // layer 0's code rows are also stored compactly (Xc of the first Combination): no gather launch on the chain
     TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
-                      p.pos_code, p.X[0]));
+                      p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
     TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
     // GCN (gnn_transformer.py:74-86) has no non-linearity between fc1, the aggregation and fc2, so
@@ -524,8 +536,8 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
         float* X = p.X[l];
-        // Combination (gnn_transformer.py:192-205): code rows only; the result overwrites them in place
-        TRY(rows_move(s, 0, Cc, D, e.Xc, X, bt.code_rows, nullptr));
+        // Combination (gnn_transformer.py:192-205): code rows only; the result overwrites them in place.  e.Xc (the code
+        // rows before the update: residual, and the q|k weight gradient's operand) was stored by the kernel that produced X
         TRY(linear(s, Cc, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
         TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
         TRY(linear_ln(s, Cc, D, e.c, D, c.P + w.wo, c.P + w.bo, e.Xc, c.P + w.ln1g, c.P + w.ln1b, e.s1, X, e.st1, c.p_drop,
@@ -533,12 +545,15 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // GCN in folded form: U = A_hat X (kept for the weight gradient) -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
         if (l == 0 && ev_fold) TRY(main_wait(s, ev_fold));
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
+        // second store of the output: the next layer's code rows (its Xc), or after the last layer the memory rows
+        // (memory = [code ; sub-token] rows, Model.py:48: compact copy for the GEMMs; the dense [B,370,*] rows the attention /
+        // copy kernels read are scattered by the projections below, rows of masked slots are never read there)
+        const bool last = l + 1 == p.nl;
         TRY(linear_ln(s, Nc, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, X, c.P + w.ln2g, c.P + w.ln2b, e.s2,
-                      p.X[l + 1], e.st2, c.p_gcn, c.seed, site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D));
+                      p.X[l + 1], e.st2, c.p_gcn, c.seed, site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D,
+                      last ? p.mem_slot : p.code_slot, last ? p.mem_c : p.enc[l + 1].Xc, last ? Mc : Cc,
+                      last ? bt.mem_rows : bt.code_rows));
     }
-    // memory = [code ; sub-token] rows (Model.py:48): compact copy for the GEMMs, dense [B,370,*] rows for the
-    // attention / copy kernels (rows of masked slots are never read there)
-    TRY(rows_move(s, 0, Mc, D, p.mem_c, p.X[p.nl], bt.mem_rows, nullptr));
     c.deferred = false;
     if (defer_memory_proj && side_on() && p.nl <= 16) {
         // The decoder consumes layer l's K|V only at its l-th cross attention and LinearSource(memory) only in the
@@ -548,20 +563,18 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         hipStream_t ss = side().aux;
         for (int l = 0; l < p.nl; ++l) {
             const size_t o = (size_t)l * 2 * D;
-            TRY(linear(ss, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, c.P + L.bkv_all + o, p.kv_c + o, KV));
-            TRY(rows_move_ld(ss, 1, Mc, 2 * D, p.kv_all + o, KV, p.kv_c + o, KV, nullptr, bt.mem_dst));
+            // the output rows go straight to their dense [B,370] slots (row map of the GEMM epilogue): no scatter launch
+            TRY(gemm_any(ss, 0, 1, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, D, p.kv_all + o, KV, c.P + L.bkv_all + o, 0,
+                         0, nullptr, bt.mem_dst));
             TRY(side_mark(&c.ev_kv[l]));
         }
-        TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
-        TRY(rows_move(ss, 1, Mc, D, p.src, p.src_c, nullptr, bt.mem_dst));
+        TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
         TRY(side_mark(&c.ev_src));
         c.deferred = true;
         return 0;
     }
-    TRY(linear(s, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, c.P + L.bkv_all, p.kv_c, KV));
-    TRY(rows_move(s, 1, Mc, KV, p.kv_all, p.kv_c, nullptr, bt.mem_dst));
-    TRY(gemm_any(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src_c, D, nullptr, 0, 0, nullptr));
-    TRY(rows_move(s, 1, Mc, D, p.src, p.src_c, nullptr, bt.mem_dst));
+    TRY(gemm_any(s, 0, 1, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, D, p.kv_all, KV, c.P + L.bkv_all, 0, 0, nullptr, bt.mem_dst));
+    TRY(gemm_any(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
     return 0;
 }
 
@@ -587,8 +600,12 @@ static int decoder_forward(Ctx& c) {
         TRY(linear_ln(s, p.TB, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c,
                       e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS)));
         TRY(linear(s, p.TB, p.F, D, e.x_c, D, c.P + w.w1, c.P + w.b1, e.h, p.F, FIRA_GEMM_RELU));
+        // the last layer's output rows that need the vocabulary head (Ctx::rows) are also stored compactly (dec_c)
+        const bool head_copy = l + 1 == p.nl && c.rows != nullptr && c.R > 0;
         TRY(linear_ln(s, p.TB, p.F, e.h, p.F, c.P + w.w2, c.P + w.b2, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.s_f, e.x_f,
-                      e.st_f, c.p_drop, c.seed, site(l, SITE_FFN)));
+                      e.st_f, c.p_drop, c.seed, site(l, SITE_FFN), nullptr, nullptr, nullptr,
+                      head_copy ? p.compact_row : nullptr, head_copy ? p.dec_c : nullptr, head_copy ? c.R : 0,
+                      head_copy ? c.rows : nullptr));
         x = e.x_f;
     }
     return 0;
@@ -603,8 +620,13 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     hipStream_t s = c.s;
     const int D = FIRA_D, Sm = p.L + p.S;
     const float* dec = p.dec[p.nl - 1].x_f;
-    TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));             // compact_row (its inverse) comes from prep()
-    TRY(linear(s, R, p.V, D, p.dec_c, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
+    // rows == Ctx::rows (a proper sub-list): decoder_forward stored them compactly already; every row: use them in place
+    const float* dec_rows = (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec;
+    if (dec_rows == dec && R != p.TB) {                         // a sub-list the decoder pass did not know about
+        TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));
+        dec_rows = p.dec_c;
+    }
+    TRY(linear(s, R, p.V, D, dec_rows, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
     TRY(gemm_any(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
     if (c.deferred) TRY(main_wait(s, c.ev_src));                   // LinearSource(memory) (side stream)
     // teacher-forced ids (dev) need every row's copy distribution; the training loss only the copy-labelled rows
@@ -636,15 +658,18 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     const bool so = side_on();
     hipStream_t ss = so ? side().aux : s;
     hipEvent_t ev_dfc = nullptr;
-    // dvtab_all, dW21|dc21, dtgt, ddec_c: accumulated into below, one fill for all of them
-    TRY(zero(s, p.zero_beg, (size_t)((char*)p.zero_end - (char*)p.zero_beg)));
+    // dvtab_all, dW21|dc21, dtgt, ddec_c: accumulated into below, one fill for all of them -- issued on the auxiliary stream
+    // at the start of the step (under the encoder's forward pass) when there is one, otherwise here
+    if (c.ev_zero) TRY(main_wait(s, c.ev_zero));
+    else TRY(zero(s, p.zero_beg, (size_t)((char*)p.zero_end - (char*)p.zero_beg)));
     if (R > 0) {
         if (so) TRY(aux_fork(s));
         // ddec_rows = dlogits W_out, split over the vocabulary axis
         TRY(gemm_any(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
                         nullptr));
         if (so) TRY(side_mark(&ev_dfc));
-        TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, p.dec_c, D, G + L.wout, G + L.bout));
+        TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec, D, G + L.wout,
+                         G + L.bout));
     }
     TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad_grouped(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
@@ -755,7 +780,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // ---- encoder layers, last to first (compact node rows) -------------------------------------------------
     float* dXn = p.dXa;
     float* other = p.dXb;
-    TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));            // AST/edit rows of the last layer feed nothing
+    if (!c.ev_zero) TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));   // AST/edit rows of the last layer feed nothing
     if (ev_dmem) TRY(main_wait(s, ev_dmem));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
     for (int l = p.nl - 1; l >= 0; --l) {
@@ -820,8 +845,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
     TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
                     FIRA_GEMM_ACCUM, 1, G + L.b2_all));
-    TRY(linear_dgrad(s, 4, p.nl * D, D, p.dvtab_all, p.nl * D, c.P + L.w2_all, G + L.mark_emb, D, true));
-    TRY(zero(s, G + L.mark_emb, (size_t)D * sizeof(float)));       // padding_idx row 0 never gets a gradient
+    // rows 1..3 only: padding_idx row 0 never gets a gradient (its slot of the zeroed gradient buffer stays untouched)
+    TRY(linear_dgrad(s, 3, p.nl * D, D, p.dvtab_all + (size_t)p.nl * D, p.nl * D, c.P + L.w2_all, G + L.mark_emb + D, D, true));
     if (side().stream && side().enabled) TRY(side_join(s));        // every weight gradient is complete past this point
     return 0;
 }
@@ -915,6 +940,14 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     }
     c.loss_sum = loss_sum;
     c.n_tok = n_tok;
+    if (side_on()) {
+        // the buffers the backward pass accumulates into are cleared now, on the auxiliary stream, beside the encoder's
+        // forward pass (they are backward-only; the previous step is complete at this point of the caller's stream)
+        TRY(aux_fork(c.s));
+        TRY(zero(side().aux, p.zero_beg, (size_t)((char*)p.zero_end - (char*)p.zero_beg)));
+        TRY(zero(side().aux, p.dXa, (size_t)batch->n_nodes * FIRA_D * sizeof(float)));
+        TRY(side_mark(&c.ev_zero));
+    }
     TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));

@@ -247,10 +247,13 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
                                                                 float p, float inv_keep, uint64_t seed,
                                                                 uint32_t site, const int32_t* __restrict__ y_rows,
                                                                 const float* __restrict__ r1_row,
-                                                                const float* __restrict__ r1_col) {
+                                                                const float* __restrict__ r1_col,
+                                                                const int32_t* __restrict__ slot2,
+                                                                float* __restrict__ y2) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
+    const int s2 = slot2 ? slot2[r] : -1;              // rows with a slot are stored a second time, compactly, at y2[slot]
     const size_t o = (size_t)r * FIRA_D + lane * 4;
     const size_t oy = y_rows ? (size_t)y_rows[r] * FIRA_D + lane * 4 : o;      // optional scatter of the output rows
     float4 a = *reinterpret_cast<const float4*>(x + o);
@@ -277,8 +280,9 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
     const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
     const float4 bt = *reinterpret_cast<const float4*>(beta + lane * 4);
     *reinterpret_cast<float4*>(x + o) = a;
-    *reinterpret_cast<float4*>(y + oy) =
-        make_float4(dx * rstd * g.x + bt.x, dy * rstd * g.y + bt.y, dz * rstd * g.z + bt.z, dw * rstd * g.w + bt.w);
+    const float4 out = make_float4(dx * rstd * g.x + bt.x, dy * rstd * g.y + bt.y, dz * rstd * g.z + bt.z, dw * rstd * g.w + bt.w);
+    *reinterpret_cast<float4*>(y + oy) = out;
+    if (s2 >= 0) *reinterpret_cast<float4*>(y2 + (size_t)s2 * FIRA_D + lane * 4) = out;
     if (stats && lane == 0) {
         stats[2 * r] = mean;
         stats[2 * r + 1] = rstd;
@@ -456,9 +460,22 @@ __global__ void prep_kernel(int B, int L, int S, int T, const int32_t* __restric
                             const int32_t* __restrict__ tar, int32_t* __restrict__ mem_valid,
                             int32_t* __restrict__ tar_valid, float* __restrict__ pos_code, float* __restrict__ pos_tar,
                             int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row,
-                            int32_t* __restrict__ iota, float* __restrict__ loss_sum, int32_t* __restrict__ n_tok) {
+                            int32_t* __restrict__ iota, float* __restrict__ loss_sum, int32_t* __restrict__ n_tok,
+                            int Nc, const int32_t* __restrict__ code_rows, int Cc, int32_t* __restrict__ code_slot,
+                            const int32_t* __restrict__ mem_rows, int Mc, int32_t* __restrict__ mem_slot) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int W = L + S;
+    if (code_slot && i < Nc) {
+        // inverse of the (ascending) code-row and memory-row lists: slot of compact node i in each list, or -1.  Kernels that
+        // produce node rows use them to store the listed rows a second time, compactly (the gather launches they replace
+        // sat on the dependent chain)
+        int lo = 0, hi = Cc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (code_rows[mid] < i) lo = mid + 1; else hi = mid; }
+        code_slot[i] = (lo < Cc && code_rows[lo] == i) ? lo : -1;
+        lo = 0; hi = Mc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mem_rows[mid] < i) lo = mid + 1; else hi = mid; }
+        mem_slot[i] = (lo < Mc && mem_rows[lo] == i) ? lo : -1;
+    }
     if (i == 0) {                                // the step's loss accumulators start at zero (no separate fills)
         if (loss_sum) *loss_sum = 0.f;
         if (n_tok) *n_tok = 0;
@@ -501,11 +518,13 @@ __global__ __launch_bounds__(256) void node_features_kernel(int Nc, const int32_
                                                             const float* __restrict__ emb,
                                                             const float* __restrict__ ast_emb,
                                                             const float* __restrict__ pos_code,
-                                                            float* __restrict__ X) {
+                                                            float* __restrict__ X, const int32_t* __restrict__ slot2,
+                                                            float* __restrict__ X2) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= Nc) return;
     const int g = node_rows[r], b = g / N, loc = g - b * N, A = N - L - S;
+    const int s2 = slot2 ? slot2[r] : -1;              // second, compact copy of the listed rows (the first layer's code rows)
     float4 v;
     if (loc < L) {
         v = *reinterpret_cast<const float4*>(emb + (size_t)sou[b * L + loc] * FIRA_D + lane * 4);
@@ -517,6 +536,7 @@ __global__ __launch_bounds__(256) void node_features_kernel(int Nc, const int32_
         v = *reinterpret_cast<const float4*>(ast_emb + (size_t)ast[b * A + loc - L - S] * FIRA_D + lane * 4);
     }
     *reinterpret_cast<float4*>(X + (size_t)r * FIRA_D + lane * 4) = v;
+    if (s2 >= 0) *reinterpret_cast<float4*>(X2 + (size_t)s2 * FIRA_D + lane * 4) = v;
 }
 
 // ---------------------------------------------------------------- host launchers
@@ -555,20 +575,22 @@ int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid) {
 }
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
          int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
-         int32_t* compact_row, int32_t* iota, float* loss_sum, int32_t* n_tok) {
-    const int n = std::max(std::max(B * (L + S), B * T), (L + T) * FIRA_D);
+         int32_t* compact_row, int32_t* iota, float* loss_sum, int32_t* n_tok, int Nc, const int32_t* code_rows, int Cc,
+         int32_t* code_slot, const int32_t* mem_rows, int Mc, int32_t* mem_slot) {
+    const int n = std::max(std::max(std::max(B * (L + S), B * T), (L + T) * FIRA_D), code_slot ? Nc : 0);
     hipLaunchKernelGGL(prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid, tar_valid,
-                       pos_code, pos_tar, R, rows, compact_row, iota, loss_sum, n_tok);
+                       pos_code, pos_tar, R, rows, compact_row, iota, loss_sum, n_tok, Nc, code_rows, Cc, code_slot, mem_rows,
+                       Mc, mem_slot);
     FIRA_CHECK_LAUNCH("prep");
     return 0;
 }
 int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
                   const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
-                  float* X) {
+                  float* X, const int32_t* slot2, float* X2) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (Nc <= 0) return 0;
     hipLaunchKernelGGL(node_features_kernel, dim3(cdiv(Nc, 4)), dim3(256), 0, s, Nc, node_rows, N, L, S, sou, sub, ast, emb,
-                       ast_emb, pos_code, X);
+                       ast_emb, pos_code, X, slot2, X2);
     FIRA_CHECK_LAUNCH("node_features");
     return 0;
 }
@@ -670,12 +692,12 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
 }
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows,
-                      const float* r1_row, const float* r1_col) {
+                      const float* r1_row, const float* r1_col, const int32_t* slot2, float* y2) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, x, res, gamma, beta, y, stats,
-                       dropout, inv_keep, seed, site, y_rows, r1_row, r1_col);
+                       dropout, inv_keep, seed, site, y_rows, r1_row, r1_col, y2 ? slot2 : nullptr, y2);
     FIRA_CHECK_LAUNCH("add_layernorm_fwd");
     return 0;
 }

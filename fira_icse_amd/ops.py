@@ -235,6 +235,18 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, inv_scale=
                                     lr, beta1, beta2, eps, step, ptr(inv_scale)), "fira_adam_step")
 
 
+def adam_step_count(p, g, m, v, lr, step, count, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Adam on g / max(count, 1): ``count`` is a device float (the all-reduced token count of a data-parallel step)."""
+    check(_lib.lib().fira_adam_step_count(cur_stream(), p.numel(), ptr(_f32(p)), ptr(_f32(g)), ptr(_f32(m)), ptr(_f32(v)),
+                                          lr, beta1, beta2, eps, step, ptr(_f32(count))), "fira_adam_step_count")
+
+
+def pack_stats(loss_sum, n_tok, out2):
+    """out2 = [loss_sum, float(n_tok)] on the device: what a rank contributes to the step's 2-scalar all-reduce."""
+    check(_lib.lib().fira_pack_stats(cur_stream(), ptr(_f32(loss_sum)), ptr(_i32(n_tok)), ptr(_f32(out2))), "fira_pack_stats")
+    return out2
+
+
 def adam_step_mb(p, g0, g1, m, v, lr, step, n_tok0, n_tok1=None, beta1=0.9, beta2=0.999, eps=1e-8):
     """Adam on g0 (+ g1) / max(n_tok0 (+ n_tok1), 1): one launch, normaliser formed on the device."""
     check(_lib.lib().fira_adam_step_mb(cur_stream(), p.numel(), ptr(_f32(p)), ptr(_f32(g0)), ptr(g1), ptr(_f32(m)),

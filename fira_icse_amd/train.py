@@ -73,18 +73,19 @@ class Trainer:
         if self.reducer is not None and self.reducer.world > 1:
             red, split, live = self.reducer, m.layout.split, m.layout.live
             red.start_early_bucket(m.gbuf, self.mid_event)
-            self.stats[0:1].copy_(loss_sum)
-            self.stats[1:2].copy_(n_tok)                       # int32 -> fp32 (exact below 2^24 tokens)
+            # one launch packs {loss_sum, float(n_tok)} (exact below 2^24 tokens); the update kernels form 1 / max(count, 1)
+            # from the all-reduced pair themselves: no torch arithmetic between the collective and Adam
+            ops.pack_stats(loss_sum, n_tok, self.stats)
             red.reduce_stats_and_start_late_bucket(m.gbuf, self.stats)
-            torch.reciprocal(self.stats[1:2].clamp_min(1.0), out=self.inv)
             self.t += 1
+            count = self.stats[1:2]
             # Adam on the head+decoder slice runs while the encoder slice is still being reduced
             red.wait_early()
-            ops.adam_step(m.flat.data[:split], m.gbuf[:split], self.m[:split], self.v[:split], self.lr, self.t, b1, b2,
-                          self.eps, inv_scale=self.inv)
+            ops.adam_step_count(m.flat.data[:split], m.gbuf[:split], self.m[:split], self.v[:split], self.lr, self.t, count,
+                                b1, b2, self.eps)
             red.wait_late()
-            ops.adam_step(m.flat.data[split:live], m.gbuf[split:live], self.m[split:live], self.v[split:live], self.lr,
-                          self.t, b1, b2, self.eps, inv_scale=self.inv)
+            ops.adam_step_count(m.flat.data[split:live], m.gbuf[split:live], self.m[split:live], self.v[split:live], self.lr,
+                                self.t, count, b1, b2, self.eps)
             return
         self.t += 1
         # [live, total) holds the tensors no kernel touches (encoder.lstm, combination_list1, gate_fc): their gradient is
@@ -106,10 +107,8 @@ class Trainer:
         zs.wait_event(self.mid_event)
         with torch.cuda.stream(zs):
             z.reduce_scatter(0, m.gbuf, self.g_sh[0])
-        self.stats[0:1].copy_(loss_sum)
-        self.stats[1:2].copy_(n_tok)                           # int32 -> fp32 (exact below 2^24 tokens)
+        ops.pack_stats(loss_sum, n_tok, self.stats)           # {loss_sum, float(n_tok)}: exact below 2^24 tokens
         torch.distributed.all_reduce(self.stats, op=torch.distributed.ReduceOp.SUM, group=z.group)
-        torch.reciprocal(self.stats[1:2].clamp_min(1.0), out=self.inv)
         self.end_event.record(main)                            # backward pass done, global token count known
         self.t += 1
         zs.wait_event(self.end_event)
@@ -120,8 +119,8 @@ class Trainer:
                 lo, hi = z.owned(b)
                 if hi > lo:
                     n = hi - lo
-                    ops.adam_step(m.flat.data[lo:hi], self.g_sh[b][:n], self.m_sh[b][:n], self.v_sh[b][:n], self.lr, self.t,
-                                  b1, b2, self.eps, inv_scale=self.inv)
+                    ops.adam_step_count(m.flat.data[lo:hi], self.g_sh[b][:n], self.m_sh[b][:n], self.v_sh[b][:n], self.lr,
+                                        self.t, self.stats[1:2], b1, b2, self.eps)
                 z.all_gather(b, m.flat.data)
         main.wait_stream(zs)                                   # the next forward pass reads every parameter
 

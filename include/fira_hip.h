@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 3
+#define FIRA_ABI_VERSION 4
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -58,10 +58,10 @@ typedef struct fira_batch {
     const int32_t* col;      /* [nnz] COMPACT node ids (position in node_rows)                               */
     const float*   val;      /* [nnz] D^-1/2 (A+I) D^-1/2 entries (fp32 of Dataset.py:291)                   */
     int32_t n_code;          /* Cc: computed code-token nodes (local < sou_len)                              */
-    const int32_t* code_rows;/* [Cc] their compact ids                                                       */
+    const int32_t* code_rows;/* [Cc] their compact ids, ASCENDING (v4: kernels invert the list by binary search)    */
     const int32_t* code_mark;/* [Cc] their mark value (0 pad,1 deleted,2 context,3 added)                    */
     int32_t n_mem;           /* Mc: computed memory nodes (local < sou_len + sub_len)                        */
-    const int32_t* mem_rows; /* [Mc] their compact ids                                                       */
+    const int32_t* mem_rows; /* [Mc] their compact ids, ASCENDING                                            */
     const int32_t* mem_dst;  /* [Mc] their dense memory row b*(sou_len+sub_len) + local                      */
     const int32_t* head_rows;/* [n_head_rows] optional: flat (b*tar_len+t) indices of the target rows whose shifted
                                 label is a vocabulary id (0 < label < vocab), ascending, no duplicates; only these
@@ -260,6 +260,12 @@ int fira_adam_step(void* stream, int64_t n, float* p, const float* g, float* m, 
 int fira_adam_step_mb(void* stream, int64_t n, float* p, const float* g0, const float* g1, float* m, float* v,
                       float lr, float beta1, float beta2, float eps, int step, const int32_t* n_tok0,
                       const int32_t* n_tok1);
+/* Data-parallel form (run_model.py:105 over the GLOBAL batch): `count` is a device float holding the all-reduced token count;
+ * the gradient is scaled by 1 / max(count, 1) inside the kernel -- no reciprocal / clamp launches between the collective and
+ * the update.  fira_pack_stats writes the pair a rank contributes to that collective: out2 = {loss_sum, (float) n_tok}.  */
+int fira_adam_step_count(void* stream, int64_t n, float* p, const float* g, float* m, float* v,
+                         float lr, float beta1, float beta2, float eps, int step, const float* count);
+int fira_pack_stats(void* stream, const float* loss_sum, const int32_t* n_tok, float* out2);
 /* out[0] = 1 / max(n_tok[0], 1) on the device */
 int fira_inv_count(void* stream, const int32_t* n_tok, float* out);
 

@@ -28,7 +28,7 @@ for ST in "$@"; do
       DT=f32; [ $ST = prof16 ] && DT=bf16
       cd /tmp; mkdir -p $OUT/prof_$DT
       timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$DT -o step -- python $REPO/bench.py --dtype $DT --steps 10 --warmup 2 --no-decode --no-cpu-baseline --no-extras > $OUT/prof_$DT/bench.log 2>&1
-      python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_$DT -name "*results.db" | head -1) 15 > $OUT/kernel_stats_$DT.md 2>&1
+      python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_$DT -name "*results.db" | head -1) 15 $OUT/timeline_$DT.md > $OUT/kernel_stats_$DT.md 2>&1
       find $OUT/prof_$DT -name "*.db" -delete
       cd $REPO; head -n 45 $OUT/kernel_stats_$DT.md ;;
     profdec)

@@ -57,6 +57,27 @@ def main():
         print("|---|---|---|---|")
         for k, v in sorted(aggq.items(), key=lambda kv: -kv[1][1])[:24]:
             print("| `%s` | %.1f | %.1f | %.1f |" % (k[:110], v[0] / steps, v[1] / steps, v[1] / v[0]))
+    if qcol and len(sys.argv) > 3:
+        # timeline of ONE step (the last adam_mb_kernel-delimited one): every dispatch on every stream, ordered by start
+        allr = cur.execute("select s.kernel_name, d.start, d.end, d.%s, d.grid_size, d.workgroup_size from %s d join %s s on d.kernel_id = s.id "
+                           "order by d.start" % (qcol, disp, sym)).fetchall() if "grid_size" in cols else \
+            [r + (0, 0) for r in cur.execute("select s.kernel_name, d.start, d.end, d.%s from %s d join %s s on d.kernel_id = s.id "
+                                             "order by d.start" % (qcol, disp, sym)).fetchall()]
+        adam = [i for i, r in enumerate(allr) if "adam_mb" in r[0]]
+        if len(adam) >= 3:
+            lo, hi = adam[-3] + 1, adam[-2] + 1
+            t0 = allr[lo][1]
+            with open(sys.argv[3], "w") as f:
+                f.write("| # | stream | start us | dur us | gap to prev on stream us | WGs | kernel |\n|---|---|---|---|---|---|---|\n")
+                last_end = {}
+                for i in range(lo, hi):
+                    name, st, en, q, gs, ws = allr[i]
+                    short = re.sub(r"\(.*", "", name).replace(".kd", "")
+                    short = re.sub(r"^_ZN4fira\d+", "", short)[:70]
+                    gap = (st - last_end[q]) / 1e3 if q in last_end else 0.0
+                    last_end[q] = max(last_end.get(q, 0), en)
+                    f.write("| %d | %s | %.1f | %.1f | %.1f | %s | `%s` |\n" % (i - lo, q, (st - t0) / 1e3, (en - st) / 1e3, gap,
+                                                                             (gs // ws) if ws else "", short))
     if per_q:
         print("\n| stream / queue | dispatches | busy us/step | span ms |")
         print("|---|---|---|---|")

@@ -389,3 +389,27 @@ def test_adam_micro_batch_form_matches_torch():
     p = p0.clone()
     ops.adam_step_mb(p, ga[0], None, torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1e-4, 1, zero)
     assert bool(torch.isfinite(p).all())
+
+
+def test_adam_count_form_and_pack_stats():
+    """Data-parallel form: fira_pack_stats writes {loss_sum, float(n_tok)}; fira_adam_step_count scales by 1 / max(count, 1)
+    formed inside the kernel from the (all-reduced) float count."""
+    from fira_icse_amd import ops
+    n = 50021
+    p0, grads = randn(n, seed=1), [randn(n, seed=40 + i, scale=0.01) for i in range(3)]
+    loss = torch.tensor([12.5], device=DEV)
+    ntok = torch.tensor([11], dtype=torch.int32, device=DEV)
+    stats = ops.pack_stats(loss, ntok, torch.zeros(2, device=DEV))
+    assert stats.tolist() == [12.5, 11.0]
+    stats += stats                                               # "all-reduce" over two identical ranks: count 22
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, gr in enumerate(grads):
+        ref.grad = gr / 22
+        opt.step()
+        ops.adam_step_count(p, gr, m, v, 1e-4, i + 1, stats[1:2])
+        assert float((p - ref.data).abs().max()) < 2e-7
+    p = p0.clone()                                               # an all-empty global batch: the normaliser is 1, not inf
+    ops.adam_step_count(p, grads[0], torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1e-4, 1, torch.zeros(1, device=DEV))
+    assert bool(torch.isfinite(p).all())

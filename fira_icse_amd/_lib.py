@@ -70,6 +70,7 @@ SIGNATURES = {
     "fira_attention_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I]),
     "fira_attention_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I,
                                 _P, _I, _P, _I, _P, _I]),
+    "fira_decode_attention": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "fira_copy_score_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fira_copy_score_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fira_head_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "fira_inv_count": (_I, [_P, _P, _P]),
     "fira_adam_step_count": (_I, [_P, _L, _P, _P, _P, _P, _F, _F, _F, _F, _I, _P]),
     "fira_pack_stats": (_I, [_P, _P, _P, _P]),
+    "fira_debug_chain": (_I, [_P, _I, _I, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_prof_enable": (None, [_I]),
     "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),

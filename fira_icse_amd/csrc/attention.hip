@@ -19,6 +19,7 @@
 namespace fira {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -361,6 +362,152 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Decode-step attention (one query per hypothesis row; run_model.py:256 through the K/V-cached step of engine.hip).
+// The MFMA kernel above spends a 32-query tile on one query and fetches K/V in fragment layout (a load instruction
+// touches 32 lines and uses 32 bytes of each); at Tq = 1 the step is a pure stream over the VALID keys' K and V rows
+// (128 bytes per key, head and operand), so this kernel is organised around that stream:
+//   * one workgroup (4 waves) per (commit, head); the qpk beam rows of a commit share its memory K/V, which is read ONCE
+//     and kept in registers for all of them;
+//   * the valid keys are compacted first (ballot + popcount), masked keys are never touched (their soft-max weight is
+//     exactly 0 in the reference: exp(-1e9 - max));
+//   * 8 lanes share a key row (16 bytes each: every load instruction covers 8 whole 128-byte rows); q.k = 4 fmas per
+//     lane + 3 xor-shuffles, p.V accumulates 4 floats per lane, reduced over the 8 key-lanes of a wave and the 4 waves
+//     at the end.
+// Self-attention with merged q|k|v projections: the newest key / value of row b (index Tk-1) is read from Knew / Vnew
+// (the projection's output row) instead of the cache, and this kernel appends it to the cache for the later steps.
+template <int NSLOT>
+__global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, const float* __restrict__ Q, int ldq,
+                                                               const float* __restrict__ K, int ldk,
+                                                               const float* __restrict__ V, int ldv,
+                                                               const int32_t* __restrict__ key_valid, float* __restrict__ O,
+                                                               int ldo, int kb, int kvb, int qpk,
+                                                               const float* __restrict__ Knew,
+                                                               const float* __restrict__ Vnew, int ldn,
+                                                               float* __restrict__ Kc_out, float* __restrict__ Vc_out) {
+    __shared__ int sm_list[MAX_TK];
+    __shared__ int sm_cnt[8];
+    __shared__ float sm_f[4][36];
+    const int bk = blockIdx.x / H, h = blockIdx.x % H;          // K/V batch entry (commit), head
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane >> 3, c = lane & 7;                       // key sub-row of the wave, 16-byte column of the head
+    // ---- ordered compaction of the valid keys (thread t looks at keys t and t + 256)
+    int nv;
+    {
+        const int k0 = t, k1 = t + 256;
+        const bool v0 = k0 < Tk && key_valid[(size_t)bk * kvb + k0] != 0;
+        const bool v1 = k1 < Tk && key_valid[(size_t)bk * kvb + k1] != 0;
+        const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1);
+        if (lane == 0) { sm_cnt[wave] = __popcll(m0); sm_cnt[4 + wave] = __popcll(m1); }
+        __syncthreads();
+        int base0 = 0, base1 = 0, tot0 = 0, tot1 = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c0 = sm_cnt[w], c1 = sm_cnt[4 + w];
+            if (w < wave) { base0 += c0; base1 += c1; }
+            tot0 += c0; tot1 += c1;
+        }
+        nv = tot0 + tot1;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (v0) sm_list[base0 + __popcll(m0 & below)] = k0;
+        if (v1) sm_list[tot0 + base1 + __popcll(m1 & below)] = k1;
+        __syncthreads();
+    }
+    const size_t hoff = (size_t)h * FIRA_DH + c * 4;
+    const float* Kb = K + (size_t)bk * kb * ldk + hoff;
+    const float* Vb = V + (size_t)bk * kb * ldv + hoff;
+    // ---- this lane's key slots: list index j*32 + wave*8 + r
+    f32x4v kf[NSLOT], vf[NSLOT];
+    bool have[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int idx = j * 32 + wave * 8 + r;
+        have[j] = idx < nv;
+        const int key = have[j] ? sm_list[idx] : 0;
+        const float* pk = Kb + (size_t)key * ldk;
+        const float* pv = Vb + (size_t)key * ldv;
+        if (Knew && key == Tk - 1) {                             // the newest key: still in the projection's output row
+            pk = Knew + (size_t)bk * ldn + hoff;
+            pv = Vnew + (size_t)bk * ldn + hoff;
+        }
+        kf[j] = have[j] ? *reinterpret_cast<const f32x4v*>(pk) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        vf[j] = have[j] ? *reinterpret_cast<const f32x4v*>(pv) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    if (Knew && Kc_out && t < 16) {                              // append the new key / value of this head to the cache
+        const int cc = t & 7;
+        const size_t src = (size_t)bk * ldn + (size_t)h * FIRA_DH + cc * 4;
+        const size_t dst = ((size_t)bk * kb + (Tk - 1)) * ldk + (size_t)h * FIRA_DH + cc * 4;
+        if (t < 8) *reinterpret_cast<f32x4v*>(Kc_out + dst) = *reinterpret_cast<const f32x4v*>(Knew + src);
+        else *reinterpret_cast<f32x4v*>(Vc_out + ((size_t)bk * kb + (Tk - 1)) * ldv + (size_t)h * FIRA_DH + cc * 4) =
+                 *reinterpret_cast<const f32x4v*>(Vnew + src);
+    }
+    for (int qi = 0; qi < qpk; ++qi) {
+        const int b = bk * qpk + qi;
+        const f32x4v q4 = *reinterpret_cast<const f32x4v*>(Q + (size_t)b * ldq + hoff);
+        float sc[NSLOT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            float d = q4.x * kf[j].x;
+            d = fmaf(q4.y, kf[j].y, d); d = fmaf(q4.z, kf[j].z, d); d = fmaf(q4.w, kf[j].w, d);
+            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            sc[j] = have[j] ? d * INV_SQRT_DH : -INFINITY;
+            mx = fmaxf(mx, sc[j]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (lane == 0) sm_f[wave][33] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(sm_f[0][33], sm_f[1][33]), fmaxf(sm_f[2][33], sm_f[3][33]));
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const float p = have[j] ? __expf(sc[j] - mx) : 0.f;
+            sum += p;
+            acc += vf[j] * p;
+        }
+        // over the 8 key sub-rows of the wave (lanes with equal c), then over the 4 waves
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            sum += __shfl_xor(sum, o, 64);
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (lane < 8) {
+            *reinterpret_cast<f32x4v*>(&sm_f[wave][lane * 4]) = acc;
+            if (lane == 0) sm_f[wave][34] = sum;
+        }
+        __syncthreads();
+        if (t < 32) {
+            const float tot = (sm_f[0][34] + sm_f[1][34]) + (sm_f[2][34] + sm_f[3][34]);
+            const float o = (sm_f[0][t] + sm_f[1][t]) + (sm_f[2][t] + sm_f[3][t]);
+            O[(size_t)b * ldo + (size_t)h * FIRA_DH + t] = nv > 0 ? o / tot : 0.f;
+        }
+        __syncthreads();
+    }
+}
+
+int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                     const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
+                     const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out) {
+    ProfScope prof(s, PROF_ATTN, 0.0);
+    if (BR <= 0) return 0;
+    FIRA_REQUIRE(Tk >= 1 && Tk <= MAX_TK && qpk >= 1 && BR % qpk == 0 && kb >= Tk && kvb >= Tk, "decode_attention: bad geometry");
+    FIRA_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 &&
+                     (uintptr_t)V % 16 == 0 && (!Knew || (ldn % 4 == 0 && (uintptr_t)Knew % 16 == 0 && (uintptr_t)Vnew % 16 == 0)),
+                 "decode_attention: rows must be 16-byte aligned");
+    FIRA_REQUIRE(!Knew || qpk == 1, "decode_attention: merged new keys need one query per K/V entry");
+    const dim3 grid((BR / qpk) * H);
+    if (Tk <= 32)
+        hipLaunchKernelGGL((decode_attention_kernel<1>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O, ldo,
+                           kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
+    else
+        hipLaunchKernelGGL((decode_attention_kernel<12>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O, ldo,
+                           kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
+    FIRA_CHECK_LAUNCH("decode_attention");
+    return 0;
+}
+
 static int check_geometry(const char* who, int Tq, int Tk, int ldq, int ldk, int ldv, const void* Q, const void* K,
                           const void* V) {
     FIRA_REQUIRE(Tq >= 1 && Tq <= 32, "%s: Tq=%d must be in 1..32", who, Tq);
@@ -417,6 +564,13 @@ int fira_attention_fwd(void* stream, int B, int H, int Tq, int Tk, const float* 
                        const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo) {
     return fira::attention_fwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
                                ldo);
+}
+int fira_decode_attention(void* stream, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                          const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
+                          const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out) {
+    FIRA_REQUIRE(Q && K && V && key_valid && O, "fira_decode_attention: null pointer argument");
+    return fira::decode_attention((hipStream_t)stream, BR, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O, ldo, kb, kvb, qpk, Knew,
+                                  Vnew, ldn, Kc_out, Vc_out);
 }
 int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                        const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O,

@@ -133,6 +133,11 @@ int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, i
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
                      int kb, int kvb, int qpk);
+// one query per row (decode step): K/V streamed once per (commit, head) over the valid keys only; optional merged new key
+int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                     const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
+                     const float* Knew = nullptr, const float* Vnew = nullptr, int ldn = 0, float* Kc_out = nullptr,
+                     float* Vc_out = nullptr);
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);

@@ -872,7 +872,7 @@ struct DecodePlan {
     int BR;
     float *kc[2], *vc[2];
     int32_t* hist[2];
-    float *x, *q, *ao, *s, *xa, *qc, *xc, *h, *tgt, *score, *gate, *logits;
+    float *x, *q, *qkv, *ao, *s, *xa, *qc, *xc, *h, *tgt, *score, *gate, *logits;
     size_t build(void* ws, const fira_dims& d, int B, int n_beam) {
         size_t used = enc.build(ws, d, B, false);
         Arena a(ws ? (char*)ws + used : nullptr);
@@ -882,7 +882,7 @@ struct DecodePlan {
             kc[i] = a.f(cache); vc[i] = a.f(cache);
             hist[i] = a.get<int32_t>((size_t)BR * T);
         }
-        x = a.f(BR * D); q = a.f(BR * D); ao = a.f(BR * D); s = a.f(BR * D); xa = a.f(BR * D); qc = a.f(BR * D);
+        x = a.f(BR * D); q = a.f(BR * D); qkv = a.f(BR * 3 * D); ao = a.f(BR * D); s = a.f(BR * D); xa = a.f(BR * D); qc = a.f(BR * D);
         xc = a.f(BR * D); h = a.f((size_t)BR * d.d_ff); tgt = a.f(BR * D);
         score = a.f((size_t)BR * (d.sou_len + d.sub_len)); gate = a.f((size_t)BR * 2);
         logits = a.f((size_t)BR * enc.ldl);
@@ -1020,19 +1020,33 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
     // token embedding + position `step` (gnn_transformer.py:110-113)
     TRY(embed_gather_fwd(s, BR, 1, tokens, params + L.dec_emb, p.pos_tar + (size_t)step * D, dp.x, 1, 0));
     const size_t lay = (size_t)BR * T * D;
+    // FIRA_DECODE_ATTN=0: the round-2 path (three projections + the 32-query MFMA attention kernel): A/B switch
+    static const bool stream_attn = [] { const char* e = getenv("FIRA_DECODE_ATTN"); return !(e && e[0] == '0'); }();
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
         float* kc = dp.kc[cur] + l * lay;
         float* vc = dp.vc[cur] + l * lay;
-        TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.q, D));
-        TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)D * D, params + w.bqkv + D, kc + (size_t)step * D, T * D));
-        TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
-        TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
+        if (stream_attn) {
+            // q|k|v as ONE product; the attention kernel reads the new key / value from its output row and appends them
+            // to the cache (decode_attention, attention.hip)
+            TRY(linear(s, BR, 3 * D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.qkv, 3 * D));
+            TRY(decode_attention(s, BR, H, step + 1, dp.qkv, 3 * D, kc, D, vc, D, dp.hist[cur], dp.ao, D, T, T, 1,
+                                 dp.qkv + D, dp.qkv + 2 * D, 3 * D, kc, vc));
+        } else {
+            TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.q, D));
+            TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)D * D, params + w.bqkv + D, kc + (size_t)step * D, T * D));
+            TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
+            TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
+        }
         TRY(linear_ln(s, BR, D, dp.ao, D, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.s,
                       dp.xa, nullptr, 0.f, 0, 0));
         TRY(linear(s, BR, D, D, dp.xa, D, params + w.wq_c, params + w.bq_c, dp.qc, D));
-        TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
-                             p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
+        if (stream_attn)
+            TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid,
+                                 dp.ao, D, Sm, Sm, n_beam));
+        else
+            TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
+                                 p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
         TRY(linear_ln(s, BR, D, dp.ao, D, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.s,
                       dp.xc, nullptr, 0.f, 0, 0));
         TRY(linear(s, BR, p.F, D, dp.xc, D, params + w.w1, params + w.b1, dp.h, p.F, FIRA_GEMM_RELU));
@@ -1071,6 +1085,30 @@ int fira_decoder_forward(void* stream, const fira_dims* d, const float* params, 
     TRY(decoder_forward(c));
     e = hipMemcpyAsync(out, p.dec[p.nl - 1].x_f, (size_t)p.TB * D * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return set_err("hipMemcpyAsync: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// Measurement aid (scripts/event_cost.py): n dependent tiny kernels on `stream`; mode 1 forks the library's weight-gradient
+// stream after every kernel (event record on `stream` + wait + a tiny kernel there) as linear_wgrad does, mode 2 does the
+// event record alone, mode 3 forks every 8th kernel.  Joins at the end.  Tells what a fork costs the dependent chain.
+__global__ void debug_tiny_kernel(float* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1.0f; }
+int fira_debug_chain(void* stream, int n, int mode, float* scratch) {
+    FIRA_REQUIRE(scratch && n > 0, "fira_debug_chain: bad argument");
+    TRY(side().init());
+    hipStream_t s = (hipStream_t)stream;
+    SideStream& sd = side();
+    for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(debug_tiny_kernel, dim3(240), dim3(256), 0, s, scratch);
+        if (mode == 1 || (mode == 3 && (i & 7) == 7)) {
+            TRY(side_fork(s));
+            hipLaunchKernelGGL(debug_tiny_kernel, dim3(240), dim3(256), 0, sd.stream, scratch + 64);
+        } else if (mode == 2) {
+            hipEvent_t e = sd.ev();
+            if (hipEventRecord(e, s) != hipSuccess) return set_err("event record failed");
+        }
+    }
+    if (mode == 1 || mode == 3) TRY(side_join(s));
+    FIRA_CHECK_LAUNCH("debug_chain");
     return 0;
 }
 

@@ -797,6 +797,14 @@ int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda,
     ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)M * N) + 2.0 * (double)N * K);
     const bool can_split = (flags & FIRA_GEMM_ACCUM) && !(flags & FIRA_GEMM_RELU) && !relu_mask;
     static const int small_mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 2; }();
+    // the coalesced tile kernel stays ahead of the tiled / panel kernels for more rounds of tiles and for long reductions
+    // (FIRA_SMALL_TILES16: A/B switch of the threshold)
+    static const long max_t32 = [] { const char* e = getenv("FIRA_SMALL_TILES16"); return e ? atol(e) : 1024L; }();
+    if (splitk <= 1 && small_mode >= 2 && K % 256 == 0 && K <= 1024 && (long)cdiv(M, 32) * cdiv(N, 32) <= max_t32 &&
+        !small_kernel_wins(M, N, K)) {
+        int rc;
+        if (gemm_bf16_tile32_try(s, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask, nullptr, &rc)) return rc;
+    }
     if (splitk <= 1 && small_mode && K % 64 == 0 && small_kernel_wins(M, N, K)) {
         int rc;
         if (small_mode != 1 && gemm_bf16_tile32_try(s, M, N, K, A, lda, Bb, ldb, C, ldc, bias, flags & 3, c_rows, relu_mask,

@@ -181,6 +181,22 @@ def attention_fwd(q, k, v, key_valid, causal=False, q_pos0=0, heads=8):
     return o
 
 
+def decode_attention(q, k, v, key_valid, tk=None, qpk=1, heads=8, knew=None, vnew=None):
+    """One query per row: q [BR,256] (any row stride), k / v [BR/qpk, kb, 256] (any row stride), key_valid int32
+    [BR/qpk, kvb] -> o [BR,256].  knew / vnew [BR,256] (row stride = their stride(0)): key tk-1 of every row comes from
+    them and is appended to k / v in place."""
+    BR = q.shape[0]
+    kb, kvb = k.shape[1], key_valid.shape[1]
+    tk = kb if tk is None else tk
+    o = torch.empty((BR, 256), dtype=torch.float32, device=q.device)
+    check(_lib.lib().fira_decode_attention(cur_stream(), BR, heads, tk, ptr(q), q.stride(0), ptr(k), k.stride(1), ptr(v),
+                                           v.stride(1), ptr(_i32(key_valid)), ptr(o), 256, kb, kvb, qpk, ptr(knew),
+                                           ptr(vnew), knew.stride(0) if knew is not None else 0,
+                                           ptr(k) if knew is not None else None, ptr(v) if knew is not None else None),
+          "fira_decode_attention")
+    return o
+
+
 def attention_bwd(q, k, v, key_valid, o, do, causal=False, q_pos0=0, heads=8):
     B, Tq, _ = q.shape
     Tk = k.shape[1]

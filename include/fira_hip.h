@@ -231,6 +231,15 @@ int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* 
                        int causal, int q_pos0, const float* O, int ldo, const float* dO, int lddo,
                        float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
 
+/* Attention of ONE query per row (the K/V-cached decode step of run_model.py:256): O[b, h*32..] = softmax(q.K^T/sqrt(32)
+ * over the valid keys) V.  Row b uses K/V batch entry b / qpk (kb rows of ldk floats per entry; key_valid [BR/qpk, kvb]):
+ * the qpk beam rows of a commit share its memory.  Masked keys are never read.  Knew / Vnew (optional, qpk == 1): row b's
+ * key / value number Tk-1 is taken from Knew[b*ldn..] / Vnew[b*ldn..] (the merged q|k|v projection's output) and is
+ * appended to Kc_out / Vc_out (same geometry as K / V) for the later steps.                                          */
+int fira_decode_attention(void* stream, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                          const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
+                          const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out);
+
 /* CopyNet score (Model.py:15-18): score[b,t,s] = w . tanh(src[b,s,:] + tgt[b,t,:]) + bias, never
  * materialising the [B,T,S,256] tensor.  bwd re-computes tanh.                                   */
 int fira_copy_score_fwd(void* stream, int B, int T, int S, const float* src, const float* tgt,
@@ -268,6 +277,10 @@ int fira_adam_step_count(void* stream, int64_t n, float* p, const float* g, floa
 int fira_pack_stats(void* stream, const float* loss_sum, const int32_t* n_tok, float* out2);
 /* out[0] = 1 / max(n_tok[0], 1) on the device */
 int fira_inv_count(void* stream, const int32_t* n_tok, float* out);
+
+/* measurement aid: n dependent tiny kernels on `stream`, optionally forking the library's side stream after each (mode 1),
+ * recording an event only (mode 2) or forking every 8th kernel (mode 3); scratch: >= 128 floats                       */
+int fira_debug_chain(void* stream, int n, int mode, float* scratch);
 
 /* =========================== model level (one call per step) =============================== */
 

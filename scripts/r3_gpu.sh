@@ -17,6 +17,18 @@ for ST in "$@"; do
       FIRA_SMALL_TILES=1024 timeout 300 python scripts/gemm_chain.py f32 2880,5100,7680 > $OUT/chain_f32_big_t1024.md 2>&1
       FIRA_SMALL_TILES=8192 timeout 300 python scripts/gemm_chain.py f32 2880,5100,7680 > $OUT/chain_f32_big_t8192.md 2>&1
       tail -n 26 $OUT/chain_f32_new.md; tail -n 14 $OUT/chain_bf16_old.md; tail -n 14 $OUT/chain_bf16_new.md; tail -n 14 $OUT/chain_f32_big_t1024.md; tail -n 14 $OUT/chain_f32_big_t8192.md ;;
+    chain16)
+      for T in 1024 2048 4096; do
+        FIRA_SMALL_TILES16=$T timeout 300 python scripts/gemm_chain.py bf16 960,1920,2880,5100 > $OUT/chain_bf16_t$T.md 2>&1; echo "chain16 $T rc=$?"; grep "^| [0-9]" $OUT/chain_bf16_t$T.md
+      done ;;
+    events)
+      timeout 120 python scripts/event_cost.py > $OUT/event_cost.txt 2>&1; cat $OUT/event_cost.txt ;;
+    decab)
+      FIRA_DECODE_ATTN=0 timeout 300 python scripts/decode_only.py > $OUT/decode_old.txt 2>&1; cat $OUT/decode_old.txt | tail -2
+      FIRA_DECODE_ATTN=1 timeout 300 python scripts/decode_only.py > $OUT/decode_new.txt 2>&1; cat $OUT/decode_new.txt | tail -2 ;;
+    dectests)
+      timeout 900 python -m pytest tests/test_decode_gpu.py tests/test_large_gpu.py tests/test_ops_gpu.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -k "decode or search or greedy or beam or attention" > $OUT/dectests.log 2>&1
+      tail -n 8 $OUT/dectests.log ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --timeout 300 > $OUT/tests.log 2>&1
       echo "tests rc=$?" >> $OUT/tests.log; tail -n 25 $OUT/tests.log ;;

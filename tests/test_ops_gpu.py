@@ -257,6 +257,45 @@ def test_attention_strided_qkv_buffer():
     assert rel_err(o, ref) < 2e-6
 
 
+@pytest.mark.parametrize("Tk,kb,qpk", [(370, 370, 1), (370, 370, 3), (17, 30, 1), (1, 30, 1), (333, 370, 2)])
+def test_decode_attention_one_query_per_row(Tk, kb, qpk):
+    """decode_attention (Tq = 1, valid keys streamed once per commit and head) against the fp64 soft-max, with the K/V rows
+    inside a wider buffer (row stride 3072 like the engine's cross-K|V of six layers) and beam rows sharing a commit."""
+    from fira_icse_amd import ops
+    Bk = 6
+    BR = Bk * qpk
+    q = randn(BR, 256, seed=1)
+    kvbuf = randn(Bk, kb, 3072, seed=2)
+    k, v = kvbuf[:, :, 512:768], kvbuf[:, :, 768:1024]
+    g = torch.Generator().manual_seed(3)
+    key_valid = (torch.rand(Bk, kb, generator=g) > 0.5).to(torch.int32).to(DEV)
+    key_valid[:, 0] = 1
+    key_valid[1, :] = 1                                          # a commit with every key valid
+    o = ops.decode_attention(q, k, v, key_valid, tk=Tk, qpk=qpk)
+    kk = k[:, :Tk].repeat_interleave(qpk, 0).double()
+    vv = v[:, :Tk].repeat_interleave(qpk, 0).double()
+    ref = torch_attention(q.double()[:, None], kk, vv, key_valid[:, :Tk].repeat_interleave(qpk, 0), False)[:, 0]
+    assert rel_err(o, ref) < 2e-6
+
+
+def test_decode_attention_merged_new_key_is_used_and_appended():
+    """Self-attention of the decode step with the merged q|k|v projection: key / value number Tk-1 come from the projection's
+    output row and are appended to the cache; equal to attending over a cache that already holds them."""
+    from fira_icse_amd import ops
+    BR, T, Tk = 10, 30, 12
+    qkv = randn(BR, 768, seed=4)
+    kc, vc = randn(BR, T, 256, seed=5), randn(BR, T, 256, seed=6)
+    hist = torch.ones(BR, T, dtype=torch.int32, device=DEV)
+    hist[3, 5] = 0
+    hist[4, Tk - 1] = 0                                          # a finished row: its newest key is masked, still appended
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    kc_ref[:, Tk - 1], vc_ref[:, Tk - 1] = qkv[:, 256:512], qkv[:, 512:]
+    ref = torch_attention(qkv[:, None, :256].double(), kc_ref[:, :Tk].double(), vc_ref[:, :Tk].double(), hist[:, :Tk], False)[:, 0]
+    o = ops.decode_attention(qkv[:, :256], kc, vc, hist, tk=Tk, knew=qkv[:, 256:512], vnew=qkv[:, 512:])
+    assert rel_err(o, ref) < 2e-6
+    assert torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+
+
 # ------------------------------------------------------------------------------------------------ copy head / loss
 def test_copy_score_fwd_bwd():
     from fira_icse_amd import ops

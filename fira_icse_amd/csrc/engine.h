@@ -45,6 +45,15 @@ int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int
                          int ldc, float* colsum);
 int gemm_group_flush(hipStream_t s);
 void gemm_group_reset();
+// coalesced 32x32 tile kernel (gemm_small.hip): shape test, launch with an optional residual epilogue (epilogue.h: EpiRes),
+// and the product with a LayerNorm prologue on its A operand (K = 256)
+struct EpiRes;
+bool gemm_tile32_takes(int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb);
+bool gemm_tile32_try(hipStream_t s, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,
+                     const float* relu_mask, const int32_t* a_rows, const EpiRes* er);
+bool gemm_tile32_ln_try(hipStream_t s, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
+                        int ldy, int flags, const float* gamma, const float* beta, float* x_out, float* stats_out, int* rc);
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows = nullptr,
                     const float* relu_mask = nullptr);
@@ -90,12 +99,6 @@ bool linear_ln_bf16_try(hipStream_t s, int M, int K, const float* X, int ldx, co
                         const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
                         float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row,
                         const float* r1_col, int* rc, bool force = false);
-// fused linear + bias (+ rank-1) + dropout + residual + LayerNorm over 32 complete rows per workgroup (linear_ln.hip);
-// returns false when it does not take the call (shape / alignment / FIRA_FUSED_LN=0): the caller runs the two kernels
-bool linear_ln_fwd_try(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* bias, const float* res,
-                       const float* gamma, const float* beta, float* sum, float* y, float* stats, float dropout,
-                       uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row, const float* r1_col,
-                       int* rc, bool force = false);
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
                       uint32_t site, const int32_t* rows = nullptr,    // rows: dy and ds are row-mapped (dy[rows[r]], ds[rows[r]])

@@ -11,6 +11,7 @@
 //   head          mem [MB,256], src [MB,256], tgt [TB,256], score [TB,370], gate [TB,2], dec_c [R,256], logits [R, ldl]
 //   backward      gradient temporaries of the same shapes (ping-pong node buffers, dkv_all, ...)
 #include "engine.h"
+#include "epilogue.h"
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -285,8 +286,8 @@ static inline int linear(hipStream_t s, int M, int N, int K, const float* X, int
 }
 // y = LN(dropout(X W^T + b [+ r c^T]) + res): the closing step of every block.  By default the product followed by the row
 // kernel; one fused launch where that was measured to win -- bf16 mode, K = 256, encoder-sized blocks (the panel kernel's
-// LayerNorm epilogue, gemm_bf16_panel.hip; FIRA_FUSED_LN_BF16) -- and, on request only, the fp32 fused kernels of
-// linear_ln.hip (FIRA_FUSED_LN=1|2|3: they lose in the step, see that file).
+// LayerNorm epilogue, gemm_bf16_panel.hip; FIRA_FUSED_LN_BF16).  (The fp32 "workgroup owns complete rows" kernels of round 2
+// lost in the step and are gone; the decoder's blocks are split at their LayerNorm instead: linear_presum below.)
 static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* b,
                             const float* res, const float* gamma, const float* beta, float* sum, float* y, float* stats,
                             float p_drop, uint64_t seed, uint32_t st, const int32_t* y_rows = nullptr,
@@ -296,10 +297,7 @@ static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx
                             const int32_t* slot2 = nullptr, float* y2 = nullptr, int n2 = 0, const int32_t* rows2 = nullptr) {
     bool fused = false;
     int rc = 0;
-    if (g_dtype == 0) {
-        fused = linear_ln_fwd_try(s, M, K, X, ldx, W, b, res, gamma, beta, sum, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col,
-                                  &rc);
-    } else {                                     // bf16: the panel kernel with a LayerNorm epilogue (gemm_bf16_panel.hip)
+    if (g_dtype != 0) {                          // bf16: the panel kernel with a LayerNorm epilogue (gemm_bf16_panel.hip)
         const uint16_t* wb;
         int ldw;
         fused = shadow_of(W, false, &wb, &ldw) && ldw == K &&
@@ -313,6 +311,23 @@ static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx
     }
     TRY(linear(s, M, FIRA_D, K, X, ldx, W, b, sum, FIRA_D));
     return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col, slot2, y2);
+}
+// The same block with its LayerNorm moved into the CONSUMER (fp32, coalesced tile kernel): the closing product stores the
+// pre-norm sum  sum = dropout(X W^T + b) + res  (EpiRes epilogue) and the next product normalises its A rows itself
+// (gemm_tile32_ln_try) -- one launch less per block on the dependent chain.  Both return false when the shape is not
+// taken; the caller then runs linear_ln / linear.
+static bool presum_on() {
+    static const bool off = [] { const char* e = getenv("FIRA_LN_PROLOGUE"); return e && e[0] == '0'; }();     // A/B switch
+    return !off && g_dtype == 0;
+}
+static inline bool linear_presum(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* b,
+                                 const float* res, float* sum, float p_drop, uint64_t seed, uint32_t st, int* rc) {
+    if (!presum_on() || !gemm_tile32_takes(1, M, FIRA_D, K, X, ldx, W, K)) return false;
+    EpiRes er;
+    er.res = res; er.ldr = FIRA_D; er.p = p_drop; er.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    er.seed = seed; er.site = st;
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * FIRA_D * (double)K, 4.0 * ((double)M * K + (double)FIRA_D * K + 2.0 * M * FIRA_D));
+    return gemm_tile32_try(s, 1, M, FIRA_D, K, X, ldx, W, K, sum, FIRA_D, b, 0, rc, nullptr, nullptr, nullptr, &er);
 }
 // dX (+)= dY W          (W stored [N,K]; reduce over N)
 static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* W, float* dX,
@@ -587,25 +602,58 @@ static int decoder_forward(Ctx& c) {
     TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
     ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
     const float* x = p.x0;
+    // pend_*: a block whose pre-norm sums are stored but whose LayerNorm is still owed (it runs in the prologue of the next
+    // product: see linear_presum).  y = LN(pend_sum) goes to pend_y, the statistics to pend_st.
+    const float *pend_sum = nullptr, *pend_g = nullptr, *pend_b = nullptr;
+    float *pend_y = nullptr, *pend_st = nullptr;
+    // Y = x W^T + b where x is either materialised or owed (pend_*): the fused launch, or the row kernel + a plain product
+    auto consume = [&](int N, const float* W, const float* b, float* Y, int flags) -> int {
+        if (pend_sum) {
+            int rc = 0;
+            const bool fused = gemm_tile32_ln_try(s, p.TB, N, pend_sum, D, W, b, Y, N, flags, pend_g, pend_b, pend_y, pend_st, &rc);
+            if (!fused)
+                rc = add_layernorm_fwd(s, p.TB, const_cast<float*>(pend_sum), nullptr, pend_g, pend_b, pend_y, pend_st, 0.f, 0, 0,
+                                       nullptr);
+            pend_sum = nullptr;
+            if (rc || fused) return rc;
+        }
+        return linear(s, p.TB, N, D, x, D, W, b, Y, N, flags);
+    };
+    // closing product of a block: y = LN(dropout(X W^T + b) + res); its LayerNorm is deferred to the next product when the
+    // shapes allow it
+    auto close_block = [&](int K, const float* X, const float* W, const float* b, const float* res, const float* g, const float* be,
+                           float* sum, float* y, float* st, uint32_t stt, bool may_defer, const int32_t* slot2, float* y2, int n2,
+                           const int32_t* rows2) -> int {
+        int rc = 0;
+        if (may_defer && linear_presum(s, p.TB, K, X, K, W, b, res, sum, c.p_drop, c.seed, stt, &rc)) {
+            pend_sum = sum; pend_g = g; pend_b = be; pend_y = y; pend_st = st;
+            return rc;
+        }
+        return linear_ln(s, p.TB, K, X, K, W, b, res, g, be, sum, y, st, c.p_drop, c.seed, stt, nullptr, nullptr, nullptr, slot2, y2,
+                         n2, rows2);
+    };
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
-        TRY(linear(s, p.TB, 3 * D, D, x, D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 3 * D));
+        TRY(consume(3 * D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 0));
         TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D));
-        TRY(linear_ln(s, p.TB, D, e.ao, D, c.P + w.wo_s, c.P + w.bo_s, x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
-                      c.p_drop, c.seed, site(l, SITE_SELF)));
-        TRY(linear(s, p.TB, D, D, e.x_a, D, c.P + w.wq_c, c.P + w.bq_c, e.qc, D));
+        TRY(close_block(D, e.ao, c.P + w.wo_s, c.P + w.bo_s, x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
+                        site(l, SITE_SELF), true, nullptr, nullptr, 0, nullptr));
+        x = e.x_a;
+        TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
         if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
         TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D));
-        TRY(linear_ln(s, p.TB, D, e.ao2, D, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c,
-                      e.st_c, c.p_drop, c.seed, site(l, SITE_CROSS)));
-        TRY(linear(s, p.TB, p.F, D, e.x_c, D, c.P + w.w1, c.P + w.b1, e.h, p.F, FIRA_GEMM_RELU));
-        // the last layer's output rows that need the vocabulary head (Ctx::rows) are also stored compactly (dec_c)
-        const bool head_copy = l + 1 == p.nl && c.rows != nullptr && c.R > 0;
-        TRY(linear_ln(s, p.TB, p.F, e.h, p.F, c.P + w.w2, c.P + w.b2, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.s_f, e.x_f,
-                      e.st_f, c.p_drop, c.seed, site(l, SITE_FFN), nullptr, nullptr, nullptr,
-                      head_copy ? p.compact_row : nullptr, head_copy ? p.dec_c : nullptr, head_copy ? c.R : 0,
-                      head_copy ? c.rows : nullptr));
+        TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
+                        site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
+        x = e.x_c;
+        TRY(consume(p.F, c.P + w.w1, c.P + w.b1, e.h, FIRA_GEMM_RELU));
+        // the last layer's output rows that need the vocabulary head (Ctx::rows) are also stored compactly (dec_c); its
+        // LayerNorm is not deferred (several consumers: vocabulary head, target projection, gate)
+        const bool last = l + 1 == p.nl;
+        const bool head_copy = last && c.rows != nullptr && c.R > 0;
+        TRY(close_block(p.F, e.h, c.P + w.w2, c.P + w.b2, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.s_f, e.x_f, e.st_f,
+                        site(l, SITE_FFN), !last, head_copy ? p.compact_row : nullptr, head_copy ? p.dec_c : nullptr,
+                        head_copy ? c.R : 0, head_copy ? c.rows : nullptr));
         x = e.x_f;
     }
     return 0;
@@ -1022,6 +1070,30 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
     const size_t lay = (size_t)BR * T * D;
     // FIRA_DECODE_ATTN=0: the round-2 path (three projections + the 32-query MFMA attention kernel): A/B switch
     static const bool stream_attn = [] { const char* e = getenv("FIRA_DECODE_ATTN"); return !(e && e[0] == '0'); }();
+    // LayerNorms deferred into the next product's prologue (see decoder_forward): pend_* = the block still owed
+    const float *pend_g = nullptr, *pend_b = nullptr;
+    float* pend_y = nullptr;
+    bool pending = false;
+    DtypeScope dtype_scope(0);                  // the search runs the reference's fp32 arithmetic
+    auto consume = [&](int N, const float* xin, const float* W, const float* b, float* Y, int flags) -> int {
+        if (pending) {
+            int rc = 0;
+            const bool fused = gemm_tile32_ln_try(s, BR, N, dp.s, D, W, b, Y, N, flags, pend_g, pend_b, pend_y, nullptr, &rc);
+            if (!fused) rc = add_layernorm_fwd(s, BR, dp.s, nullptr, pend_g, pend_b, pend_y, nullptr, 0.f, 0, 0, nullptr);
+            pending = false;
+            if (rc || fused) return rc;
+        }
+        return linear(s, BR, N, D, xin, D, W, b, Y, N, flags);
+    };
+    auto close_block = [&](int K, const float* X, const float* W, const float* b, const float* res, const float* g, const float* be,
+                           float* y, bool may_defer) -> int {
+        int rc = 0;
+        if (may_defer && linear_presum(s, BR, K, X, K, W, b, res, dp.s, 0.f, 0, 0, &rc)) {
+            pending = true; pend_g = g; pend_b = be; pend_y = y;
+            return rc;
+        }
+        return linear_ln(s, BR, K, X, K, W, b, res, g, be, dp.s, y, nullptr, 0.f, 0, 0);
+    };
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
         float* kc = dp.kc[cur] + l * lay;
@@ -1029,29 +1101,30 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
         if (stream_attn) {
             // q|k|v as ONE product; the attention kernel reads the new key / value from its output row and appends them
             // to the cache (decode_attention, attention.hip)
-            TRY(linear(s, BR, 3 * D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.qkv, 3 * D));
+            TRY(consume(3 * D, dp.x, params + w.wqkv, params + w.bqkv, dp.qkv, 0));
             TRY(decode_attention(s, BR, H, step + 1, dp.qkv, 3 * D, kc, D, vc, D, dp.hist[cur], dp.ao, D, T, T, 1,
                                  dp.qkv + D, dp.qkv + 2 * D, 3 * D, kc, vc));
         } else {
+            if (pending) {                      // three separate products read x: materialise it first
+                TRY(add_layernorm_fwd(s, BR, dp.s, nullptr, pend_g, pend_b, pend_y, nullptr, 0.f, 0, 0, nullptr));
+                pending = false;
+            }
             TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.q, D));
             TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)D * D, params + w.bqkv + D, kc + (size_t)step * D, T * D));
             TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
             TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
         }
-        TRY(linear_ln(s, BR, D, dp.ao, D, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.s,
-                      dp.xa, nullptr, 0.f, 0, 0));
-        TRY(linear(s, BR, D, D, dp.xa, D, params + w.wq_c, params + w.bq_c, dp.qc, D));
+        TRY(close_block(D, dp.ao, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, true));
+        TRY(consume(D, dp.xa, params + w.wq_c, params + w.bq_c, dp.qc, 0));
         if (stream_attn)
             TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid,
                                  dp.ao, D, Sm, Sm, n_beam));
         else
             TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                                  p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
-        TRY(linear_ln(s, BR, D, dp.ao, D, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.s,
-                      dp.xc, nullptr, 0.f, 0, 0));
-        TRY(linear(s, BR, p.F, D, dp.xc, D, params + w.w1, params + w.b1, dp.h, p.F, FIRA_GEMM_RELU));
-        TRY(linear_ln(s, BR, p.F, dp.h, p.F, params + w.w2, params + w.b2, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.s,
-                      dp.x, nullptr, 0.f, 0, 0));
+        TRY(close_block(D, dp.ao, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, true));
+        TRY(consume(p.F, dp.xc, params + w.w1, params + w.b1, dp.h, FIRA_GEMM_RELU));
+        TRY(close_block(p.F, dp.h, params + w.w2, params + w.b2, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, l + 1 < p.nl));
     }
     TRY(linear(s, BR, p.V, D, dp.x, D, params + L.wout, params + L.bout, dp.logits, p.ldl));
     TRY(gemm_f32(s, 0, 1, BR, D, D, dp.x, D, params + L.wt, D, dp.tgt, D, nullptr, 0, 1));

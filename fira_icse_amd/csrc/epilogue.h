@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 namespace fira {
 
@@ -28,11 +29,23 @@ __device__ __forceinline__ float buf_load_f32(rsrc_t r, unsigned off) {
 // byte offsets are 31-bit: a plain output must stay below 2 GiB (host-side check of every launcher)
 inline bool epilogue_fits(long rows, long ldc) { return rows * ldc * 4 < (1L << 31); }
 
+// Optional closing step of a post-LN residual block's product (gnn_transformer.py:161,174): the stored value is the PRE-NORM
+// sum  s = dropout(acc + bias) + res  -- what add_layernorm_fwd would form from the plain product -- so that the LayerNorm
+// itself can run in the prologue of the kernel that consumes it (gemm_tile32_kernel<.., LN_A>).  Dropout element index =
+// row * 256 + col, as in the row kernel (the backward kernels re-derive the same mask).
+struct EpiRes {
+    const float* res = nullptr;      // [M, ldr] residual rows (nullptr: feature off)
+    int ldr = 0;
+    float p = 0.f, inv_keep = 1.f;
+    uint64_t seed = 0;
+    uint32_t site = 0;
+};
+
 template <int NV>
 __device__ __forceinline__ void epilogue_col(const float (&acc)[NV], const int (&row)[NV], int col, int M, int N,
                                              float* __restrict__ C, int ldc, const float* __restrict__ bias, bool relu,
                                              bool accum, bool atomic, const int32_t* __restrict__ c_rows,
-                                             const float* __restrict__ relu_mask) {
+                                             const float* __restrict__ relu_mask, const EpiRes er = EpiRes()) {
     const rsrc_t rC = buf_rsrc(C, 0x7fffffffu);
     const bool colok = col < N;
     const unsigned cb = (unsigned)col * 4u;
@@ -68,6 +81,21 @@ __device__ __forceinline__ void epilogue_col(const float (&acc)[NV], const int (
         const rsrc_t rM = buf_rsrc(relu_mask, 0x7fffffffu);
 #pragma unroll
         for (int i = 0; i < NV; ++i) keep[i] = buf_load_f32(rM, moff[i]) > 0.f ? 1.f : 0.f;
+    }
+    if (er.res) {                                           // wave-uniform: pre-norm sum of a residual block
+        const rsrc_t rR = buf_rsrc(er.res, 0x7fffffffu);
+        float rv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            rv[i] = buf_load_f32(rR, (moff[i] & FIRA_OOB) ? FIRA_OOB : (unsigned)row[i] * (unsigned)er.ldr * 4u + cb);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float v = acc[i] + bv;
+            if (er.p > 0.f) v *= dropout_scale(er.seed, er.site, (uint32_t)row[i] * FIRA_D + (uint32_t)col, er.p, er.inv_keep);
+            v += rv[i];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, off[i], 0, 0);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {

@@ -178,14 +178,29 @@ __device__ __forceinline__ f32x16 tile32_compute(const char* slot, int fa0, int 
 
 // NCH = chunks per wave (K = 128 * NCH): the chunk loop is unrolled at compile time, so the two register sets of the
 // loads in flight are named registers and the accumulator never leaves the AGPRs
-template <bool B_KCONTIG, int NCH>
+// LN_A (K = 256 only): the A operand is the PRE-NORM sum s of a residual block (EpiRes of the producing product); the kernel
+// normalises its 32 complete rows itself before the MFMAs -- a = (s - mean) * rstd * gamma + beta, two-pass statistics like
+// add_layernorm_fwd (wave partials over the wave's 64 columns, combined through LDS: two barriers) -- and the workgroups of
+// column tile 0 store the normalised rows (x_out: the block's output, read by later kernels as residual / saved activation)
+// and the row statistics (stats_out: mean, rstd for the backward pass).  This replaces the LayerNorm launch between two
+// products of the dependent chain (gnn_transformer.py:161 -> :147, :174 -> :170).
+struct LnA {
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float* x_out = nullptr;          // [M, 256]
+    float* stats_out = nullptr;      // [M, 2] or nullptr
+};
+
+template <bool B_KCONTIG, int NCH, bool LN_A = false>
 __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias, int flags,
                                                           const int32_t* __restrict__ c_rows,
                                                           const float* __restrict__ relu_mask,
-                                                          const int32_t* __restrict__ a_rows, int tiles_n) {
+                                                          const int32_t* __restrict__ a_rows, int tiles_n, const EpiRes er,
+                                                          const LnA ln) {
     __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+    __shared__ float ln_red[2][4][32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-chunked tile order (bijective for any grid size)
@@ -229,6 +244,61 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     ChunkRegs R0, R1;
     tile32_fetch<B_KCONTIG>(R0, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, wave << 5, ldb);
     if (NCH > 1) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4) << 5, ldb);
+    if (LN_A) {
+        static_assert(!LN_A || NCH == 2, "the LayerNorm prologue needs the whole row in the two chunks of the four waves");
+        // this lane holds, of rows 8j + lr (j = 0..3), the four columns kc + ((ls ^ sw_j) << 2) .. + 3 of each chunk
+        auto sum8 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
+        auto hsum = [](const f32x4 v) { return (v.x + v.y) + (v.z + v.w); };
+        float mean[4], rstd[4];
+        {
+            const float p0 = sum8(hsum(R0.a0) + hsum(R1.a0)), p1 = sum8(hsum(R0.a1) + hsum(R1.a1));
+            const float p2 = sum8(hsum(R0.a2) + hsum(R1.a2)), p3 = sum8(hsum(R0.a3) + hsum(R1.a3));
+            if (ls == 0) { ln_red[0][wave][lr] = p0; ln_red[0][wave][8 + lr] = p1; ln_red[0][wave][16 + lr] = p2; ln_red[0][wave][24 + lr] = p3; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                mean[j] = ((ln_red[0][0][8 * j + lr] + ln_red[0][1][8 * j + lr]) + (ln_red[0][2][8 * j + lr] + ln_red[0][3][8 * j + lr])) *
+                          (1.0f / FIRA_D);
+        }
+        {
+            auto sq = [](const f32x4 v, float m) { const f32x4 d = v - m; return (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); };
+            const float p0 = sum8(sq(R0.a0, mean[0]) + sq(R1.a0, mean[0])), p1 = sum8(sq(R0.a1, mean[1]) + sq(R1.a1, mean[1]));
+            const float p2 = sum8(sq(R0.a2, mean[2]) + sq(R1.a2, mean[2])), p3 = sum8(sq(R0.a3, mean[3]) + sq(R1.a3, mean[3]));
+            if (ls == 0) { ln_red[1][wave][lr] = p0; ln_red[1][wave][8 + lr] = p1; ln_red[1][wave][16 + lr] = p2; ln_red[1][wave][24 + lr] = p3; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float var = ((ln_red[1][0][8 * j + lr] + ln_red[1][1][8 * j + lr]) + (ln_red[1][2][8 * j + lr] + ln_red[1][3][8 * j + lr])) *
+                                  (1.0f / FIRA_D);
+                rstd[j] = 1.0f / sqrtf(var + 1e-5f);
+            }
+        }
+        // columns of this lane: chunk c (k base kc = (wave + 4c) * 32), rows j even -> ls ^ sw_even, j odd -> ls ^ sw_odd
+        const int ce = (ls ^ sw_even) << 2, co = (ls ^ sw_odd) << 2;
+        const int k0 = wave << 5, k1 = (wave + 4) << 5;
+        const f32x4 g0e = *reinterpret_cast<const f32x4*>(ln.gamma + k0 + ce), g0o = *reinterpret_cast<const f32x4*>(ln.gamma + k0 + co);
+        const f32x4 g1e = *reinterpret_cast<const f32x4*>(ln.gamma + k1 + ce), g1o = *reinterpret_cast<const f32x4*>(ln.gamma + k1 + co);
+        const f32x4 b0e = *reinterpret_cast<const f32x4*>(ln.beta + k0 + ce), b0o = *reinterpret_cast<const f32x4*>(ln.beta + k0 + co);
+        const f32x4 b1e = *reinterpret_cast<const f32x4*>(ln.beta + k1 + ce), b1o = *reinterpret_cast<const f32x4*>(ln.beta + k1 + co);
+        R0.a0 = (R0.a0 - mean[0]) * rstd[0] * g0e + b0e; R1.a0 = (R1.a0 - mean[0]) * rstd[0] * g1e + b1e;
+        R0.a1 = (R0.a1 - mean[1]) * rstd[1] * g0o + b0o; R1.a1 = (R1.a1 - mean[1]) * rstd[1] * g1o + b1o;
+        R0.a2 = (R0.a2 - mean[2]) * rstd[2] * g0e + b0e; R1.a2 = (R1.a2 - mean[2]) * rstd[2] * g1e + b1e;
+        R0.a3 = (R0.a3 - mean[3]) * rstd[3] * g0o + b0o; R1.a3 = (R1.a3 - mean[3]) * rstd[3] * g1o + b1o;
+        if (n0 == 0) {                              // column tile 0 publishes the block's output rows and statistics
+            const int r0 = m0 + lr, r1 = m0 + 8 + lr, r2 = m0 + 16 + lr, r3 = m0 + 24 + lr;
+            float* xo = ln.x_out;
+            if (r0 < M) { *reinterpret_cast<f32x4*>(xo + (size_t)r0 * FIRA_D + k0 + ce) = R0.a0; *reinterpret_cast<f32x4*>(xo + (size_t)r0 * FIRA_D + k1 + ce) = R1.a0; }
+            if (r1 < M) { *reinterpret_cast<f32x4*>(xo + (size_t)r1 * FIRA_D + k0 + co) = R0.a1; *reinterpret_cast<f32x4*>(xo + (size_t)r1 * FIRA_D + k1 + co) = R1.a1; }
+            if (r2 < M) { *reinterpret_cast<f32x4*>(xo + (size_t)r2 * FIRA_D + k0 + ce) = R0.a2; *reinterpret_cast<f32x4*>(xo + (size_t)r2 * FIRA_D + k1 + ce) = R1.a2; }
+            if (r3 < M) { *reinterpret_cast<f32x4*>(xo + (size_t)r3 * FIRA_D + k0 + co) = R0.a3; *reinterpret_cast<f32x4*>(xo + (size_t)r3 * FIRA_D + k1 + co) = R1.a3; }
+            if (ln.stats_out && wave == 0 && ls == 0) {
+                if (r0 < M) { ln.stats_out[2 * r0] = mean[0]; ln.stats_out[2 * r0 + 1] = rstd[0]; }
+                if (r1 < M) { ln.stats_out[2 * r1] = mean[1]; ln.stats_out[2 * r1 + 1] = rstd[1]; }
+                if (r2 < M) { ln.stats_out[2 * r2] = mean[2]; ln.stats_out[2 * r2 + 1] = rstd[2]; }
+                if (r3 < M) { ln.stats_out[2 * r3] = mean[3]; ln.stats_out[2 * r3 + 1] = rstd[3]; }
+            }
+        }
+    }
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci) {
         if ((ci & 1) == 0) {
@@ -246,7 +316,7 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
     __syncthreads();
     {
-        const int ln = threadIdx.x & 63, rq = threadIdx.x >> 6;
+        const int lnn = threadIdx.x & 63, rq = threadIdx.x >> 6;
         float vals[4];
         int rows[4];
         const float* p0 = reinterpret_cast<const float*>(smem);
@@ -254,40 +324,70 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
         for (int i = 0; i < 4; ++i) {
             const int idx = threadIdx.x + 256 * i, r = rq + 4 * i;
             vals[i] = (p0[idx] + p0[2048 + idx]) + (p0[4096 + idx] + p0[6144 + idx]);
-            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lnn >> 5);
         }
-        epilogue_col<4>(vals, rows, n0 + (ln & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
-                        c_rows, relu_mask);
+        epilogue_col<4>(vals, rows, n0 + (lnn & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
+                        c_rows, relu_mask, er);
     }
 }
 
 template <bool B_KCONTIG, int NCH>
 static void tile32_launch(hipStream_t s, dim3 grid, int M, int N, const float* A, int lda, const float* B, int ldb, float* C,
                           int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask,
-                          const int32_t* a_rows, int tiles_n) {
-    hipLaunchKernelGGL((gemm_tile32_kernel<B_KCONTIG, NCH>), grid, dim3(256), 0, s, M, N, A, lda, B, ldb, C, ldc, bias, flags,
-                       c_rows, relu_mask, a_rows, tiles_n);
+                          const int32_t* a_rows, int tiles_n, const EpiRes& er) {
+    hipLaunchKernelGGL((gemm_tile32_kernel<B_KCONTIG, NCH, false>), grid, dim3(256), 0, s, M, N, A, lda, B, ldb, C, ldc, bias,
+                       flags, c_rows, relu_mask, a_rows, tiles_n, er, LnA());
+}
+
+// shapes the coalesced tile kernel takes (the engine asks before it plans a fused LayerNorm prologue / residual epilogue)
+bool gemm_tile32_takes(int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb) {
+    static const int mode = [] { const char* e = getenv("FIRA_SMALL_GEMM"); return e ? atoi(e) : 2; }();
+    if (mode == 1 || M <= 0 || N <= 0) return false;
+    if (K % 128 != 0 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0 || ldb % 4 != 0 || ((uintptr_t)B % 16) != 0) return false;
+    const int nch = K / 128;
+    if (nch != 1 && nch != 2 && nch != 3 && nch != 4 && nch != 6 && nch != 8) return false;
+    if (!tB && N % 32 != 0) return false;                               // [K,N] tiles are read as whole 128-byte row segments
+    return true;
 }
 
 // true if the coalesced tile kernel took the call (FIRA_SMALL_GEMM=1 keeps the round-2 fragment-load kernel: A/B switch)
 bool gemm_tile32_try(hipStream_t s, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,
-                     const float* relu_mask, const int32_t* a_rows) {
-    if (K % 128 != 0 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0 || ldb % 4 != 0 || ((uintptr_t)B % 16) != 0) return false;
+                     const float* relu_mask, const int32_t* a_rows, const EpiRes* er_in) {
+    if (!gemm_tile32_takes(tB, M, N, K, A, lda, B, ldb)) return false;
+    const EpiRes er = er_in ? *er_in : EpiRes();
     const int nch = K / 128;
-    if (nch != 1 && nch != 2 && nch != 3 && nch != 4 && nch != 6 && nch != 8) return false;
-    if (!tB && N % 32 != 0) return false;                               // [K,N] tiles are read as whole 128-byte row segments
     const int tiles_n = cdiv(N, 32);
     const dim3 grid(cdiv(M, 32) * tiles_n);
 #define FIRA_T32(NCH)                                                                                                  \
     case NCH:                                                                                                          \
-        if (tB) tile32_launch<true, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n); \
-        else tile32_launch<false, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n); \
+        if (tB) tile32_launch<true, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n, er); \
+        else tile32_launch<false, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n, er); \
         break;
     switch (nch) { FIRA_T32(1) FIRA_T32(2) FIRA_T32(3) FIRA_T32(4) FIRA_T32(6) FIRA_T32(8) }
 #undef FIRA_T32
     hipError_t e = hipGetLastError();
     *rc = e != hipSuccess ? set_err("gemm_tile32: %s", hipGetErrorString(e)) : 0;
+    return true;
+}
+
+// Y = LN(S) W^T + b (+ relu) in one launch, S the pre-norm sums [M,256] of a residual block (see LnA): W is an nn.Linear
+// weight [N,256].  Also stores x = LN(S) [M,256] and the row statistics.  false: shape not taken (the caller runs the row
+// kernel and a plain product instead).
+bool gemm_tile32_ln_try(hipStream_t s, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
+                        int ldy, int flags, const float* gamma, const float* beta, float* x_out, float* stats_out, int* rc) {
+    if (!gemm_tile32_takes(1, M, N, FIRA_D, S, lds, W, FIRA_D)) return false;
+    static const bool off = [] { const char* e = getenv("FIRA_LN_PROLOGUE"); return e && e[0] == '0'; }();     // A/B switch
+    if (off || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16) || ((uintptr_t)x_out % 16)) return false;
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)FIRA_D, 4.0 * ((double)M * FIRA_D + (double)N * FIRA_D + (double)M * N));
+    const int tiles_n = cdiv(N, 32);
+    LnA ln;
+    ln.gamma = gamma; ln.beta = beta; ln.x_out = x_out; ln.stats_out = stats_out;
+    hipLaunchKernelGGL((gemm_tile32_kernel<true, 2, true>), dim3(cdiv(M, 32) * tiles_n), dim3(256), 0, s, M, N, S, lds, W, FIRA_D,
+                       Y, ldy, bias, flags & 3, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, tiles_n,
+                       EpiRes(), ln);
+    hipError_t e = hipGetLastError();
+    *rc = e != hipSuccess ? set_err("gemm_tile32_ln: %s", hipGetErrorString(e)) : 0;
     return true;
 }
 
@@ -304,11 +404,11 @@ bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const fl
     // the coalesced tile kernel keeps winning for more rounds of tiles than the fragment-load one did (FIRA_SMALL_TILES: A/B)
     static const long max_tiles = [] { const char* e = getenv("FIRA_SMALL_TILES"); return e ? atol(e) : 1024L; }();
     if (!tA && mode != 1 && M > 64 && tiles > 1024 && tiles <= max_tiles) {
-        if (gemm_tile32_try(s, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rc, c_rows, relu_mask, nullptr)) return true;
+        if (gemm_tile32_try(s, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rc, c_rows, relu_mask, nullptr, nullptr)) return true;
     }
     if (tA || (M > 64 && tiles > 1024) || K % 32 != 0 || K < 64 || lda % 4 != 0 || ((uintptr_t)A % 16) != 0) return false;
     if (tB && (ldb % 4 != 0 || ((uintptr_t)B % 16) != 0)) return false;
-    if (mode != 1 && gemm_tile32_try(s, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rc, c_rows, relu_mask, nullptr))
+    if (mode != 1 && gemm_tile32_try(s, tB, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, rc, c_rows, relu_mask, nullptr, nullptr))
         return true;
     dim3 grid(cdiv(N, 32), cdiv(M, 32));
     if (tB) hipLaunchKernelGGL(gemm_small_kernel<true>, grid, dim3(256), 0, s, M, N, K, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask);
@@ -319,3 +419,29 @@ bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const fl
 }
 
 }  // namespace fira
+
+extern "C" {
+int fira_linear_presum_f32(void* stream, int M, int K, const float* X, int ldx, const float* W, const float* bias,
+                           const float* res, float* sum, float dropout, uint64_t seed, uint32_t stream_id) {
+    FIRA_REQUIRE(X && W && res && sum && M > 0, "fira_linear_presum_f32: bad argument");
+    FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_linear_presum_f32: dropout must be in [0,1)");
+    fira::EpiRes er;
+    er.res = res; er.ldr = FIRA_D; er.p = dropout; er.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
+    er.seed = seed; er.site = stream_id;
+    int rc = 0;
+    if (!fira::gemm_tile32_try((hipStream_t)stream, 1, M, FIRA_D, K, X, ldx, W, K, sum, FIRA_D, bias, 0, &rc, nullptr, nullptr,
+                               nullptr, &er))
+        return fira::set_err("fira_linear_presum_f32: shape %d x 256 x %d / alignment not taken by the tile kernel", M, K);
+    return rc;
+}
+int fira_ln_linear_f32(void* stream, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
+                       int ldy, int relu, const float* gamma, const float* beta, float* x_out, float* stats_out) {
+    FIRA_REQUIRE(S && W && Y && gamma && beta && x_out && M > 0 && N > 0, "fira_ln_linear_f32: bad argument");
+    int rc = 0;
+    if (!fira::gemm_tile32_ln_try((hipStream_t)stream, M, N, S, lds, W, bias, Y, ldy, relu ? FIRA_GEMM_RELU : 0, gamma, beta, x_out,
+                                  stats_out, &rc))
+        return fira::set_err("fira_ln_linear_f32: shape %d x %d / alignment not taken by the tile kernel", M, N);
+    return rc;
+}
+}
+

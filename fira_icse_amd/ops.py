@@ -118,17 +118,27 @@ def add_layernorm_fwd(x, res, gamma, beta, dropout=0.0, seed=0, site=0):
     return y, x, stats
 
 
-def linear_layernorm_fwd(x, w, bias, res, gamma, beta, dropout=0.0, seed=0, site=0):
-    """One launch for LayerNorm(dropout(x @ w.T + bias) + res): returns (y, pre-norm sum, stats[M,2])."""
+def linear_presum(x, w, bias, res, dropout=0.0, seed=0, site=0):
+    """Pre-norm sum of a residual block: dropout(x @ w.T + bias) + res  (w [256, K])."""
     M, K = x.shape
     assert w.shape == (256, K) and x.stride(1) == 1
-    y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
-    s = torch.empty_like(y)
-    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
-    check(_lib.lib().fira_linear_layernorm_fwd(cur_stream(), M, K, ptr(x), x.stride(0), ptr(_f32(w)), ptr(bias), ptr(res),
-                                               ptr(_f32(gamma)), ptr(_f32(beta)), ptr(s), ptr(y), ptr(stats), dropout,
-                                               seed, site), "fira_linear_layernorm_fwd")
-    return y, s, stats
+    s = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_linear_presum_f32(cur_stream(), M, K, ptr(x), x.stride(0), ptr(_f32(w)), ptr(bias), ptr(_f32(res)),
+                                            ptr(s), dropout, seed, site), "fira_linear_presum_f32")
+    return s
+
+
+def ln_linear(s, w, bias, gamma, beta, relu=False):
+    """(LN(s) @ w.T + bias [relu], LN(s), stats[M,2]) in one launch: the LayerNorm runs in the product's prologue."""
+    M = s.shape[0]
+    N = w.shape[0]
+    assert w.shape[1] == 256 and s.shape[1] == 256 and s.stride(1) == 1
+    y = torch.empty((M, N), dtype=torch.float32, device=s.device)
+    x = torch.empty((M, 256), dtype=torch.float32, device=s.device)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=s.device)
+    check(_lib.lib().fira_ln_linear_f32(cur_stream(), M, N, ptr(s), s.stride(0), ptr(_f32(w)), ptr(bias), ptr(y), N, int(relu),
+                                        ptr(_f32(gamma)), ptr(_f32(beta)), ptr(x), ptr(stats)), "fira_ln_linear_f32")
+    return y, x, stats
 
 
 def linear_layernorm_bf16_fwd(x, wb, bias, res, gamma, beta, dropout=0.0, seed=0, site=0):

@@ -180,15 +180,18 @@ int fira_combination_bwd(void* stream, int M, const float* qk, const float* vtab
 int fira_add_layernorm_fwd(void* stream, int M, float* x, const float* res, const float* gamma,
                            const float* beta, float* y, float* stats, float dropout, uint64_t seed,
                            uint32_t stream_id);
-/* The product and the row step above in ONE launch: y = LayerNorm(dropout(X W^T + bias) + res) * gamma + beta with
- * X [M,K] (row pitch ldx), W [256,K] an nn.Linear weight; sum [M,256] (optional) receives the pre-norm rows and
- * stats [M,2] (optional) {mean, rstd}, exactly what fira_add_layernorm_fwd leaves behind, so the backward entry
- * below serves both.  K a multiple of 32, operands 16-byte aligned (else error).  fp32 MFMA.
- * Replaces e.g. `self.norm(x + self.dropout(self.linear(...)))` at gnn_transformer.py:161,174,205.  */
-int fira_linear_layernorm_fwd(void* stream, int M, int K, const float* X, int ldx, const float* W,
-                              const float* bias, const float* res, const float* gamma, const float* beta,
-                              float* sum, float* y, float* stats, float dropout, uint64_t seed,
-                              uint32_t stream_id);
+/* A post-LN residual block split at its LayerNorm (gnn_transformer.py:161,174): the closing product stores the PRE-NORM sum
+ *     sum[M,256] = dropout(X W^T + bias) + res          X [M,K] (row pitch ldx), W [256,K], K in {128..1024 step 128}
+ * (what fira_add_layernorm_fwd forms from the plain product; same dropout element indices), and the product that consumes the
+ * block's output normalises its A rows itself:
+ *     Y[M,N] = LN(S) W^T + bias (+relu)                 S [M,256] (row pitch lds), W [N,256];  x_out [M,256] = LN(S) and
+ *                                                       stats_out [M,2] = {mean, rstd} are stored as well
+ * -- one launch less per block on the dependent chain than product + row kernel + product.  fp32 MFMA, operands 16-byte
+ * aligned; returns an error for shapes the coalesced tile kernel does not take (the engine then uses the three launches). */
+int fira_linear_presum_f32(void* stream, int M, int K, const float* X, int ldx, const float* W, const float* bias,
+                           const float* res, float* sum, float dropout, uint64_t seed, uint32_t stream_id);
+int fira_ln_linear_f32(void* stream, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
+                       int ldy, int relu, const float* gamma, const float* beta, float* x_out, float* stats_out);
 /* bf16 mode twin (K = 256): Wb is the [256,256] bf16 shadow of the weight (fira_weight_shadow), row pitch ldb a multiple
  * of 8; X is rounded to bf16 while staged, fp32 accumulation, fp32 LayerNorm.  M >= 64.                                  */
 int fira_linear_layernorm_bf16_fwd(void* stream, int M, const float* X, int ldx, const uint16_t* Wb, int ldb,

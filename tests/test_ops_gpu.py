@@ -152,29 +152,31 @@ def test_combination_gate_fwd_bwd():
     assert rel_err(dvtab, vtab.grad) < 1e-5
 
 
-@pytest.mark.parametrize("M,K", [(960, 256), (960, 1024), (12001, 256), (65, 256), (7, 1024), (1920, 64)])
+@pytest.mark.parametrize("M,K,N", [(960, 256, 256), (960, 1024, 1024), (1921, 256, 768), (64, 1024, 256), (7, 256, 2), (5100, 256, 1024)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_linear_layernorm_fused_equals_the_two_kernels(M, K, p):
-    """The fused launch against gemm + add_layernorm_fwd (same dropout stream): the sums differ only by the K summation
-    order (<= 2e-6 relative), masks are IDENTICAL (zeros of the pre-residual rows coincide), stats/y within 1e-5."""
+def test_residual_block_split_at_its_layernorm(M, K, N, p):
+    """fira_linear_presum_f32 + fira_ln_linear_f32 (LayerNorm in the consumer's prologue) against the three launches they
+    replace -- product, add_layernorm_fwd (same dropout stream), product: the pre-norm sums are IDENTICAL (same MFMA chain,
+    same epilogue order, same mask), the normalised rows / statistics / consumer output differ by reduction order only."""
     from fira_icse_amd import ops
     x = randn(M, K + 8, seed=1)[:, :K]                       # a strided view: ldx != K
     w, b = randn(256, K, seed=2, scale=K ** -0.5), randn(256, seed=3)
     res, gamma, beta = randn(M, 256, seed=4), 1 + 0.1 * randn(256, seed=5), 0.1 * randn(256, seed=6)
-    y, s, st = ops.linear_layernorm_fwd(x, w, b, res, gamma, beta, p, seed=91, site=13)
+    w2, b2 = randn(N, 256, seed=7, scale=1 / 16), randn(N, seed=8)
+    s = ops.linear_presum(x, w, b, res, p, seed=91, site=13)
     lin = ops.gemm(x, w, bias=b, transB=True)
     y0, s0, st0 = ops.add_layernorm_fwd(lin.clone(), res, gamma, beta, p, seed=91, site=13)
-    assert rel_err(s, s0) < 2e-6 and rel_err(y, y0) < 1e-5 and rel_err(st, st0) < 1e-5
-    ref = F.linear(x.double(), w.double(), b.double())
-    if p == 0:
-        ref_y = F.layer_norm(ref + res.double(), (256,), gamma.double(), beta.double())
-        assert rel_err(y, ref_y) < 5e-6
-    else:
-        dropped0, dropped = (s0 - res) == 0, (s - res) == 0
-        assert torch.equal(dropped, dropped0) and 0.07 < dropped.float().mean() < 0.13
-    # no residual, no bias, no saved rows
-    y1, _, _ = ops.linear_layernorm_fwd(x, w, None, None, gamma, beta)
-    assert rel_err(y1, F.layer_norm(F.linear(x.double(), w.double()), (256,), gamma.double(), beta.double())) < 5e-6
+    assert torch.equal(s, s0)
+    if p > 0:
+        dropped = (s - res) == 0
+        assert 0.07 < float(dropped.float().mean()) < 0.13
+    for relu in (False, True):
+        out, y, st = ops.ln_linear(s, w2, b2, gamma, beta, relu=relu)
+        ref_out = ops.gemm(y0, w2, bias=b2, transB=True, relu=relu)
+        assert rel_err(y, y0) < 1e-5 and rel_err(st, st0) < 1e-5 and rel_err(out, ref_out) < 1e-5
+    ref_y = F.layer_norm(s.double(), (256,), gamma.double(), beta.double())
+    assert rel_err(y, ref_y) < 5e-6
+    assert rel_err(out, F.relu(F.linear(ref_y, w2.double(), b2.double()))) < 5e-6
 
 
 def test_add_layernorm_fwd_bwd_and_dropout_mask():

@@ -166,7 +166,10 @@ def test_residual_block_split_at_its_layernorm(M, K, N, p):
     s = ops.linear_presum(x, w, b, res, p, seed=91, site=13)
     lin = ops.gemm(x, w, bias=b, transB=True)
     y0, s0, st0 = ops.add_layernorm_fwd(lin.clone(), res, gamma, beta, p, seed=91, site=13)
-    assert torch.equal(s, s0)
+    if ((M + 31) // 32) * 8 <= 1024:                          # ops.gemm runs the same tile kernel: one MFMA chain
+        assert torch.equal(s, s0)
+    else:                                                    # beyond 1024 tiles ops.gemm is the LDS-tiled kernel (another k order)
+        assert rel_err(s, s0) < 1e-6
     if p > 0:
         dropped = (s - res) == 0
         assert 0.07 < float(dropped.float().mean()) < 0.13

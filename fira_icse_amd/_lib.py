@@ -31,12 +31,12 @@ class Batch(C.Structure):
                 ("n_mem", C.c_int32), ("mem_rows", C.c_void_p), ("mem_dst", C.c_void_p), ("head_rows", C.c_void_p),
                 ("n_head_rows", C.c_int32), ("n_emb_items", C.c_int32), ("emb_item_tok", C.c_void_p),
                 ("emb_item_ptr", C.c_void_p), ("emb_rows", C.c_void_p), ("n_ast_items", C.c_int32),
-                ("ast_rows", C.c_void_p), ("ast_ids", C.c_void_p)]
+                ("ast_rows", C.c_void_p), ("ast_ids", C.c_void_p), ("dec_off", C.c_void_p), ("n_dec_rows", C.c_int32)]
 
 
 class TrainOpts(C.Structure):
     _fields_ = [("dropout", C.c_float), ("gcn_dropout", C.c_float), ("seed", C.c_uint64), ("compact_head", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("compact_dec", C.c_int32), ("zero_grads", C.c_int32)]
 
 
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
@@ -57,6 +57,7 @@ SIGNATURES = {
     "fira_weight_shadow": (_I, [_P, _I, _I, _P, _P, _P]),
     "fira_gemm_bf16_wb": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_csr_spmm_f32": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I]),
+    "fira_csr_spmm": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I]),
     "fira_embed_gather_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I]),
     "fira_embed_gather_bwd": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I]),
     "fira_combination_fwd": (_I, [_P, _I, _P, _P, _P, _P, _F, _U64, _U32]),
@@ -127,7 +128,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fira_abi_version() != 4:
+    if lib.fira_abi_version() != 5:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib
 

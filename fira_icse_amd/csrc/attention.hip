@@ -62,7 +62,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
                                                                 const float* __restrict__ V, int ldv,
                                                                 const int32_t* __restrict__ key_valid, int causal,
                                                                 int q_pos0, float* __restrict__ O, int ldo, int kb,
-                                                                int kvb, int qpk) {
+                                                                int kvb, int qpk, const int32_t* __restrict__ q_off,
+                                                                int self_kv) {
+    // q_off (optional): the queries of batch entry b are rows q_off[b] .. q_off[b+1] of Q / O (a ragged, compact row
+    // layout: the decoder's computed target rows); with self_kv the keys / values are the same rows of K / V.  key_valid
+    // stays dense (kvb entries per batch entry).
     // kb: K/V rows per batch entry, kvb: key_valid entries per batch entry, qpk: consecutive query batches
     // that share one K/V batch entry (beam rows of one commit share the encoder memory)
     __shared__ int sm_kv[MAX_TK];
@@ -72,14 +76,18 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     const int bk = b / qpk;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int NT = (Tk + 31) / 32;
-    for (int i = t; i < Tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)bk * kvb + i];
+    const int qb = q_off ? q_off[b] : b * Tq;
+    const int tq = q_off ? q_off[b + 1] - qb : Tq;
+    const bool selfk = q_off && self_kv;
+    const int tk = selfk ? tq : Tk;
+    const int NT = (tk + 31) / 32;
+    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)bk * kvb + i];
     __syncthreads();
-    K += (size_t)bk * kb * ldk;           // this batch entry's key/value rows
-    V += (size_t)bk * kb * ldv;
+    K += (selfk ? (size_t)qb : (size_t)bk * kb) * ldk;           // this batch entry's key/value rows
+    V += (selfk ? (size_t)qb : (size_t)bk * kb) * ldv;
 
     float bq[16];
-    load_frag(bq, Q + ((size_t)b * Tq + l31) * ldq + h * FIRA_DH + kh * 16, l31 < Tq);
+    load_frag(bq, Q + ((size_t)qb + l31) * ldq + h * FIRA_DH + kh * 16, l31 < tq);
 
     f32x16 st[TPW];
     float mx = -INFINITY;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
         if (kt < NT) {
             float ak[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + (size_t)key * ldk + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
+            load_frag(ak, K + (size_t)key * ldk + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool masked;
-                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, Tk, sm_kv, causal, q_pos0, masked);
+                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, tk, sm_kv, causal, q_pos0, masked);
                 st[i][r] = x;
                 mx = fmaxf(mx, x);
             }
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int key = kt * 32 + acc_row(s, kh);
-                vv[s] = (key < Tk && sm_kv[key < Tk ? key : 0] != 0) ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
+                vv[s] = (key < tk && sm_kv[key < tk ? key : 0] != 0) ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] * inv_sum, vv[s], o);
@@ -160,13 +168,13 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
             for (int w = 0; w < NW; ++w) v += sm_o[w * 1024 + idx];
             const int r = idx >> 6, ln = idx & 63;
             const int q = acc_row(r, ln >> 5);
-            if (q < Tq) O[((size_t)b * Tq + q) * ldo + h * FIRA_DH + (ln & 31)] = v;
+            if (q < tq) O[((size_t)qb + q) * ldo + h * FIRA_DH + (ln & 31)] = v;
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = acc_row(r, kh);
-            if (q < Tq) O[((size_t)b * Tq + q) * ldo + h * FIRA_DH + l31] = o[r];
+            if (q < tq) O[((size_t)qb + q) * ldo + h * FIRA_DH + l31] = o[r];
         }
     }
 }
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     int H, int Tq, int Tk, const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
     const float* __restrict__ V, int ldv, const int32_t* __restrict__ key_valid, int causal, int q_pos0,
     const float* __restrict__ O, int ldo, const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq,
-    float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv) {
+    float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, const int32_t* __restrict__ q_off, int self_kv) {
     __shared__ int sm_kv[MAX_TK];
     __shared__ float sm_red[NW][32];
     __shared__ float sm_m[32], sm_sum[32], sm_delta[32];
@@ -184,18 +192,23 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int NT = (Tk + 31) / 32;
-    for (int i = t; i < Tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)b * Tk + i];
+    const int qb = q_off ? q_off[b] : b * Tq;                  // ragged query rows: see attention_fwd_kernel
+    const int tq = q_off ? q_off[b + 1] - qb : Tq;
+    const bool selfk = q_off && self_kv;
+    const int tk = selfk ? tq : Tk;
+    const size_t kbase = selfk ? (size_t)qb : (size_t)b * Tk;
+    const int NT = (tk + 31) / 32;
+    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)b * Tk + i];
     __syncthreads();
 
     // operand fragments indexed by "row = lane&31": queries
     float bq[16], bdo[16];
-    load_frag(bq, Q + ((size_t)b * Tq + l31) * ldq + h * FIRA_DH + kh * 16, l31 < Tq);
-    load_frag(bdo, dO + ((size_t)b * Tq + l31) * lddo + h * FIRA_DH + kh * 16, l31 < Tq);
+    load_frag(bq, Q + ((size_t)qb + l31) * ldq + h * FIRA_DH + kh * 16, l31 < tq);
+    load_frag(bdo, dO + ((size_t)qb + l31) * lddo + h * FIRA_DH + kh * 16, l31 < tq);
     float delta;
     {
         float bo[16];
-        load_frag(bo, O + ((size_t)b * Tq + l31) * ldo + h * FIRA_DH + kh * 16, l31 < Tq);
+        load_frag(bo, O + ((size_t)qb + l31) * ldo + h * FIRA_DH + kh * 16, l31 < tq);
         float d = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) d = fmaf(bdo[s], bo[s], d);
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         if (kt < NT) {
             float ak[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
+            load_frag(ak, K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool masked;
-                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, Tk, sm_kv, causal, q_pos0, masked);
+                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, tk, sm_kv, causal, q_pos0, masked);
                 st[i][r] = x;
                 mx = fmaxf(mx, x);
             }
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         if (kt < NT) {
             float av[16];
             const int key = kt * 32 + l31;
-            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
+            load_frag(av, V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 dpt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
@@ -281,12 +294,12 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
-                kvv[s] = (kr < Tk && sm_kv[kr < Tk ? kr : 0] != 0) ? K[((size_t)b * Tk + kr) * ldk + h * FIRA_DH + l31] : 0.f;
+                kvv[s] = (kr < tk && sm_kv[kr < tk ? kr : 0] != 0) ? K[(kbase + kr) * ldk + h * FIRA_DH + l31] : 0.f;
             }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
-                const bool dead = kr >= Tk || sm_kv[kr < Tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
+                const bool dead = kr >= tk || sm_kv[kr < tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
                 const float p = st[i][s] * inv_sum;
                 const float ds = dead ? 0.f : p * (dpt[s] - delta) * INV_SQRT_DH;
                 dq = MFMA32(ds, kvv[s], dq);                                    // dQ += dS K
@@ -303,13 +316,13 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             for (int w = 0; w < NW; ++w) v += sm_o[w * 1024 + idx];
             const int r = idx >> 6, ln = idx & 63;
             const int q = acc_row(r, ln >> 5);
-            if (q < Tq) dQ[((size_t)b * Tq + q) * lddq + h * FIRA_DH + (ln & 31)] = v;
+            if (q < tq) dQ[((size_t)qb + q) * lddq + h * FIRA_DH + (ln & 31)] = v;
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = acc_row(r, kh);
-            if (q < Tq) dQ[((size_t)b * Tq + q) * lddq + h * FIRA_DH + l31] = dq[r];
+            if (q < tq) dQ[((size_t)qb + q) * lddq + h * FIRA_DH + l31] = dq[r];
         }
     }
 
@@ -318,8 +331,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int q = acc_row(s, kh);
-        qrow[s] = q < Tq ? Q[((size_t)b * Tq + q) * ldq + h * FIRA_DH + l31] : 0.f;
-        dorow[s] = q < Tq ? dO[((size_t)b * Tq + q) * lddo + h * FIRA_DH + l31] : 0.f;
+        qrow[s] = q < tq ? Q[((size_t)qb + q) * ldq + h * FIRA_DH + l31] : 0.f;
+        dorow[s] = q < tq ? dO[((size_t)qb + q) * lddo + h * FIRA_DH + l31] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         if (kt < NT) {
             float ak[16], av[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + ((size_t)b * Tk + key) * ldk + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
-            load_frag(av, V + ((size_t)b * Tk + key) * ldv + h * FIRA_DH + kh * 16, key < Tk && sm_kv[key < Tk ? key : 0] != 0);
+            load_frag(ak, K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
+            load_frag(av, V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 sN, dpN;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
@@ -344,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             for (int s = 0; s < 16; ++s) {
                 const int q = acc_row(s, kh);
                 bool masked;
-                const float x = mask_score(sN[s], key, q, Tk, sm_kv, causal, q_pos0, masked);
+                const float x = mask_score(sN[s], key, q, tk, sm_kv, causal, q_pos0, masked);
                 const float p = expf(x - sm_m[q]) * sm_sum[q];
                 const float ds = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
                 dk = MFMA32(ds, qrow[s], dk);         // dK += dS^T Q
@@ -353,9 +366,9 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = kt * 32 + acc_row(r, kh);
-                if (kr < Tk) {
-                    dK[((size_t)b * Tk + kr) * lddk + h * FIRA_DH + l31] = dk[r];
-                    dV[((size_t)b * Tk + kr) * lddv + h * FIRA_DH + l31] = dv[r];
+                if (kr < tk) {
+                    dK[(kbase + kr) * lddk + h * FIRA_DH + l31] = dk[r];
+                    dV[(kbase + kr) * lddv + h * FIRA_DH + l31] = dv[r];
                 }
             }
         }
@@ -520,28 +533,30 @@ static int check_geometry(const char* who, int Tq, int Tk, int ldq, int ldk, int
 
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                     int kb, int kvb, int qpk) {
+                     int kb, int kvb, int qpk, const int32_t* q_off, int self_kv) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_fwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(kb >= Tk && kvb >= Tk && qpk >= 1, "attention_fwd: bad batch strides");
     if (Tk <= 32)
         hipLaunchKernelGGL((attention_fwd_kernel<1, 1>), dim3(B * H), dim3(64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, ldv,
-                           key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk);
+                           key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv);
     else
         hipLaunchKernelGGL((attention_fwd_kernel<12, 1>), dim3(B * H), dim3(768), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V,
-                           ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk);
+                           ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv);
     FIRA_CHECK_LAUNCH("attention_fwd");
     return 0;
 }
 int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
-                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo) {
-    return attention_fwd_ex(s, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O, ldo, Tk, Tk, 1);
+                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
+                  const int32_t* q_off, int self_kv) {
+    return attention_fwd_ex(s, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O, ldo, Tk, Tk, 1, q_off, self_kv);
 }
 
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
-                  const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv) {
+                  const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
+                  const int32_t* q_off, int self_kv) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_bwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
@@ -549,10 +564,10 @@ int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, i
                  "attention_bwd: O/dO rows must be 16-byte aligned");
     if (Tk <= 32)
         hipLaunchKernelGGL((attention_bwd_kernel<1, 1>), dim3(B * H), dim3(64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, ldv,
-                           key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv);
+                           key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv);
     else
         hipLaunchKernelGGL((attention_bwd_kernel<12, 1>), dim3(B * H), dim3(768), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V,
-                           ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv);
+                           ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv);
     FIRA_CHECK_LAUNCH("attention_bwd");
     return 0;
 }

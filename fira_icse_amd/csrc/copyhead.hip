@@ -30,7 +30,10 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ score, int qpk,
                                                              const int32_t* __restrict__ mem_valid, int slots,
-                                                             const int32_t* __restrict__ tar_label, int V) {
+                                                             const int32_t* __restrict__ tar_label, int V,
+                                                             const int32_t* __restrict__ t_off) {
+    // t_off (optional, [B+1]): ragged target rows -- commit b's rows are t_off[b] .. t_off[b+1] of tgt / score (the
+    // decoder's computed target rows, position t = row - t_off[b]); labels stay dense [B, T]
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     __shared__ unsigned sm_mask;
     const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
@@ -38,11 +41,13 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
     // [gen ; copy], Model.py:80-86); the others are left unwritten and head_loss neither reads nor propagates them
     if (t0 == 0) sm_mask = tar_label ? 0u : 0xffffffffu;
     __syncthreads();
-    if (tar_label && t0 < T - 1 && tar_label[b * T + t0 + 1] >= V) atomicOr(&sm_mask, 1u << t0);
+    const int tb = t_off ? t_off[b] : b * T;
+    const int Tb = t_off ? t_off[b + 1] - tb : T;
+    if (tar_label && t0 < Tb && t0 < T - 1 && tar_label[b * T + t0 + 1] >= V) atomicOr(&sm_mask, 1u << t0);
     src += (size_t)(b / qpk) * S * FIRA_D - (size_t)b * S * FIRA_D;     // qpk target batches share one memory
     const int32_t* mv = mem_valid ? mem_valid + (size_t)(b / qpk) * S : nullptr;
-    for (int i = t0; i < T * (FIRA_D / 4); i += 256)
-        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
+    for (int i = t0; i < Tb * (FIRA_D / 4); i += 256)
+        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)tb * FIRA_D)[i];
     __syncthreads();
     const unsigned mask = sm_mask;
     if (mask == 0u) return;
@@ -51,11 +56,11 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
     const int j_end = min(S, (int)(blockIdx.x + 1) * slots);
     for (int j = blockIdx.x * slots + wave; j < j_end; j += 4) {
         if (mv && mv[j] == 0) {                       // masked slot: its score is replaced by -1e9 downstream
-            if (lane < T) score[((size_t)b * T + lane) * S + j] = 0.f;
+            if (lane < Tb) score[((size_t)tb + lane) * S + j] = 0.f;
             continue;
         }
         const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < Tb; ++t) {
             if (!((mask >> t) & 1u)) continue;
             const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
             float a = w4.x * tanh_fast(s4.x + x.x);
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
             a = fmaf(w4.z, tanh_fast(s4.z + x.z), a);
             a = fmaf(w4.w, tanh_fast(s4.w + x.w), a);
             a = wave_sum(a);
-            if (lane == 0) score[((size_t)b * T + t) * S + j] = a + c;
+            if (lane == 0) score[((size_t)tb + t) * S + j] = a + c;
         }
     }
 }
@@ -81,7 +86,8 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
                                                              float* __restrict__ dsrc, float* __restrict__ dtgt,
                                                              float* __restrict__ dw, float* __restrict__ dbias,
                                                              const int32_t* __restrict__ mem_valid, int slots,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part,
+                                                             const int32_t* __restrict__ t_off) {
     constexpr int SLOTS_MAX = 16;
     __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
     __shared__ float sm_dt[T_MAX * FIRA_D];
@@ -90,12 +96,14 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
     __shared__ unsigned sm_mask;
     const int b = blockIdx.y, t0 = threadIdx.x, lane = t0 & 63, wave = t0 >> 6;
     const int j0 = blockIdx.x * slots, j_end = min(S, j0 + slots);
+    const int tb = t_off ? t_off[b] : b * T;                       // ragged target rows: see copy_score_fwd_kernel
+    const int Tb = t_off ? t_off[b + 1] - tb : T;
     if (t0 == 0) sm_mask = 0u;
     __syncthreads();
-    for (int i = t0; i < T * slots; i += 256) {
+    for (int i = t0; i < Tb * slots; i += 256) {
         const int t = i / slots, j = j0 + i % slots;
         float g = 0.f;
-        if (j < j_end && !(mem_valid && mem_valid[(size_t)b * S + j] == 0)) g = dscore[((size_t)b * T + t) * S + j];
+        if (j < j_end && !(mem_valid && mem_valid[(size_t)b * S + j] == 0)) g = dscore[((size_t)tb + t) * S + j];
         sm_g[t * SLOTS_MAX + i % slots] = g;
         if (g != 0.f) atomicOr(&sm_mask, 1u << t);
     }
@@ -109,8 +117,8 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
             for (int i = t0; i < FIRA_D + 1; i += 256) my_part[i] = 0.f;
         return;
     }
-    for (int i = t0; i < T * (FIRA_D / 4); i += 256)
-        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)b * T * FIRA_D)[i];
+    for (int i = t0; i < Tb * (FIRA_D / 4); i += 256)
+        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)tb * FIRA_D)[i];
     for (int i = t0; i < T_MAX * FIRA_D; i += 256) sm_dt[i] = 0.f;
     for (int i = t0; i < FIRA_D + 1; i += 256) sm_dw[i] = 0.f;
     __syncthreads();
@@ -157,8 +165,8 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
     for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
     if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
     __syncthreads();
-    for (int i = t0; i < T * FIRA_D; i += 256)
-        if ((mask >> (i / FIRA_D)) & 1u) unsafeAtomicAdd(&dtgt[(size_t)b * T * FIRA_D + i], sm_dt[i]);
+    for (int i = t0; i < Tb * FIRA_D; i += 256)
+        if ((mask >> (i / FIRA_D)) & 1u) unsafeAtomicAdd(&dtgt[(size_t)tb * FIRA_D + i], sm_dt[i]);
     if (my_part) {
         // deferred reduction (rowops.hip): B * S/16 workgroups adding to the same 257 addresses serialise in L2 (~50 ns per
         // same-address atomic: 1536 workgroups = ~75 us, most of this kernel's former run time)
@@ -213,10 +221,15 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
                                                         float* __restrict__ gate_logits,
                                                         const int32_t* __restrict__ tar_label,
                                                         float* __restrict__ loss_sum, int32_t* __restrict__ n_tok,
-                                                        int32_t* __restrict__ argmax_out, int want_grad) {
+                                                        int32_t* __restrict__ argmax_out, int want_grad,
+                                                        const int32_t* __restrict__ row_bt) {
     __shared__ float smf[4];
     __shared__ int smi[4];
-    const int bt = blockIdx.x, b = bt / T, t = bt - b * T, tid = threadIdx.x;
+    // bt: row of score / gate_logits / compact_row (a computed target row when row_bt lists them: row_bt[bt] = its flat
+    // b*T + t position; otherwise bt is that position itself)
+    const int bt = blockIdx.x, tid = threadIdx.x;
+    const int flat = row_bt ? row_bt[bt] : bt;
+    const int b = flat / T, t = flat - b * T;
     const int crow = compact_row ? compact_row[bt] : bt;
     const int y = (t + 1 < T) ? tar_label[b * T + t + 1] : 0;        // label = cat(tar_label, 0)[:, 1:]
     float* lrow = crow >= 0 ? logits + (size_t)crow * ldl : nullptr;
@@ -536,49 +549,49 @@ int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl
 
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* bias, float* score, int qpk, const int32_t* mem_valid, const int32_t* tar_label,
-                      int V) {
+                      int V, const int32_t* t_off) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX && qpk >= 1, "copy_score_fwd: T=%d > %d", T, T_MAX);
     const int slots = 8;          // memory slots per workgroup: small chunks so that masked stretches cost nothing
     hipLaunchKernelGGL(copy_score_fwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, bias, score,
-                       qpk, mem_valid, slots, tar_label, V);
+                       qpk, mem_valid, slots, tar_label, V, t_off);
     FIRA_CHECK_LAUNCH("copy_score_fwd");
     return 0;
 }
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score) {
-    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1, nullptr, nullptr, 0);
+    return copy_score_fwd_ex(s, B, T, S, src, tgt, w, bias, score, 1, nullptr, nullptr, 0, nullptr);
 }
 int copy_score_bwd_blocks(int B, int S) { return B > 0 ? cdiv(S, 16) * B : 0; }
 int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid,
-                      float* part) {
+                      float* part, const int32_t* t_off) {
     ProfScope prof(s, PROF_COPY, 0.0);
     if (B <= 0) return 0;
     FIRA_REQUIRE(T <= T_MAX, "copy_score_bwd: T=%d > %d", T, T_MAX);
     const int slots = 16;                                   // == SLOTS_MAX of the kernel
     hipLaunchKernelGGL(copy_score_bwd_kernel, dim3(cdiv(S, slots), B), dim3(256), 0, s, T, S, src, tgt, w, dscore, dsrc,
-                       dtgt, dw, dbias, mem_valid, slots, part);
+                       dtgt, dw, dbias, mem_valid, slots, part, t_off);
     FIRA_CHECK_LAUNCH("copy_score_bwd");
     return 0;
 }
 int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias) {
-    return copy_score_bwd_ex(s, B, T, S, src, tgt, w, dscore, dsrc, dtgt, dw, dbias, nullptr, nullptr);
+    return copy_score_bwd_ex(s, B, T, S, src, tgt, w, dscore, dsrc, dtgt, dw, dbias, nullptr, nullptr, nullptr);
 }
 int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
               float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,
-              int32_t* n_tok, int32_t* argmax_out, int want_grad) {
+              int32_t* n_tok, int32_t* argmax_out, int want_grad, const int32_t* row_bt) {
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (BT <= 0) return 0;
     const bool reg = (V % 2 == 0) && (V / 2 <= 256 * HL_PAIRS) && (ldl % 2 == 0) && ((uintptr_t)logits % 8 == 0);
     if (reg)
         hipLaunchKernelGGL(head_loss_kernel<true>, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
-                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
+                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad, row_bt);
     else
         hipLaunchKernelGGL(head_loss_kernel<false>, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
-                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad);
+                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad, row_bt);
     FIRA_CHECK_LAUNCH("head_loss");
     return 0;
 }

@@ -35,14 +35,16 @@ int weight_shadows(hipStream_t s, const ShadowTable& tab, const float* P, uint16
 int gemm_bf16_wb_ex(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
                     int ldc, const float* bias, int flags, int splitk, const int32_t* c_rows = nullptr,
                     const float* relu_mask = nullptr);
+// max_split (both grouped queues): 0 = the default split of the reduction (sized for ~40 problems sharing the chip);
+// a small group of long reductions (one encoder layer's three weight gradients) asks for more slabs
 int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                              float* C, int ldc, float* colsum);
+                              float* C, int ldc, float* colsum, int max_split = 0);
 int gemm_bf16_group_flush(hipStream_t s);
 bool gemm_bf16_takes(int M, int N, int K);     // false: the product is too small for the bf16 tiles (runs in fp32)
 void gemm_bf16_group_reset();
 // grouped weight gradients (one launch for many small dW += dY^T X problems; see gemm_f32.hip)
 int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                         int ldc, float* colsum);
+                         int ldc, float* colsum, int max_split = 0);
 int gemm_group_flush(hipStream_t s);
 void gemm_group_reset();
 // coalesced 32x32 tile kernel (gemm_small.hip): shape test, launch with an optional residual epilogue (epilogue.h: EpiRes),
@@ -113,7 +115,15 @@ int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const in
          int32_t* compact_row, int32_t* iota, float* loss_sum = nullptr, int32_t* n_tok = nullptr,    // the two scalars are zeroed
          // optional: slot of every compact node in the ascending code-row / memory-row lists (-1: not listed)
          int Nc = 0, const int32_t* code_rows = nullptr, int Cc = 0, int32_t* code_slot = nullptr,
-         const int32_t* mem_rows = nullptr, int Mc = 0, int32_t* mem_slot = nullptr);
+         const int32_t* mem_rows = nullptr, int Mc = 0, int32_t* mem_slot = nullptr,
+         // optional: computed target rows (fira_batch.dec_off) -> row_bt[compact row] = flat b*T+t, rows_c[k] = compact row of
+         // head row k; compact_row is then indexed by compact row
+         const int32_t* dec_off = nullptr, int32_t* row_bt = nullptr, int32_t* rows_c = nullptr);
+// the decoder's token embedding on a list of target rows (row_bt[r] = flat b*T + t) and its backward
+int embed_rows_fwd(hipStream_t s, int R, int T, const int32_t* row_bt, const int32_t* idx, const float* table,
+                   const float* pos, float* out);
+int embed_rows_bwd(hipStream_t s, int R, const int32_t* row_bt, const int32_t* idx, float* dtable, const float* dout,
+                   int padding_idx);
 int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
                   const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
                   float* X, const int32_t* slot2 = nullptr, float* X2 = nullptr);   // rows with a slot also go to X2[slot]
@@ -131,11 +141,14 @@ int permute_cache(hipStream_t s, int nl, int BR, int T, int len, const int32_t* 
                   const float* vsrc, float* kdst, float* vdst, const int32_t* hist_src, int32_t* hist_dst);
 int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist);
 
+// q_off (optional, [B+1]): ragged query rows -- batch entry b's queries are rows q_off[b] .. q_off[b+1] of Q / O / dO / dQ
+// (at most Tq of them); self_kv: its keys / values are the same rows of K / V (/ dK / dV).  key_valid stays dense.
 int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
-                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo);
+                  const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
+                  const int32_t* q_off = nullptr, int self_kv = 0);
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                     int kb, int kvb, int qpk);
+                     int kb, int kvb, int qpk, const int32_t* q_off = nullptr, int self_kv = 0);
 // one query per row (decode step): K/V streamed once per (commit, head) over the valid keys only; optional merged new key
 int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
@@ -143,17 +156,19 @@ int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int l
                      float* Vc_out = nullptr);
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
-                  const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
+                  const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
+                  const int32_t* q_off = nullptr, int self_kv = 0);
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score);
 // mem_valid (optional, [B/qpk, S]): slots with 0 are skipped (score 0 / zero gradient): they are masked to -1e9 later
 int copy_score_fwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* bias, float* score, int qpk, const int32_t* mem_valid,
-                      const int32_t* tar_label = nullptr, int V = 0);
+                      const int32_t* tar_label = nullptr, int V = 0,
+                      const int32_t* t_off = nullptr);      // [B+1] ragged target rows (tgt / score rows of commit b)
 // part (optional): [copy_score_bwd_blocks(B, S), COPY_PART_STRIDE] partial rows {dw[256] | dbias} instead of atomics
 int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                       const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias, const int32_t* mem_valid,
-                      float* part = nullptr);
+                      float* part = nullptr, const int32_t* t_off = nullptr);
 int copy_score_bwd_blocks(int B, int S);
 constexpr int COPY_PART_STRIDE = 264;
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
@@ -164,7 +179,8 @@ int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const f
                    const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias);
 int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,
               float* score, const int32_t* mem_valid, float* gate_logits, const int32_t* tar_label, float* loss_sum,
-              int32_t* n_tok, int32_t* argmax_out, int want_grad);
+              int32_t* n_tok, int32_t* argmax_out, int want_grad,
+              const int32_t* row_bt = nullptr);      // BT computed target rows, row_bt[r] = flat b*T + t (nullptr: r itself)
 int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
               float beta2, float eps, int step, const float* scale_ptr, int scale_is_count = 0);
 

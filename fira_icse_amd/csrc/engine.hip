@@ -51,7 +51,7 @@ struct DecGrad {
 struct Plan {
     int B, NB, CB, MB, TB, N, L, S, A, T, V, ldl, nl, F;
     float *pos_code, *pos_tar;
-    int32_t *mem_valid, *tar_valid, *compact_row, *iota, *code_slot, *mem_slot;
+    int32_t *mem_valid, *tar_valid, *compact_row, *iota, *code_slot, *mem_slot, *row_bt, *rows_c;
     std::vector<float*> X;          // nl + 1 node buffers
     std::vector<EncSave> enc;
     std::vector<DecSave> dec;
@@ -83,6 +83,8 @@ struct Plan {
         tar_valid = a.get<int32_t>((size_t)TB);
         compact_row = a.get<int32_t>((size_t)TB);
         iota = a.get<int32_t>((size_t)TB);
+        row_bt = a.get<int32_t>((size_t)TB);          // computed target rows (fira_batch.dec_off): compact row -> flat b*T + t
+        rows_c = a.get<int32_t>((size_t)TB);          // the head-row list in compact-row indexing
         code_slot = a.get<int32_t>((size_t)NB);
         mem_slot = a.get<int32_t>((size_t)NB);
         inv_ntok = a.f(64);
@@ -436,6 +438,25 @@ static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const
     }
     return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
 }
+// One encoder layer's three weight gradients (folded GCN weight, Combination output and q|k projections): queued while
+// the layer's data-gradient chain runs, then issued as ONE grouped launch behind ONE fork (enc_wgrads_flush) -- every fork
+// is an event record on the caller's stream, i.e. a barrier packet in the dependent chain (scripts/event_cost.py: ~4-5 us
+// each), and the layer used to pay four of them.  FIRA_ENC_WGRAD_GROUP=0: one fork + launch per gradient (A/B switch).
+static inline bool enc_group_on() {
+    static const bool off = [] { const char* e = getenv("FIRA_ENC_WGRAD_GROUP"); return e && e[0] == '0'; }();
+    SideStream& sd = side();
+    return !off && sd.stream && sd.enabled;
+}
+static inline int enc_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx, float* dW,
+                            float* db) {
+    if (!enc_group_on()) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    SideStream& sd = side();
+    if (g_dtype == 1) {
+        if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+        return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, 32);
+    }
+    return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, 32);
+}
 static inline int flush_grouped_wgrads(hipStream_t s) {
     SideStream& sd = side();
     if (!(sd.stream && sd.enabled)) return 0;
@@ -493,6 +514,13 @@ struct Ctx {
     // target rows that need the vocabulary head (fira_batch.head_rows, or nullptr = every row -> Plan::iota)
     int R = 0;
     const int32_t* rows = nullptr;
+    // computed target rows (fira_batch.dec_off + fira_train_opts.compact_dec): the decoder, the head and their backward run
+    // on Td rows -- commit b's are dec_off[b] .. dec_off[b+1], flat position row_bt[r]; rows / compact_row then index
+    // those rows (rows_dense keeps the caller's flat head-row list for the prep launch).  No list: Td = B*T, all nullptr.
+    int Td = 0;
+    const int32_t* dec_off = nullptr;
+    const int32_t* row_bt = nullptr;
+    const int32_t* rows_dense = nullptr;
     bool deferred = false;
     float* loss_sum = nullptr;      // zeroed by the prep launch (head_loss accumulates into them)
     int32_t* n_tok = nullptr;
@@ -512,9 +540,10 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     hipStream_t s = c.s;
     const int D = FIRA_D, Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem, KV = p.nl * 2 * D;
     // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
+    const int32_t* head_list = c.dec_off ? c.rows_dense : c.rows;          // flat (b*T + t) head rows, as the caller lists them
     TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
-             p.pos_tar, c.R, c.rows, bt.tar ? p.compact_row : nullptr, c.rows ? nullptr : p.iota, c.loss_sum, c.n_tok,
-             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot));
+             p.pos_tar, c.R, head_list, bt.tar ? p.compact_row : nullptr, head_list ? nullptr : p.iota, c.loss_sum, c.n_tok,
+             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot, c.dec_off, p.row_bt, p.rows_c));
     // layer 0's code rows are also stored compactly (Xc of the first Combination): no gather launch on the chain
     TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
                       p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc));
@@ -599,7 +628,8 @@ static int decoder_forward(Ctx& c) {
     const Layout& L = *c.L;
     hipStream_t s = c.s;
     const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
-    TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
+    if (c.row_bt) TRY(embed_rows_fwd(s, c.Td, p.T, c.row_bt, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0));
+    else TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
     ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
     const float* x = p.x0;
     // pend_*: a block whose pre-norm sums are stored but whose LayerNorm is still owed (it runs in the prologue of the next
@@ -610,14 +640,14 @@ static int decoder_forward(Ctx& c) {
     auto consume = [&](int N, const float* W, const float* b, float* Y, int flags) -> int {
         if (pend_sum) {
             int rc = 0;
-            const bool fused = gemm_tile32_ln_try(s, p.TB, N, pend_sum, D, W, b, Y, N, flags, pend_g, pend_b, pend_y, pend_st, &rc);
+            const bool fused = gemm_tile32_ln_try(s, c.Td, N, pend_sum, D, W, b, Y, N, flags, pend_g, pend_b, pend_y, pend_st, &rc);
             if (!fused)
-                rc = add_layernorm_fwd(s, p.TB, const_cast<float*>(pend_sum), nullptr, pend_g, pend_b, pend_y, pend_st, 0.f, 0, 0,
+                rc = add_layernorm_fwd(s, c.Td, const_cast<float*>(pend_sum), nullptr, pend_g, pend_b, pend_y, pend_st, 0.f, 0, 0,
                                        nullptr);
             pend_sum = nullptr;
             if (rc || fused) return rc;
         }
-        return linear(s, p.TB, N, D, x, D, W, b, Y, N, flags);
+        return linear(s, c.Td, N, D, x, D, W, b, Y, N, flags);
     };
     // closing product of a block: y = LN(dropout(X W^T + b) + res); its LayerNorm is deferred to the next product when the
     // shapes allow it
@@ -625,24 +655,26 @@ static int decoder_forward(Ctx& c) {
                            float* sum, float* y, float* st, uint32_t stt, bool may_defer, const int32_t* slot2, float* y2, int n2,
                            const int32_t* rows2) -> int {
         int rc = 0;
-        if (may_defer && linear_presum(s, p.TB, K, X, K, W, b, res, sum, c.p_drop, c.seed, stt, &rc)) {
+        if (may_defer && linear_presum(s, c.Td, K, X, K, W, b, res, sum, c.p_drop, c.seed, stt, &rc)) {
             pend_sum = sum; pend_g = g; pend_b = be; pend_y = y; pend_st = st;
             return rc;
         }
-        return linear_ln(s, p.TB, K, X, K, W, b, res, g, be, sum, y, st, c.p_drop, c.seed, stt, nullptr, nullptr, nullptr, slot2, y2,
+        return linear_ln(s, c.Td, K, X, K, W, b, res, g, be, sum, y, st, c.p_drop, c.seed, stt, nullptr, nullptr, nullptr, slot2, y2,
                          n2, rows2);
     };
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
         TRY(consume(3 * D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 0));
-        TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D));
+        TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D,
+                          c.dec_off, 1));
         TRY(close_block(D, e.ao, c.P + w.wo_s, c.P + w.bo_s, x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
                         site(l, SITE_SELF), true, nullptr, nullptr, 0, nullptr));
         x = e.x_a;
         TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
         if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
-        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D));
+        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D,
+                          c.dec_off, 0));
         TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
                         site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
         x = e.x_c;
@@ -670,19 +702,19 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     const float* dec = p.dec[p.nl - 1].x_f;
     // rows == Ctx::rows (a proper sub-list): decoder_forward stored them compactly already; every row: use them in place
     const float* dec_rows = (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec;
-    if (dec_rows == dec && R != p.TB) {                         // a sub-list the decoder pass did not know about
+    if (dec_rows == dec && R != c.Td) {                         // a sub-list the decoder pass did not know about
         TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));
         dec_rows = p.dec_c;
     }
     TRY(linear(s, R, p.V, D, dec_rows, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
-    TRY(gemm_any(s, 0, 1, p.TB, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
+    TRY(gemm_any(s, 0, 1, c.Td, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
     if (c.deferred) TRY(main_wait(s, c.ev_src));                   // LinearSource(memory) (side stream)
     // teacher-forced ids (dev) need every row's copy distribution; the training loss only the copy-labelled rows
     TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid,
-                          argmax_out ? nullptr : c.bt->tar_label, p.V));
-    TRY(linear(s, p.TB, 2, D, dec, D, c.P + L.wp, c.P + L.bp, p.gate, 2));
-    TRY(head_loss(s, p.TB, p.T, p.V, Sm, p.compact_row, p.logits, p.ldl, p.score, p.mem_valid, p.gate,
-                  c.bt->tar_label, loss_sum, n_tok, argmax_out, want_grad));
+                          argmax_out ? nullptr : c.bt->tar_label, p.V, c.dec_off));
+    TRY(linear(s, c.Td, 2, D, dec, D, c.P + L.wp, c.P + L.bp, p.gate, 2));
+    TRY(head_loss(s, c.Td, p.T, p.V, Sm, p.compact_row, p.logits, p.ldl, p.score, p.mem_valid, p.gate,
+                  c.bt->tar_label, loss_sum, n_tok, argmax_out, want_grad, c.row_bt));
     return 0;
 }
 
@@ -719,20 +751,20 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec, D, G + L.wout,
                          G + L.bout));
     }
-    TRY(linear_dgrad(s, p.TB, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
-    TRY(linear_wgrad_grouped(s, p.TB, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
+    TRY(linear_dgrad(s, c.Td, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
+    TRY(linear_wgrad_grouped(s, c.Td, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
     {
         const int nb = copy_score_bwd_blocks(p.B, Sm);
         float* part = red().alloc((size_t)nb * COPY_PART_STRIDE);
         TRY(copy_score_bwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, p.score, p.dsrc, p.dtgt, G + L.wres, G + L.bres,
-                              p.mem_valid, part));
+                              p.mem_valid, part, c.dec_off));
         if (part) {
             red().add(G + L.wres, part, D, nb, COPY_PART_STRIDE);
             red().add(G + L.bres, part + D, 1, nb, COPY_PART_STRIDE);
         }
     }
-    TRY(linear_dgrad(s, p.TB, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
-    TRY(linear_wgrad_grouped(s, p.TB, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
+    TRY(linear_dgrad(s, c.Td, D, D, p.dtgt, D, c.P + L.wt, p.ddec, D, true));
+    TRY(linear_wgrad_grouped(s, c.Td, D, D, p.dtgt, D, dec, D, G + L.wt, nullptr));
     TRY(rows_move(s, 0, Mc, D, p.dsrc_c, p.dsrc, bt.mem_dst, nullptr));
     // d memory (compact rows) = dsrc Ws + sum_l dKV_l Wkv_l: nothing reads it before the encoder's backward pass, so
     // the whole accumulation lives on the side stream (in order: this product initialises dmem_c, the per-layer
@@ -754,21 +786,21 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         DecGrad& g = p.decg[l];
         const float* x_in = l == 0 ? p.x0 : p.dec[l - 1].x_f;
         // FeedForward (gnn_transformer.py:170-174)
-        TRY(ln_bwd(s, p.TB, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
+        TRY(ln_bwd(s, c.Td, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
                               c.p_drop, c.seed, site(l, SITE_FFN)));
-        TRY(linear_wgrad_grouped(s, p.TB, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
+        TRY(linear_wgrad_grouped(s, c.Td, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
         // d hidden = (dYf W2) masked by the saved activation > 0: ReLU backward in the GEMM epilogue
-        TRY(gemm_any(s, 0, 0, p.TB, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
-        TRY(linear_wgrad_grouped(s, p.TB, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
-        TRY(linear_dgrad(s, p.TB, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
+        TRY(gemm_any(s, 0, 0, c.Td, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
+        TRY(linear_wgrad_grouped(s, c.Td, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
+        TRY(linear_dgrad(s, c.Td, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
         // cross attention
-        TRY(ln_bwd(s, p.TB, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
+        TRY(ln_bwd(s, c.Td, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
                               c.p_drop, c.seed, site(l, SITE_CROSS)));
-        TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
-        TRY(linear_dgrad(s, p.TB, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
+        TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
+        TRY(linear_dgrad(s, c.Td, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                           p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, KV,
-                          p.dkv_all + l * 2 * D + D, KV));
+                          p.dkv_all + l * 2 * D + D, KV, c.dec_off, 0));
         if (so) {                                // this layer's dK|dV -> compact rows -> d memory, beside the chain
             const size_t o = (size_t)l * 2 * D;
             TRY(aux_fork(s));
@@ -778,24 +810,25 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
             prof_decoder_tag(+1);
             TRY(rc_kv);
         }
-        TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
-        TRY(linear_dgrad(s, p.TB, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
+        TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
+        TRY(linear_dgrad(s, c.Td, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
         // self attention
-        TRY(ln_bwd(s, p.TB, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
+        TRY(ln_bwd(s, c.Td, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
                               c.p_drop, c.seed, site(l, SITE_SELF)));
-        TRY(linear_wgrad_grouped(s, p.TB, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
-        TRY(linear_dgrad(s, p.TB, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
+        TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
+        TRY(linear_dgrad(s, c.Td, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
         TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
-                          e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D));
-        TRY(linear_wgrad_grouped(s, p.TB, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
-        TRY(linear_dgrad(s, p.TB, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
+                          e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1));
+        TRY(linear_wgrad_grouped(s, c.Td, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
+        TRY(linear_dgrad(s, c.Td, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
         dy = p.dT_a;
     }
     TRY(flush_grouped_wgrads(s));                                  // the decoder's and the head's small weight gradients
     // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions
     // carry an exactly-zero gradient (never attended as keys, zero loss weight): skipping id 0 only drops the
     // hundreds of serialised atomic additions of 0.0 onto table row 0.
-    TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
+    if (c.row_bt) TRY(embed_rows_bwd(s, c.Td, c.row_bt, c.bt->tar, G + L.dec_emb, dy, 0));
+    else TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
     // cross-attention K|V projections of all layers (computed memory rows only)
     hipEvent_t ev_dmem = nullptr;
     if (so) {
@@ -843,22 +876,29 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         //   and back to the reference's parameters: dW2 += dW21 W1^T + dc b1^T, dW1 += W2^T dW21, db1 += W2^T dc
         float* dW21 = p.dW21 + (size_t)l * D * D;
         float* dc21 = p.dc21 + (size_t)l * D;
-        TRY(linear_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, dW21, G + w.fc2b));
-        {
+        const bool grouped = enc_group_on();
+        // back to the reference's parameters (reads dW21: after its weight gradient on the same stream)
+        auto unfold = [&]() -> int {
             hipStream_t ws = s;
-            if (side().stream && side().enabled) { TRY(side_fork(s)); ws = side().stream; }
+            if (side().stream && side().enabled) {
+                if (!grouped) TRY(side_fork(s));
+                ws = side().stream;
+            }
             TRY(colsum(ws, Nc, D, g.dY2, D, dc21, p.rsum));
             TRY(gemm_f32_ex(ws, 0, 1, D, D, D, dW21, D, c.P + w.fc1w, D, G + w.fc2w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
             TRY(gemm_f32_ex(ws, 1, 0, D, D, D, c.P + w.fc2w, D, dW21, D, G + w.fc1w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
             TRY(gcn_bias_unfold(ws, c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b));
-        }
+            return 0;
+        };
+        TRY(enc_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, dW21, G + w.fc2b));
+        if (!grouped) TRY(unfold());
         TRY(linear_dgrad(s, Nc, D, D, g.dY2, D, p.W21 + (size_t)l * D * D, p.dNB2, D, false));  // dU
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, other, D, 0, 1, 1, nullptr));   // other = ds + A_hat dU
         // Combination on the code rows, in place inside `other` through the code-row map: the LayerNorm backward reads
         // dG[code rows] and leaves the residual-branch gradient there; the q|k projection's dgrad adds to the same rows
         TRY(ln_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,
                               c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
-        TRY(linear_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
+        TRY(enc_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
         TRY(linear_dgrad(s, Cc, D, D, g.dYc, D, c.P + w.wo, p.dCB_a, D, false));               // d c
         {
             const int nb = combination_bwd_blocks(Cc);
@@ -869,7 +909,11 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                 for (int k = 0; k < 4; ++k)
                     red().add(p.dvtab_all + (size_t)k * p.nl * D + l * D, part + k * D, D, nb, 4 * D);
         }
-        TRY(linear_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
+        TRY(enc_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
+        if (grouped) {                           // the layer's three weight gradients: one fork, one launch, then the unfold
+            TRY(flush_grouped_wgrads(s));
+            TRY(unfold());
+        }
         TRY(gemm_any(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
                         bt.code_rows));                                                        // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
@@ -977,24 +1021,38 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     const ShadowTable* tab = bf16 ? shadow_table(*L) : nullptr;
     ShadowScope shadow_scope(params, L->total, bf16 ? p.wb : nullptr, bf16 ? p.wbt : nullptr, tab);
     if (bf16) TRY(weight_shadows(c.s, *tab, params, p.wb, p.wbt));
-    int R = p.TB;
+    // computed target rows: the decoder / head run on the prefix rows the batch lists (fira_batch.dec_off)
+    c.Td = p.TB;
+    if (opts && opts->compact_dec && batch->dec_off) {
+        FIRA_REQUIRE(batch->n_dec_rows >= batch->B && batch->n_dec_rows <= p.TB, "bad n_dec_rows %d", batch->n_dec_rows);
+        c.Td = batch->n_dec_rows;
+        c.dec_off = batch->dec_off;
+        c.row_bt = p.row_bt;
+    }
+    int R = c.Td;
     const int32_t* rows = p.iota;
     if (opts && opts->compact_head && batch->head_rows) {
         R = batch->n_head_rows;
-        rows = batch->head_rows;
-        FIRA_REQUIRE(R >= 0 && R <= p.TB, "bad n_head_rows %d", R);
+        FIRA_REQUIRE(R >= 0 && R <= c.Td, "bad n_head_rows %d", R);
+        c.rows_dense = batch->head_rows;
+        rows = c.dec_off ? p.rows_c : batch->head_rows;        // in the indexing of the rows the decoder computes
         c.R = R;
         c.rows = rows;
     }
     c.loss_sum = loss_sum;
     c.n_tok = n_tok;
+    const bool zero_g = opts && opts->zero_grads;
     if (side_on()) {
         // the buffers the backward pass accumulates into are cleared now, on the auxiliary stream, beside the encoder's
-        // forward pass (they are backward-only; the previous step is complete at this point of the caller's stream)
+        // forward pass (they are backward-only; the previous step is complete at this point of the caller's stream) -- and
+        // with them, on request, the gradient buffer itself (111 MB the caller would otherwise fill ahead of the step)
         TRY(aux_fork(c.s));
         TRY(zero(side().aux, p.zero_beg, (size_t)((char*)p.zero_end - (char*)p.zero_beg)));
         TRY(zero(side().aux, p.dXa, (size_t)batch->n_nodes * FIRA_D * sizeof(float)));
+        if (zero_g) TRY(zero(side().aux, grads, (size_t)L->live * sizeof(float)));
         TRY(side_mark(&c.ev_zero));
+    } else if (zero_g) {
+        TRY(zero(c.s, grads, (size_t)L->live * sizeof(float)));
     }
     TRY(encoder_forward(c, true));
     TRY(decoder_forward(c));
@@ -1016,6 +1074,7 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
     FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     TRY(check_counts(batch, p));
     Ctx c{(hipStream_t)stream, L, batch, params, nullptr, &p, 0.f, 0.f, 0};
+    c.Td = p.TB;
     c.loss_sum = loss_sum;
     c.n_tok = n_tok;
     const ShadowTable* tab = dtype == 1 ? shadow_table(*L) : nullptr;
@@ -1150,6 +1209,7 @@ int fira_decoder_forward(void* stream, const fira_dims* d, const float* params, 
     b.B = B;
     b.tar = tar;
     Ctx c{s, L, &b, params, nullptr, &p, 0.f, 0.f, 0};
+    c.Td = p.TB;
     TRY(fill_pos_tables(s, p.L, p.pos_code, p.T, p.pos_tar));
     hipError_t e = hipMemcpyAsync(p.mem_valid, mem_valid, (size_t)p.MB * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return set_err("hipMemcpyAsync: %s", hipGetErrorString(e));

@@ -764,7 +764,7 @@ int gemm_bf16_group_flush(hipStream_t s) {
 }
 // dW[M,N] += A^T B with A = dY [K,M], B = X [K,N]; db[M] += column sums of dY.  Queued; runs at the next flush on `s`.
 int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                              float* C, int ldc, float* colsum) {
+                              float* C, int ldc, float* colsum, int max_split) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     FIRA_REQUIRE(bf16_shape_ok(1, 0, M, N, K, A, lda, B, ldb), "gemm_bf16_group_add_wgrad: unsupported shape %dx%dx%d", M, N, K);
     GroupTable16& t = group16().t;
@@ -778,7 +778,7 @@ int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A
     q.tiles_m = cdiv(M, 64); q.tiles_n = cdiv(N, 64);
     // the group shares the chip (a few thousand workgroups in all): short K chains (<= 8 tiles) matter more than the
     // extra atomics of a split
-    q.splitk = std::max(1, std::min(8, K / 512));
+    q.splitk = std::max(1, std::min(max_split > 0 ? max_split : 8, K / 512));
     q.k_chunk = cdiv(cdiv(K, q.splitk), HK) * HK;
     t.wg_start[t.n + 1] = t.wg_start[t.n] + q.tiles_m * q.tiles_n * q.splitk;
     ++t.n;

@@ -449,7 +449,7 @@ int gemm_group_flush(hipStream_t s) {
 }
 // dW[M,N] += A^T B with A = dY [K,M], B = X [K,N]; db[M] += column sums of dY.  Queued; runs at the next flush on `s`.
 int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
-                         int ldc, float* colsum) {
+                         int ldc, float* colsum, int max_split) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     GroupTable& t = group().t;
     if (t.n == GROUP_MAX) {
@@ -462,6 +462,7 @@ int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int
     q.tiles_n = cdiv(N, 64);
     // the whole group shares the chip: two K splits per tile keep the tail short without drowning the result in atomics
     q.splitk = K >= 512 ? 2 : 1;
+    if (max_split > 0) q.splitk = std::max(1, std::min(max_split, K / 512));
     q.k_chunk = cdiv(cdiv(K, q.splitk), BK) * BK;
     t.wg_start[t.n + 1] = t.wg_start[t.n] + cdiv(M, 64) * q.tiles_n * q.splitk;
     ++t.n;

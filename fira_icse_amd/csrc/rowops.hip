@@ -51,6 +51,37 @@ __global__ __launch_bounds__(256) void embed_gather_bwd_kernel(int rows, int L, 
     unsafeAtomicAdd(p + 3, g.w);
 }
 
+// The decoder's token embedding on the computed target rows (fira_batch.dec_off): compact row r is flat position
+// row_bt[r] = b*T + t;  out[r] = table[idx[b*T+t]] + pos[t]  and its backward (padding_idx semantics as above).
+__global__ __launch_bounds__(256) void embed_rows_fwd_kernel(int R, int T, const int32_t* __restrict__ row_bt,
+                                                             const int32_t* __restrict__ idx,
+                                                             const float* __restrict__ table,
+                                                             const float* __restrict__ pos, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int d = row_bt[r], t = d % T;
+    float4 v = *reinterpret_cast<const float4*>(table + (size_t)idx[d] * FIRA_D + lane * 4);
+    const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)t * FIRA_D + lane * 4);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    *reinterpret_cast<float4*>(out + (size_t)r * FIRA_D + lane * 4) = v;
+}
+__global__ __launch_bounds__(256) void embed_rows_bwd_kernel(int R, const int32_t* __restrict__ row_bt,
+                                                             const int32_t* __restrict__ idx, float* __restrict__ dtable,
+                                                             const float* __restrict__ dout, int padding_idx) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int id = idx[row_bt[r]];
+    if (id == padding_idx) return;
+    const float4 g = *reinterpret_cast<const float4*>(dout + (size_t)r * FIRA_D + lane * 4);
+    float* p = dtable + (size_t)id * FIRA_D + lane * 4;
+    unsafeAtomicAdd(p + 0, g.x);
+    unsafeAtomicAdd(p + 1, g.y);
+    unsafeAtomicAdd(p + 2, g.z);
+    unsafeAtomicAdd(p + 3, g.w);
+}
+
 // Grouped form: the positions were grouped by table row on the host (fira_batch.emb_*).  One wave per item sums its
 // <= 32 gradient rows in registers and adds the result to the table row once: a token that occurs 1000 times in the
 // batch costs 32 same-address atomics per element instead of 1000 serialised ones.
@@ -462,7 +493,11 @@ __global__ void prep_kernel(int B, int L, int S, int T, const int32_t* __restric
                             int R, const int32_t* __restrict__ rows, int32_t* __restrict__ compact_row,
                             int32_t* __restrict__ iota, float* __restrict__ loss_sum, int32_t* __restrict__ n_tok,
                             int Nc, const int32_t* __restrict__ code_rows, int Cc, int32_t* __restrict__ code_slot,
-                            const int32_t* __restrict__ mem_rows, int Mc, int32_t* __restrict__ mem_slot) {
+                            const int32_t* __restrict__ mem_rows, int Mc, int32_t* __restrict__ mem_slot,
+                            // computed target rows (fira_batch.dec_off; nullptr = every row): row_bt[compact row] = its flat
+                            // b*T + t index, rows_c[k] = compact row of head row k; compact_row is then indexed by compact row
+                            const int32_t* __restrict__ dec_off, int32_t* __restrict__ row_bt,
+                            int32_t* __restrict__ rows_c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int W = L + S;
     if (code_slot && i < Nc) {
@@ -496,7 +531,15 @@ __global__ void prep_kernel(int B, int L, int S, int T, const int32_t* __restric
                 }
                 v = (lo < R && rows[lo] == i) ? lo : -1;
             }
-            compact_row[i] = v;
+            int ci = i;                          // position of flat row i in the computed-row layout (-1: left out)
+            if (dec_off) {
+                const int b = i / T, t = i - b * T, o = dec_off[b];
+                ci = t < dec_off[b + 1] - o ? o + t : -1;
+                if (ci >= 0) row_bt[ci] = i;
+                if (rows && v >= 0) rows_c[v] = ci >= 0 ? ci : 0;      // (a head row is always a computed row)
+                if (!rows) v = ci;                                     // no head-row list: every computed row, in order
+            }
+            if (ci >= 0) compact_row[ci] = v;
         }
         if (iota) iota[i] = i;
     }
@@ -576,11 +619,12 @@ int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid) {
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,
          int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
          int32_t* compact_row, int32_t* iota, float* loss_sum, int32_t* n_tok, int Nc, const int32_t* code_rows, int Cc,
-         int32_t* code_slot, const int32_t* mem_rows, int Mc, int32_t* mem_slot) {
+         int32_t* code_slot, const int32_t* mem_rows, int Mc, int32_t* mem_slot, const int32_t* dec_off, int32_t* row_bt,
+         int32_t* rows_c) {
     const int n = std::max(std::max(std::max(B * (L + S), B * T), (L + T) * FIRA_D), code_slot ? Nc : 0);
     hipLaunchKernelGGL(prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid, tar_valid,
                        pos_code, pos_tar, R, rows, compact_row, iota, loss_sum, n_tok, Nc, code_rows, Cc, code_slot, mem_rows,
-                       Mc, mem_slot);
+                       Mc, mem_slot, dec_off, row_bt, rows_c);
     FIRA_CHECK_LAUNCH("prep");
     return 0;
 }
@@ -608,6 +652,22 @@ int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const floa
     hipLaunchKernelGGL(embed_gather_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, rows, L, idx, table, pos, out,
                        out_bstride, out_off);
     FIRA_CHECK_LAUNCH("embed_gather_fwd");
+    return 0;
+}
+int embed_rows_fwd(hipStream_t s, int R, int T, const int32_t* row_bt, const int32_t* idx, const float* table,
+                   const float* pos, float* out) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(embed_rows_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, R, T, row_bt, idx, table, pos, out);
+    FIRA_CHECK_LAUNCH("embed_rows_fwd");
+    return 0;
+}
+int embed_rows_bwd(hipStream_t s, int R, const int32_t* row_bt, const int32_t* idx, float* dtable, const float* dout,
+                   int padding_idx) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    if (R <= 0) return 0;
+    hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, R, row_bt, idx, dtable, dout, padding_idx);
+    FIRA_CHECK_LAUNCH("embed_rows_bwd");
     return 0;
 }
 int embed_gather_bwd_small(hipStream_t s, int B, int L, const int32_t* idx, float* dtable, const float* dout,

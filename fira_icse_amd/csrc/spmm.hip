@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
 // 4 rows at once with register sums only.  A row's (col, val) list is first copied into LDS with coalesced loads by
 // the group's own 16 lanes, so the inner loop touches LDS only: one broadcast ds_read_b64 for (col, val) and one
 // ds_read_b128 for the neighbour's float4, 8 neighbours in flight per lane.
+// crossover densities (fira_csr_spmm; profiles/r3_spmm_crossover.md): CSR row-wave below 2 %; fp32: the LDS-slab CSR
+// kernel up to ~27 %, the block-dense fp32 MFMA kernel above (it is MFMA-bound: 17 GFLOP per launch whatever the
+// density); bf16 operands allowed: the block-dense bf16 kernel from 2.5 %
+constexpr double SPMM_LDS_AT = 0.02, SPMM_DENSE_AT_F32 = 0.27, SPMM_DENSE_AT_BF16 = 0.025;
 constexpr int SLAB = 64;
 constexpr int STAGE = 64;             // (col,val) entries staged per group per pass
 constexpr int LDS_WAVES = 16;         // 1024 threads: 4 waves per SIMD keep the LDS pipe busy
@@ -179,6 +183,8 @@ __global__ __launch_bounds__(1024) void spmm_lds_kernel(int graph_rows, const in
 
 int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                 int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum);
+int csr_spmm_dense(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                   int ldx, float* Y, int ldy, int graph_rows, int bf16);          // spmm_dense.hip
 int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
              int ldx, float* Y, int ldy, int graph_rows, int variant) {
     return csr_spmm_ex(s, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant, 0, nullptr);
@@ -186,7 +192,9 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
 int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                 int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum) {
     if (n_rows <= 0) return 0;
-    FIRA_REQUIRE(!((accum || rowsum) && variant == 2), "csr_spmm: accumulate / row sums need the row-per-wave variant");
+    FIRA_REQUIRE(!((accum || rowsum) && variant >= 2), "csr_spmm: accumulate / row sums need the row-per-wave variant");
+    FIRA_REQUIRE(variant >= 0 && variant <= 4, "csr_spmm: variant must be 0..4");
+    if (variant >= 3) return csr_spmm_dense(s, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant == 4);
     FIRA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0),
                  "csr_spmm: feature rows must be 16-byte aligned");
     if (variant == 0) variant = 1;
@@ -216,6 +224,27 @@ int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t*
 }
 
 }  // namespace fira
+
+// Variant choice from the measured crossover (profiles/r3_spmm_crossover.md; 128 graphs x 512 nodes): the row-per-wave CSR
+// kernel wins while a row gathers a handful of neighbours, then the LDS-slab CSR kernel, then the block-dense MFMA kernels
+// (thresholds above: fraction of the N x N block that is non-zero); bf16 operands only where the caller's dtype says so.
+extern "C" int fira_csr_spmm(void* stream, int n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col,
+                             const float* val, const float* X, int ldx, float* Y, int ldy, int graph_rows, int variant,
+                             int dtype) {
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_csr_spmm: dtype must be FIRA_F32 or FIRA_BF16");
+    if (variant == 0) {
+        variant = 1;
+        if (graph_rows > 0 && graph_rows <= 512 && n_rows > 0 && n_rows % graph_rows == 0) {
+            const double density = (double)nnz / ((double)n_rows * graph_rows);
+            if (dtype == FIRA_BF16 && density >= fira::SPMM_DENSE_AT_BF16) variant = 4;
+            else if (density >= fira::SPMM_DENSE_AT_F32) variant = 3;
+            else if (density >= fira::SPMM_LDS_AT) variant = 2;
+        }
+    } else if (variant == 3 && dtype == FIRA_BF16) {
+        variant = 4;
+    }
+    return fira::csr_spmm((hipStream_t)stream, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant);
+}
 
 extern "C" int fira_csr_spmm_f32(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col,
                                  const float* val, const float* X, int ldx, float* Y, int ldy, int graph_rows,

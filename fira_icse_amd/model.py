@@ -287,6 +287,19 @@ class DeviceBatch:
             head_rows = np.nonzero(((shifted > 0) & (shifted < V)).reshape(-1))[0]
             self.n_head_rows = int(head_rows.shape[0])
         self.n_ast_items, self.n_emb_items = int(ast_rows.shape[0]), int(item_tok.shape[0])
+        # computed target rows (fira_batch.dec_off): per commit the prefix of positions that are read by someone -- as an
+        # attention key (tar != 0) or as a loss row (shifted label != 0); the padded tail is left out of the decoder
+        dec_off, self.n_dec_rows, self.dec_rows_host = None, 0, None
+        if hb.tar is not None and hb.tar_label is not None:
+            T = hb.tar.shape[1]
+            used = np.asarray(hb.tar) != 0
+            used[:, :-1] |= np.asarray(hb.tar_label)[:, 1:] != 0
+            length = np.where(used.any(axis=1), T - np.argmax(used[:, ::-1], axis=1), 1).astype(np.int64)
+            dec_off = np.zeros(self.B + 1, dtype=np.int64)
+            np.cumsum(length, out=dec_off[1:])
+            self.n_dec_rows = int(dec_off[-1])
+            b_of = np.repeat(np.arange(self.B, dtype=np.int64), length)
+            self.dec_rows_host = (b_of * T + np.arange(self.n_dec_rows) - dec_off[b_of]).astype(np.int32)   # dense b*T + t
         fields = [("sou", hb.sou, np.int32), ("tar", hb.tar, np.int32), ("mark", hb.mark, np.int32),
                   ("ast_change", hb.ast_change, np.int32), ("tar_label", hb.tar_label, np.int32),
                   ("sub_token", hb.sub_token, np.int32), ("node_rows", node_rows, np.int32),
@@ -295,7 +308,7 @@ class DeviceBatch:
                   ("mem_rows", mem_rows, np.int32), ("mem_dst", mem_dst, np.int32), ("head_rows", head_rows, np.int32),
                   ("ast_rows", ast_rows, np.int32), ("ast_ids", ast_ids, np.int32),
                   ("emb_item_tok", item_tok, np.int32), ("emb_item_ptr", item_ptr, np.int32),
-                  ("emb_rows", emb_rows, np.int32)]
+                  ("emb_rows", emb_rows, np.int32), ("dec_off", dec_off, np.int32)]
         plan, off = [], 0
         for name, a, dt in fields:
             if a is None:
@@ -345,7 +358,7 @@ class DeviceBatch:
             p(self.sub_token), self.n_nodes, p(self.node_rows), p(self.rowptr), p(self.col), p(self.val), self.n_code,
             p(self.code_rows), p(self.code_mark), self.n_mem, p(self.mem_rows), p(self.mem_dst), p(self.head_rows),
             self.n_head_rows, self.n_emb_items, p(self.emb_item_tok), p(self.emb_item_ptr), p(self.emb_rows),
-            self.n_ast_items, p(self.ast_rows), p(self.ast_ids))
+            self.n_ast_items, p(self.ast_rows), p(self.ast_ids), p(self.dec_off), self.n_dec_rows)
 
     def wait_ready(self):
         """Order the CURRENT stream behind this batch's host->device copy.  The copy is enqueued on the stream that was
@@ -403,6 +416,8 @@ class TransModel(nn.Module):
         self.dropout_rank = 0
         self.dropout_step = 0
         self.compact_head = True
+        # training: decoder / head on the computed target rows only (fira_batch.dec_off); FIRA_COMPACT_DEC=0: A/B switch
+        self.compact_dec = os.environ.get("FIRA_COMPACT_DEC", "1") != "0"
         self.compute_dtype = "f32"             # "f32" (the reference's arithmetic) | "bf16" (BASELINE configs[2])
         if init:
             self.load_state_dict(reference_init_state_dict(self.cfg))
@@ -447,12 +462,13 @@ class TransModel(nn.Module):
         run_model.py:104-108 minus the optimizer).  Dropout follows ``self.training`` unless given."""
         lib = _lib.lib()
         db.wait_ready()
-        if zero_grad:
-            self.gbuf[:self.layout.live].zero_()           # tensors past `live` never receive a gradient (SURVEY.md F6)
+        # zero_grad: the library clears gbuf[0, live) itself (opts.zero_grads), beside the encoder's forward pass; tensors
+        # past `live` never receive a gradient (SURVEY.md F6)
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
         pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
         self.dropout_step += 1
-        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0, self._dtype_code())
+        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0, self._dtype_code(),
+                              1 if self.compact_dec else 0, 1 if zero_grad else 0)
         ws = self.workspace(db.B, 1)
         _lib.check(lib.fira_train_fwd_bwd(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                           _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),

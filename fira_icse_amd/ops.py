@@ -63,10 +63,18 @@ def gemm_wb(A, Bb, *, bias=None, relu=False, out=None, accumulate=False, splitk=
     return out
 
 
-def csr_spmm(rowptr, col, val, X, graph_rows=0, variant=0, out=None):
-    X = _f32(X)
-    Y = torch.empty_like(X) if out is None else _f32(out)
+def csr_spmm(rowptr, col, val, X, graph_rows=0, variant=0, out=None, dtype=0, auto=False):
+    """Z = A_hat X over a block-diagonal CSR.  variant 1/2: CSR gather kernels, 3/4: block-dense fp32 / bf16 MFMA;
+    ``auto`` (with variant 0): the library picks by density (fira_csr_spmm), ``dtype`` 1 allows bf16 operands."""
+    for t in (X,) + ((out,) if out is not None else ()):      # rows may be strided (a column block of a wider buffer)
+        assert t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1
+    Y = torch.empty_like(X, memory_format=torch.contiguous_format) if out is None else out
     assert Y.shape == X.shape
+    if auto or variant >= 3:
+        check(_lib.lib().fira_csr_spmm(cur_stream(), X.shape[0], int(col.numel()), ptr(_i32(rowptr)), ptr(_i32(col)),
+                                       ptr(_f32(val)), ptr(X), X.stride(0), ptr(Y), Y.stride(0), graph_rows, variant, dtype),
+              "fira_csr_spmm")
+        return Y
     check(_lib.lib().fira_csr_spmm_f32(cur_stream(), X.shape[0], ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)),
                                        ptr(X), X.stride(0), ptr(Y), Y.stride(0), graph_rows, variant),
           "fira_csr_spmm_f32")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 4
+#define FIRA_ABI_VERSION 5
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -79,6 +79,16 @@ typedef struct fira_batch {
     int32_t n_ast_items;
     const int32_t* ast_rows;     /* [n_ast_items] compact node ids                                               */
     const int32_t* ast_ids;      /* [n_ast_items] their ast_change ids (never 0)                                  */
+    /* ---- optional (v5): computed TARGET rows.  The decoder of a training step only has to run on the positions that are
+     * read by someone: position t of commit b matters as an attention key while tar[b,t] != 0 and as a loss row while the
+     * shifted label tar_label[b,t+1] != 0 -- the padded tail (about 45 % of the B*30 rows on FIRA's data; it is computed by
+     * the reference too, gnn_transformer.py:108-122, but carries zero loss weight, Model.py:82, and is masked as a key)
+     * can be left out.  dec_off[b] .. dec_off[b+1] = the range of commit b's rows in the compact target-row layout; the
+     * rows kept are the PREFIX t < dec_off[b+1] - dec_off[b] of its tar_len positions (so compact position == position,
+     * causal order is preserved) and the prefix must cover every position with a non-zero id or shifted label.
+     * NULL (or fira_train_opts.compact_dec == 0) = all B*tar_len rows. */
+    const int32_t* dec_off;      /* [B + 1] ascending, dec_off[0] = 0, 1 <= dec_off[b+1] - dec_off[b] <= tar_len          */
+    int32_t n_dec_rows;          /* dec_off[B]                                                                         */
 } fira_batch;
 
 typedef struct fira_train_opts {
@@ -89,6 +99,11 @@ typedef struct fira_train_opts {
     int32_t  dtype;          /* FIRA_F32 (reference arithmetic) or FIRA_BF16: nn.Linear products on the bf16 MFMA with
                                 fp32 accumulation (operands rounded to bf16, everything stored in fp32) -- BASELINE
                                 configs[2]; LayerNorm / soft-max / loss / Adam are fp32 in both modes           */
+    int32_t  compact_dec;    /* (v5) 1 = run the decoder / output head on the rows of fira_batch.dec_off only: loss and
+                                gradients are those of the dense run (only rows nobody reads are skipped); the dropout
+                                element index of a decoder site is then (compact row) * 256 + column            */
+    int32_t  zero_grads;     /* (v5) 1 = the call clears grads[0, live) itself, beside the encoder's forward pass on a
+                                library-owned stream, instead of the caller filling 111 MB ahead of the step    */
 } fira_train_opts;
 #define FIRA_F32 0
 #define FIRA_BF16 1
@@ -157,6 +172,16 @@ int fira_gemm_bf16_wb(void* stream, int M, int N, int K, const float* A, int lda
  * (needs graph_rows > 0: rows per graph, cols local to the graph's row block).                  */
 int fira_csr_spmm_f32(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val,
                       const float* X, int ldx, float* Y, int ldy, int graph_rows, int variant);
+/* The same aggregation with the block-dense MFMA variants and the measured variant choice:
+ *   3  block-dense, fp32 MFMA   (graph_rows <= 512; a workgroup densifies 32 rows of one graph's adjacency into LDS
+ *                                and multiplies them with the graph's feature rows: the literal torch.bmm of
+ *                                gnn_transformer.py:80, fp32 arithmetic)
+ *   4  block-dense, bf16 MFMA   (A_hat and X rounded to bf16, fp32 accumulate: torch.autocast's bmm, FIRA_BF16 only)
+ *   0  auto: by density nnz / (n_rows * graph_rows) -- row-per-wave CSR below the measured crossover, block-dense above
+ *      (profiles/r3_spmm_crossover.md); dtype (FIRA_F32 | FIRA_BF16) says whether bf16 operands are allowed.
+ * CSR rows must hold sorted column ids (equal neighbours are summed), as data.py builds them.                       */
+int fira_csr_spmm(void* stream, int n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
+                  const float* X, int ldx, float* Y, int ldy, int graph_rows, int variant, int dtype);
 
 /* out[(b*out_bstride + out_off + i), :] = table[idx[b*L + i], :] (+ pos[i,:])  — the embedding
  * gathers of gnn_transformer.py:46-52,110-113 written straight into the node buffer.           */

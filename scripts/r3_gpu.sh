@@ -49,6 +49,19 @@ for ST in "$@"; do
       python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_dec -name "*results.db" | head -1) 1 > $OUT/kernel_stats_decode.md 2>&1
       find $OUT/prof_dec -name "*.db" -delete
       cd $REPO; head -n 40 $OUT/kernel_stats_decode.md ;;
+    cross)
+      timeout 600 python scripts/spmm_crossover.py > $OUT/spmm_crossover.md 2> $OUT/spmm_crossover.err; echo "crossover rc=$?"; cat $OUT/spmm_crossover.md; tail -n 3 $OUT/spmm_crossover.err ;;
+    newtests)
+      timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_spmm_bench_gpu.py tests/test_model_gpu.py tests/test_dropout_gpu.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -x > $OUT/newtests.log 2>&1
+      tail -n 15 $OUT/newtests.log ;;
+    ab)
+      for i in 1 2; do
+        for V in "FIRA_COMPACT_DEC=0 FIRA_ENC_WGRAD_GROUP=0" "FIRA_COMPACT_DEC=0 FIRA_ENC_WGRAD_GROUP=1" "FIRA_COMPACT_DEC=1 FIRA_ENC_WGRAD_GROUP=1"; do
+          for BS in 32 64; do
+            echo -n "$V batch $BS: "; env $V timeout 300 python bench.py --batch $BS --no-decode --no-cpu-baseline --no-extras --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']), 'commits/s', round(d['ms_per_step'],3), 'ms', 'host', round(d['host_enqueue_ms_per_step'],2))"
+          done
+        done
+      done 2>&1 | tee $OUT/ab.txt ;;
     shapes)
       timeout 300 python scripts/gemm_step_shapes.py f32 32 > $OUT/gemm_shapes_f32_b32.txt 2>&1
       timeout 300 python scripts/gemm_step_shapes.py f32 64 > $OUT/gemm_shapes_f32_b64.txt 2>&1

@@ -72,8 +72,10 @@ def test_training_mode_loss_and_gradients_vs_oracle_with_the_same_masks():
             m = ops.dropout_mask(seed, site, db.n_nodes * 256, p).cpu().view(-1, 256)
             full = torch.ones(B * N, 256)
             full[node_rows] = m
-        else:                                                  # decoder sites: x [B, T, 256], rows b*T + t
-            full = ops.dropout_mask(seed, site, B * T * 256, p).cpu().view(-1, 256)
+        else:                                                  # decoder sites: x [B, T, 256]; rows = computed target rows
+            m = ops.dropout_mask(seed, site, db.n_dec_rows * 256, p).cpu().view(-1, 256)
+            full = torch.ones(B * T, 256)                      # (the padded tail is not computed: its mask is irrelevant)
+            full[torch.from_numpy(db.dec_rows_host).long()] = m
         return x * full.view(x.shape)
 
     tb = util.to_torch_batch(hb, cfg)

@@ -106,3 +106,25 @@ def test_native_collate_rejects_an_index_outside_the_store(store):
     cfg, st = store
     with pytest.raises((FiraError, IndexError)):
         st.batch([0, len(st)])
+
+
+def test_computed_target_rows_are_the_prefix_that_covers_keys_and_loss_rows(store):
+    """fira_batch.dec_off (DeviceBatch): per commit the shortest prefix of the 30 target positions that contains every
+    non-zero id (attention keys) and every position whose shifted label is non-zero (loss rows); at least one row."""
+    cfg, st = store
+    hb = st.batch(range(40))
+    hb.tar[3, :] = 0                                  # a commit without any target token keeps one row
+    hb.tar_label[3, :] = 0
+    hb.tar[5, 20] = 7                                 # a hole: position 20 used although 12..19 may be padding
+    db = M.DeviceBatch(hb, cfg, device="cpu")
+    off = db.dec_off.numpy()
+    T = cfg.tar_len
+    assert off[0] == 0 and off[-1] == db.n_dec_rows == len(db.dec_rows_host)
+    tar, lab = np.asarray(hb.tar), np.asarray(hb.tar_label)
+    for b in range(len(hb)):
+        n = int(off[b + 1] - off[b])
+        used = [t for t in range(T) if tar[b, t] != 0 or (t + 1 < T and lab[b, t + 1] != 0)]
+        assert n == (max(used) + 1 if used else 1), (b, n, used)
+        assert list(db.dec_rows_host[off[b]:off[b + 1]]) == [b * T + t for t in range(n)]
+    assert off[4] - off[3] == 1 and off[6] - off[5] >= 21
+    assert db.n_dec_rows < len(hb) * T                # the synthetic messages are shorter than 30 tokens

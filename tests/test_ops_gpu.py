@@ -112,6 +112,69 @@ def test_csr_spmm_vs_dense_bmm(variant, N, nnz):
     assert rel_err(Y, ref) < 1e-6
 
 
+def dense_graph_batch(B, N, density, seed):
+    """symmetric random adjacency blocks with a full diagonal -> block-diagonal CSR (sorted unique columns) + dense copy"""
+    rng = np.random.default_rng(seed)
+    m = rng.random((B, N, N)) < density / 2
+    m = m | m.transpose(0, 2, 1) | np.eye(N, dtype=bool)[None]
+    dense = np.where(m, rng.uniform(0.05, 1.0, (B, N, N)), 0.0).astype(np.float32)
+    b, r, c = np.nonzero(dense)
+    rowptr = np.zeros(B * N + 1, dtype=np.int64)
+    np.cumsum(np.bincount(b * N + r, minlength=B * N), out=rowptr[1:])
+    t = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=DEV)
+    return t(rowptr, np.int32), t(b * N + c, np.int32), t(dense[b, r, c], np.float32), torch.tensor(dense, device=DEV)
+
+
+@pytest.mark.parametrize("N,density", [(512, 0.23), (512, 0.03), (500, 0.01), (96, 0.3), (64, 0.2), (33, 0.2)])
+def test_block_dense_spmm_fp32_and_bf16(N, density):
+    """Variants 3 / 4 (spmm_dense.hip): a workgroup densifies its rows of the graph's adjacency into LDS and runs the
+    reference's literal bmm (gnn_transformer.py:80) on the matrix cores.  fp32 MFMA: the fp32 product (1e-6); bf16 MFMA:
+    equal to the fp64 product of the bf16-ROUNDED operands (fp32 accumulation only), 4e-3 from the unrounded one."""
+    from fira_icse_amd import ops
+    B = 3
+    rowptr, col, val, dense = dense_graph_batch(B, N, density, seed=N + 1)
+    X = randn(B * N, 256, seed=12)
+    ref = torch.bmm(dense.double(), X.view(B, N, 256).double()).view(B * N, 256)
+    Y = ops.csr_spmm(rowptr, col, val, X, graph_rows=N, variant=3)
+    assert rel_err(Y, ref) < 1e-6
+    Yb = ops.csr_spmm(rowptr, col, val, X, graph_rows=N, variant=4)
+    ref_b = torch.bmm(dense.bfloat16().double(), X.bfloat16().view(B, N, 256).double()).view(B * N, 256)
+    assert rel_err(Yb, ref_b) < 2e-6
+    assert rel_err(Yb, ref) < 6e-3
+    # the density-based choice (fira_csr_spmm, variant 0): the same numbers as whichever kernel it picks
+    Ya = ops.csr_spmm(rowptr, col, val, X, graph_rows=N, variant=0, auto=True)
+    assert rel_err(Ya, ref) < 1e-6
+    Yab = ops.csr_spmm(rowptr, col, val, X, graph_rows=N, variant=0, auto=True, dtype=1)
+    assert rel_err(Yab, ref) < 6e-3
+    # strided feature rows (ld 320) and an output that must keep its other columns
+    Xw = torch.zeros(B * N, 320, device=DEV); Xw[:, :256] = X
+    Yw = torch.full((B * N, 320), 7.0, device=DEV)
+    ops.csr_spmm(rowptr, col, val, Xw[:, :256], graph_rows=N, variant=3, out=Yw[:, :256])
+    assert torch.equal(Yw[:, :256], Y) and float((Yw[:, 256:] - 7.0).abs().max()) == 0
+
+
+def test_block_dense_spmm_sums_repeated_columns():
+    """Sorted rows may repeat a column (a multigraph edge list that was not merged): the dense tile holds their sum."""
+    from fira_icse_amd import ops
+    N = 64
+    rowptr, col, val = [0], [], []
+    dense = np.zeros((N, N), dtype=np.float64)
+    rng = np.random.default_rng(5)
+    for r in range(N):
+        cs = sorted(rng.integers(0, N, 9).tolist() + [r, r])          # repeats on purpose
+        for c in cs:
+            v = float(np.float32(rng.uniform(0.1, 1.0)))
+            dense[r, c] += v
+            col.append(c); val.append(v)
+        rowptr.append(len(col))
+    t = lambda a, dt: torch.tensor(np.array(a, dtype=dt), device=DEV)
+    X = randn(N, 256, seed=3)
+    ref = torch.tensor(dense, device=DEV) @ X.double()
+    for variant in (1, 3):
+        Y = ops.csr_spmm(t(rowptr, np.int32), t(col, np.int32), t(val, np.float32), X, graph_rows=N, variant=variant)
+        assert rel_err(Y, ref) < 1e-6, variant
+
+
 # ------------------------------------------------------------------------------------------------ row ops
 def test_embed_gather_and_scatter():
     from fira_icse_amd import ops

@@ -10,7 +10,7 @@ from fira_icse_amd import graphs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_config5_full_size_properties(variant):
     from fira_icse_amd import ops
     B, N = 128, 512
@@ -23,10 +23,11 @@ def test_config5_full_size_properties(variant):
     AY = ops.csr_spmm(rp, c, v, Y, graph_rows=N, variant=variant)
     # linearity: A(2X - 3Y) == 2AX - 3AY
     lin = ops.csr_spmm(rp, c, v, (2 * X - 3 * Y).contiguous(), graph_rows=N, variant=variant)
-    assert float((lin - (2 * AX - 3 * AY)).abs().max()) < 2e-4
+    # (bf16 operands: 2X - 3Y is rounded on its own, so linearity holds to bf16 resolution only)
+    assert float((lin - (2 * AX - 3 * AY)).abs().max()) < (2e-4 if variant != 4 else 0.15)
     # symmetry of A_hat: <Y, A X> == <A Y, X>   (why the backward reuses the forward kernel)
     a, b = float((Y.double() * AX.double()).sum()), float((AY.double() * X.double()).sum())
-    assert abs(a - b) / abs(a) < 1e-6
+    assert abs(a - b) / abs(a) < (1e-6 if variant != 4 else 5e-2)
     # one graph against the dense product
     b0 = 17
     lo, hi = int(rowptr[b0 * N]), int(rowptr[(b0 + 1) * N])
@@ -34,4 +35,8 @@ def test_config5_full_size_properties(variant):
     rows = np.repeat(np.arange(N), np.diff(rowptr[b0 * N:(b0 + 1) * N + 1]))
     dense[rows, col[lo:hi] - b0 * N] = torch.from_numpy(val[lo:hi]).double()
     ref = dense.cuda() @ X[b0 * N:(b0 + 1) * N].double()
-    assert float((AX[b0 * N:(b0 + 1) * N].double() - ref).norm() / ref.norm()) < 1e-6
+    err = float((AX[b0 * N:(b0 + 1) * N].double() - ref).norm() / ref.norm())
+    assert err < (1e-6 if variant != 4 else 6e-3)
+    if variant == 4:                                             # exact up to fp32 accumulation on the bf16-rounded operands
+        ref_b = dense.float().bfloat16().double().cuda() @ X[b0 * N:(b0 + 1) * N].bfloat16().double()
+        assert float((AX[b0 * N:(b0 + 1) * N].double() - ref_b).norm() / ref_b.norm()) < 2e-6

@@ -531,11 +531,115 @@ __global__ __launch_bounds__(256) void decode_dist_reg_kernel(int V, int S, cons
         if (best_p) best_p[r] = pg >= pc ? pg : pc;
     }
 }
+// The decode loop's form: 1024 threads per hypothesis row (16 waves: the 64 rows of a greedy batch are 64 workgroups, and
+// with 256 threads each a CU ran one wave per SIMD behind 100 dependent-latency loads), the row's logits requested once
+// and kept in registers (25 per thread), and the 2-way gate LinearProb(x) formed here from the decoder row instead of
+// by its own [64 x 2 x 256] product launch.  First-occurrence arg-max as torch.argmax.
+constexpr int DDW_NT = 1024, DDW_NPT = 25;
+__device__ __forceinline__ float block16_sum(float v, float* sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DDW_NT / 64; ++k) t += sm[k];
+    return t;
+}
+__device__ __forceinline__ void block16_argmax(float& v, int& idx, float* smv, int* smi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { smv[threadIdx.x >> 6] = v; smi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    v = smv[0]; idx = smi[0];
+#pragma unroll
+    for (int k = 1; k < DDW_NT / 64; ++k)
+        if (smv[k] > v || (smv[k] == v && smi[k] < idx)) { v = smv[k]; idx = smi[k]; }
+}
+__global__ __launch_bounds__(DDW_NT) void decode_dist_wide_kernel(int V, int S, const float* __restrict__ logits, int ldl,
+                                                                  const float* __restrict__ score,
+                                                                  const int32_t* __restrict__ mem_valid, int qpk,
+                                                                  const float* __restrict__ gate_logits,
+                                                                  const float* __restrict__ xrow,
+                                                                  const float* __restrict__ wp,
+                                                                  const float* __restrict__ bp, float* __restrict__ dist,
+                                                                  int32_t* __restrict__ best_id, float* __restrict__ best_p) {
+    __shared__ float smf[DDW_NT / 64];
+    __shared__ int smi[DDW_NT / 64];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const rsrc_t rL = buf_rsrc(logits + (size_t)r * ldl, (unsigned)V * 4u);
+    float x[DDW_NPT];
+#pragma unroll
+    for (int i = 0; i < DDW_NPT; ++i) x[i] = buf_load_f32(rL, (unsigned)(tid + DDW_NT * i) * 4u);   // past V: 0, replaced below
+    const float* srow = score + (size_t)r * S;
+    const int32_t* mv = mem_valid + (size_t)(r / qpk) * S;
+    float z0, z1;
+    if (gate_logits) {
+        z0 = gate_logits[2 * r]; z1 = gate_logits[2 * r + 1];
+    } else {                                                   // gate = x wp^T + bp: two 256-long dot products
+        const float xv = tid < FIRA_D ? xrow[(size_t)r * FIRA_D + tid] : 0.f;
+        const float a0 = tid < FIRA_D ? xv * wp[tid] : 0.f, a1 = tid < FIRA_D ? xv * wp[FIRA_D + tid] : 0.f;
+        z0 = block16_sum(a0, smf) + bp[0];
+        z1 = block16_sum(a1, smf) + bp[1];
+    }
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+    float cmax = -INFINITY, gmax = -INFINITY;
+    int cidx = 0x7fffffff, gidx = 0x7fffffff;
+    const float sv = tid < S ? (mv[tid] ? srow[tid] : -1e9f) : -INFINITY;       // S <= 1024: one slot per thread
+    if (tid < S) { cmax = sv; cidx = tid; }
+    block16_argmax(cmax, cidx, smf, smi);
+    const float ce = tid < S ? expf(sv - cmax) : 0.f;
+    const float csum = block16_sum(ce, smf);
+#pragma unroll
+    for (int i = 0; i < DDW_NPT; ++i) {                      // ascending index within the thread: first maximum wins
+        const int j = tid + DDW_NT * i;
+        x[i] = j < V ? x[i] : -INFINITY;
+        if (x[i] > gmax) { gmax = x[i]; gidx = j; }
+    }
+    block16_argmax(gmax, gidx, smf, smi);
+    float gsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < DDW_NPT; ++i) {
+        x[i] = expf(x[i] - gmax);                            // exp(-inf) = 0 past V
+        gsum += x[i];
+    }
+    gsum = block16_sum(gsum, smf);
+    if (dist) {
+        float* drow = dist + (size_t)r * (V + S);
+        const float sg = g0 * (1.0f / gsum), sc = g1 * (1.0f / csum);
+        const rsrc_t rD = buf_rsrc(drow, (unsigned)V * 4u);
+#pragma unroll
+        for (int i = 0; i < DDW_NPT; ++i)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sg * x[i]), rD, (unsigned)(tid + DDW_NT * i) * 4u, 0, 0);
+        if (tid < S) drow[V + tid] = sc * ce;
+    }
+    if (tid == 0 && best_id) {
+        const float pg = g0 * (1.0f / gsum), pc = g1 * (1.0f / csum);
+        best_id[r] = pg >= pc ? gidx : V + cidx;
+        if (best_p) best_p[r] = pg >= pc ? pg : pc;
+    }
+}
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
-                float* best_p) {
+                float* best_p, const float* x, const float* wp, const float* bp) {
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (R <= 0) return 0;
+    FIRA_REQUIRE(gate_logits || (x && wp && bp), "decode_dist: needs the gate logits or the rows / weights to form them");
+    static const int wide_mode = [] { const char* e = getenv("FIRA_DECODE_DIST_WIDE"); return e ? atoi(e) : 1; }();   // A/B switch
+    if ((wide_mode || !gate_logits) && V <= DDW_NPT * DDW_NT && S <= DDW_NT) {
+        hipLaunchKernelGGL(decode_dist_wide_kernel, dim3(R), dim3(DDW_NT), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
+                           gate_logits, x, wp, bp, dist, best_id, best_p);
+        FIRA_CHECK_LAUNCH("decode_dist");
+        return 0;
+    }
+    FIRA_REQUIRE(gate_logits, "decode_dist: vocabulary %d / %d memory slots need precomputed gate logits", V, S);
     static const int reg_mode = [] { const char* e = getenv("FIRA_DECODE_DIST_REG"); return e ? atoi(e) : 1; }();   // A/B switch
     if (reg_mode && V <= DD_NPT * 256)
         hipLaunchKernelGGL(decode_dist_reg_kernel, dim3(R), dim3(256), 0, s, V, S, logits, ldl, score, mem_valid, qpk,

@@ -83,7 +83,7 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
 int combination_bwd_blocks(int M);
 // deferred column reductions (rowops.hip)
 struct RedEntry { float* dst; const float* src; int width, n_part, stride; };
-constexpr int RED_MAX = 64;
+constexpr int RED_MAX = 96;
 struct RedTable {
     int n = 0;
     int wg_start[RED_MAX + 1] = {0};
@@ -104,9 +104,15 @@ bool linear_ln_bf16_try(hipStream_t s, int M, int K, const float* X, int ldx, co
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
                       uint32_t site, const int32_t* rows = nullptr,    // rows: dy and ds are row-mapped (dy[rows[r]], ds[rows[r]])
-                      float* part = nullptr);   // part: [add_layernorm_bwd_blocks(M), 512] partial {dgamma | dbeta} rows instead of atomics
+                      float* part = nullptr,    // part: [add_layernorm_bwd_blocks(M), 512] partial {dgamma | dbeta} rows instead of atomics
+                      // row_w (with part): partial rows are 1024 wide, {dgamma | dbeta | sum_r dx[r,:] | sum_r row_w[r] dx[r,:]}
+                      // with dx the un-dropped gradient rows (what dx_drop receives)
+                      const float* row_w = nullptr);
 int add_layernorm_bwd_blocks(int M);
 int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float* dc, float* dW2, float* db1);
+struct UnfoldEntry { const float *W2, *b1, *dc; float *dW2, *db1; };
+struct UnfoldTable { int n = 0; UnfoldEntry e[16]; };
+int gcn_bias_unfold_all(hipStream_t s, const UnfoldTable& tab);      // every GCN layer in one launch
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight = nullptr);
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
 // 3 out[dst[r]]=in[src[r]]
@@ -140,6 +146,9 @@ int tar_mask(hipStream_t s, int n, const int32_t* tar, int32_t* valid);
 int permute_cache(hipStream_t s, int nl, int BR, int T, int len, const int32_t* parent, const float* ksrc,
                   const float* vsrc, float* kdst, float* vdst, const int32_t* hist_src, int32_t* hist_dst);
 int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist);
+// the two in one launch for the decode step: hist[r, step] = tokens[r] != 0;  x[r] = table[tokens[r]] + pos_row
+int decode_embed(hipStream_t s, int BR, int T, int step, const int32_t* tokens, const float* table, const float* pos_row,
+                 float* x, int32_t* hist);
 
 // q_off (optional, [B+1]): ragged query rows -- batch entry b's queries are rows q_off[b] .. q_off[b+1] of Q / O / dO / dQ
 // (at most Tq of them); self_kv: its keys / values are the same rows of K / V (/ dK / dV).  key_valid stays dense.
@@ -171,9 +180,10 @@ int copy_score_bwd_ex(hipStream_t s, int B, int T, int S, const float* src, cons
                       float* part = nullptr, const int32_t* t_off = nullptr);
 int copy_score_bwd_blocks(int B, int S);
 constexpr int COPY_PART_STRIDE = 264;
+// gate_logits == nullptr: the 2-way gate LinearProb(x) = x wp^T + bp is formed inside (x [R,256], wp [2,256], bp [2])
 int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl, const float* score,
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
-                float* best_p);
+                float* best_p, const float* x = nullptr, const float* wp = nullptr, const float* bp = nullptr);
 int inv_count(hipStream_t s, const int32_t* n_tok, float* out);
 int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias);

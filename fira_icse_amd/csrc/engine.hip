@@ -129,8 +129,8 @@ struct Plan {
         if (training) {
             dXa = a.f((size_t)NB * D); dXb = a.f((size_t)NB * D); dNB2 = a.f((size_t)NB * D);
             dCB_a = a.f((size_t)CB * D);
-            red_cap = (size_t)nl * ((size_t)std::min(1024, cdiv(NB, 8)) + std::min(1024, cdiv(CB, 8))) * 2 * D   // encoder LNs
-                    + (size_t)3 * nl * std::min(1024, cdiv(TB, 8)) * 2 * D                                      // decoder LNs
+            red_cap = (size_t)nl * ((size_t)cdiv(NB, 16) * 4 * D + (size_t)cdiv(CB, 16) * 2 * D)                 // encoder LNs (GCN: + 2 sums)
+                    + (size_t)3 * nl * cdiv(TB, 16) * 2 * D                                                      // decoder LNs
                     + (size_t)nl * cdiv(CB, 16) * 4 * D                                                          // Combination
                     + (size_t)cdiv(L + S, 16) * B * COPY_PART_STRIDE + 4096;                                     // copy head
             red_buf = a.f(red_cap);
@@ -487,13 +487,27 @@ static RedCollector& red() { static thread_local RedCollector r; return r; }
 // LayerNorm backward with its dgamma / dbeta reduction deferred
 static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma, float* ds,
                   float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed, uint32_t st,
-                  const int32_t* rows = nullptr) {
+                  const int32_t* rows = nullptr,
+                  // optional (GCN blocks): the kernel also leaves sum_r dx[r,:] -> dsum and sum_r row_w[r] dx[r,:] -> dwsum
+                  // (deferred like dgamma / dbeta); *extras tells whether it did (false: no room for the partial rows)
+                  const float* row_w = nullptr, float* dsum = nullptr, float* dwsum = nullptr, bool* extras = nullptr) {
     const int nb = add_layernorm_bwd_blocks(M);
-    float* part = red().alloc((size_t)nb * 2 * FIRA_D);
-    TRY(add_layernorm_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st, rows, part));
+    static const bool no_extra = [] { const char* e = getenv("FIRA_LN_BWD_EXTRA"); return e && e[0] == '0'; }();   // A/B switch
+    const bool want = row_w && dsum && dwsum && !no_extra;
+    float* part = want ? red().alloc((size_t)nb * 4 * FIRA_D) : nullptr;
+    const bool ex = part != nullptr;
+    if (!part) part = red().alloc((size_t)nb * 2 * FIRA_D);
+    if (extras) *extras = ex;
+    const int w = ex ? 4 * FIRA_D : 2 * FIRA_D;
+    TRY(add_layernorm_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st, rows, part,
+                          ex ? row_w : nullptr));
     if (part) {
-        red().add(dgamma, part, FIRA_D, nb, 2 * FIRA_D);
-        red().add(dbeta, part + FIRA_D, FIRA_D, nb, 2 * FIRA_D);
+        red().add(dgamma, part, FIRA_D, nb, w);
+        red().add(dbeta, part + FIRA_D, FIRA_D, nb, w);
+        if (ex) {
+            red().add(dsum, part + 2 * FIRA_D, FIRA_D, nb, w);
+            red().add(dwsum, part + 3 * FIRA_D, FIRA_D, nb, w);
+        }
     }
     return 0;
 }
@@ -861,6 +875,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // ---- encoder layers, last to first (compact node rows) -------------------------------------------------
     float* dXn = p.dXa;
     float* other = p.dXb;
+    UnfoldTable unfold_tab;                  // GCN layers whose dc comes out of the deferred reduction at the end
     if (!c.ev_zero) TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));   // AST/edit rows of the last layer feed nothing
     if (ev_dmem) TRY(main_wait(s, ev_dmem));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
@@ -868,14 +883,20 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
         EncGrad& g = p.encg[l];
+        // (the LayerNorm backward also leaves the column sums of dY the folded form needs: db2 and dc, deferred)
+        float* dc21 = p.dc21 + (size_t)l * D;
+        bool sums = false;
         TRY(ln_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, g.dY2, G + w.ln2g, G + w.ln2b, c.p_gcn,
-                              c.seed, site(l, SITE_GCN)));
+                              c.seed, site(l, SITE_GCN), nullptr, p.rsum, G + w.fc2b, dc21, &sums));
+        if (sums && unfold_tab.n < 16)
+            unfold_tab.e[unfold_tab.n++] = UnfoldEntry{c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b};
+        else
+            sums = false;
         // GCN, folded form (see encoder_forward): Y = U W21^T + r c^T + b2 with U = A_hat X
         //   weight space: dW21 += dY^T U (+ db2 by the fused column sums), dc += dY^T r           (side stream)
         //   data space:   dU = dY W21, dX += A_hat dU                                              (main stream)
         //   and back to the reference's parameters: dW2 += dW21 W1^T + dc b1^T, dW1 += W2^T dW21, db1 += W2^T dc
         float* dW21 = p.dW21 + (size_t)l * D * D;
-        float* dc21 = p.dc21 + (size_t)l * D;
         const bool grouped = enc_group_on();
         // back to the reference's parameters (reads dW21: after its weight gradient on the same stream)
         auto unfold = [&]() -> int {
@@ -884,13 +905,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                 if (!grouped) TRY(side_fork(s));
                 ws = side().stream;
             }
-            TRY(colsum(ws, Nc, D, g.dY2, D, dc21, p.rsum));
+            if (!sums) TRY(colsum(ws, Nc, D, g.dY2, D, dc21, p.rsum));
             TRY(gemm_f32_ex(ws, 0, 1, D, D, D, dW21, D, c.P + w.fc1w, D, G + w.fc2w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
             TRY(gemm_f32_ex(ws, 1, 0, D, D, D, c.P + w.fc2w, D, dW21, D, G + w.fc1w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
-            TRY(gcn_bias_unfold(ws, c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b));
+            if (!sums) TRY(gcn_bias_unfold(ws, c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b));
             return 0;
         };
-        TRY(enc_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, dW21, G + w.fc2b));
+        TRY(enc_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, dW21, sums ? nullptr : G + w.fc2b));
         if (!grouped) TRY(unfold());
         TRY(linear_dgrad(s, Nc, D, D, g.dY2, D, p.W21 + (size_t)l * D * D, p.dNB2, D, false));  // dU
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, other, D, 0, 1, 1, nullptr));   // other = ds + A_hat dU
@@ -940,6 +961,9 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // rows 1..3 only: padding_idx row 0 never gets a gradient (its slot of the zeroed gradient buffer stays untouched)
     TRY(linear_dgrad(s, 3, p.nl * D, D, p.dvtab_all + (size_t)p.nl * D, p.nl * D, c.P + L.w2_all, G + L.mark_emb + D, D, true));
     if (side().stream && side().enabled) TRY(side_join(s));        // every weight gradient is complete past this point
+    // dc of every GCN layer is final (deferred reduction above) and so are the side stream's additions to dW2: back to the
+    // reference's fc2.weight / fc1.bias gradients, one launch for all layers
+    TRY(gcn_bias_unfold_all(s, unfold_tab));
     return 0;
 }
 
@@ -1123,9 +1147,8 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
     if (n_beam > 1 && step > 0)
         TRY(permute_cache(s, p.nl, BR, T, step, parent, dp.kc[prev], dp.vc[prev], dp.kc[cur], dp.vc[cur], dp.hist[prev],
                           dp.hist[cur]));
-    TRY(mark_history(s, BR, T, step, tokens, dp.hist[cur]));
-    // token embedding + position `step` (gnn_transformer.py:110-113)
-    TRY(embed_gather_fwd(s, BR, 1, tokens, params + L.dec_emb, p.pos_tar + (size_t)step * D, dp.x, 1, 0));
+    // key-valid history of this step + token embedding + position `step` (gnn_transformer.py:110-113): one launch
+    TRY(decode_embed(s, BR, T, step, tokens, params + L.dec_emb, p.pos_tar + (size_t)step * D, dp.x, dp.hist[cur]));
     const size_t lay = (size_t)BR * T * D;
     // FIRA_DECODE_ATTN=0: the round-2 path (three projections + the 32-query MFMA attention kernel): A/B switch
     static const bool stream_attn = [] { const char* e = getenv("FIRA_DECODE_ATTN"); return !(e && e[0] == '0'); }();
@@ -1183,13 +1206,15 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
                                  p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
         TRY(close_block(D, dp.ao, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, true));
         TRY(consume(p.F, dp.xc, params + w.w1, params + w.b1, dp.h, FIRA_GEMM_RELU));
-        TRY(close_block(p.F, dp.h, params + w.w2, params + w.b2, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, l + 1 < p.nl));
+        // (the last block's LayerNorm is owed too: the target projection of the copy head consumes it and leaves x behind)
+        TRY(close_block(p.F, dp.h, params + w.w2, params + w.b2, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, true));
     }
+    TRY(consume(D, dp.x, params + L.wt, nullptr, dp.tgt, 0));      // LinearTarget(LN(..)) [+ x materialised]
     TRY(linear(s, BR, p.V, D, dp.x, D, params + L.wout, params + L.bout, dp.logits, p.ldl));
-    TRY(gemm_f32(s, 0, 1, BR, D, D, dp.x, D, params + L.wt, D, dp.tgt, D, nullptr, 0, 1));
     TRY(copy_score_fwd_ex(s, BR, 1, Sm, p.src, dp.tgt, params + L.wres, params + L.bres, dp.score, n_beam, p.mem_valid));
-    TRY(linear(s, BR, 2, D, dp.x, D, params + L.wp, params + L.bp, dp.gate, 2));
-    TRY(decode_dist(s, BR, p.V, Sm, dp.logits, p.ldl, dp.score, p.mem_valid, n_beam, dp.gate, dist, best_id, best_p));
+    // the 2-way gate LinearProb(x) is formed inside the distribution kernel
+    TRY(decode_dist(s, BR, p.V, Sm, dp.logits, p.ldl, dp.score, p.mem_valid, n_beam, nullptr, dist, best_id, best_p, dp.x,
+                    params + L.wp, params + L.bp));
     return 0;
 }
 

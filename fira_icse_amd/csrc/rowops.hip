@@ -327,7 +327,11 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
 // through buffer descriptors (rows past M read zeros and drop their stores), so there is no branch around a memory
 // instruction -- with the per-row `if`s and the optional row map read inside the loop, every store was followed by an
 // s_waitcnt vmcnt(0) and each 2-row iteration cost two dependent round trips (see epilogue.h).
+// EXTRA (engine, GCN blocks): two more column sums of the un-dropped gradient rows dx -- sum_r dx[r,:] (the folded
+// product's bias gradient) and sum_r row_w[r] * dx[r,:] (the gradient of c = W2 b1, which reaches the output through the
+// rank-1 term (A_hat 1) c^T) -- so that no separate column-sum launch reads dx again.
 constexpr int LNB_ROWS = 16;                    // rows per workgroup and step (4 waves x 4 rows)
+template <bool EXTRA>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const float* dy,   // may alias ds (row-mapped, in place)
                                                                 const float* __restrict__ sum,
                                                                 const float* __restrict__ stats,
@@ -336,13 +340,14 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float p, float inv_keep, uint64_t seed, uint32_t site,
                                                                 int steps, const int32_t* __restrict__ rows,
-                                                                float* __restrict__ part) {
-    __shared__ float red[2 * FIRA_D];
+                                                                float* __restrict__ part,
+                                                                const float* __restrict__ row_w) {
+    constexpr int NV = EXTRA ? 4 : 2;               // column-sum vectors per workgroup: dgamma | dbeta (| sum dx | sum w dx)
+    __shared__ __attribute__((aligned(16))) float red[4][NV * FIRA_D];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t; i < 2 * FIRA_D; i += 256) red[i] = 0.f;
-    __syncthreads();
     const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
-    f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f}, dsum = {0.f, 0.f, 0.f, 0.f}, dwsum = {0.f, 0.f, 0.f, 0.f};
+    const rsrc_t rW = buf_rsrc(EXTRA ? (const void*)row_w : (const void*)sum, EXTRA ? (unsigned)M * 4u : 0u);
     const rsrc_t rDy = buf_rsrc(dy, 0x7fffffffu), rDs = buf_rsrc(ds, 0x7fffffffu);
     const rsrc_t rSum = buf_rsrc(sum, (unsigned)M * FIRA_D * 4u), rStats = buf_rsrc(stats, (unsigned)M * 8u);
     const rsrc_t rMap = buf_rsrc(rows ? (const void*)rows : (const void*)sum, rows ? (unsigned)M * 4u : 0u);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
         const int r0 = (blockIdx.x * steps + st) * LNB_ROWS + wave * 4;
         unsigned om[4];
         f32x4 d[4], sv[4];
-        float mean[4], rstd[4];
+        float mean[4], rstd[4], rw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                       // dy / ds live in the mapped rows
             const unsigned mapped = __builtin_amdgcn_raw_buffer_load_b32(rMap, (unsigned)(r0 + u) * 4u, 0, 0);
@@ -367,6 +372,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
             sv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rSum, o, 0, 0));
             mean[u] = buf_load_f32(rStats, (unsigned)r * 8u);
             rstd[u] = buf_load_f32(rStats, (unsigned)r * 8u + 4u);
+            rw[u] = buf_load_f32(rW, (unsigned)r * 4u);     // (no EXTRA: zero records, reads 0)
         }
         f32x4 xh[4], h[4];
         float m1[4], m2[4];
@@ -399,23 +405,33 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
             }
             // no dx_drop: the descriptor has zero records and the store is dropped
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32v4_t, o4), rDx, (unsigned)r * (FIRA_D * 4u) + lo, 0, 0);
+            if (EXTRA) {                                    // rows past M: o4 = 0
+                dsum += o4;
+                dwsum += o4 * rw[u];
+            }
         }
     }
-    atomicAdd(&red[lane * 4 + 0], dg.x); atomicAdd(&red[lane * 4 + 1], dg.y);
-    atomicAdd(&red[lane * 4 + 2], dg.z); atomicAdd(&red[lane * 4 + 3], dg.w);
-    atomicAdd(&red[FIRA_D + lane * 4 + 0], db.x); atomicAdd(&red[FIRA_D + lane * 4 + 1], db.y);
-    atomicAdd(&red[FIRA_D + lane * 4 + 2], db.z); atomicAdd(&red[FIRA_D + lane * 4 + 3], db.w);
-    __syncthreads();
-    if (part) {
-        // deferred reduction (engine): every workgroup stores its 2 x 256 partial sums; one reducer launch adds them up.
-        // (n workgroups adding to the SAME 512 addresses serialise in L2: ~30 ns per same-address atomic, i.e. ~15 us of
-        // tail for 500 workgroups -- more than the kernel's streaming time for the decoder-sized launches)
-        for (int i = t; i < 2 * FIRA_D; i += 256) part[(size_t)blockIdx.x * 2 * FIRA_D + i] = red[i];
-        return;
+    // the four waves park their column sums side by side (plain 16-byte LDS stores: no zero fill, no LDS atomics) and the
+    // workgroup adds them up
+    *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = dg;
+    *reinterpret_cast<f32x4*>(&red[wave][FIRA_D + lane * 4]) = db;
+    if (EXTRA) {
+        *reinterpret_cast<f32x4*>(&red[wave][2 * FIRA_D + lane * 4]) = dsum;
+        *reinterpret_cast<f32x4*>(&red[wave][3 * FIRA_D + lane * 4]) = dwsum;
     }
-    for (int i = t; i < FIRA_D; i += 256) {
-        unsafeAtomicAdd(&dgamma[i], red[i]);
-        unsafeAtomicAdd(&dbeta[i], red[FIRA_D + i]);
+    __syncthreads();
+    for (int i = t; i < NV * FIRA_D; i += 256) {
+        const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        if (part) {
+            // deferred reduction (engine): every workgroup stores its NV x 256 partial sums; one reducer launch adds them
+            // up.  (n workgroups adding to the SAME 512 addresses serialise in L2: ~30 ns per same-address atomic, i.e.
+            // ~15 us of tail for 500 workgroups -- more than the kernel's streaming time for the decoder-sized launches)
+            part[(size_t)blockIdx.x * NV * FIRA_D + i] = v;
+        } else if (i < FIRA_D) {
+            unsafeAtomicAdd(&dgamma[i], v);
+        } else if (i < 2 * FIRA_D) {
+            unsafeAtomicAdd(&dbeta[i - FIRA_D], v);
+        }
     }
 }
 
@@ -429,6 +445,15 @@ __global__ __launch_bounds__(256) void gcn_bias_unfold_kernel(const float* __res
     const float dci = dc[i];
     dW2[(size_t)i * FIRA_D + k] += dci * b1[k];
     unsafeAtomicAdd(&db1[k], W2[(size_t)i * FIRA_D + k] * dci);
+}
+// the same for every GCN layer in one launch (grid.y = layer): the dc vectors come out of the deferred reduction at
+// the end of the backward pass
+__global__ __launch_bounds__(256) void gcn_bias_unfold_all_kernel(UnfoldTable tab) {
+    const UnfoldEntry& q = tab.e[blockIdx.y];
+    const int i = blockIdx.x, k = threadIdx.x;
+    const float dci = q.dc[i];
+    q.dW2[(size_t)i * FIRA_D + k] += dci * q.b1[k];
+    unsafeAtomicAdd(&q.db1[k], q.W2[(size_t)i * FIRA_D + k] * dci);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,15 +794,26 @@ static int ln_bwd_steps(int M, bool deferred) { return deferred ? 1 : std::max(1
 int add_layernorm_bwd_blocks(int M) { return M > 0 ? cdiv(M, LNB_ROWS) : 0; }
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
-                      uint32_t site, const int32_t* rows, float* part) {
+                      uint32_t site, const int32_t* rows, float* part, const float* row_w) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     FIRA_REQUIRE(M < (1 << 21), "add_layernorm_bwd: %d rows exceed the 2 GiB the kernel addresses", M);
+    FIRA_REQUIRE(!(row_w && !part), "add_layernorm_bwd: the extra column sums need the partial-row output");
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     const int steps = ln_bwd_steps(M, part != nullptr);
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3(cdiv(M, LNB_ROWS * steps)), dim3(256), 0, s, M, dy, sum, stats, gamma, ds,
-                       dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part);
+    if (row_w)
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<true>, dim3(cdiv(M, LNB_ROWS * steps)), dim3(256), 0, s, M, dy, sum, stats,
+                           gamma, ds, dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part, row_w);
+    else
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<false>, dim3(cdiv(M, LNB_ROWS * steps)), dim3(256), 0, s, M, dy, sum, stats,
+                           gamma, ds, dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part, row_w);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");
+    return 0;
+}
+int gcn_bias_unfold_all(hipStream_t s, const UnfoldTable& tab) {
+    if (tab.n <= 0) return 0;
+    hipLaunchKernelGGL(gcn_bias_unfold_all_kernel, dim3(FIRA_D, tab.n), dim3(FIRA_D), 0, s, tab);
+    FIRA_CHECK_LAUNCH("gcn_bias_unfold_all");
     return 0;
 }
 int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float* dc, float* dW2, float* db1) {
@@ -827,6 +863,28 @@ int permute_cache(hipStream_t s, int nl, int BR, int T, int len, const int32_t* 
 __global__ void mark_history_kernel(int BR, int T, int step, const int32_t* __restrict__ tokens, int32_t* __restrict__ hist) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r < BR) hist[r * T + step] = tokens[r] != 0;
+}
+// One decode step's first launch: hist[r, step] = tokens[r] != 0 (key-valid history of the self-attention cache) and
+// x[r] = table[tokens[r]] + pos_row (gnn_transformer.py:110-113 at position `step`), one wave per hypothesis row.
+__global__ __launch_bounds__(256) void decode_embed_kernel(int BR, int T, int step, const int32_t* __restrict__ tokens,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ pos_row, float* __restrict__ x,
+                                                           int32_t* __restrict__ hist) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= BR) return;
+    const int id = tokens[r];
+    float4 v = *reinterpret_cast<const float4*>(table + (size_t)id * FIRA_D + lane * 4);
+    const float4 p = *reinterpret_cast<const float4*>(pos_row + lane * 4);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    *reinterpret_cast<float4*>(x + (size_t)r * FIRA_D + lane * 4) = v;
+    if (lane == 0) hist[r * T + step] = id != 0;
+}
+int decode_embed(hipStream_t s, int BR, int T, int step, const int32_t* tokens, const float* table, const float* pos_row,
+                 float* x, int32_t* hist) {
+    hipLaunchKernelGGL(decode_embed_kernel, dim3(cdiv(BR, 4)), dim3(256), 0, s, BR, T, step, tokens, table, pos_row, x, hist);
+    FIRA_CHECK_LAUNCH("decode_embed");
+    return 0;
 }
 int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist) {
     hipLaunchKernelGGL(mark_history_kernel, dim3(cdiv(BR, 256)), dim3(256), 0, s, BR, T, step, tokens, hist);

@@ -342,8 +342,12 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
     return decode
 
 
-def gemm_objects(prof, dtype, prof_steps, traffic):
-    """`roofline` (MFMA), `roofline_hbm` and the decoder-GEMM sub-object of one profiled leg (fira_prof_* HIP events)."""
+def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
+    """`roofline` (MFMA), `roofline_hbm` and the decoder-GEMM sub-object of one profiled leg (fira_prof_* HIP events).
+    dec_rows = (computed target rows, B*30 rows) of the profiled batches: the decoder runs on the computed rows only
+    (fira_batch.dec_off), so its EXECUTED FLOP are below the reference's dense B*30-row products; both rates are reported
+    -- `achieved` / `frac` on the executed FLOP, `*_dense_equiv` on the FLOP of the dense shapes over the
+    same time."""
     gemm = prof["gemm"]
     dec = gemm["decoder"]
     g_s = max(gemm["ms"], 1e-9) * 1e-3
@@ -370,6 +374,14 @@ def gemm_objects(prof, dtype, prof_steps, traffic):
                     "hbm_GBs": dec["bytes"] / d_s / 1e9,
                     "note": "the decoder's M = B*30 row products only (forward + data gradients), FLOP / summed launch "
                             "time: the quantity north_star's >= 40 % MFMA target is set on"}
+    if dec_rows and dec_rows[0] > 0:
+        ratio = dec_rows[1] / dec_rows[0]
+        decoder_gemm["rows_computed_over_dense"] = dec_rows[0] / dec_rows[1]
+        decoder_gemm["achieved_dense_equiv"] = decoder_gemm["achieved"] * ratio
+        decoder_gemm["frac_dense_equiv"] = decoder_gemm["frac"] * ratio
+        dense_work = gemm["work"] + dec["work"] * (ratio - 1.0)
+        roofline["achieved_dense_equiv"] = dense_work / g_s / 1e12
+        roofline["frac_dense_equiv"] = dense_work / g_s / 1e12 / peak_tf
     return roofline, roofline_hbm, decoder_gemm
 
 
@@ -446,6 +458,12 @@ def main():
         lib.fira_prof_enable(0)
         return prof
 
+    def dec_rows_of(bs, n):
+        """(computed target rows, dense B*30 rows) of the first n profiled batches"""
+        used = [bs[i % len(bs)] for i in range(n)]
+        dense = sum(b.B * cfg.tar_len for b in used)
+        return (sum(b.n_dec_rows for b in used) if model.compact_dec else dense, dense)
+
     def side_leg(dtype, Bx, steps, warmup, pool, with_host=False):
         """One more training configuration measured like the headline (same trainer, other dtype / batch)."""
         model.compute_dtype = dtype
@@ -453,7 +471,7 @@ def main():
         dt, t_enq = timed_leg(bs, steps, warmup)
         prof = profiled(bs)
         tr = traffic_all.get(dtype) or {}
-        roof, roof_hbm, dec = gemm_objects(prof, dtype, 3, tr)
+        roof, roof_hbm, dec = gemm_objects(prof, dtype, 3, tr, dec_rows_of(bs, 3))
         obj = {"commits_per_s": steps * Bx * world / dt, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": Bx,
                "dtype": dtype, "steps": steps, "host_enqueue_ms_per_step": t_enq / steps * 1e3, "roofline": roof,
                "decoder_gemm": dec, "kernel_time_ms_per_step": {k: v["ms"] / 3 for k, v in prof.items()}}
@@ -474,7 +492,7 @@ def main():
     prof = profiled(batches, prof_steps)
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     traffic = traffic_all.get(a.dtype) or (traffic_all if a.dtype == "f32" and "gemm" in traffic_all else {})
-    roofline, roofline_hbm, decoder_gemm = gemm_objects(prof, a.dtype, prof_steps, traffic)
+    roofline, roofline_hbm, decoder_gemm = gemm_objects(prof, a.dtype, prof_steps, traffic, dec_rows_of(batches, prof_steps))
     spmm = prof["spmm"]
     spmm_bytes_step = spmm["work"] + 8.0 * nnz_mean * spmm["count"]         # + (col,val) of the batch's nnz
     spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9,

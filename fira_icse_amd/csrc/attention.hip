@@ -82,12 +82,38 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     const int tk = selfk ? tq : Tk;
     const int NT = (tk + 31) / 32;
     for (int i = t; i < tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)bk * kvb + i];
-    __syncthreads();
     K += (selfk ? (size_t)qb : (size_t)bk * kb) * ldk;           // this batch entry's key/value rows
     V += (selfk ? (size_t)qb : (size_t)bk * kb) * ldv;
 
+    // every operand of the wave is requested here, before the key mask has reached LDS: the fragments of masked keys are
+    // zeroed afterwards instead of not being loaded (one memory round trip instead of three; see the backward kernel)
     float bq[16];
-    load_frag(bq, Q + ((size_t)qb + l31) * ldq + h * FIRA_DH + kh * 16, l31 < tq);
+    load_frag(bq, Q + ((size_t)qb + min(l31, tq - 1)) * ldq + h * FIRA_DH + kh * 16, true);
+    float ak[TPW][16], vv[TPW][16];                  // K fragment of key tile*32 + l31; V rows of key acc_row(s,kh)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = min(wave + i * NW, NT - 1);
+        load_frag(ak[i], K + (size_t)min(kt * 32 + l31, tk - 1) * ldk + h * FIRA_DH + kh * 16, true);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) vv[i][s] = V[(size_t)min(kt * 32 + acc_row(s, kh), tk - 1) * ldv + h * FIRA_DH + l31];
+    }
+    __syncthreads();
+    if (l31 >= tq) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bq[s] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+        const int key = kt * 32 + l31;
+        const bool ok = kt < NT && key < tk && sm_kv[key < tk ? key : 0] != 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int kr = kt * 32 + acc_row(s, kh);
+            if (!ok) ak[i][s] = 0.f;
+            if (!(kt < NT && kr < tk && sm_kv[kr < tk ? kr : 0] != 0)) vv[i][s] = 0.f;
+        }
+    }
 
     f32x16 st[TPW];
     float mx = -INFINITY;
@@ -97,14 +123,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
         if (kt < NT) {
-            float ak[16];
-            const int key = kt * 32 + l31;
-            load_frag(ak, K + (size_t)key * ldk + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[s], bq[s], acc);
+            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[i][s], bq[s], acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool masked;
@@ -147,14 +170,8 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         if (kt < NT) {
-            float vv[16];                       // all 16 row loads in flight before the MFMA chain
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int key = kt * 32 + acc_row(s, kh);
-                vv[s] = (key < tk && sm_kv[key < tk ? key : 0] != 0) ? V[(size_t)key * ldv + h * FIRA_DH + l31] : 0.f;
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] * inv_sum, vv[s], o);
+            for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] * inv_sum, vv[i][s], o);
         }
     }
     // o[r]: query = acc_row(r, kh), d = l31
@@ -179,6 +196,10 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     }
 }
 
+// Backward.  Every operand a wave needs -- its K / V fragments, the K rows of its key tile, the query-side fragments and
+// rows -- is requested at the top of the kernel, before the key mask has even reached LDS: the fragments of masked keys
+// are zeroed afterwards instead of not being loaded (their rows lie inside the caller's buffers), so the kernel waits for
+// ONE memory round trip instead of one per phase (round 2 loaded K and V twice, phase by phase, behind the mask).
 template <int NW, int TPW>
 __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     int H, int Tq, int Tk, const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
@@ -189,6 +210,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     __shared__ float sm_red[NW][32];
     __shared__ float sm_m[32], sm_sum[32], sm_delta[32];
     __shared__ float sm_o[NW > 1 ? NW * 1024 : 1];
+    __shared__ float sm_q[32 * 33], sm_do[32 * 33];             // Q and dO tiles [query][d] (pitch 33) for phase N's row operands
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -199,16 +221,52 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     const size_t kbase = selfk ? (size_t)qb : (size_t)b * Tk;
     const int NT = (tk + 31) / 32;
     for (int i = t; i < tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)b * Tk + i];
-    __syncthreads();
 
-    // operand fragments indexed by "row = lane&31": queries
-    float bq[16], bdo[16];
-    load_frag(bq, Q + ((size_t)qb + l31) * ldq + h * FIRA_DH + kh * 16, l31 < tq);
-    load_frag(bdo, dO + ((size_t)qb + l31) * lddo + h * FIRA_DH + kh * 16, l31 < tq);
+    // ---- all operands, one round trip (rows past the end are clamped to a real row and zeroed below) ----------
+    const int ql = min(l31, tq - 1);
+    float bq[16], bdo[16], bo[16];                   // fragments X[query = lane&31][kh*16 + s]
+    load_frag(bq, Q + ((size_t)qb + ql) * ldq + h * FIRA_DH + kh * 16, true);
+    load_frag(bdo, dO + ((size_t)qb + ql) * lddo + h * FIRA_DH + kh * 16, true);
+    load_frag(bo, O + ((size_t)qb + ql) * ldo + h * FIRA_DH + kh * 16, true);
+    float ak[TPW][16], av[TPW][16], kvv[TPW][16];    // K / V fragments of key = tile*32 + l31; K rows of key acc_row(s,kh)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = min(wave + i * NW, NT - 1);
+        const int key = min(kt * 32 + l31, tk - 1);
+        load_frag(ak[i], K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, true);
+        load_frag(av[i], V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, true);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int kr = min(kt * 32 + acc_row(s, kh), tk - 1);
+            kvv[i][s] = K[(kbase + kr) * ldk + h * FIRA_DH + l31];
+        }
+    }
+    __syncthreads();
+    if (l31 >= tq) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { bq[s] = 0.f; bdo[s] = 0.f; bo[s] = 0.f; }
+    }
+    if (wave == 0) {                                 // the same tiles, transposed access in phase N: through LDS
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            sm_q[l31 * 33 + kh * 16 + s] = bq[s];
+            sm_do[l31 * 33 + kh * 16 + s] = bdo[s];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int kt = wave + i * NW;
+        const int key = kt * 32 + l31;
+        const bool ok = kt < NT && key < tk && sm_kv[key < tk ? key : 0] != 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int kr = kt * 32 + acc_row(s, kh);
+            if (!ok) { ak[i][s] = 0.f; av[i][s] = 0.f; }
+            if (!(kt < NT && kr < tk && sm_kv[kr < tk ? kr : 0] != 0)) kvv[i][s] = 0.f;
+        }
+    }
     float delta;
     {
-        float bo[16];
-        load_frag(bo, O + ((size_t)qb + l31) * ldo + h * FIRA_DH + kh * 16, l31 < tq);
         float d = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) d = fmaf(bdo[s], bo[s], d);
@@ -224,14 +282,11 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
         if (kt < NT) {
-            float ak[16];
-            const int key = kt * 32 + l31;
-            load_frag(ak, K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[s], bq[s], acc);
+            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[i][s], bq[s], acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool masked;
@@ -282,27 +337,18 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         if (kt < NT) {
-            float av[16];
-            const int key = kt * 32 + l31;
-            load_frag(av, V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 dpt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) dpt = MFMA32(av[s], bdo[s], dpt);       // dP^T = V dO^T
-            float kvv[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int kr = kt * 32 + acc_row(s, kh);
-                kvv[s] = (kr < tk && sm_kv[kr < tk ? kr : 0] != 0) ? K[(kbase + kr) * ldk + h * FIRA_DH + l31] : 0.f;
-            }
+            for (int s = 0; s < 16; ++s) dpt = MFMA32(av[i][s], bdo[s], dpt);       // dP^T = V dO^T
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
                 const bool dead = kr >= tk || sm_kv[kr < tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
                 const float p = st[i][s] * inv_sum;
                 const float ds = dead ? 0.f : p * (dpt[s] - delta) * INV_SQRT_DH;
-                dq = MFMA32(ds, kvv[s], dq);                                    // dQ += dS K
+                dq = MFMA32(ds, kvv[i][s], dq);                                    // dQ += dS K
             }
         }
     }
@@ -327,28 +373,24 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     }
 
     // ---- phase N (register row = query, lane column = key): dK, dV ---------------------------------
-    float qrow[16], dorow[16];              // B operands: X[query = acc_row(s,kh)][d = l31]
+    float qrow[16], dorow[16];              // B operands: X[query = acc_row(s,kh)][d = l31] (rows >= tq are zero)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const int q = acc_row(s, kh);
-        qrow[s] = q < tq ? Q[((size_t)qb + q) * ldq + h * FIRA_DH + l31] : 0.f;
-        dorow[s] = q < tq ? dO[((size_t)qb + q) * lddo + h * FIRA_DH + l31] : 0.f;
+        qrow[s] = sm_q[acc_row(s, kh) * 33 + l31];
+        dorow[s] = sm_do[acc_row(s, kh) * 33 + l31];
     }
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         if (kt < NT) {
-            float ak[16], av[16];
             const int key = kt * 32 + l31;
-            load_frag(ak, K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
-            load_frag(av, V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, key < tk && sm_kv[key < tk ? key : 0] != 0);
             f32x16 sN, dpN;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                sN = MFMA32(bq[s], ak[s], sN);        // S   = Q K^T
-                dpN = MFMA32(bdo[s], av[s], dpN);     // dP  = dO V^T
+                sN = MFMA32(bq[s], ak[i][s], sN);        // S   = Q K^T
+                dpN = MFMA32(bdo[s], av[i][s], dpN);     // dP  = dO V^T
             }
             f32x16 dk, dv;
 #pragma unroll

@@ -358,6 +358,8 @@ def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
     roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
                 "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_traffic.sh (counters cannot "
+                                  "be read inside this process): profiles/traffic.json, batch 32 (f32) / 64 (bf16)",
                 "algorithmic_flop_per_launch": gemm["work"] / max(gemm["count"], 1),
                 "launches_per_step": gemm["count"] // prof_steps, "avg_launch_us": 1e3 * gemm["ms"] / max(gemm["count"], 1),
                 "share_of_kernel_time": gemm["ms"] / total_ms}

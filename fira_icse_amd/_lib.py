@@ -72,6 +72,9 @@ SIGNATURES = {
     "fira_attention_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I]),
     "fira_attention_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I,
                                 _P, _I, _P, _I, _P, _I]),
+    "fira_attention_fwd_ex": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I]),
+    "fira_attention_bwd_ex": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I,
+                                   _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_decode_attention": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "fira_copy_score_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fira_copy_score_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -23,6 +23,38 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// One 32-deep product of two fragments (16 values per lane, k = (lane>>5)*16 + s on both sides) accumulated into a
+// 32x32 tile.  fp32: the exact 16-step v_mfma_f32_32x32x2_f32 chain.  BF (bf16 mode of the engine: torch.autocast runs
+// the attention matmuls on bf16 operands with fp32 accumulation): both fragments are rounded to bf16 (RNE) and the
+// product is TWO v_mfma_f32_32x32x16_bf16 -- slot e of lane group g holds k = g*16 + 8 j + e in step j on both sides, so
+// every k is paired once; the dependent chain shrinks from 16 x 64 to 2 x 32 cycles.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t apk2(float a, float b) {
+    const af32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));      // v_cvt_pk_bf16_f32
+}
+template <bool BF>
+__device__ __forceinline__ f32x16 chain16(const float (&a)[16], const float (&b)[16], f32x16 acc) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint4 ua, ub;
+            ua.x = apk2(a[8 * j], a[8 * j + 1]); ua.y = apk2(a[8 * j + 2], a[8 * j + 3]);
+            ua.z = apk2(a[8 * j + 4], a[8 * j + 5]); ua.w = apk2(a[8 * j + 6], a[8 * j + 7]);
+            ub.x = apk2(b[8 * j], b[8 * j + 1]); ub.y = apk2(b[8 * j + 2], b[8 * j + 3]);
+            ub.z = apk2(b[8 * j + 4], b[8 * j + 5]); ub.w = apk2(b[8 * j + 6], b[8 * j + 7]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ua), __builtin_bit_cast(abf16x8, ub), acc,
+                                                          0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = MFMA32(a[s], b[s], acc);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
 // fragment X[row][col0 + kh*16 + s], s = 0..15; zero when !valid
@@ -56,7 +88,7 @@ __device__ __forceinline__ float mask_score(float raw, int key, int query, int T
     return masked ? -1e9f : raw * INV_SQRT_DH;
 }
 
-template <int NW, int TPW>
+template <int NW, int TPW, bool BF>
 __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, int Tk, const float* __restrict__ Q,
                                                                 int ldq, const float* __restrict__ K, int ldk,
                                                                 const float* __restrict__ V, int ldv,
@@ -126,8 +158,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[i][s], bq[s], acc);
+            acc = chain16<BF>(ak[i], bq, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool masked;
@@ -170,8 +201,10 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         if (kt < NT) {
+            float pn[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) o = MFMA32(st[i][s] * inv_sum, vv[i][s], o);
+            for (int s = 0; s < 16; ++s) pn[s] = st[i][s] * inv_sum;
+            o = chain16<BF>(pn, vv[i], o);
         }
     }
     // o[r]: query = acc_row(r, kh), d = l31
@@ -200,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 // rows -- is requested at the top of the kernel, before the key mask has even reached LDS: the fragments of masked keys
 // are zeroed afterwards instead of not being loaded (their rows lie inside the caller's buffers), so the kernel waits for
 // ONE memory round trip instead of one per phase (round 2 loaded K and V twice, phase by phase, behind the mask).
-template <int NW, int TPW>
+template <int NW, int TPW, bool BF>
 __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     int H, int Tq, int Tk, const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
     const float* __restrict__ V, int ldv, const int32_t* __restrict__ key_valid, int causal, int q_pos0,
@@ -285,8 +318,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = MFMA32(ak[i][s], bq[s], acc);
+            acc = chain16<BF>(ak[i], bq, acc);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 bool masked;
@@ -340,16 +372,16 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             f32x16 dpt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) dpt = MFMA32(av[i][s], bdo[s], dpt);       // dP^T = V dO^T
+            dpt = chain16<BF>(av[i], bdo, dpt);                                     // dP^T = V dO^T
+            float dsv[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int kr = kt * 32 + acc_row(s, kh);
                 const bool dead = kr >= tk || sm_kv[kr < tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
                 const float p = st[i][s] * inv_sum;
-                const float ds = dead ? 0.f : p * (dpt[s] - delta) * INV_SQRT_DH;
-                dq = MFMA32(ds, kvv[i][s], dq);                                    // dQ += dS K
+                dsv[s] = dead ? 0.f : p * (dpt[s] - delta) * INV_SQRT_DH;
             }
+            dq = chain16<BF>(dsv, kvv[i], dq);                                     // dQ += dS K
         }
     }
     if (NW > 1) {
@@ -387,24 +419,23 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             f32x16 sN, dpN;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                sN = MFMA32(bq[s], ak[i][s], sN);        // S   = Q K^T
-                dpN = MFMA32(bdo[s], av[i][s], dpN);     // dP  = dO V^T
-            }
+            sN = chain16<BF>(bq, ak[i], sN);             // S   = Q K^T
+            dpN = chain16<BF>(bdo, av[i], dpN);          // dP  = dO V^T
             f32x16 dk, dv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+            float pv[16], dsn[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int q = acc_row(s, kh);
                 bool masked;
                 const float x = mask_score(sN[s], key, q, tk, sm_kv, causal, q_pos0, masked);
                 const float p = expf(x - sm_m[q]) * sm_sum[q];
-                const float ds = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
-                dk = MFMA32(ds, qrow[s], dk);         // dK += dS^T Q
-                dv = MFMA32(p, dorow[s], dv);         // dV += P^T dO
+                pv[s] = p;
+                dsn[s] = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
             }
+            dk = chain16<BF>(dsn, qrow, dk);          // dK += dS^T Q
+            dv = chain16<BF>(pv, dorow, dv);          // dV += P^T dO
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = kt * 32 + acc_row(r, kh);
@@ -575,41 +606,42 @@ static int check_geometry(const char* who, int Tq, int Tk, int ldq, int ldk, int
 
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                     int kb, int kvb, int qpk, const int32_t* q_off, int self_kv) {
+                     int kb, int kvb, int qpk, const int32_t* q_off, int self_kv, int bf16) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_fwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(kb >= Tk && kvb >= Tk && qpk >= 1, "attention_fwd: bad batch strides");
-    if (Tk <= 32)
-        hipLaunchKernelGGL((attention_fwd_kernel<1, 1>), dim3(B * H), dim3(64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, ldv,
-                           key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv);
-    else
-        hipLaunchKernelGGL((attention_fwd_kernel<12, 1>), dim3(B * H), dim3(768), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V,
-                           ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv);
+#define FIRA_ATT_FWD(NW_, BF_)                                                                                      \
+    hipLaunchKernelGGL((attention_fwd_kernel<NW_, 1, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
+                       ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv)
+    if (Tk <= 32) { if (bf16) FIRA_ATT_FWD(1, true); else FIRA_ATT_FWD(1, false); }
+    else { if (bf16) FIRA_ATT_FWD(12, true); else FIRA_ATT_FWD(12, false); }
+#undef FIRA_ATT_FWD
     FIRA_CHECK_LAUNCH("attention_fwd");
     return 0;
 }
 int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                  const int32_t* q_off, int self_kv) {
-    return attention_fwd_ex(s, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O, ldo, Tk, Tk, 1, q_off, self_kv);
+                  const int32_t* q_off, int self_kv, int bf16) {
+    return attention_fwd_ex(s, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O, ldo, Tk, Tk, 1, q_off, self_kv,
+                            bf16);
 }
 
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
-                  const int32_t* q_off, int self_kv) {
+                  const int32_t* q_off, int self_kv, int bf16) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_bwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(ldo % 4 == 0 && lddo % 4 == 0 && (uintptr_t)O % 16 == 0 && (uintptr_t)dO % 16 == 0,
                  "attention_bwd: O/dO rows must be 16-byte aligned");
-    if (Tk <= 32)
-        hipLaunchKernelGGL((attention_bwd_kernel<1, 1>), dim3(B * H), dim3(64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, ldv,
-                           key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv);
-    else
-        hipLaunchKernelGGL((attention_bwd_kernel<12, 1>), dim3(B * H), dim3(768), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V,
-                           ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv);
+#define FIRA_ATT_BWD(NW_, BF_)                                                                                      \
+    hipLaunchKernelGGL((attention_bwd_kernel<NW_, 1, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
+                       ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv)
+    if (Tk <= 32) { if (bf16) FIRA_ATT_BWD(1, true); else FIRA_ATT_BWD(1, false); }
+    else { if (bf16) FIRA_ATT_BWD(12, true); else FIRA_ATT_BWD(12, false); }
+#undef FIRA_ATT_BWD
     FIRA_CHECK_LAUNCH("attention_bwd");
     return 0;
 }
@@ -635,5 +667,20 @@ int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* 
                        int lddv) {
     return fira::attention_bwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
                                ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv);
+}
+int fira_attention_fwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                          const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
+                          const int32_t* q_off, int self_kv, int dtype) {
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_attention_fwd_ex: dtype must be FIRA_F32 or FIRA_BF16");
+    return fira::attention_fwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
+                               ldo, q_off, self_kv, dtype == FIRA_BF16);
+}
+int fira_attention_bwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
+                          const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O,
+                          int ldo, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV,
+                          int lddv, const int32_t* q_off, int self_kv, int dtype) {
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_attention_bwd_ex: dtype must be FIRA_F32 or FIRA_BF16");
+    return fira::attention_bwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
+                               ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv, dtype == FIRA_BF16);
 }
 }

@@ -154,10 +154,11 @@ int decode_embed(hipStream_t s, int BR, int T, int step, const int32_t* tokens, 
 // (at most Tq of them); self_kv: its keys / values are the same rows of K / V (/ dK / dV).  key_valid stays dense.
 int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                  const int32_t* q_off = nullptr, int self_kv = 0);
+                  const int32_t* q_off = nullptr, int self_kv = 0,
+                  int bf16 = 0);      // 1: operands of the four matmuls rounded to bf16, bf16 MFMA, fp32 accumulate / soft-max
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                     int kb, int kvb, int qpk, const int32_t* q_off = nullptr, int self_kv = 0);
+                     int kb, int kvb, int qpk, const int32_t* q_off = nullptr, int self_kv = 0, int bf16 = 0);
 // one query per row (decode step): K/V streamed once per (commit, head) over the valid keys only; optional merged new key
 int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
@@ -166,7 +167,7 @@ int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int l
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
-                  const int32_t* q_off = nullptr, int self_kv = 0);
+                  const int32_t* q_off = nullptr, int self_kv = 0, int bf16 = 0);
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score);
 // mem_valid (optional, [B/qpk, S]): slots with 0 are skipped (score 0 / zero gradient): they are masked to -1e9 later

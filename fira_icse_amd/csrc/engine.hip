@@ -512,6 +512,13 @@ static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const
     return 0;
 }
 
+// bf16 mode: the attention matmuls run on bf16 operands too (torch.autocast semantics); FIRA_ATTN_BF16=0 keeps the fp32
+// MFMA chains (A/B switch)
+static inline int attn_bf16() {
+    static const bool off = [] { const char* e = getenv("FIRA_ATTN_BF16"); return e && e[0] == '0'; }();
+    return g_dtype == 1 && !off;
+}
+
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
 static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
 
@@ -681,14 +688,14 @@ static int decoder_forward(Ctx& c) {
         DecSave& e = p.dec[l];
         TRY(consume(3 * D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 0));
         TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D,
-                          c.dec_off, 1));
+                          c.dec_off, 1, attn_bf16()));
         TRY(close_block(D, e.ao, c.P + w.wo_s, c.P + w.bo_s, x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
                         site(l, SITE_SELF), true, nullptr, nullptr, 0, nullptr));
         x = e.x_a;
         TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
         if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
         TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D,
-                          c.dec_off, 0));
+                          c.dec_off, 0, attn_bf16()));
         TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
                         site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
         x = e.x_c;
@@ -814,7 +821,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_dgrad(s, c.Td, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
                           p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, KV,
-                          p.dkv_all + l * 2 * D + D, KV, c.dec_off, 0));
+                          p.dkv_all + l * 2 * D + D, KV, c.dec_off, 0, attn_bf16()));
         if (so) {                                // this layer's dK|dV -> compact rows -> d memory, beside the chain
             const size_t o = (size_t)l * 2 * D;
             TRY(aux_fork(s));
@@ -832,7 +839,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
         TRY(linear_dgrad(s, c.Td, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
         TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
-                          e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1));
+                          e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1, attn_bf16()));
         TRY(linear_wgrad_grouped(s, c.Td, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
         TRY(linear_dgrad(s, c.Td, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
         dy = p.dT_a;

@@ -188,6 +188,27 @@ def colsum(X):
     return out
 
 
+def attention_ragged_fwd(q, k, v, key_valid, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8):
+    """The engine's form (fira_attention_fwd_ex): q [R,256] compact query rows, commit b's are q_off[b] .. q_off[b+1]
+    (<= Tq of them); k / v [B*Tk,256] dense, or the same compact rows with self_kv; dtype 1 = bf16 MFMA."""
+    B = q_off.numel() - 1
+    o = torch.zeros_like(q)
+    check(_lib.lib().fira_attention_fwd_ex(cur_stream(), B, heads, Tq, Tk, ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v),
+                                           v.stride(0), ptr(_i32(key_valid)), int(causal), 0, ptr(o), 256, ptr(_i32(q_off)),
+                                           int(self_kv), dtype), "fira_attention_fwd_ex")
+    return o
+
+
+def attention_ragged_bwd(q, k, v, key_valid, o, do, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8):
+    B = q_off.numel() - 1
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    check(_lib.lib().fira_attention_bwd_ex(cur_stream(), B, heads, Tq, Tk, ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v),
+                                           v.stride(0), ptr(_i32(key_valid)), int(causal), 0, ptr(_f32(o)), 256,
+                                           ptr(_f32(do)), 256, ptr(dq), 256, ptr(dk), 256, ptr(dv), 256, ptr(_i32(q_off)),
+                                           int(self_kv), dtype), "fira_attention_bwd_ex")
+    return dq, dk, dv
+
+
 def attention_fwd(q, k, v, key_valid, causal=False, q_pos0=0, heads=8):
     """q [B,Tq,256], k/v [B,Tk,256] (any row stride), key_valid int32 [B,Tk] -> o [B,Tq,256]."""
     B, Tq, _ = q.shape

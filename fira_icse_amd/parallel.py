@@ -106,10 +106,10 @@ class ShardedOptimizerComm:
     followed by an all-gather), but every rank updates, and keeps Adam moments for, only 1/world of the parameters.
 
     Each readiness bucket [lo, hi) (head+decoder, encoder) is cut into ``world`` chunks of ceil((hi-lo)/world) elements;
-    rank r owns chunk r clipped to the bucket.  The collectives run on the padded window [lo, lo + world*chunk): the
-    <= world-1 elements past ``hi`` belong to the next region of the flat buffer (the first encoder parameters, or the
-    never-trained tail [live, total)); their reduced gradients are ignored and the gathered "parameters" written back
-    there are the unchanged values every rank already holds.
+    rank r owns chunk r clipped to the bucket.  The bucket bounds are multiples of 64 elements (256-byte aligned tensor
+    offsets, csrc/layout.cpp), so for world in {2, 4, 8, 16, 32, 64} the chunks tile the bucket exactly and the collectives
+    run in place on gbuf[lo:hi] / flat[lo:hi].  A world size that does not divide the bucket (3, in the tests) goes through
+    a zero-padded scratch window of world*chunk elements: nothing outside [lo, hi) is ever read or written.
     """
 
     def __init__(self, split: int, live: int, total: int, group=None):
@@ -120,8 +120,6 @@ class ShardedOptimizerComm:
         self.buckets = []
         for lo, hi in ((0, split), (split, live)):
             chunk = -(-(hi - lo) // self.world)
-            if lo + self.world * chunk > total:
-                raise ValueError("flat buffer too short for the padded bucket [%d, %d)" % (lo, lo + self.world * chunk))
             a = min(hi, lo + self.rank * chunk)
             self.buckets.append({"lo": lo, "hi": hi, "chunk": chunk, "a": a, "b": min(hi, a + chunk)})
 
@@ -132,8 +130,12 @@ class ShardedOptimizerComm:
     def reduce_scatter(self, b: int, gbuf: torch.Tensor, out: torch.Tensor):
         """out[:chunk] = sum over ranks of gbuf[window of this rank]; enqueued on the current stream."""
         q = self.buckets[b]
-        lo, chunk = q["lo"], q["chunk"]
-        window = gbuf[lo:lo + self.world * chunk]
+        lo, hi, chunk = q["lo"], q["hi"], q["chunk"]
+        if self.world * chunk == hi - lo:
+            window = gbuf[lo:hi]
+        else:                                      # ragged bucket: zero-padded scratch, the bucket itself is only read
+            window = torch.zeros(self.world * chunk, dtype=gbuf.dtype, device=gbuf.device)
+            window[:hi - lo].copy_(gbuf[lo:hi])
         if self.world == 1:
             out[:chunk].copy_(window)
         elif self.native:
@@ -146,10 +148,15 @@ class ShardedOptimizerComm:
     def all_gather(self, b: int, flat: torch.Tensor):
         """Every rank's chunk of the (updated) parameters -> all ranks, in place in the flat parameter buffer."""
         q = self.buckets[b]
-        lo, chunk = q["lo"], q["chunk"]
+        lo, hi, chunk = q["lo"], q["hi"], q["chunk"]
         if self.world == 1:
             return
-        window = flat[lo:lo + self.world * chunk]
+        exact = self.world * chunk == hi - lo
+        if exact:
+            window = flat[lo:hi]
+        else:                                      # ragged bucket: gather into scratch, copy the bucket's part back
+            window = torch.zeros(self.world * chunk, dtype=flat.dtype, device=flat.device)
+            window[:hi - lo].copy_(flat[lo:hi])
         mine = window[self.rank * chunk:(self.rank + 1) * chunk]
         if self.native:
             # (a copy of the own chunk as the input: RCCL allows the in-place form, torch's checks on overlapping
@@ -160,6 +167,8 @@ class ShardedOptimizerComm:
             dist.all_gather(parts, mine.clone(), group=self.group)
             for r, part in enumerate(parts):
                 window[r * chunk:(r + 1) * chunk].copy_(part)
+        if not exact:
+            flat[lo:hi].copy_(window[:hi - lo])
 
     def gather_full(self, shards: List[torch.Tensor], total: int) -> torch.Tensor:
         """Full-length [total] tensor from the per-bucket owned shards of every rank (checkpointing; collective)."""

@@ -258,6 +258,21 @@ int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* 
                        const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
                        int causal, int q_pos0, const float* O, int ldo, const float* dO, int lddo,
                        float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
+/* The forms the engine calls (v5):
+ *   q_off  (optional, [B+1]) ragged query rows: batch entry b's queries are rows q_off[b] .. q_off[b+1] of Q / O / dO /
+ *          dQ (at most Tq of them: the decoder's computed target rows, fira_batch.dec_off); self_kv != 0: its keys and
+ *          values are the same rows of K / V / dK / dV (self-attention).  key_valid stays dense [B, Tk].
+ *   dtype  FIRA_BF16: the operands of the four matmuls (Q K^T, P V and their gradients) are rounded to bf16 and
+ *          multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; scaling, mask, soft-max in fp32 -- what
+ *          torch.autocast does to Attention.forward (gnn_transformer.py:149-156).  FIRA_F32: exact fp32 MFMA chains. */
+int fira_attention_fwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq,
+                          const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
+                          int causal, int q_pos0, float* O, int ldo, const int32_t* q_off, int self_kv, int dtype);
+int fira_attention_bwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq,
+                          const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
+                          int causal, int q_pos0, const float* O, int ldo, const float* dO, int lddo,
+                          float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
+                          const int32_t* q_off, int self_kv, int dtype);
 
 /* Attention of ONE query per row (the K/V-cached decode step of run_model.py:256): O[b, h*32..] = softmax(q.K^T/sqrt(32)
  * over the valid keys) V.  Row b uses K/V batch entry b / qpk (kb rows of ldk floats per entry; key_valid [BR/qpk, kvb]):

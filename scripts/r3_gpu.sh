@@ -62,6 +62,16 @@ for ST in "$@"; do
           done
         done
       done 2>&1 | tee $OUT/ab.txt ;;
+    pmc)
+      for DT in f32 bf16; do
+        bash scripts/pmc_traffic.sh $DT > /dev/null 2>&1
+        python scripts/pmc_traffic_summary.py gpurun_out/pmc_traffic_$DT $OUT/pmc_traffic_$DT.md $OUT/traffic.json $DT; echo "pmc $DT rc=$?"
+        find gpurun_out/pmc_traffic_$DT -name "*.csv" -delete
+      done
+      cat $OUT/traffic.json | head -40 ;;
+    chainfinal)
+      timeout 300 python scripts/gemm_chain.py f32 > $OUT/gemm_chain_f32.md 2>&1; timeout 300 python scripts/gemm_chain.py bf16 > $OUT/gemm_chain_bf16.md 2>&1
+      tail -n 12 $OUT/gemm_chain_f32.md ;;
     shapes)
       timeout 300 python scripts/gemm_step_shapes.py f32 32 > $OUT/gemm_shapes_f32_b32.txt 2>&1
       timeout 300 python scripts/gemm_step_shapes.py f32 64 > $OUT/gemm_shapes_f32_b64.txt 2>&1

@@ -43,6 +43,9 @@ def test_param_layout_matches_reference_checkpoint_keys(lib):
     for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
         assert a1 <= b0
     assert all(off % 64 == 0 for off, _ in lay.entries.values())
+    # the two gradient-readiness buckets are multiples of 64 elements: they split exactly over 2 / 4 / 8 ranks (ZeRO-1
+    # reduce-scatter / all-gather run in place, parallel.ShardedOptimizerComm)
+    assert lay.split % 64 == 0 and lay.live % 64 == 0 and 0 < lay.split < lay.live <= lay.total
     assert lay.entries["out_fc.weight"][1] == (24650, 256)
     assert lay.entries["copy_net.LinearProb.bias"][1] == (2,)
     # fused groups are contiguous: q|k of a Combination, q|k|v of self-attention, k|v of all cross-attentions

@@ -314,6 +314,61 @@ def test_attention_fwd_bwd(Tq, Tk, causal):
     assert rel_err(dv, v.grad) < 5e-6
 
 
+@pytest.mark.parametrize("self_kv", [True, False])
+def test_attention_on_ragged_query_rows_and_bf16_operands(self_kv):
+    """fira_attention_{fwd,bwd}_ex, the forms the engine calls: (1) RAGGED query rows -- commit b's queries are a prefix
+    of its 30 positions, stored compactly (fira_batch.dec_off); with self_kv the keys / values are the same compact rows
+    (causal self-attention), otherwise a dense [B,370] memory -- must equal the dense computation on the rows that exist;
+    (2) dtype bf16: the four matmuls on bf16-rounded operands, fp32 accumulation and soft-max (torch.autocast's
+    Attention.forward): forward equal to the fp64 result of the ROUNDED operands / probabilities, gradients within
+    bf16 resolution of the exact ones."""
+    from fira_icse_amd import ops
+    B, T, S = 6, 30, 370
+    lens = [30, 1, 17, 29, 8, 12]
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    rows = torch.cat([torch.arange(n) + b * T for b, n in enumerate(lens)]).to(DEV)
+    Tk = T if self_kv else S
+    q = randn(B, T, 256, seed=1).double().requires_grad_(True)
+    k = randn(B, Tk, 256, seed=2).double().requires_grad_(True)
+    v = randn(B, Tk, 256, seed=3).double().requires_grad_(True)
+    g = torch.Generator().manual_seed(4)
+    if self_kv:                                    # keys = the prefix positions themselves (all valid), causal
+        key_valid = torch.zeros(B, T, dtype=torch.int32, device=DEV)
+        for b, n in enumerate(lens):
+            key_valid[b, :n] = 1
+    else:
+        key_valid = (torch.rand(B, S, generator=g) > 0.3).to(torch.int32).to(DEV)
+        key_valid[:, 0] = 1
+    ref = torch_attention(q, k, v, key_valid, self_kv)
+    do_dense = torch.zeros(B * T, 256, device=DEV)
+    do_dense[rows] = randn(len(rows), 256, seed=5)
+    ref.backward(do_dense.view(B, T, 256).double())
+    qc = q.detach().float().view(B * T, 256)[rows].contiguous()
+    if self_kv:
+        kc, vc = (t.detach().float().view(B * T, 256)[rows].contiguous() for t in (k, v))
+    else:
+        kc, vc = (t.detach().float().reshape(B * S, 256) for t in (k, v))
+    pick = (lambda t: t.reshape(B * T, 256)[rows]) if self_kv else (lambda t: t.reshape(B * S, 256))
+    doc = do_dense[rows].contiguous()
+    for dtype, tol_o, tol_g in ((0, 2e-6, 5e-6), (1, 1e-2, 2e-2)):
+        o = ops.attention_ragged_fwd(qc, kc, vc, key_valid, off, T, Tk, causal=self_kv, self_kv=self_kv, dtype=dtype)
+        assert rel_err(o, ref.reshape(B * T, 256)[rows]) < tol_o, dtype
+        dq, dk, dv = ops.attention_ragged_bwd(qc, kc, vc, key_valid, o, doc, off, T, Tk, causal=self_kv, self_kv=self_kv,
+                                              dtype=dtype)
+        assert rel_err(dq, q.grad.reshape(B * T, 256)[rows]) < tol_g, dtype
+        assert rel_err(dk, pick(k.grad)) < tol_g and rel_err(dv, pick(v.grad)) < tol_g, dtype
+    # bf16 forward against the same arithmetic in fp64: rounded q, k, v and rounded probabilities
+    r16 = lambda t: t.detach().float().bfloat16().double()
+    qh, kh, vh = (r16(t).view(B, -1, 8, 32).transpose(1, 2) for t in (q, k, v))
+    w = qh @ kh.transpose(-1, -2) / math.sqrt(32)
+    mask = key_valid[:, None, None, :].bool()
+    if self_kv:
+        mask = mask & (torch.arange(Tk, device=DEV)[None, :] <= torch.arange(T, device=DEV)[:, None])[None, None]
+    w = torch.softmax(w.masked_fill(~mask, -1e9), -1).float().bfloat16().double()
+    ref16 = (w @ vh).transpose(1, 2).reshape(B * T, 256)[rows]
+    assert rel_err(o, ref16) < 5e-5
+
+
 def test_attention_strided_qkv_buffer():
     """Q|K|V read straight out of the fused [rows, 768] projection buffer (row stride 768)."""
     from fira_icse_amd import ops

@@ -258,8 +258,8 @@ def cpu_baseline(cfg, store, seconds_budget=30.0):
         med = float(np.median(times[1:])) if len(times) > 1 else times[0]
         return B / med, len(times)
 
-    v4, n4 = train_leg(4, 8, 0.2 * seconds_budget)
-    v32, n32 = train_leg(32, 4, 0.4 * seconds_budget)
+    v4, n4 = train_leg(4, 12, 0.2 * seconds_budget)
+    v32, n32 = train_leg(32, 10, 0.5 * seconds_budget)           # ~1.2 s per step on 32 threads: 10 steps ~ 12-15 s
 
     def search_leg(B, beam, steps):
         hb = store.batch(range(B))
@@ -268,11 +268,11 @@ def cpu_baseline(cfg, store, seconds_budget=30.0):
                       t(hb.sub_token), beam, max_steps=steps)
         return B * steps / (time.time() - t0)
 
-    g20 = search_leg(20, 1, 3)
-    b20 = search_leg(20, 3, 2)
+    g20 = search_leg(20, 1, 4)
+    b20 = search_leg(20, 3, 3)
     return {"value": v32, "unit": "commits/s", "cores": threads, "kind": "port",
             "sample": "train steps (fwd+bwd+Adam, dropout off, fp32, dense f64->f32 adjacency as the reference feeds "
-                      "it): %d at batch 32 (value), %d at batch 4; search: 3 greedy / 2 beam-3 steps at batch 20 with "
+                      "it): %d at batch 32 (value = batch / median step time), %d at batch 4; search: 4 greedy / 3 beam-3 steps at batch 20 with "
                       "the encoder pass (full recompute per step as the reference does); %.0f s in total" %
                       (n32, n4, time.time() - t_all),
             "train_batch4_commits_per_s": v4, "train_batch32_commits_per_s": v32,

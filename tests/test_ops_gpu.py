@@ -153,6 +153,24 @@ def test_block_dense_spmm_fp32_and_bf16(N, density):
     assert torch.equal(Yw[:, :256], Y) and float((Yw[:, 256:] - 7.0).abs().max()) == 0
 
 
+def test_row_wave_spmm_on_a_large_batch():
+    """A launch of the size the engine issues at batch 64+ (19 500 rows) incl. rows longer than one 64-entry chunk."""
+    from fira_icse_amd import ops
+    B, N = 30, 650
+    _, _, _, dense = dense_graph_batch(B, N, 0.006, seed=3)
+    dense[:, 5, :200] = 0.25                                    # a few rows / columns with ~200 entries
+    dense[:, :200, 5] = 0.25
+    dn = dense.cpu().numpy()
+    b, r, c = np.nonzero(dn)
+    rp = np.zeros(B * N + 1, dtype=np.int64)
+    np.cumsum(np.bincount(b * N + r, minlength=B * N), out=rp[1:])
+    t = lambda a, dt: torch.tensor(np.asarray(a, dtype=dt), device=DEV)
+    X = randn(B * N, 256, seed=13)
+    ref = torch.bmm(dense.double(), X.view(B, N, 256).double()).view(B * N, 256)
+    Y = ops.csr_spmm(t(rp, np.int32), t(b * N + c, np.int32), t(dn[b, r, c], np.float32), X, graph_rows=N, variant=1)
+    assert rel_err(Y, ref) < 1e-6
+
+
 def test_block_dense_spmm_sums_repeated_columns():
     """Sorted rows may repeat a column (a multigraph edge list that was not merged): the dense tile holds their sum."""
     from fira_icse_amd import ops

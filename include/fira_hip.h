@@ -329,7 +329,8 @@ int fira_debug_chain(void* stream, int n, int mode, float* scratch);
 
 /* forward + backward of TransModel.forward(..., 'train') (Model.py:38-84, run_model.py:104-108):
  * grads (flat, same layout as params) += d(loss_sum)/dparams; loss_sum / n_tok are device scalars
- * that are overwritten.  grads must be zeroed by the caller when a fresh gradient is wanted.       */
+ * that are overwritten.  A fresh gradient: zero grads[0, live) first, or set opts->zero_grads and the
+ * call clears it itself (beside the encoder's forward pass, on a library-owned stream).            */
 int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
                        float* grads, void* workspace, size_t workspace_bytes, const fira_train_opts* opts,
                        float* loss_sum, int32_t* n_tok, void* mid_event);

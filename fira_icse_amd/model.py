@@ -255,7 +255,9 @@ class _PinnedRing:
         if ev is not None:
             ev.synchronize()
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+            # page-locking is a millisecond-scale driver call: grow with headroom so that a slightly larger batch (the arena
+            # follows the batch's node / edge counts) does not re-pin the slot
+            buf = torch.empty(max(nbytes + nbytes // 2, 1 << 20), dtype=torch.uint8).pin_memory()
         ev = torch.cuda.Event()                    # created lazily on the device current at record() time
         self.slots[i] = (buf, ev)
         return buf, ev

@@ -893,12 +893,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         // (the LayerNorm backward also leaves the column sums of dY the folded form needs: db2 and dc, deferred)
         float* dc21 = p.dc21 + (size_t)l * D;
         bool sums = false;
+        const bool room = unfold_tab.n < 16;     // (asked for only when the closing unfold launch can take the layer)
         TRY(ln_bwd(s, Nc, dXn, e.s2, e.st2, c.P + w.ln2g, other, g.dY2, G + w.ln2g, G + w.ln2b, c.p_gcn,
-                              c.seed, site(l, SITE_GCN), nullptr, p.rsum, G + w.fc2b, dc21, &sums));
-        if (sums && unfold_tab.n < 16)
-            unfold_tab.e[unfold_tab.n++] = UnfoldEntry{c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b};
-        else
-            sums = false;
+                              c.seed, site(l, SITE_GCN), nullptr, room ? p.rsum : nullptr, G + w.fc2b, dc21, &sums));
+        if (sums) unfold_tab.e[unfold_tab.n++] = UnfoldEntry{c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b};
         // GCN, folded form (see encoder_forward): Y = U W21^T + r c^T + b2 with U = A_hat X
         //   weight space: dW21 += dY^T U (+ db2 by the fused column sums), dc += dY^T r           (side stream)
         //   data space:   dU = dY W21, dX += A_hat dU                                              (main stream)

@@ -325,6 +325,28 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
               "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
                       "steps executed, the unit of BASELINE.md's CPU figure.  Weights: %d training steps on the "
                       "synthetic commits (untimed), fp32 search" % a.decode_train_steps}
+    # the same greedy search streaming a bf16 copy of the cross K|V (FIRA_DECODE_KV_BF16; not the default: the ids are no
+    # longer bit-identical to the fp32 search) -- reported beside the fp32 figure, with the token agreement
+    try:
+        s16 = Searcher(model, kv_bf16=True)
+        for _ in range(2):
+            out16, length16, p16 = s16.greedy(dbd)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out16, length16, p16 = s16.greedy(dbd)
+        barrier()
+        d16 = (time.perf_counter() - t0) / reps
+        steps16 = int(length16.max().item()) - 1
+        toks16 = int((length16 - 1).sum().item())
+        valid = torch.arange(out.shape[1], device=out.device)[None, :] < torch.minimum(length, length16)[:, None]
+        kv16_bytes = w_bytes + kv_bytes // 2 + 4 * Bd * Sm * 256 // 2 + logit_bytes      # K|V halved, LinearSource rows fp32
+        decode["bf16_kv"] = {"ms_per_step": d16 / max(steps16, 1) * 1e3, "tokens_per_s": toks16 * world / d16,
+                             "steps_run": steps16, "bytes_per_step": kv16_bytes,
+                             "token_agreement_with_fp32": float((out == out16)[valid].float().mean().item()),
+                             "same_length": float((length == length16).float().mean().item())}
+    except Exception as e:
+        decode["bf16_kv"] = {"error": repr(e)}
     # the reference's own test configuration: beam 3, batch 20 (run_model.py:401-415)
     dbb = DeviceBatch(store.batch(range(20)), cfg, model.device_)
     for _ in range(2):

@@ -93,6 +93,8 @@ SIGNATURES = {
     "fira_host_collate_csr": (_I, [_I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "fira_forward_dev": (_I, [_P, _DP, _BP, _P, _P, _Z, _P, _P, _P, _I]),
     "fira_decode_begin": (_I, [_P, _DP, _BP, _P, _P, _Z, _I]),
+    "fira_decode_begin_ex": (_I, [_P, _DP, _BP, _P, _P, _Z, _I, _I]),
+    "fira_decode_step_ex": (_I, [_P, _DP, _P, _P, _Z, _I, _I, _I, _P, _P, _P, _P, _P, _I]),
     "fira_beam_prepare": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "fira_beam_select": (_I, [_P, _DP, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fira_greedy_advance": (_I, [_P, _DP, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

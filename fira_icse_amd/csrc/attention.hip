@@ -462,10 +462,16 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 //     at the end.
 // Self-attention with merged q|k|v projections: the newest key / value of row b (index Tk-1) is read from Knew / Vnew
 // (the projection's output row) instead of the cache, and this kernel appends it to the cache for the later steps.
-template <int NSLOT>
+// KV16: K / V rows are raw bf16 (the optional bf16 cross-K|V cache of the decode loop: 64 bytes per key, head and operand
+// instead of 128; 8 lanes x 8 bytes); the arithmetic stays fp32 on the widened values.  ldk / ldv count ELEMENTS.
+__device__ __forceinline__ f32x4v widen4(uint2 u) {
+    return f32x4v{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                  __uint_as_float(u.y & 0xffff0000u)};
+}
+template <int NSLOT, bool KV16>
 __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, const float* __restrict__ Q, int ldq,
-                                                               const float* __restrict__ K, int ldk,
-                                                               const float* __restrict__ V, int ldv,
+                                                               const void* __restrict__ Kv, int ldk,
+                                                               const void* __restrict__ Vv, int ldv,
                                                                const int32_t* __restrict__ key_valid, float* __restrict__ O,
                                                                int ldo, int kb, int kvb, int qpk,
                                                                const float* __restrict__ Knew,
@@ -500,8 +506,12 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
         __syncthreads();
     }
     const size_t hoff = (size_t)h * FIRA_DH + c * 4;
+    const float* K = static_cast<const float*>(Kv);
+    const float* V = static_cast<const float*>(Vv);
     const float* Kb = K + (size_t)bk * kb * ldk + hoff;
     const float* Vb = V + (size_t)bk * kb * ldv + hoff;
+    const uint16_t* Kh = static_cast<const uint16_t*>(Kv) + (size_t)bk * kb * ldk + hoff;
+    const uint16_t* Vh = static_cast<const uint16_t*>(Vv) + (size_t)bk * kb * ldv + hoff;
     // ---- this lane's key slots: list index j*32 + wave*8 + r
     f32x4v kf[NSLOT], vf[NSLOT];
     bool have[NSLOT];
@@ -516,8 +526,13 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
             pk = Knew + (size_t)bk * ldn + hoff;
             pv = Vnew + (size_t)bk * ldn + hoff;
         }
-        kf[j] = have[j] ? *reinterpret_cast<const f32x4v*>(pk) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        vf[j] = have[j] ? *reinterpret_cast<const f32x4v*>(pv) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (KV16) {
+            kf[j] = have[j] ? widen4(*reinterpret_cast<const uint2*>(Kh + (size_t)key * ldk)) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            vf[j] = have[j] ? widen4(*reinterpret_cast<const uint2*>(Vh + (size_t)key * ldv)) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        } else {
+            kf[j] = have[j] ? *reinterpret_cast<const f32x4v*>(pk) : f32x4v{0.f, 0.f, 0.f, 0.f};
+            vf[j] = have[j] ? *reinterpret_cast<const f32x4v*>(pv) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
     }
     if (Knew && Kc_out && t < 16) {                              // append the new key / value of this head to the cache
         const int cc = t & 7;
@@ -573,6 +588,24 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
     }
 }
 
+// bf16 K / V rows (raw bf16, ldk / ldv in elements, rows 8-byte aligned): the decode loop's optional bf16 cross-K|V cache
+int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const uint16_t* K, int ldk,
+                          const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk) {
+    ProfScope prof(s, PROF_ATTN, 0.0);
+    if (BR <= 0) return 0;
+    FIRA_REQUIRE(Tk >= 1 && Tk <= MAX_TK && qpk >= 1 && BR % qpk == 0 && kb >= Tk && kvb >= Tk, "decode_attention: bad geometry");
+    FIRA_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 8 == 0 &&
+                     (uintptr_t)V % 8 == 0, "decode_attention: rows must be 8-byte (bf16) / 16-byte (fp32) aligned");
+    const dim3 grid((BR / qpk) * H);
+    if (Tk <= 32)
+        hipLaunchKernelGGL((decode_attention_kernel<1, true>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
+                           ldo, kb, kvb, qpk, nullptr, nullptr, 0, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((decode_attention_kernel<12, true>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
+                           ldo, kb, kvb, qpk, nullptr, nullptr, 0, nullptr, nullptr);
+    FIRA_CHECK_LAUNCH("decode_attention_kv16");
+    return 0;
+}
 int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
                      const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out) {
@@ -585,11 +618,11 @@ int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int l
     FIRA_REQUIRE(!Knew || qpk == 1, "decode_attention: merged new keys need one query per K/V entry");
     const dim3 grid((BR / qpk) * H);
     if (Tk <= 32)
-        hipLaunchKernelGGL((decode_attention_kernel<1>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O, ldo,
-                           kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
+        hipLaunchKernelGGL((decode_attention_kernel<1, false>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
+                           ldo, kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
     else
-        hipLaunchKernelGGL((decode_attention_kernel<12>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O, ldo,
-                           kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
+        hipLaunchKernelGGL((decode_attention_kernel<12, false>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
+                           ldo, kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
     FIRA_CHECK_LAUNCH("decode_attention");
     return 0;
 }

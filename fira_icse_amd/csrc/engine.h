@@ -164,6 +164,9 @@ int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int l
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
                      const float* Knew = nullptr, const float* Vnew = nullptr, int ldn = 0, float* Kc_out = nullptr,
                      float* Vc_out = nullptr);
+int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const uint16_t* K, int ldk,
+                          const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk);
+int rows_to_bf16(hipStream_t s, int64_t n, const float* in, uint16_t* out);      // out[i] = bf16(in[i]) (RNE), n % 4 == 0
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,

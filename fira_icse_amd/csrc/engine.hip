@@ -994,6 +994,7 @@ struct DecodePlan {
     float *kc[2], *vc[2];
     int32_t* hist[2];
     float *x, *q, *qkv, *ao, *s, *xa, *qc, *xc, *h, *tgt, *score, *gate, *logits;
+    uint16_t* kv16;                  // optional bf16 copy of the cross K|V rows of all layers (FIRA_DECODE_KV_BF16)
     size_t build(void* ws, const fira_dims& d, int B, int n_beam) {
         size_t used = enc.build(ws, d, B, false);
         Arena a(ws ? (char*)ws + used : nullptr);
@@ -1007,6 +1008,7 @@ struct DecodePlan {
         xc = a.f(BR * D); h = a.f((size_t)BR * d.d_ff); tgt = a.f(BR * D);
         score = a.f((size_t)BR * (d.sou_len + d.sub_len)); gate = a.f((size_t)BR * 2);
         logits = a.f((size_t)BR * enc.ldl);
+        kv16 = a.get<uint16_t>((size_t)enc.MB * d.n_layer * 2 * D);
         return used + a.used;
     }
 };
@@ -1117,10 +1119,15 @@ int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, 
 
 int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,
                       size_t workspace_bytes, int n_beam) {
+    return fira_decode_begin_ex(stream, d, batch, params, workspace, workspace_bytes, n_beam, 0);
+}
+int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,
+                         size_t workspace_bytes, int n_beam, int flags) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
     TRY(check_batch(batch));
     FIRA_REQUIRE(params && workspace && n_beam >= 1, "bad argument");
+    FIRA_REQUIRE((flags & ~FIRA_DECODE_KV_BF16) == 0, "fira_decode_begin_ex: unknown flags %d", flags);
     DecodePlan dp;
     const size_t need = dp.build(workspace, *d, batch->B, n_beam);
     FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
@@ -1131,12 +1138,21 @@ int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch,
     TRY(check_counts(batch, p));
     TRY(encoder_forward(c, false));     // also leaves kv_all (cross K|V of all layers) and src = LinearSource(memory)
     TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers
+    // optional: the cross K|V rows the step loop streams 30 times, once more in bf16 (half the bytes per step; rows of
+    // masked slots are converted too -- they are never read)
+    if (flags & FIRA_DECODE_KV_BF16) TRY(rows_to_bf16(c.s, (int64_t)p.MB * p.nl * 2 * FIRA_D, p.kv_all, dp.kv16));
     return 0;
 }
 
 int fira_decode_step(void* stream, const fira_dims* d, const float* params, void* workspace, size_t workspace_bytes,
                      int B, int n_beam, int step, const int32_t* tokens, const int32_t* parent, float* dist,
                      int32_t* best_id, float* best_p) {
+    return fira_decode_step_ex(stream, d, params, workspace, workspace_bytes, B, n_beam, step, tokens, parent, dist, best_id,
+                               best_p, 0);
+}
+int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, void* workspace, size_t workspace_bytes,
+                        int B, int n_beam, int step, const int32_t* tokens, const int32_t* parent, float* dist,
+                        int32_t* best_id, float* best_p, int flags) {
     const Layout* Lp = get_layout(d);
     if (!Lp) return 1;
     const Layout& L = *Lp;
@@ -1203,7 +1219,10 @@ int fira_decode_step(void* stream, const fira_dims* d, const float* params, void
         }
         TRY(close_block(D, dp.ao, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, true));
         TRY(consume(D, dp.xa, params + w.wq_c, params + w.bq_c, dp.qc, 0));
-        if (stream_attn)
+        if (stream_attn && (flags & FIRA_DECODE_KV_BF16))
+            TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, KV, dp.kv16 + l * 2 * D + D, KV, p.mem_valid,
+                                      dp.ao, D, Sm, Sm, n_beam));
+        else if (stream_attn)
             TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid,
                                  dp.ao, D, Sm, Sm, n_beam));
         else

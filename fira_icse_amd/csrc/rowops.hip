@@ -886,6 +886,26 @@ int decode_embed(hipStream_t s, int BR, int T, int step, const int32_t* tokens, 
     FIRA_CHECK_LAUNCH("decode_embed");
     return 0;
 }
+// fp32 -> raw bf16 (round to nearest even), 4 elements per thread: the decode loop's optional bf16 copy of the cross K|V
+typedef __bf16 rbf16x2 __attribute__((ext_vector_type(2)));
+typedef float rf32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(int64_t n4, const float4* __restrict__ in, uint2* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = in[i];
+        const rf32x2 a = {v.x, v.y}, b = {v.z, v.w};
+        out[i] = uint2{__builtin_bit_cast(uint32_t, __builtin_convertvector(a, rbf16x2)),
+                       __builtin_bit_cast(uint32_t, __builtin_convertvector(b, rbf16x2))};
+    }
+}
+int rows_to_bf16(hipStream_t s, int64_t n, const float* in, uint16_t* out) {
+    if (n <= 0) return 0;
+    FIRA_REQUIRE(n % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 8 == 0, "rows_to_bf16: bad size / alignment");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 32)), dim3(256), 0, s, n4,
+                       reinterpret_cast<const float4*>(in), reinterpret_cast<uint2*>(out));
+    FIRA_CHECK_LAUNCH("rows_to_bf16");
+    return 0;
+}
 int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist) {
     hipLaunchKernelGGL(mark_history_kernel, dim3(cdiv(BR, 256)), dim3(256), 0, s, BR, T, step, tokens, hist);
     FIRA_CHECK_LAUNCH("mark_history");

@@ -20,9 +20,12 @@ from .model import DeviceBatch, TransModel
 
 
 class Searcher:
-    def __init__(self, model: TransModel):
+    def __init__(self, model: TransModel, kv_bf16: bool = False):
+        """``kv_bf16``: stream a bf16 copy of the cross-attention K|V in the step loop (FIRA_DECODE_KV_BF16: half of the
+        bytes a step moves; ids no longer bit-identical to the fp32 search -- off by default)."""
         self.model = model
         self.cfg = model.cfg
+        self.flags = 1 if kv_bf16 else 0
         self._ws = {}
 
     def _workspace(self, B, beam):
@@ -37,16 +40,16 @@ class Searcher:
     def _begin(self, db, beam):
         ws = self._workspace(db.B, beam)
         db.wait_ready()
-        _lib.check(_lib.lib().fira_decode_begin(_lib.cur_stream(), C.byref(self.model.dims), C.byref(db.struct),
-                                                _lib.ptr(self.model.flat.data), _lib.ptr(ws), ws.numel(), beam),
-                   "fira_decode_begin")
+        _lib.check(_lib.lib().fira_decode_begin_ex(_lib.cur_stream(), C.byref(self.model.dims), C.byref(db.struct),
+                                                   _lib.ptr(self.model.flat.data), _lib.ptr(ws), ws.numel(), beam,
+                                                   self.flags), "fira_decode_begin")
         return ws
 
     def _step(self, ws, B, beam, step, tokens, parent, dist, best_id, best_p):
-        _lib.check(_lib.lib().fira_decode_step(_lib.cur_stream(), C.byref(self.model.dims),
-                                               _lib.ptr(self.model.flat.data), _lib.ptr(ws), ws.numel(), B, beam, step,
-                                               _lib.ptr(tokens), _lib.ptr(parent), _lib.ptr(dist), _lib.ptr(best_id),
-                                               _lib.ptr(best_p)), "fira_decode_step")
+        _lib.check(_lib.lib().fira_decode_step_ex(_lib.cur_stream(), C.byref(self.model.dims),
+                                                  _lib.ptr(self.model.flat.data), _lib.ptr(ws), ws.numel(), B, beam, step,
+                                                  _lib.ptr(tokens), _lib.ptr(parent), _lib.ptr(dist), _lib.ptr(best_id),
+                                                  _lib.ptr(best_p), self.flags), "fira_decode_step")
 
     # ------------------------------------------------------------------ greedy (beam 1): no sort, no dist tensor
     def _greedy_state(self, B):

@@ -354,6 +354,17 @@ int fira_decode_begin(void* stream, const fira_dims* d, const fira_batch* batch,
 int fira_decode_step(void* stream, const fira_dims* d, const float* params, void* workspace,
                      size_t workspace_bytes, int B, int n_beam, int step, const int32_t* tokens,
                      const int32_t* parent, float* dist, int32_t* best_id, float* best_p);
+/* The same two calls with option flags (both calls of one search must carry the same flags):
+ *   FIRA_DECODE_KV_BF16  keep a bf16 copy of the cross-attention K|V rows of all layers and stream THAT in every step
+ *                        (the cross K|V are 315 of the 379 MB a step moves at batch 64); the arithmetic stays fp32 on the
+ *                        widened values.  Not the default: with it the searched ids are no longer bit-identical to the
+ *                        reference's fp32 run (bench.py reports the agreement). */
+#define FIRA_DECODE_KV_BF16 1
+int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
+                         void* workspace, size_t workspace_bytes, int n_beam, int flags);
+int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, void* workspace,
+                        size_t workspace_bytes, int B, int n_beam, int step, const int32_t* tokens,
+                        const int32_t* parent, float* dist, int32_t* best_id, float* best_p, int flags);
 
 /* Hypothesis bookkeeping of the search loop on the device (run_model.py:225-246 and :268-340).  State per commit:
  * gen [B*n_beam, tar_len] ids starting with <start>, length [B*n_beam], prob [B*n_beam] (slot 0 starts at 1, the others

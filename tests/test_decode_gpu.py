@@ -51,6 +51,25 @@ def test_greedy_matches_reference_output_lines(setup):
     assert lines_of(search.best(out2, length2, prob2), raw, ids) == gold
 
 
+def test_search_with_a_bf16_cross_kv_copy_agrees_with_the_fp32_search(setup):
+    """FIRA_DECODE_KV_BF16 (Searcher(kv_bf16=True)): the step loop streams a bf16 copy of the cross-attention K|V (half of
+    the bytes a step moves).  Not bit-identical by construction -- the attention scores see bf16-rounded keys / values --
+    but the search must stay the same search: on the peaked fixture weights every greedy and beam-3 hypothesis is the
+    reference's line; in general the token agreement is reported by bench.py."""
+    from fira_icse_amd.decode import Searcher
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    gold = json.load(open(os.path.join(util.GOLDEN, "decode_ref.json")))
+    s16 = Searcher(model, kv_bf16=True)
+    out, length, prob = s16.greedy(db)
+    out0, length0, prob0 = search.greedy(db)
+    agree = float((out == out0).float().mean())
+    assert agree > 0.95, agree
+    assert torch.allclose(prob, prob0, rtol=5e-2)
+    assert lines_of(s16.best(out, length, prob), raw, ids) == gold["beam1"]
+    gen, length3, prob3 = s16.beam(db, 3)
+    assert lines_of(s16.best(gen, length3, prob3), raw, ids) == gold["beam3"]
+
+
 def test_beam3_matches_reference_output_lines(setup):
     cfg, raw, ids, hb, sd, model, db, search = setup
     gold = json.load(open(os.path.join(util.GOLDEN, "decode_ref.json")))["beam3"]

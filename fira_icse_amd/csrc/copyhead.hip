@@ -362,6 +362,122 @@ __global__ __launch_bounds__(256) void head_loss_kernel(int T, int V, int S, con
     }
 }
 
+// Training-time variant of head_loss_kernel<true> (no arg-max output).  The full kernel spends ~35 VALU instructions per
+// logit (two libm expf, first-maximum bookkeeping) and is instruction-bound, not memory-bound: 71 us for 530 rows, 76 us
+// for 1 020 (four resident workgroups per CU either way).  Here the generator soft-max costs ONE exponential per logit:
+// e = exp(x - max) replaces x in its register, is summed, and is scaled into the gradient.
+// exp(x - m) = exp2(fma(x, log2 e, -m log2 e)): the rounding of m log2 e is a common factor of every term of the row and
+// cancels in e / sum, the fma rounds x log2 e once (relative error <= 1.3e-6 at x - m = -40, < 1e-7 near the maximum).
+__global__ __launch_bounds__(256) void head_loss_train_kernel(int T, int V, int S, const int32_t* __restrict__ compact_row,
+                                                              float* __restrict__ logits, int ldl,
+                                                              float* __restrict__ score,
+                                                              const int32_t* __restrict__ mem_valid,
+                                                              float* __restrict__ gate_logits,
+                                                              const int32_t* __restrict__ tar_label,
+                                                              float* __restrict__ loss_sum, int32_t* __restrict__ n_tok,
+                                                              int want_grad, const int32_t* __restrict__ row_bt) {
+    __shared__ float smf[4];
+    constexpr float L2E = 1.4426950408889634f;
+    const int bt = blockIdx.x, tid = threadIdx.x;
+    const int flat = row_bt ? row_bt[bt] : bt;
+    const int b = flat / T, t = flat - b * T;
+    const int crow = compact_row ? compact_row[bt] : bt;
+    const int y = (t + 1 < T) ? tar_label[b * T + t + 1] : 0;        // label = cat(tar_label, 0)[:, 1:]
+    float* lrow = crow >= 0 ? logits + (size_t)crow * ldl : nullptr;
+    float* srow = score + (size_t)bt * S;
+    const int32_t* mv = mem_valid + (size_t)b * S;
+
+    const float z0 = gate_logits[2 * bt], z1 = gate_logits[2 * bt + 1];
+    const float zm = fmaxf(z0, z1);
+    const float e0 = expf(z0 - zm), e1 = expf(z1 - zm);
+    const float g0 = e0 / (e0 + e1), g1 = e1 / (e0 + e1);
+
+    // copy soft-max statistics: only rows whose label is a copy slot need them
+    float cmax = -INFINITY, csum = 1.f;
+    const bool copy_row = y >= V && y - V < S;
+    if (copy_row) {
+        for (int j = tid; j < S; j += 256) cmax = fmaxf(cmax, mv[j] ? srow[j] : -1e9f);
+        cmax = block_max(cmax, smf);
+        csum = 0.f;
+        for (int j = tid; j < S; j += 256) csum += expf((mv[j] ? srow[j] : -1e9f) - cmax);
+        csum = block_sum(csum, smf);
+    }
+
+    // generator soft-max: the row's logits live in registers from here to the gradient store
+    float2 reg[HL_PAIRS];
+    const int n2 = V >> 1;
+    float gsum = 1.f, c = 0.f, ly = 0.f;
+    if (lrow) {
+        const float2* l2 = reinterpret_cast<const float2*>(lrow);
+#pragma unroll
+        for (int i = 0; i < HL_PAIRS; ++i) {
+            const int j2 = tid + 256 * i;
+            reg[i] = j2 < n2 ? l2[j2] : make_float2(-INFINITY, -INFINITY);
+        }
+        if (y != 0 && y < V) ly = lrow[y];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < HL_PAIRS; ++i) m = fmaxf(m, fmaxf(reg[i].x, reg[i].y));
+        c = -block_max(m, smf) * L2E;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < HL_PAIRS; ++i) {                 // exp2(-inf) = 0 for the slots past V
+            reg[i].x = __builtin_amdgcn_exp2f(fmaf(reg[i].x, L2E, c));
+            reg[i].y = __builtin_amdgcn_exp2f(fmaf(reg[i].y, L2E, c));
+            s0 += reg[i].x;
+            s1 += reg[i].y;
+        }
+        gsum = block_sum(s0 + s1, smf);
+    }
+    const float ey = __builtin_amdgcn_exp2f(fmaf(ly, L2E, c));          // the label's own term, as its register holds it
+
+    bool live = false, is_copy = false;
+    float p = 1.f;
+    if (y != 0) {
+        if (y < V) {
+            if (lrow) { p = g0 * (ey / gsum); live = true; }
+        } else if (copy_row) {
+            is_copy = true;
+            p = g1 * (expf((mv[y - V] ? srow[y - V] : -1e9f) - cmax) / csum);
+            live = true;
+        }
+    }
+    const bool pass = live && p >= 1e-10f && p <= 1.0f;     // clamp(min=1e-10,max=1) blocks the gradient outside
+    if (live && tid == 0 && loss_sum) {
+        const float pc = fminf(fmaxf(p, 1e-10f), 1.0f);
+        unsafeAtomicAdd(loss_sum, -logf(pc));
+        atomicAdd(n_tok, 1);
+    }
+    if (!want_grad) return;
+    __syncthreads();      // every thread has read srow[y-V] before the scores are overwritten
+
+    if (tid == 0) {
+        gate_logits[2 * bt] = pass ? g0 - (is_copy ? 0.f : 1.f) : 0.f;
+        gate_logits[2 * bt + 1] = pass ? g1 - (is_copy ? 1.f : 0.f) : 0.f;
+    }
+    const bool copy_grad = pass && is_copy;
+    const float inv_csum = 1.0f / csum;
+    for (int j = tid; j < S; j += 256) {
+        float d = 0.f;
+        if (copy_grad && mv[j]) d = expf(srow[j] - cmax) * inv_csum - (j == y - V ? 1.f : 0.f);
+        srow[j] = d;
+    }
+    if (lrow) {
+        const bool gen_grad = pass && !is_copy;
+        const float inv_gsum = 1.0f / gsum;
+        const float scale = gen_grad ? inv_gsum : 0.f;       // e is finite: rows without a generator gradient store zeros
+        float2* l2 = reinterpret_cast<float2*>(lrow);
+#pragma unroll
+        for (int i = 0; i < HL_PAIRS; ++i) {
+            const int j2 = tid + 256 * i;
+            if (j2 < n2) l2[j2] = make_float2(reg[i].x * scale, reg[i].y * scale);
+        }
+        // "- [j == y]": the thread that stored the label's pair rewrites that one element (same thread, same address:
+        // program order holds)
+        if (gen_grad && tid == ((y >> 1) & 255)) lrow[y] = ey * inv_gsum - 1.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam defaults, run_model.py:396), one fused pass over the flat parameter buffer.
 __global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
@@ -690,7 +806,11 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (BT <= 0) return 0;
     const bool reg = (V % 2 == 0) && (V / 2 <= 256 * HL_PAIRS) && (ldl % 2 == 0) && ((uintptr_t)logits % 8 == 0);
-    if (reg)
+    static const bool fast = [] { const char* e = getenv("FIRA_HEAD_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (reg && !argmax_out && fast)
+        hipLaunchKernelGGL(head_loss_train_kernel, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
+                           mem_valid, gate_logits, tar_label, loss_sum, n_tok, want_grad, row_bt);
+    else if (reg)
         hipLaunchKernelGGL(head_loss_kernel<true>, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
                            mem_valid, gate_logits, tar_label, loss_sum, n_tok, argmax_out, want_grad, row_bt);
     else

@@ -48,8 +48,19 @@ struct DecGrad {
     float *dYf, *dh, *dYc, *dq, *dYs, *dqkv;
 };
 
+
+// Row pitch of the dense cross-attention K|V rows (kv_all / dkv_all: [B*370, 6 * 512] fp32).  The attention kernels read
+// ONE 128-byte head slice per key row; at the natural pitch of 12 288 bytes = 48 x 256 the slices of a whole launch land
+// on 8 of the 128 memory channels (gcd(48, 128) = 16).  Padding the row by 64 floats makes the pitch 49 x 256 bytes: every
+// channel in turn.  FIRA_KV_PAD overrides the pad (floats, multiple of 4; 0 = the natural pitch) for A/B runs.
+static int kv_row_pad() {
+    static const int pad = [] { const char* e = getenv("FIRA_KV_PAD"); const int v = e ? atoi(e) : 64; return v < 0 ? 0 : (v + 3) / 4 * 4; }();
+    return pad;
+}
+
 struct Plan {
     int B, NB, CB, MB, TB, N, L, S, A, T, V, ldl, nl, F;
+    int kvp;                        // row pitch (floats) of kv_all / dkv_all: nl * 512 + kv_row_pad()
     float *pos_code, *pos_tar;
     int32_t *mem_valid, *tar_valid, *compact_row, *iota, *code_slot, *mem_slot, *row_bt, *rows_c;
     std::vector<float*> X;          // nl + 1 node buffers
@@ -113,7 +124,8 @@ struct Plan {
         kv_c = a.f((size_t)MB * nl * 2 * D);
         src_c = a.f((size_t)MB * D);
         x0 = a.f((size_t)TB * D);
-        kv_all = a.f((size_t)MB * nl * 2 * D);
+        kvp = nl * 2 * D + kv_row_pad();
+        kv_all = a.f((size_t)MB * kvp);
         dec.resize(nl);
         for (int l = 0; l < nl; ++l) {
             DecSave& e = dec[l];
@@ -143,7 +155,7 @@ struct Plan {
             zero_end = (float*)a.get<char>(0);
             dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
             dkv_c = a.f((size_t)MB * nl * 2 * D);
-            dkv_all = a.f((size_t)MB * nl * 2 * D);
+            dkv_all = a.f((size_t)MB * kvp);
             ddec = a.f((size_t)TB * D);
             dT_a = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
             encg.resize(nl);
@@ -629,7 +641,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         for (int l = 0; l < p.nl; ++l) {
             const size_t o = (size_t)l * 2 * D;
             // the output rows go straight to their dense [B,370] slots (row map of the GEMM epilogue): no scatter launch
-            TRY(gemm_any(ss, 0, 1, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, D, p.kv_all + o, KV, c.P + L.bkv_all + o, 0,
+            TRY(gemm_any(ss, 0, 1, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, D, p.kv_all + o, p.kvp, c.P + L.bkv_all + o, 0,
                          0, nullptr, bt.mem_dst));
             TRY(side_mark(&c.ev_kv[l]));
         }
@@ -638,7 +650,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         c.deferred = true;
         return 0;
     }
-    TRY(gemm_any(s, 0, 1, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, D, p.kv_all, KV, c.P + L.bkv_all, 0, 0, nullptr, bt.mem_dst));
+    TRY(gemm_any(s, 0, 1, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, D, p.kv_all, p.kvp, c.P + L.bkv_all, 0, 0, nullptr, bt.mem_dst));
     TRY(gemm_any(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
     return 0;
 }
@@ -694,7 +706,7 @@ static int decoder_forward(Ctx& c) {
         x = e.x_a;
         TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
         if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
-        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid, 0, 0, e.ao2, D,
+        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp, p.mem_valid, 0, 0, e.ao2, D,
                           c.dec_off, 0, attn_bf16()));
         TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
                         site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
@@ -819,13 +831,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                               c.p_drop, c.seed, site(l, SITE_CROSS)));
         TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
         TRY(linear_dgrad(s, c.Td, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
-        TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
-                          p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, KV,
-                          p.dkv_all + l * 2 * D + D, KV, c.dec_off, 0, attn_bf16()));
+        TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
+                          p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
+                          p.dkv_all + l * 2 * D + D, p.kvp, c.dec_off, 0, attn_bf16()));
         if (so) {                                // this layer's dK|dV -> compact rows -> d memory, beside the chain
             const size_t o = (size_t)l * 2 * D;
             TRY(aux_fork(s));
-            TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, KV, bt.mem_dst, nullptr));
+            TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, p.kvp, bt.mem_dst, nullptr));
             prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
             const int rc_kv = linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
             prof_decoder_tag(+1);
@@ -856,7 +868,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(side_mark(&ev_dmem));                // dmem_c / dkv_c are complete at this point of the auxiliary stream
         TRY(main_wait(side().stream, ev_dmem));  // the K|V weight gradient below reads dkv_c
     } else {
-        TRY(rows_move(s, 0, Mc, KV, p.dkv_c, p.dkv_all, bt.mem_dst, nullptr));
+        TRY(rows_move_ld(s, 0, Mc, KV, p.dkv_c, KV, p.dkv_all, p.kvp, bt.mem_dst, nullptr));
         TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
     }
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
@@ -1008,7 +1020,7 @@ struct DecodePlan {
         xc = a.f(BR * D); h = a.f((size_t)BR * d.d_ff); tgt = a.f(BR * D);
         score = a.f((size_t)BR * (d.sou_len + d.sub_len)); gate = a.f((size_t)BR * 2);
         logits = a.f((size_t)BR * enc.ldl);
-        kv16 = a.get<uint16_t>((size_t)enc.MB * d.n_layer * 2 * D);
+        kv16 = a.get<uint16_t>((size_t)enc.MB * enc.kvp);
         return used + a.used;
     }
 };
@@ -1141,7 +1153,7 @@ int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* bat
     TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers
     // optional: the cross K|V rows the step loop streams 30 times, once more in bf16 (half the bytes per step; rows of
     // masked slots are converted too -- they are never read)
-    if (flags & FIRA_DECODE_KV_BF16) TRY(rows_to_bf16(c.s, (int64_t)p.MB * p.nl * 2 * FIRA_D, p.kv_all, dp.kv16));
+    if (flags & FIRA_DECODE_KV_BF16) TRY(rows_to_bf16(c.s, (int64_t)p.MB * p.kvp, p.kv_all, dp.kv16));
     return 0;
 }
 
@@ -1221,13 +1233,13 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
         TRY(close_block(D, dp.ao, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, true));
         TRY(consume(D, dp.xa, params + w.wq_c, params + w.bq_c, dp.qc, 0));
         if (stream_attn && (flags & FIRA_DECODE_KV_BF16))
-            TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, KV, dp.kv16 + l * 2 * D + D, KV, p.mem_valid,
+            TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, p.kvp, dp.kv16 + l * 2 * D + D, p.kvp, p.mem_valid,
                                       dp.ao, D, Sm, Sm, n_beam));
         else if (stream_attn)
-            TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV, p.mem_valid,
+            TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp, p.mem_valid,
                                  dp.ao, D, Sm, Sm, n_beam));
         else
-            TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, KV, p.kv_all + l * 2 * D + D, KV,
+            TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
                                  p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
         TRY(close_block(D, dp.ao, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, true));
         TRY(consume(p.F, dp.xc, params + w.w1, params + w.b1, dp.h, FIRA_GEMM_RELU));
@@ -1264,7 +1276,7 @@ int fira_decoder_forward(void* stream, const fira_dims* d, const float* params, 
     hipError_t e = hipMemcpyAsync(p.mem_valid, mem_valid, (size_t)p.MB * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return set_err("hipMemcpyAsync: %s", hipGetErrorString(e));
     TRY(tar_mask(s, p.TB, tar, p.tar_valid));
-    TRY(linear(s, p.MB, KV, D, memory, D, params + L->wkv_all, params + L->bkv_all, p.kv_all, KV));
+    TRY(linear(s, p.MB, KV, D, memory, D, params + L->wkv_all, params + L->bkv_all, p.kv_all, p.kvp));
     TRY(decoder_forward(c));
     e = hipMemcpyAsync(out, p.dec[p.nl - 1].x_f, (size_t)p.TB * D * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return set_err("hipMemcpyAsync: %s", hipGetErrorString(e));

@@ -62,6 +62,15 @@ for ST in "$@"; do
           done
         done
       done 2>&1 | tee $OUT/ab.txt ;;
+    ab2)
+      one() { env $1 timeout 200 python bench.py $2 --no-decode --no-cpu-baseline --no-extras --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_time_ms_per_step']; print(round(d['value']), 'commits/s', round(d['ms_per_step'],3), 'ms', 'attn', round(k['attention'],3), 'rowops', round(k['rowops'],3), 'head', round(k['head'],3))"; }
+      for i in 1 2; do
+        for V in "FIRA_KV_PAD=0 FIRA_HEAD_FAST=0" "FIRA_KV_PAD=64 FIRA_HEAD_FAST=0" "FIRA_KV_PAD=64 FIRA_HEAD_FAST=1"; do
+          echo -n "$V f32 b32: "; one "$V" "--batch 32"
+          [ $i = 1 ] && { echo -n "$V bf16 b64: "; one "$V" "--dtype bf16 --batch 64"; }
+        done
+      done 2>&1 | tee $OUT/ab2.txt
+      for V in "FIRA_KV_PAD=0" "FIRA_KV_PAD=64"; do echo -n "$V decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done 2>&1 | tee -a $OUT/ab2.txt ;;
     pmc)
       for DT in f32 bf16; do
         bash scripts/pmc_traffic.sh $DT > /dev/null 2>&1

@@ -572,22 +572,15 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     const fira_batch& bt = *c.bt;
     hipStream_t s = c.s;
     const int D = FIRA_D, Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem, KV = p.nl * 2 * D;
-    // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
-    const int32_t* head_list = c.dec_off ? c.rows_dense : c.rows;          // flat (b*T + t) head rows, as the caller lists them
-    TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
-             p.pos_tar, c.R, head_list, bt.tar ? p.compact_row : nullptr, head_list ? nullptr : p.iota, c.loss_sum, c.n_tok,
-             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot, c.dec_off, p.row_bt, p.rows_c));
-    // layer 0's code rows are also stored compactly (Xc of the first Combination): no gather launch on the chain
-    TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
-                      p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc));
-    // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
-    TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
     // GCN (gnn_transformer.py:74-86) has no non-linearity between fc1, the aggregation and fc2, so
     //     fc2(A_hat fc1(X)) = (A_hat X) (W2 W1)^T + (A_hat 1) (W2 b1)^T + b2 :
     // one [Nc,256]x[256,256] product per layer instead of two (and one dgrad, one wgrad in the backward pass); the folded
     // 256x256 weights are formed here, per step, from the current parameters (same value up to fp32 re-association).
-    // They only read parameters: with the auxiliary stream they run beside the embedding / first Combination kernels.
-    hipEvent_t ev_fold = nullptr;
+    // They only read parameters: the auxiliary stream forms them from the very start of the call, beside the embedding /
+    // first Combination kernels.  Layer 0's pair is marked on its own (the caller's stream reaches its first GCN product
+    // ~100 us into the call, 12 launches of the auxiliary stream would not be through by then); the rest is awaited at
+    // layer 1.
+    hipEvent_t ev_fold0 = nullptr, ev_fold = nullptr;
     {
         const bool ax = side_on();
         hipStream_t fs = ax ? side().aux : s;
@@ -596,6 +589,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const EncLayer& w = L.enc[l];
             TRY(gemm_f32_ex(fs, 0, 0, D, D, D, c.P + w.fc2w, D, c.P + w.fc1w, D, p.W21 + (size_t)l * D * D, D, nullptr, 0, 0, nullptr));
             TRY(gemm_f32_ex(fs, 0, 1, D, 1, D, c.P + w.fc2w, D, c.P + w.fc1b, D, p.c21 + (size_t)l * D, 1, nullptr, 0, 0, nullptr));
+            if (ax && l == 0 && !g_Wb && p.nl > 1) TRY(side_mark(&ev_fold0));
         }
         if (g_Wb) {                                  // bf16 mode: shadows of the folded weights, on the same stream
             ShadowTable t21;
@@ -608,7 +602,18 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             g_W21 = p.W21; g_W21n = (int64_t)p.nl * D * D; g_W21b = p.w21b; g_W21bT = p.w21bt;
         }
         if (ax) TRY(side_mark(&ev_fold));
+        if (!ev_fold0) ev_fold0 = ev_fold;           // bf16 mode / one layer: a single mark
     }
+    // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
+    const int32_t* head_list = c.dec_off ? c.rows_dense : c.rows;          // flat (b*T + t) head rows, as the caller lists them
+    TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
+             p.pos_tar, c.R, head_list, bt.tar ? p.compact_row : nullptr, head_list ? nullptr : p.iota, c.loss_sum, c.n_tok,
+             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot, c.dec_off, p.row_bt, p.rows_c));
+    // layer 0's code rows are also stored compactly (Xc of the first Combination): no gather launch on the chain
+    TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
+                      p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc));
+    // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
+    TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
     for (int l = 0; l < p.nl; ++l) {
         const EncLayer& w = L.enc[l];
         EncSave& e = p.enc[l];
@@ -620,8 +625,9 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         TRY(linear_ln(s, Cc, D, e.c, D, c.P + w.wo, c.P + w.bo, e.Xc, c.P + w.ln1g, c.P + w.ln1b, e.s1, X, e.st1, c.p_drop,
                       c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
         // GCN in folded form: U = A_hat X (kept for the weight gradient) -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
-        if (l == 0 && ev_fold) TRY(main_wait(s, ev_fold));
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
+        if (l == 0 && ev_fold0) TRY(main_wait(s, ev_fold0));              // the product below is the first reader of W21 / c21
+        if (l == 1 && ev_fold && ev_fold != ev_fold0) TRY(main_wait(s, ev_fold));
         // second store of the output: the next layer's code rows (its Xc), or after the last layer the memory rows
         // (memory = [code ; sub-token] rows, Model.py:48: compact copy for the GEMMs; the dense [B,370,*] rows the attention /
         // copy kernels read are scattered by the projections below, rows of masked slots are never read there)
@@ -872,7 +878,9 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
     }
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
-    TRY(deferred_reduce(s, red().tab));      // decoder LayerNorms, copy head: their gradients are final after this launch
+    // decoder LayerNorms, copy head: their partial rows were written before the fork of the weight gradient above, and only
+    // the end of the step (or the mid-event below, which waits for this stream) reads the sums: off the dependent chain
+    TRY(deferred_reduce(side().stream && side().enabled ? side().stream : s, red().tab));
     if (mid_event) {                         // gradients of [0, split) are final from here on
         // The event fires when BOTH the caller's stream and the weight-gradient stream have reached this point, without
         // holding up either of them: the auxiliary stream (idle for the rest of the backward pass) waits for the two and
@@ -956,6 +964,21 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                         bt.code_rows));                                                        // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
+    // encoder LayerNorms, dvtab_all and the two products that read it: beside the embedding kernels below, on the auxiliary
+    // stream (idle since the decoder's backward pass)
+    hipEvent_t ev_tail = nullptr;
+    {
+        const bool ax = side_on();
+        hipStream_t rs = ax ? side().aux : s;
+        if (ax) TRY(aux_fork(s));
+        TRY(deferred_reduce(rs, red().tab));
+        // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
+        TRY(gemm_f32_ex(rs, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
+                        FIRA_GEMM_ACCUM, 1, G + L.b2_all));
+        // rows 1..3 only: padding_idx row 0 never gets a gradient (its slot of the zeroed gradient buffer stays untouched)
+        TRY(linear_dgrad(rs, 3, p.nl * D, D, p.dvtab_all + (size_t)p.nl * D, p.nl * D, c.P + L.w2_all, G + L.mark_emb + D, D, true));
+        if (ax) TRY(side_mark(&ev_tail));
+    }
     // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39)
     if (bt.emb_item_tok && bt.emb_item_ptr && bt.emb_rows && bt.ast_rows && bt.ast_ids && L.d.ast_vocab <= 128) {
         // the batch lists its id-carrying nodes by compact row: the gradient is read where the backward pass left it
@@ -971,12 +994,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         else
             TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     }
-    TRY(deferred_reduce(s, red().tab));      // encoder LayerNorms, dvtab_all (read by the products below)
-    // value projection of the mark table: vtab_all = mark_emb W2_all^T + b2_all
-    TRY(gemm_f32_ex(s, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
-                    FIRA_GEMM_ACCUM, 1, G + L.b2_all));
-    // rows 1..3 only: padding_idx row 0 never gets a gradient (its slot of the zeroed gradient buffer stays untouched)
-    TRY(linear_dgrad(s, 3, p.nl * D, D, p.dvtab_all + (size_t)p.nl * D, p.nl * D, c.P + L.w2_all, G + L.mark_emb + D, D, true));
+    if (ev_tail) TRY(main_wait(s, ev_tail));
     if (side().stream && side().enabled) TRY(side_join(s));        // every weight gradient is complete past this point
     // dc of every GCN layer is final (deferred reduction above) and so are the side stream's additions to dW2: back to the
     // reference's fc2.weight / fc1.bias gradients, one launch for all layers

@@ -71,6 +71,17 @@ for ST in "$@"; do
         done
       done 2>&1 | tee $OUT/ab2.txt
       for V in "FIRA_KV_PAD=0" "FIRA_KV_PAD=64"; do echo -n "$V decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done 2>&1 | tee -a $OUT/ab2.txt ;;
+    ab3)   # two BUILDS on one box: fira_icse_amd/libfira_hip_prev.so (built from the previous commit) vs the tree's library
+      one() { env $1 timeout 200 python bench.py $2 --no-decode --no-cpu-baseline --no-extras --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_time_ms_per_step']; print(round(d['value']), 'commits/s', round(d['ms_per_step'],3), 'ms', 'host', round(d['host_enqueue_ms_per_step'],2))"; }
+      for i in 1 2 3; do
+        for V in "FIRA_HIP_LIB=$REPO/fira_icse_amd/libfira_hip_prev.so" "FIRA_X=1"; do
+          echo -n "${V##*/} f32 b32: "; one "$V" "--batch 32"
+          [ $i = 1 ] && { echo -n "${V##*/} bf16 b64: "; one "$V" "--dtype bf16 --batch 64"; }
+        done
+      done 2>&1 | tee $OUT/ab3.txt ;;
+    gradtests)
+      timeout 900 python -m pytest tests/test_model_gpu.py tests/test_large_gpu.py tests/test_dp_gpu.py tests/test_bf16_gpu.py tests/test_dropout_gpu.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -x > $OUT/gradtests.log 2>&1
+      tail -n 6 $OUT/gradtests.log ;;
     pmc)
       for DT in f32 bf16; do
         bash scripts/pmc_traffic.sh $DT > /dev/null 2>&1

@@ -114,6 +114,7 @@ struct UnfoldEntry { const float *W2, *b1, *dc; float *dW2, *db1; };
 struct UnfoldTable { int n = 0; UnfoldEntry e[16]; };
 int gcn_bias_unfold_all(hipStream_t s, const UnfoldTable& tab);      // every GCN layer in one launch
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight = nullptr);
+int rank2_rows(hipStream_t s, int M, const float* g, const float* w, float* out);   // out[M,256] = g[M,2] w[2,256]
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],
 // 3 out[dst[r]]=in[src[r]]
 int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const int32_t* sub, const int32_t* tar,

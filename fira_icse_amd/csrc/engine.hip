@@ -790,7 +790,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec, D, G + L.wout,
                          G + L.bout));
     }
-    TRY(linear_dgrad(s, c.Td, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
+    if (g_dtype == 0) TRY(rank2_rows(s, c.Td, p.gate, c.P + L.wp, p.ddec));        // ddec = dgate Wp: a rank-2 row kernel
+    else TRY(linear_dgrad(s, c.Td, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad_grouped(s, c.Td, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
     {
         const int nb = copy_score_bwd_blocks(p.B, Sm);
@@ -866,8 +867,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions
     // carry an exactly-zero gradient (never attended as keys, zero loss weight): skipping id 0 only drops the
     // hundreds of serialised atomic additions of 0.0 onto table row 0.
-    if (c.row_bt) TRY(embed_rows_bwd(s, c.Td, c.row_bt, c.bt->tar, G + L.dec_emb, dy, 0));
-    else TRY(embed_gather_bwd(s, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
+    // (nothing on the chain reads it: behind the fork of the grouped launch above, on the weight-gradient stream; dy is a
+    // decoder-only buffer, untouched until the next step)
+    {
+        hipStream_t es = (side().stream && side().enabled) ? side().stream : s;
+        if (c.row_bt) TRY(embed_rows_bwd(es, c.Td, c.row_bt, c.bt->tar, G + L.dec_emb, dy, 0));
+        else TRY(embed_gather_bwd(es, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
+    }
     // cross-attention K|V projections of all layers (computed memory rows only)
     hipEvent_t ev_dmem = nullptr;
     if (so) {

@@ -839,6 +839,25 @@ int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float
     FIRA_CHECK_LAUNCH("gcn_bias_unfold");
     return 0;
 }
+// out[r, :] = g[r,0] * w[0, :] + g[r,1] * w[1, :]   (the data gradient of the 2-way copy gate, Model.py:19: a rank-2 product;
+// the tiled GEMM kernel spent 23 us of the dependent chain on it, queued behind the vocabulary projection's gradients)
+__global__ __launch_bounds__(256) void rank2_rows_kernel(int M, const float* __restrict__ g, const float* __restrict__ w,
+                                                         float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const float g0 = g[2 * r], g1 = g[2 * r + 1];
+    const float4 a = *reinterpret_cast<const float4*>(w + lane * 4), b = *reinterpret_cast<const float4*>(w + FIRA_D + lane * 4);
+    *reinterpret_cast<float4*>(out + (size_t)r * FIRA_D + lane * 4) =
+        make_float4(fmaf(g0, a.x, g1 * b.x), fmaf(g0, a.y, g1 * b.y), fmaf(g0, a.z, g1 * b.z), fmaf(g0, a.w, g1 * b.w));
+}
+int rank2_rows(hipStream_t s, int M, const float* g, const float* w, float* out) {
+    ProfScope prof(s, PROF_ROWOPS, 0.0);
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(rank2_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, g, w, out);
+    FIRA_CHECK_LAUNCH("rank2_rows");
+    return 0;
+}
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0 || N <= 0) return 0;

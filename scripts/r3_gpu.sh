@@ -82,6 +82,10 @@ for ST in "$@"; do
     gradtests)
       timeout 900 python -m pytest tests/test_model_gpu.py tests/test_large_gpu.py tests/test_dp_gpu.py tests/test_bf16_gpu.py tests/test_dropout_gpu.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -x > $OUT/gradtests.log 2>&1
       tail -n 6 $OUT/gradtests.log ;;
+    abdec)   # decode loop: previous build vs the tree's library, alternating
+      for i in 1 2; do
+        for V in "FIRA_HIP_LIB=$REPO/fira_icse_amd/libfira_hip_prev.so" "FIRA_X=1"; do echo -n "${V##*/} decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done
+      done 2>&1 | tee $OUT/abdec.txt ;;
     pmc)
       for DT in f32 bf16; do
         bash scripts/pmc_traffic.sh $DT > /dev/null 2>&1

@@ -11,6 +11,7 @@
 //   head          mem [MB,256], src [MB,256], tgt [TB,256], score [TB,370], gate [TB,2], dec_c [R,256], logits [R, ldl]
 //   backward      gradient temporaries of the same shapes (ping-pong node buffers, dkv_all, ...)
 #include "engine.h"
+#include <hip/hip_ext.h>
 #include "epilogue.h"
 #include <stdlib.h>
 #include <map>
@@ -1317,6 +1318,19 @@ int fira_debug_chain(void* stream, int n, int mode, float* scratch) {
     hipStream_t s = (hipStream_t)stream;
     SideStream& sd = side();
     for (int i = 0; i < n; ++i) {
+        if (mode >= 4 && mode <= 6) {
+            // the event rides on the kernel's own completion signal (hipExtLaunchKernelGGL's stopEvent): no barrier packet
+            // of its own on `stream`.  4: attached to every kernel, nobody waits; 5: the other stream waits for it and runs
+            // a kernel (a fork without hipEventRecord); 6: the same for every 8th kernel
+            const bool ev = mode != 6 || (i & 7) == 7;
+            hipEvent_t e = ev ? sd.ev() : nullptr;
+            hipExtLaunchKernelGGL(debug_tiny_kernel, dim3(240), dim3(256), 0, s, nullptr, e, 0, scratch);
+            if (ev && mode != 4) {
+                if (hipStreamWaitEvent(sd.stream, e, 0) != hipSuccess) return set_err("stream wait failed");
+                hipLaunchKernelGGL(debug_tiny_kernel, dim3(240), dim3(256), 0, sd.stream, scratch + 64);
+            }
+            continue;
+        }
         hipLaunchKernelGGL(debug_tiny_kernel, dim3(240), dim3(256), 0, s, scratch);
         if (mode == 1 || (mode == 3 && (i & 7) == 7)) {
             TRY(side_fork(s));
@@ -1326,7 +1340,7 @@ int fira_debug_chain(void* stream, int n, int mode, float* scratch) {
             if (hipEventRecord(e, s) != hipSuccess) return set_err("event record failed");
         }
     }
-    if (mode == 1 || mode == 3) TRY(side_join(s));
+    if (mode == 1 || mode == 3 || mode == 5 || mode == 6) TRY(side_join(s));
     FIRA_CHECK_LAUNCH("debug_chain");
     return 0;
 }

@@ -8,8 +8,9 @@ from fira_icse_amd import _lib
 lib = _lib.lib()
 scratch = torch.zeros(256, device="cuda")
 n = 2000
-names = {0: "plain chain", 1: "fork after every kernel", 2: "event record after every kernel", 3: "fork every 8th kernel"}
-for mode in (0, 1, 2, 3, 0, 10, 11, 12, 13):
+names = {0: "plain chain", 1: "fork after every kernel", 2: "event record after every kernel", 3: "fork every 8th kernel",
+         4: "stop event on every kernel", 5: "stop-event fork after every kernel", 6: "stop-event fork every 8th kernel"}
+for mode in (0, 1, 2, 3, 4, 5, 6, 0, 10, 11, 12, 13, 14, 15, 16):
     ahead = mode >= 10          # host far ahead of the GPU: a 30 ms spin kernel first, so the chain is queued before it starts
     mode = mode % 10
     for rep in range(2):

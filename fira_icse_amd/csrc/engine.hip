@@ -842,12 +842,16 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
                           p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
                           p.dkv_all + l * 2 * D + D, p.kvp, c.dec_off, 0, attn_bf16()));
-        if (so) {                                // this layer's dK|dV -> compact rows -> d memory, beside the chain
+        if (so && (l % 2 == 0 || l == 0)) {
+            // dK|dV of this layer and of the one above it (adjacent column blocks of dkv_all / row blocks of the stacked K|V
+            // weight) -> compact rows -> d memory, beside the chain.  TWO layers per fork: a fork costs the dependent chain
+            // ~15 us (r3_event_cost.txt) and hides ~20 us of work per layer
+            const int nlay = std::min(2, p.nl - l);
             const size_t o = (size_t)l * 2 * D;
             TRY(aux_fork(s));
-            TRY(rows_move_ld(ss, 0, Mc, 2 * D, p.dkv_c + o, KV, p.dkv_all + o, p.kvp, bt.mem_dst, nullptr));
+            TRY(rows_move_ld(ss, 0, Mc, nlay * 2 * D, p.dkv_c + o, KV, p.dkv_all + o, p.kvp, bt.mem_dst, nullptr));
             prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
-            const int rc_kv = linear_dgrad(ss, Mc, 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
+            const int rc_kv = linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
             prof_decoder_tag(+1);
             TRY(rc_kv);
         }

@@ -134,11 +134,17 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
         for (int s = 0; s < 16; ++s) bq[s] = 0.f;
     }
+    // live[i]: the wave's key tile holds at least one unmasked key.  A tile without one contributes nothing: its scores are
+    // the constant -1e9, its soft-max weights exp(-1e9 - max) are exactly 0 next to any real score (and its V fragment is
+    // zero-filled anyway), so both MFMA chains are skipped -- on FIRA-shaped batches about half of the twelve memory tiles
+    // (padding behind the code tokens and behind the sub-tokens), which halves the load of the SIMD's MFMA pipe.
+    bool live[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         const int key = kt * 32 + l31;
         const bool ok = kt < NT && key < tk && sm_kv[key < tk ? key : 0] != 0;
+        live[i] = __ballot(ok) != 0;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int kr = kt * 32 + acc_row(s, kh);
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
         const int kt = wave + i * NW;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
-        if (kt < NT) {
+        if (kt < NT && live[i]) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -163,6 +169,13 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
             for (int r = 0; r < 16; ++r) {
                 bool masked;
                 const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, tk, sm_kv, causal, q_pos0, masked);
+                st[i][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        } else if (kt < NT) {                            // every key masked: the scores mask_score would return
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = kt * 32 + acc_row(r, kh) < tk ? -1e9f : -INFINITY;
                 st[i][r] = x;
                 mx = fmaxf(mx, x);
             }
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
-        if (kt < NT) {
+        if (kt < NT && live[i]) {
             float pn[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) pn[s] = st[i][s] * inv_sum;
@@ -286,11 +299,13 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             sm_do[l31 * 33 + kh * 16 + s] = bdo[s];
         }
     }
+    bool live[TPW];                                  // see attention_fwd_kernel: tiles without an unmasked key skip their MFMA chains
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
         const int key = kt * 32 + l31;
         const bool ok = kt < NT && key < tk && sm_kv[key < tk ? key : 0] != 0;
+        live[i] = __ballot(ok) != 0;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int kr = kt * 32 + acc_row(s, kh);
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         const int kt = wave + i * NW;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
-        if (kt < NT) {
+        if (kt < NT && live[i]) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -323,6 +338,13 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             for (int r = 0; r < 16; ++r) {
                 bool masked;
                 const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, tk, sm_kv, causal, q_pos0, masked);
+                st[i][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        } else if (kt < NT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = kt * 32 + acc_row(r, kh) < tk ? -1e9f : -INFINITY;
                 st[i][r] = x;
                 mx = fmaxf(mx, x);
             }
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int kt = wave + i * NW;
-        if (kt < NT) {
+        if (kt < NT && live[i]) {                      // a tile of masked keys: dS = 0, nothing flows into dQ
             f32x16 dpt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
@@ -419,23 +441,25 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             f32x16 sN, dpN;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
-            sN = chain16<BF>(bq, ak[i], sN);             // S   = Q K^T
-            dpN = chain16<BF>(bdo, av[i], dpN);          // dP  = dO V^T
             f32x16 dk, dv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-            float pv[16], dsn[16];
+            if (live[i]) {
+                sN = chain16<BF>(bq, ak[i], sN);             // S   = Q K^T
+                dpN = chain16<BF>(bdo, av[i], dpN);          // dP  = dO V^T
+                float pv[16], dsn[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int q = acc_row(s, kh);
-                bool masked;
-                const float x = mask_score(sN[s], key, q, tk, sm_kv, causal, q_pos0, masked);
-                const float p = expf(x - sm_m[q]) * sm_sum[q];
-                pv[s] = p;
-                dsn[s] = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
-            }
-            dk = chain16<BF>(dsn, qrow, dk);          // dK += dS^T Q
-            dv = chain16<BF>(pv, dorow, dv);          // dV += P^T dO
+                for (int s = 0; s < 16; ++s) {
+                    const int q = acc_row(s, kh);
+                    bool masked;
+                    const float x = mask_score(sN[s], key, q, tk, sm_kv, causal, q_pos0, masked);
+                    const float p = expf(x - sm_m[q]) * sm_sum[q];
+                    pv[s] = p;
+                    dsn[s] = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
+                }
+                dk = chain16<BF>(dsn, qrow, dk);          // dK += dS^T Q
+                dv = chain16<BF>(pv, dorow, dv);          // dV += P^T dO
+            }                                             // (a tile of masked keys: its dK / dV rows are zero)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kr = kt * 32 + acc_row(r, kh);

@@ -72,10 +72,10 @@ SIGNATURES = {
     "fira_attention_fwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I]),
     "fira_attention_bwd": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I,
                                 _P, _I, _P, _I, _P, _I]),
-    "fira_attention_fwd_ex": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I]),
+    "fira_attention_fwd_ex": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P]),
     "fira_attention_bwd_ex": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _I,
-                                   _P, _I, _P, _I, _P, _I, _P, _I, _I]),
-    "fira_decode_attention": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
+                                   _P, _I, _P, _I, _P, _I, _P, _I, _I, _P]),
+    "fira_decode_attention": (_I, [_P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "fira_copy_score_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "fira_copy_score_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "fira_head_loss": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
@@ -133,7 +133,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fira_abi_version() != 5:
+    # FIRA_HIP_LIB (A/B timing of an older build through the model-level entry points, whose signatures did not change
+    # between v5 and v6) may load a v5 library; the tree's own library must be v6
+    ok = (6,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6)
+    if lib.fira_abi_version() not in ok:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib
 

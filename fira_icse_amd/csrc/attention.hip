@@ -95,10 +95,12 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
                                                                 const int32_t* __restrict__ key_valid, int causal,
                                                                 int q_pos0, float* __restrict__ O, int ldo, int kb,
                                                                 int kvb, int qpk, const int32_t* __restrict__ q_off,
-                                                                int self_kv) {
+                                                                int self_kv, const int32_t* __restrict__ k_off) {
     // q_off (optional): the queries of batch entry b are rows q_off[b] .. q_off[b+1] of Q / O (a ragged, compact row
-    // layout: the decoder's computed target rows); with self_kv the keys / values are the same rows of K / V.  key_valid
-    // stays dense (kvb entries per batch entry).
+    // layout: the decoder's computed target rows); with self_kv the keys / values are the same rows of K / V.
+    // k_off (optional, cross attention): RAGGED key rows -- the keys / values of K/V batch entry bk are rows
+    // k_off[bk] .. k_off[bk+1] of K / V (at most Tk of them: the commit's computed memory rows, no padding rows in between),
+    // and key_valid is indexed by the same compact rows.  Otherwise key_valid is dense (kvb entries per batch entry).
     // kb: K/V rows per batch entry, kvb: key_valid entries per batch entry, qpk: consecutive query batches
     // that share one K/V batch entry (beam rows of one commit share the encoder memory)
     __shared__ int sm_kv[MAX_TK];
@@ -111,11 +113,21 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     const int qb = q_off ? q_off[b] : b * Tq;
     const int tq = q_off ? q_off[b + 1] - qb : Tq;
     const bool selfk = q_off && self_kv;
-    const int tk = selfk ? tq : Tk;
+    const int k0 = (k_off && !selfk) ? k_off[bk] : 0;
+    const int tk = selfk ? tq : (k_off ? min(k_off[bk + 1] - k0, Tk) : Tk);
     const int NT = (tk + 31) / 32;
-    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)bk * kvb + i];
-    K += (selfk ? (size_t)qb : (size_t)bk * kb) * ldk;           // this batch entry's key/value rows
-    V += (selfk ? (size_t)qb : (size_t)bk * kb) * ldv;
+    if (tk <= 0) {                                   // no key at all (never in the engine: a commit has its <start> token)
+        for (int idx = t; idx < tq * FIRA_DH; idx += NW * 64)
+            O[((size_t)qb + idx / FIRA_DH) * ldo + h * FIRA_DH + idx % FIRA_DH] = 0.f;
+        return;
+    }
+    {
+        const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)bk * kvb);
+        for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
+    }
+    const size_t krow0 = selfk ? (size_t)qb : (k_off ? (size_t)k0 : (size_t)bk * kb);
+    K += krow0 * ldk;                                // this batch entry's key/value rows
+    V += krow0 * ldv;
 
     // every operand of the wave is requested here, before the key mask has reached LDS: the fragments of masked keys are
     // zeroed afterwards instead of not being loaded (one memory round trip instead of three; see the backward kernel)
@@ -124,10 +136,15 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     float ak[TPW][16], vv[TPW][16];                  // K fragment of key tile*32 + l31; V rows of key acc_row(s,kh)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int kt = min(wave + i * NW, NT - 1);
-        load_frag(ak[i], K + (size_t)min(kt * 32 + l31, tk - 1) * ldk + h * FIRA_DH + kh * 16, true);
+        const int kt = wave + i * NW;
+        if (kt < NT) {                               // (wave-uniform: a wave without a key tile requests nothing)
+            load_frag(ak[i], K + (size_t)min(kt * 32 + l31, tk - 1) * ldk + h * FIRA_DH + kh * 16, true);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) vv[i][s] = V[(size_t)min(kt * 32 + acc_row(s, kh), tk - 1) * ldv + h * FIRA_DH + l31];
+            for (int s = 0; s < 16; ++s) vv[i][s] = V[(size_t)min(kt * 32 + acc_row(s, kh), tk - 1) * ldv + h * FIRA_DH + l31];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { ak[i][s] = 0.f; vv[i][s] = 0.f; }
+        }
     }
     __syncthreads();
     if (l31 >= tq) {
@@ -222,13 +239,16 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     }
     // o[r]: query = acc_row(r, kh), d = l31
     if (NW > 1) {
+        const int nwa = min(NW, NT);                 // waves that own a key tile (the others hold zeros: not exchanged)
+        if (wave < nwa) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sm_o[wave * 1024 + r * 64 + lane] = o[r];
+            for (int r = 0; r < 16; ++r) sm_o[wave * 1024 + r * 64 + lane] = o[r];
+        }
         __syncthreads();
         for (int idx = t; idx < 1024; idx += NW * 64) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += sm_o[w * 1024 + idx];
+            for (int w = 0; w < NW; ++w) if (w < nwa) v += sm_o[w * 1024 + idx];
             const int r = idx >> 6, ln = idx & 63;
             const int q = acc_row(r, ln >> 5);
             if (q < tq) O[((size_t)qb + q) * ldo + h * FIRA_DH + (ln & 31)] = v;
@@ -251,7 +271,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     int H, int Tq, int Tk, const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
     const float* __restrict__ V, int ldv, const int32_t* __restrict__ key_valid, int causal, int q_pos0,
     const float* __restrict__ O, int ldo, const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq,
-    float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, const int32_t* __restrict__ q_off, int self_kv) {
+    float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, const int32_t* __restrict__ q_off, int self_kv,
+    const int32_t* __restrict__ k_off) {             // k_off: ragged key rows, see attention_fwd_kernel
     __shared__ int sm_kv[MAX_TK];
     __shared__ float sm_red[NW][32];
     __shared__ float sm_m[32], sm_sum[32], sm_delta[32];
@@ -263,10 +284,19 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     const int qb = q_off ? q_off[b] : b * Tq;                  // ragged query rows: see attention_fwd_kernel
     const int tq = q_off ? q_off[b + 1] - qb : Tq;
     const bool selfk = q_off && self_kv;
-    const int tk = selfk ? tq : Tk;
-    const size_t kbase = selfk ? (size_t)qb : (size_t)b * Tk;
+    const int k0 = (k_off && !selfk) ? k_off[b] : 0;
+    const int tk = selfk ? tq : (k_off ? min(k_off[b + 1] - k0, Tk) : Tk);
+    const size_t kbase = selfk ? (size_t)qb : (k_off ? (size_t)k0 : (size_t)b * Tk);
     const int NT = (tk + 31) / 32;
-    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = key_valid[(size_t)b * Tk + i];
+    if (tk <= 0) {                                   // no key: nothing flows back to the queries (and there is no dK / dV row)
+        for (int idx = t; idx < tq * FIRA_DH; idx += NW * 64)
+            dQ[((size_t)qb + idx / FIRA_DH) * lddq + h * FIRA_DH + idx % FIRA_DH] = 0.f;
+        return;
+    }
+    {
+        const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)b * Tk);
+        for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
+    }
 
     // ---- all operands, one round trip (rows past the end are clamped to a real row and zeroed below) ----------
     const int ql = min(l31, tq - 1);
@@ -277,14 +307,19 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     float ak[TPW][16], av[TPW][16], kvv[TPW][16];    // K / V fragments of key = tile*32 + l31; K rows of key acc_row(s,kh)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        const int kt = min(wave + i * NW, NT - 1);
-        const int key = min(kt * 32 + l31, tk - 1);
-        load_frag(ak[i], K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, true);
-        load_frag(av[i], V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, true);
+        const int kt = wave + i * NW;
+        if (kt < NT) {                               // (wave-uniform: a wave without a key tile requests nothing)
+            const int key = min(kt * 32 + l31, tk - 1);
+            load_frag(ak[i], K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, true);
+            load_frag(av[i], V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, true);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int kr = min(kt * 32 + acc_row(s, kh), tk - 1);
-            kvv[i][s] = K[(kbase + kr) * ldk + h * FIRA_DH + l31];
+            for (int s = 0; s < 16; ++s) {
+                const int kr = min(kt * 32 + acc_row(s, kh), tk - 1);
+                kvv[i][s] = K[(kbase + kr) * ldk + h * FIRA_DH + l31];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { ak[i][s] = 0.f; av[i][s] = 0.f; kvv[i][s] = 0.f; }
         }
     }
     __syncthreads();
@@ -407,13 +442,16 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         }
     }
     if (NW > 1) {
+        const int nwa = min(NW, NT);                 // waves that own a key tile
+        if (wave < nwa) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sm_o[wave * 1024 + r * 64 + lane] = dq[r];
+            for (int r = 0; r < 16; ++r) sm_o[wave * 1024 + r * 64 + lane] = dq[r];
+        }
         __syncthreads();
         for (int idx = t; idx < 1024; idx += NW * 64) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) v += sm_o[w * 1024 + idx];
+            for (int w = 0; w < NW; ++w) if (w < nwa) v += sm_o[w * 1024 + idx];
             const int r = idx >> 6, ln = idx & 63;
             const int q = acc_row(r, ln >> 5);
             if (q < tq) dQ[((size_t)qb + q) * lddq + h * FIRA_DH + (ln & 31)] = v;
@@ -500,7 +538,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
                                                                int ldo, int kb, int kvb, int qpk,
                                                                const float* __restrict__ Knew,
                                                                const float* __restrict__ Vnew, int ldn,
-                                                               float* __restrict__ Kc_out, float* __restrict__ Vc_out) {
+                                                               float* __restrict__ Kc_out, float* __restrict__ Vc_out,
+                                                               const int32_t* __restrict__ k_off) {
+    // k_off (optional): ragged key rows -- commit bk's keys / values are rows k_off[bk] .. k_off[bk+1] of K / V and
+    // key_valid is indexed by the same compact rows (the engine's cross K|V of the computed memory rows)
     __shared__ int sm_list[MAX_TK];
     __shared__ int sm_cnt[8];
     __shared__ float sm_f[4][36];
@@ -509,10 +550,14 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
     const int r = lane >> 3, c = lane & 7;                       // key sub-row of the wave, 16-byte column of the head
     // ---- ordered compaction of the valid keys (thread t looks at keys t and t + 256)
     int nv;
+    const int kbeg = k_off ? k_off[bk] : 0;
+    if (k_off) Tk = min(Tk, k_off[bk + 1] - kbeg);
+    const size_t krow0 = k_off ? (size_t)kbeg : (size_t)bk * kb;
     {
+        const int32_t* kvp = key_valid + (k_off ? (size_t)kbeg : (size_t)bk * kvb);
         const int k0 = t, k1 = t + 256;
-        const bool v0 = k0 < Tk && key_valid[(size_t)bk * kvb + k0] != 0;
-        const bool v1 = k1 < Tk && key_valid[(size_t)bk * kvb + k1] != 0;
+        const bool v0 = k0 < Tk && kvp[k0] != 0;
+        const bool v1 = k1 < Tk && kvp[k1] != 0;
         const unsigned long long m0 = __ballot(v0), m1 = __ballot(v1);
         if (lane == 0) { sm_cnt[wave] = __popcll(m0); sm_cnt[4 + wave] = __popcll(m1); }
         __syncthreads();
@@ -532,10 +577,10 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
     const size_t hoff = (size_t)h * FIRA_DH + c * 4;
     const float* K = static_cast<const float*>(Kv);
     const float* V = static_cast<const float*>(Vv);
-    const float* Kb = K + (size_t)bk * kb * ldk + hoff;
-    const float* Vb = V + (size_t)bk * kb * ldv + hoff;
-    const uint16_t* Kh = static_cast<const uint16_t*>(Kv) + (size_t)bk * kb * ldk + hoff;
-    const uint16_t* Vh = static_cast<const uint16_t*>(Vv) + (size_t)bk * kb * ldv + hoff;
+    const float* Kb = K + krow0 * ldk + hoff;
+    const float* Vb = V + krow0 * ldv + hoff;
+    const uint16_t* Kh = static_cast<const uint16_t*>(Kv) + krow0 * ldk + hoff;
+    const uint16_t* Vh = static_cast<const uint16_t*>(Vv) + krow0 * ldv + hoff;
     // ---- this lane's key slots: list index j*32 + wave*8 + r
     f32x4v kf[NSLOT], vf[NSLOT];
     bool have[NSLOT];
@@ -614,7 +659,8 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
 
 // bf16 K / V rows (raw bf16, ldk / ldv in elements, rows 8-byte aligned): the decode loop's optional bf16 cross-K|V cache
 int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const uint16_t* K, int ldk,
-                          const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk) {
+                          const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
+                          const int32_t* k_off) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (BR <= 0) return 0;
     FIRA_REQUIRE(Tk >= 1 && Tk <= MAX_TK && qpk >= 1 && BR % qpk == 0 && kb >= Tk && kvb >= Tk, "decode_attention: bad geometry");
@@ -623,30 +669,30 @@ int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, 
     const dim3 grid((BR / qpk) * H);
     if (Tk <= 32)
         hipLaunchKernelGGL((decode_attention_kernel<1, true>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
-                           ldo, kb, kvb, qpk, nullptr, nullptr, 0, nullptr, nullptr);
+                           ldo, kb, kvb, qpk, nullptr, nullptr, 0, nullptr, nullptr, k_off);
     else
         hipLaunchKernelGGL((decode_attention_kernel<12, true>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
-                           ldo, kb, kvb, qpk, nullptr, nullptr, 0, nullptr, nullptr);
+                           ldo, kb, kvb, qpk, nullptr, nullptr, 0, nullptr, nullptr, k_off);
     FIRA_CHECK_LAUNCH("decode_attention_kv16");
     return 0;
 }
 int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
-                     const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out) {
+                     const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out, const int32_t* k_off) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (BR <= 0) return 0;
     FIRA_REQUIRE(Tk >= 1 && Tk <= MAX_TK && qpk >= 1 && BR % qpk == 0 && kb >= Tk && kvb >= Tk, "decode_attention: bad geometry");
     FIRA_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && (uintptr_t)Q % 16 == 0 && (uintptr_t)K % 16 == 0 &&
                      (uintptr_t)V % 16 == 0 && (!Knew || (ldn % 4 == 0 && (uintptr_t)Knew % 16 == 0 && (uintptr_t)Vnew % 16 == 0)),
                  "decode_attention: rows must be 16-byte aligned");
-    FIRA_REQUIRE(!Knew || qpk == 1, "decode_attention: merged new keys need one query per K/V entry");
+    FIRA_REQUIRE(!Knew || (qpk == 1 && !k_off), "decode_attention: merged new keys need one query per K/V entry and dense key rows");
     const dim3 grid((BR / qpk) * H);
     if (Tk <= 32)
         hipLaunchKernelGGL((decode_attention_kernel<1, false>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
-                           ldo, kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
+                           ldo, kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out, k_off);
     else
         hipLaunchKernelGGL((decode_attention_kernel<12, false>), grid, dim3(256), 0, s, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O,
-                           ldo, kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out);
+                           ldo, kb, kvb, qpk, Knew, Vnew, ldn, Kc_out, Vc_out, k_off);
     FIRA_CHECK_LAUNCH("decode_attention");
     return 0;
 }
@@ -663,14 +709,14 @@ static int check_geometry(const char* who, int Tq, int Tk, int ldq, int ldk, int
 
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                     int kb, int kvb, int qpk, const int32_t* q_off, int self_kv, int bf16) {
+                     int kb, int kvb, int qpk, const int32_t* q_off, int self_kv, int bf16, const int32_t* k_off) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_fwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(kb >= Tk && kvb >= Tk && qpk >= 1, "attention_fwd: bad batch strides");
 #define FIRA_ATT_FWD(NW_, BF_)                                                                                      \
     hipLaunchKernelGGL((attention_fwd_kernel<NW_, 1, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
-                       ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv)
+                       ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv, k_off)
     if (Tk <= 32) { if (bf16) FIRA_ATT_FWD(1, true); else FIRA_ATT_FWD(1, false); }
     else { if (bf16) FIRA_ATT_FWD(12, true); else FIRA_ATT_FWD(12, false); }
 #undef FIRA_ATT_FWD
@@ -679,15 +725,15 @@ int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q
 }
 int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                  const int32_t* q_off, int self_kv, int bf16) {
+                  const int32_t* q_off, int self_kv, int bf16, const int32_t* k_off) {
     return attention_fwd_ex(s, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O, ldo, Tk, Tk, 1, q_off, self_kv,
-                            bf16);
+                            bf16, k_off);
 }
 
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
-                  const int32_t* q_off, int self_kv, int bf16) {
+                  const int32_t* q_off, int self_kv, int bf16, const int32_t* k_off) {
     ProfScope prof(s, PROF_ATTN, 0.0);
     if (B <= 0) return 0;
     if (int e = check_geometry("attention_bwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
@@ -695,7 +741,7 @@ int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, i
                  "attention_bwd: O/dO rows must be 16-byte aligned");
 #define FIRA_ATT_BWD(NW_, BF_)                                                                                      \
     hipLaunchKernelGGL((attention_bwd_kernel<NW_, 1, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
-                       ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv)
+                       ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv, k_off)
     if (Tk <= 32) { if (bf16) FIRA_ATT_BWD(1, true); else FIRA_ATT_BWD(1, false); }
     else { if (bf16) FIRA_ATT_BWD(12, true); else FIRA_ATT_BWD(12, false); }
 #undef FIRA_ATT_BWD
@@ -713,10 +759,11 @@ int fira_attention_fwd(void* stream, int B, int H, int Tq, int Tk, const float* 
 }
 int fira_decode_attention(void* stream, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                           const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
-                          const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out) {
+                          const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out,
+                          const int32_t* k_off) {
     FIRA_REQUIRE(Q && K && V && key_valid && O, "fira_decode_attention: null pointer argument");
     return fira::decode_attention((hipStream_t)stream, BR, H, Tk, Q, ldq, K, ldk, V, ldv, key_valid, O, ldo, kb, kvb, qpk, Knew,
-                                  Vnew, ldn, Kc_out, Vc_out);
+                                  Vnew, ldn, Kc_out, Vc_out, k_off);
 }
 int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                        const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O,
@@ -727,17 +774,19 @@ int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* 
 }
 int fira_attention_fwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                           const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                          const int32_t* q_off, int self_kv, int dtype) {
+                          const int32_t* q_off, int self_kv, int dtype, const int32_t* k_off) {
     FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_attention_fwd_ex: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(!(k_off && self_kv), "fira_attention_fwd_ex: k_off (ragged memory rows) and self_kv exclude each other");
     return fira::attention_fwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
-                               ldo, q_off, self_kv, dtype == FIRA_BF16);
+                               ldo, q_off, self_kv, dtype == FIRA_BF16, k_off);
 }
 int fira_attention_bwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                           const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O,
                           int ldo, const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV,
-                          int lddv, const int32_t* q_off, int self_kv, int dtype) {
+                          int lddv, const int32_t* q_off, int self_kv, int dtype, const int32_t* k_off) {
     FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_attention_bwd_ex: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(!(k_off && self_kv), "fira_attention_bwd_ex: k_off (ragged memory rows) and self_kv exclude each other");
     return fira::attention_bwd((hipStream_t)stream, B, H, Tq, Tk, Q, ldq, K, ldk, V, ldv, key_valid, causal, q_pos0, O,
-                               ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv, dtype == FIRA_BF16);
+                               ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv, dtype == FIRA_BF16, k_off);
 }
 }

@@ -125,7 +125,10 @@ int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const in
          const int32_t* mem_rows = nullptr, int Mc = 0, int32_t* mem_slot = nullptr,
          // optional: computed target rows (fira_batch.dec_off) -> row_bt[compact row] = flat b*T+t, rows_c[k] = compact row of
          // head row k; compact_row is then indexed by compact row
-         const int32_t* dec_off = nullptr, int32_t* row_bt = nullptr, int32_t* rows_c = nullptr);
+         const int32_t* dec_off = nullptr, int32_t* row_bt = nullptr, int32_t* rows_c = nullptr,
+         // optional: the computed memory rows as ragged attention keys -- mem_dst [Mc] ascending dense slots (b*(L+S) + local)
+         // -> mem_off [B+1] (commit b's range of the list) and mem_valid_c [Mc] (key mask per listed row)
+         const int32_t* mem_dst = nullptr, int32_t* mem_off = nullptr, int32_t* mem_valid_c = nullptr);
 // the decoder's token embedding on a list of target rows (row_bt[r] = flat b*T + t) and its backward
 int embed_rows_fwd(hipStream_t s, int R, int T, const int32_t* row_bt, const int32_t* idx, const float* table,
                    const float* pos, float* out);
@@ -156,22 +159,27 @@ int decode_embed(hipStream_t s, int BR, int T, int step, const int32_t* tokens, 
 int attention_fwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
                   const int32_t* q_off = nullptr, int self_kv = 0,
-                  int bf16 = 0);      // 1: operands of the four matmuls rounded to bf16, bf16 MFMA, fp32 accumulate / soft-max
+                  int bf16 = 0,       // 1: operands of the four matmuls rounded to bf16, bf16 MFMA, fp32 accumulate / soft-max
+                  // k_off (optional, [B+1], cross attention): ragged KEY rows -- batch entry b's keys / values are rows
+                  // k_off[b] .. k_off[b+1] of K / V (at most Tk) and key_valid is indexed by the same compact rows
+                  const int32_t* k_off = nullptr);
 int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, float* O, int ldo,
-                     int kb, int kvb, int qpk, const int32_t* q_off = nullptr, int self_kv = 0, int bf16 = 0);
+                     int kb, int kvb, int qpk, const int32_t* q_off = nullptr, int self_kv = 0, int bf16 = 0,
+                     const int32_t* k_off = nullptr);
 // one query per row (decode step): K/V streamed once per (commit, head) over the valid keys only; optional merged new key
 int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
                      const float* Knew = nullptr, const float* Vnew = nullptr, int ldn = 0, float* Kc_out = nullptr,
-                     float* Vc_out = nullptr);
+                     float* Vc_out = nullptr, const int32_t* k_off = nullptr);
 int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const uint16_t* K, int ldk,
-                          const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk);
+                          const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
+                          const int32_t* k_off = nullptr);
 int rows_to_bf16(hipStream_t s, int64_t n, const float* in, uint16_t* out);      // out[i] = bf16(in[i]) (RNE), n % 4 == 0
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
-                  const int32_t* q_off = nullptr, int self_kv = 0, int bf16 = 0);
+                  const int32_t* q_off = nullptr, int self_kv = 0, int bf16 = 0, const int32_t* k_off = nullptr);
 int copy_score_fwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* bias, float* score);
 // mem_valid (optional, [B/qpk, S]): slots with 0 are skipped (score 0 / zero gradient): they are masked to -1e9 later

@@ -7,7 +7,8 @@
 //   node buffers  X[l] [NB,256], l = 0..6   layer inputs; X[l] code rows are updated in place by the Combination
 //   per enc layer Xc [CB,256] (code rows before the update), qk [CB,512], c [CB,256], s1 [CB,256] + stats,
 //                 Z [NB,256], s2 [NB,256] + stats
-//   decoder       kv_all [MB, 6*512], per layer qkv [TB,768], ao, s_a, x_a, qc, ao2, s_c, x_c, h [TB,1024], s_f, x_f
+//   decoder       kv_all [Mc <= MB, 6*512 + pad] (cross-attention K|V of the COMPUTED memory rows, commit b's rows at
+//                 mem_off[b] .. mem_off[b+1]), per layer qkv [TB,768], ao, s_a, x_a, qc, ao2, s_c, x_c, h [TB,1024], s_f, x_f
 //   head          mem [MB,256], src [MB,256], tgt [TB,256], score [TB,370], gate [TB,2], dec_c [R,256], logits [R, ldl]
 //   backward      gradient temporaries of the same shapes (ping-pong node buffers, dkv_all, ...)
 #include "engine.h"
@@ -50,7 +51,7 @@ struct DecGrad {
 };
 
 
-// Row pitch of the dense cross-attention K|V rows (kv_all / dkv_all: [B*370, 6 * 512] fp32).  The attention kernels read
+// Row pitch of the cross-attention K|V rows (kv_all / dkv_all: [computed memory rows, 6 * 512] fp32).  The attention kernels read
 // ONE 128-byte head slice per key row; at the natural pitch of 12 288 bytes = 48 x 256 the slices of a whole launch land
 // on 8 of the 128 memory channels (gcd(48, 128) = 16).  Padding the row by 64 floats makes the pitch 49 x 256 bytes: every
 // channel in turn.  FIRA_KV_PAD overrides the pad (floats, multiple of 4; 0 = the natural pitch) for A/B runs.
@@ -64,12 +65,13 @@ struct Plan {
     int kvp;                        // row pitch (floats) of kv_all / dkv_all: nl * 512 + kv_row_pad()
     float *pos_code, *pos_tar;
     int32_t *mem_valid, *tar_valid, *compact_row, *iota, *code_slot, *mem_slot, *row_bt, *rows_c;
+    int32_t *mem_off, *mem_valid_c;      // ragged cross-attention keys: commit b's computed memory rows, their key mask
     std::vector<float*> X;          // nl + 1 node buffers
     std::vector<EncSave> enc;
     std::vector<DecSave> dec;
     std::vector<EncGrad> encg;      // per-layer weight-gradient operands: never reused inside a step, so the
     std::vector<DecGrad> decg;      // wgrad GEMMs can run on the side stream while the dgrad chain continues
-    float *vtab_all, *H, *mem, *mem_c, *kv_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
+    float *vtab_all, *H, *mem, *mem_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *W21, *c21, *rsum;        // GCN: per layer fc2.weight . fc1.weight [256,256] and fc2.weight . fc1.bias [256]; A_hat 1
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
@@ -80,7 +82,7 @@ struct Plan {
     uint16_t *w21b = nullptr, *w21bt = nullptr;  // the same for the folded GCN weights W21 (formed per step)
     float* red_buf = nullptr;                    // per-workgroup partial rows of the deferred column reductions
     size_t red_cap = 0;
-    float *dmem_c, *dsrc, *dsrc_c, *dkv_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
+    float *dmem_c, *dsrc, *dsrc_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
         Arena a(ws);
@@ -99,6 +101,8 @@ struct Plan {
         rows_c = a.get<int32_t>((size_t)TB);          // the head-row list in compact-row indexing
         code_slot = a.get<int32_t>((size_t)NB);
         mem_slot = a.get<int32_t>((size_t)NB);
+        mem_off = a.get<int32_t>((size_t)B + 1);
+        mem_valid_c = a.get<int32_t>((size_t)MB);
         inv_ntok = a.f(64);
         {
             const Layout* lay = get_layout(&d);
@@ -122,7 +126,6 @@ struct Plan {
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
         mem_c = a.f((size_t)MB * D);
-        kv_c = a.f((size_t)MB * nl * 2 * D);
         src_c = a.f((size_t)MB * D);
         x0 = a.f((size_t)TB * D);
         kvp = nl * 2 * D + kv_row_pad();
@@ -155,7 +158,6 @@ struct Plan {
             ddec_c = a.f((size_t)TB * D);
             zero_end = (float*)a.get<char>(0);
             dmem_c = a.f((size_t)MB * D); dsrc = a.f((size_t)MB * D); dsrc_c = a.f((size_t)MB * D);
-            dkv_c = a.f((size_t)MB * nl * 2 * D);
             dkv_all = a.f((size_t)MB * kvp);
             ddec = a.f((size_t)TB * D);
             dT_a = a.f((size_t)TB * D); dT_c = a.f((size_t)TB * D);
@@ -556,6 +558,9 @@ struct Ctx {
     const int32_t* row_bt = nullptr;
     const int32_t* rows_dense = nullptr;
     bool deferred = false;
+    // cross-attention K|V rows: the computed memory rows only, ragged per commit (Plan::mem_off / mem_valid_c) -- what
+    // encoder_forward leaves; false: a dense [B, 370] memory supplied by the caller (fira_decoder_forward)
+    bool kv_ragged = false;
     float* loss_sum = nullptr;      // zeroed by the prep launch (head_loss accumulates into them)
     int32_t* n_tok = nullptr;
     hipEvent_t ev_kv[16] = {};
@@ -609,7 +614,9 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     const int32_t* head_list = c.dec_off ? c.rows_dense : c.rows;          // flat (b*T + t) head rows, as the caller lists them
     TRY(prep(s, p.B, p.L, p.S, p.T, bt.sou, bt.sub_token, bt.tar, p.mem_valid, bt.tar ? p.tar_valid : nullptr, p.pos_code,
              p.pos_tar, c.R, head_list, bt.tar ? p.compact_row : nullptr, head_list ? nullptr : p.iota, c.loss_sum, c.n_tok,
-             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot, c.dec_off, p.row_bt, p.rows_c));
+             Nc, bt.code_rows, Cc, p.code_slot, bt.mem_rows, Mc, p.mem_slot, c.dec_off, p.row_bt, p.rows_c, bt.mem_dst,
+             p.mem_off, p.mem_valid_c));
+    c.kv_ragged = true;
     // layer 0's code rows are also stored compactly (Xc of the first Combination): no gather launch on the chain
     TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
                       p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc));
@@ -630,8 +637,9 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         if (l == 0 && ev_fold0) TRY(main_wait(s, ev_fold0));              // the product below is the first reader of W21 / c21
         if (l == 1 && ev_fold && ev_fold != ev_fold0) TRY(main_wait(s, ev_fold));
         // second store of the output: the next layer's code rows (its Xc), or after the last layer the memory rows
-        // (memory = [code ; sub-token] rows, Model.py:48: compact copy for the GEMMs; the dense [B,370,*] rows the attention /
-        // copy kernels read are scattered by the projections below, rows of masked slots are never read there)
+        // (memory = [code ; sub-token] rows, Model.py:48: compact copy for the GEMMs.  The cross-attention K|V stay in that
+        // compact row order -- the attention kernels take commit b's key range from mem_off; the dense [B,370,256] rows the
+        // copy kernels read are scattered by LinearSource's projection below, rows of masked slots are never read there)
         const bool last = l + 1 == p.nl;
         TRY(linear_ln(s, Nc, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, X, c.P + w.ln2g, c.P + w.ln2b, e.s2,
                       p.X[l + 1], e.st2, c.p_gcn, c.seed, site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D,
@@ -647,17 +655,17 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         hipStream_t ss = side().aux;
         for (int l = 0; l < p.nl; ++l) {
             const size_t o = (size_t)l * 2 * D;
-            // the output rows go straight to their dense [B,370] slots (row map of the GEMM epilogue): no scatter launch
             TRY(gemm_any(ss, 0, 1, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, D, p.kv_all + o, p.kvp, c.P + L.bkv_all + o, 0,
-                         0, nullptr, bt.mem_dst));
+                         0, nullptr));
             TRY(side_mark(&c.ev_kv[l]));
         }
+        // (LinearSource: output rows straight to their dense [B,370] slots through the row map of the GEMM epilogue)
         TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
         TRY(side_mark(&c.ev_src));
         c.deferred = true;
         return 0;
     }
-    TRY(gemm_any(s, 0, 1, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, D, p.kv_all, p.kvp, c.P + L.bkv_all, 0, 0, nullptr, bt.mem_dst));
+    TRY(gemm_any(s, 0, 1, Mc, KV, D, p.mem_c, D, c.P + L.wkv_all, D, p.kv_all, p.kvp, c.P + L.bkv_all, 0, 0, nullptr));
     TRY(gemm_any(s, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
     return 0;
 }
@@ -713,8 +721,9 @@ static int decoder_forward(Ctx& c) {
         x = e.x_a;
         TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
         if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
-        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp, p.mem_valid, 0, 0, e.ao2, D,
-                          c.dec_off, 0, attn_bf16()));
+        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
+                          c.kv_ragged ? p.mem_valid_c : p.mem_valid, 0, 0, e.ao2, D, c.dec_off, 0, attn_bf16(),
+                          c.kv_ragged ? p.mem_off : nullptr));
         TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
                         site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
         x = e.x_c;
@@ -839,19 +848,19 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                               c.p_drop, c.seed, site(l, SITE_CROSS)));
         TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
         TRY(linear_dgrad(s, c.Td, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
+        // (ragged key rows: dkv_all holds the computed memory rows only, every one of them written by this launch)
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
-                          p.mem_valid, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
-                          p.dkv_all + l * 2 * D + D, p.kvp, c.dec_off, 0, attn_bf16()));
+                          p.mem_valid_c, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
+                          p.dkv_all + l * 2 * D + D, p.kvp, c.dec_off, 0, attn_bf16(), p.mem_off));
         if (so && (l % 2 == 0 || l == 0)) {
             // dK|dV of this layer and of the one above it (adjacent column blocks of dkv_all / row blocks of the stacked K|V
-            // weight) -> compact rows -> d memory, beside the chain.  TWO layers per fork: a fork costs the dependent chain
+            // weight) -> d memory, beside the chain.  TWO layers per fork: a fork costs the dependent chain
             // ~15 us (r3_event_cost.txt) and hides ~20 us of work per layer
             const int nlay = std::min(2, p.nl - l);
             const size_t o = (size_t)l * 2 * D;
             TRY(aux_fork(s));
-            TRY(rows_move_ld(ss, 0, Mc, nlay * 2 * D, p.dkv_c + o, KV, p.dkv_all + o, p.kvp, bt.mem_dst, nullptr));
             prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
-            const int rc_kv = linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_c + o, KV, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
+            const int rc_kv = linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_all + o, p.kvp, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
             prof_decoder_tag(+1);
             TRY(rc_kv);
         }
@@ -882,13 +891,11 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // cross-attention K|V projections of all layers (computed memory rows only)
     hipEvent_t ev_dmem = nullptr;
     if (so) {
-        TRY(side_mark(&ev_dmem));                // dmem_c / dkv_c are complete at this point of the auxiliary stream
-        TRY(main_wait(side().stream, ev_dmem));  // the K|V weight gradient below reads dkv_c
+        TRY(side_mark(&ev_dmem));                // dmem_c is complete at this point of the auxiliary stream
     } else {
-        TRY(rows_move_ld(s, 0, Mc, KV, p.dkv_c, KV, p.dkv_all, p.kvp, bt.mem_dst, nullptr));
-        TRY(linear_dgrad(s, Mc, KV, D, p.dkv_c, KV, c.P + L.wkv_all, p.dmem_c, D, true));
+        TRY(linear_dgrad(s, Mc, KV, D, p.dkv_all, p.kvp, c.P + L.wkv_all, p.dmem_c, D, true));
     }
-    TRY(linear_wgrad(s, Mc, KV, D, p.dkv_c, KV, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
+    TRY(linear_wgrad(s, Mc, KV, D, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     // decoder LayerNorms, copy head: their partial rows were written before the fork of the weight gradient above, and only
     // the end of the step (or the mid-event below, which waits for this stream) reads the sums: off the dependent chain
     TRY(deferred_reduce(side().stream && side().enabled ? side().stream : s, red().tab));
@@ -1182,7 +1189,7 @@ int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* bat
     TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers
     // optional: the cross K|V rows the step loop streams 30 times, once more in bf16 (half the bytes per step; rows of
     // masked slots are converted too -- they are never read)
-    if (flags & FIRA_DECODE_KV_BF16) TRY(rows_to_bf16(c.s, (int64_t)p.MB * p.kvp, p.kv_all, dp.kv16));
+    if (flags & FIRA_DECODE_KV_BF16) TRY(rows_to_bf16(c.s, (int64_t)b2.n_mem * p.kvp, p.kv_all, dp.kv16));
     return 0;
 }
 
@@ -1262,14 +1269,14 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
         TRY(close_block(D, dp.ao, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, true));
         TRY(consume(D, dp.xa, params + w.wq_c, params + w.bq_c, dp.qc, 0));
         if (stream_attn && (flags & FIRA_DECODE_KV_BF16))
-            TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, p.kvp, dp.kv16 + l * 2 * D + D, p.kvp, p.mem_valid,
-                                      dp.ao, D, Sm, Sm, n_beam));
+            TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, p.kvp, dp.kv16 + l * 2 * D + D, p.kvp, p.mem_valid_c,
+                                      dp.ao, D, Sm, Sm, n_beam, p.mem_off));
         else if (stream_attn)
-            TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp, p.mem_valid,
-                                 dp.ao, D, Sm, Sm, n_beam));
+            TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp, p.mem_valid_c,
+                                 dp.ao, D, Sm, Sm, n_beam, nullptr, nullptr, 0, nullptr, nullptr, p.mem_off));
         else
             TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
-                                 p.mem_valid, 0, 0, dp.ao, D, Sm, Sm, n_beam));
+                                 p.mem_valid_c, 0, 0, dp.ao, D, Sm, Sm, n_beam, nullptr, 0, 0, p.mem_off));
         TRY(close_block(D, dp.ao, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, true));
         TRY(consume(p.F, dp.xc, params + w.w1, params + w.b1, dp.h, FIRA_GEMM_RELU));
         // (the last block's LayerNorm is owed too: the target projection of the copy head consumes it and leaves x behind)

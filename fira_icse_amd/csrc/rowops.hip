@@ -540,9 +540,22 @@ __global__ void prep_kernel(int B, int L, int S, int T, const int32_t* __restric
                             // computed target rows (fira_batch.dec_off; nullptr = every row): row_bt[compact row] = its flat
                             // b*T + t index, rows_c[k] = compact row of head row k; compact_row is then indexed by compact row
                             const int32_t* __restrict__ dec_off, int32_t* __restrict__ row_bt,
-                            int32_t* __restrict__ rows_c) {
+                            int32_t* __restrict__ rows_c,
+                            // computed MEMORY rows as ragged attention keys: mem_off[b] .. mem_off[b+1] = commit b's range in
+                            // the (ascending) mem_dst list, mem_valid_c[k] = key mask of compact memory row k
+                            const int32_t* __restrict__ mem_dst, int32_t* __restrict__ mem_off,
+                            int32_t* __restrict__ mem_valid_c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int W = L + S;
+    if (mem_off && i <= B) {                     // first list entry whose dense slot is >= i*W
+        int lo = 0, hi = Mc;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (mem_dst[mid] < i * W) lo = mid + 1; else hi = mid; }
+        mem_off[i] = lo;
+    }
+    if (mem_valid_c && i < Mc) {
+        const int d = mem_dst[i], b = d / W, j = d - b * W;
+        mem_valid_c[i] = (j < L ? sou[b * L + j] : sub[b * S + j - L]) != 0;
+    }
     if (code_slot && i < Nc) {
         // inverse of the (ascending) code-row and memory-row lists: slot of compact node i in each list, or -1.  Kernels that
         // produce node rows use them to store the listed rows a second time, compactly (the gather launches they replace
@@ -663,11 +676,11 @@ int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const in
          int32_t* mem_valid, int32_t* tar_valid, float* pos_code, float* pos_tar, int R, const int32_t* rows,
          int32_t* compact_row, int32_t* iota, float* loss_sum, int32_t* n_tok, int Nc, const int32_t* code_rows, int Cc,
          int32_t* code_slot, const int32_t* mem_rows, int Mc, int32_t* mem_slot, const int32_t* dec_off, int32_t* row_bt,
-         int32_t* rows_c) {
+         int32_t* rows_c, const int32_t* mem_dst, int32_t* mem_off, int32_t* mem_valid_c) {
     const int n = std::max(std::max(std::max(B * (L + S), B * T), (L + T) * FIRA_D), code_slot ? Nc : 0);
     hipLaunchKernelGGL(prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, B, L, S, T, sou, sub, tar, mem_valid, tar_valid,
                        pos_code, pos_tar, R, rows, compact_row, iota, loss_sum, n_tok, Nc, code_rows, Cc, code_slot, mem_rows,
-                       Mc, mem_slot, dec_off, row_bt, rows_c);
+                       Mc, mem_slot, dec_off, row_bt, rows_c, mem_dst, mem_dst ? mem_off : nullptr, mem_dst ? mem_valid_c : nullptr);
     FIRA_CHECK_LAUNCH("prep");
     return 0;
 }

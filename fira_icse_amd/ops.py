@@ -188,24 +188,31 @@ def colsum(X):
     return out
 
 
-def attention_ragged_fwd(q, k, v, key_valid, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8):
+def attention_ragged_fwd(q, k, v, key_valid, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8, k_off=None):
     """The engine's form (fira_attention_fwd_ex): q [R,256] compact query rows, commit b's are q_off[b] .. q_off[b+1]
-    (<= Tq of them); k / v [B*Tk,256] dense, or the same compact rows with self_kv; dtype 1 = bf16 MFMA."""
+    (<= Tq of them); k / v [B*Tk,256] dense, or the same compact rows with self_kv, or (k_off [B+1]) RAGGED key rows:
+    commit b's keys are rows k_off[b] .. k_off[b+1] of k / v and key_valid is a flat mask over those rows;
+    dtype 1 = bf16 MFMA."""
     B = q_off.numel() - 1
     o = torch.zeros_like(q)
+    ko = None if k_off is None else _i32(k_off)
     check(_lib.lib().fira_attention_fwd_ex(cur_stream(), B, heads, Tq, Tk, ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v),
                                            v.stride(0), ptr(_i32(key_valid)), int(causal), 0, ptr(o), 256, ptr(_i32(q_off)),
-                                           int(self_kv), dtype), "fira_attention_fwd_ex")
+                                           int(self_kv), dtype, ptr(ko)), "fira_attention_fwd_ex")
     return o
 
 
-def attention_ragged_bwd(q, k, v, key_valid, o, do, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8):
+def attention_ragged_bwd(q, k, v, key_valid, o, do, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8, k_off=None,
+                         fill=0.0):
+    """fill: value the gradient buffers hold before the call (the kernel must overwrite every row it owns)."""
     B = q_off.numel() - 1
-    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    dq, dk, dv = torch.full_like(q, fill), torch.full_like(k, fill), torch.full_like(v, fill)
+    ko = None if k_off is None else _i32(k_off)
     check(_lib.lib().fira_attention_bwd_ex(cur_stream(), B, heads, Tq, Tk, ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v),
                                            v.stride(0), ptr(_i32(key_valid)), int(causal), 0, ptr(_f32(o)), 256,
-                                           ptr(_f32(do)), 256, ptr(dq), 256, ptr(dk), 256, ptr(dv), 256, ptr(_i32(q_off)),
-                                           int(self_kv), dtype), "fira_attention_bwd_ex")
+                                           ptr(_f32(do)), 256, ptr(dq), dq.stride(0), ptr(dk), dk.stride(0), ptr(dv),
+                                           dv.stride(0), ptr(_i32(q_off)), int(self_kv), dtype, ptr(ko)),
+          "fira_attention_bwd_ex")
     return dq, dk, dv
 
 
@@ -220,18 +227,26 @@ def attention_fwd(q, k, v, key_valid, causal=False, q_pos0=0, heads=8):
     return o
 
 
-def decode_attention(q, k, v, key_valid, tk=None, qpk=1, heads=8, knew=None, vnew=None):
+def decode_attention(q, k, v, key_valid, tk=None, qpk=1, heads=8, knew=None, vnew=None, k_off=None):
     """One query per row: q [BR,256] (any row stride), k / v [BR/qpk, kb, 256] (any row stride), key_valid int32
     [BR/qpk, kvb] -> o [BR,256].  knew / vnew [BR,256] (row stride = their stride(0)): key tk-1 of every row comes from
-    them and is appended to k / v in place."""
+    them and is appended to k / v in place.  k_off [BR/qpk + 1]: ragged key rows -- k / v are [rows, 256] (any row stride),
+    entry e's keys are rows k_off[e] .. k_off[e+1], key_valid a flat mask over those rows (tk = the largest range)."""
     BR = q.shape[0]
-    kb, kvb = k.shape[1], key_valid.shape[1]
+    if k_off is not None:
+        kb = kvb = tk
+        ldk, ldv = k.stride(0), v.stride(0)
+    else:
+        kb, kvb = k.shape[1], key_valid.shape[1]
+        ldk, ldv = k.stride(1), v.stride(1)
     tk = kb if tk is None else tk
     o = torch.empty((BR, 256), dtype=torch.float32, device=q.device)
-    check(_lib.lib().fira_decode_attention(cur_stream(), BR, heads, tk, ptr(q), q.stride(0), ptr(k), k.stride(1), ptr(v),
-                                           v.stride(1), ptr(_i32(key_valid)), ptr(o), 256, kb, kvb, qpk, ptr(knew),
+    ko = None if k_off is None else _i32(k_off)
+    check(_lib.lib().fira_decode_attention(cur_stream(), BR, heads, tk, ptr(q), q.stride(0), ptr(k), ldk, ptr(v),
+                                           ldv, ptr(_i32(key_valid)), ptr(o), 256, kb, kvb, qpk, ptr(knew),
                                            ptr(vnew), knew.stride(0) if knew is not None else 0,
-                                           ptr(k) if knew is not None else None, ptr(v) if knew is not None else None),
+                                           ptr(k) if knew is not None else None, ptr(v) if knew is not None else None,
+                                           ptr(ko)),
           "fira_decode_attention")
     return o
 

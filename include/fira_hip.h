@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 5
+#define FIRA_ABI_VERSION 6
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -258,30 +258,43 @@ int fira_attention_bwd(void* stream, int B, int H, int Tq, int Tk, const float* 
                        const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
                        int causal, int q_pos0, const float* O, int ldo, const float* dO, int lddo,
                        float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv);
-/* The forms the engine calls (v5):
+/* Precondition of all attention entry points: every (batch entry, query) sees at least ONE unmasked key.  The reference's
+ * masked_fill(-1e9) + softmax would then average V uniformly over ALL Tk keys, masked ones included; the kernels never read
+ * rows of masked keys, so an all-masked row returns 0 instead (FIRA batches cannot produce one: position 0 of every
+ * commit is its <start> token, Dataset.py:140, and a causal query always sees itself).
+ * The forms the engine calls (v5, k_off: v6):
  *   q_off  (optional, [B+1]) ragged query rows: batch entry b's queries are rows q_off[b] .. q_off[b+1] of Q / O / dO /
  *          dQ (at most Tq of them: the decoder's computed target rows, fira_batch.dec_off); self_kv != 0: its keys and
  *          values are the same rows of K / V / dK / dV (self-attention).  key_valid stays dense [B, Tk].
+ *   k_off  (optional, [B+1], not with self_kv) ragged KEY rows: batch entry b's keys / values are rows k_off[b] ..
+ *          k_off[b+1] of K / V / dK / dV (at most Tk of them) and key_valid is indexed by the same compact rows
+ *          (key_valid[k_off[b] + i]).  The engine keeps the cross-attention K|V of the COMPUTED memory rows only
+ *          (fira_batch.mem_rows: ~47 % of the B*370 slots), in that layout -- the padded slots of the reference's
+ *          [B,370] memory (Model.py:48,61) are masked keys whose soft-max weight is exactly 0.
  *   dtype  FIRA_BF16: the operands of the four matmuls (Q K^T, P V and their gradients) are rounded to bf16 and
  *          multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; scaling, mask, soft-max in fp32 -- what
  *          torch.autocast does to Attention.forward (gnn_transformer.py:149-156).  FIRA_F32: exact fp32 MFMA chains. */
 int fira_attention_fwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq,
                           const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
-                          int causal, int q_pos0, float* O, int ldo, const int32_t* q_off, int self_kv, int dtype);
+                          int causal, int q_pos0, float* O, int ldo, const int32_t* q_off, int self_kv, int dtype,
+                          const int32_t* k_off);
 int fira_attention_bwd_ex(void* stream, int B, int H, int Tq, int Tk, const float* Q, int ldq,
                           const float* K, int ldk, const float* V, int ldv, const int32_t* key_valid,
                           int causal, int q_pos0, const float* O, int ldo, const float* dO, int lddo,
                           float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,
-                          const int32_t* q_off, int self_kv, int dtype);
+                          const int32_t* q_off, int self_kv, int dtype, const int32_t* k_off);
 
 /* Attention of ONE query per row (the K/V-cached decode step of run_model.py:256): O[b, h*32..] = softmax(q.K^T/sqrt(32)
  * over the valid keys) V.  Row b uses K/V batch entry b / qpk (kb rows of ldk floats per entry; key_valid [BR/qpk, kvb]):
  * the qpk beam rows of a commit share its memory.  Masked keys are never read.  Knew / Vnew (optional, qpk == 1): row b's
  * key / value number Tk-1 is taken from Knew[b*ldn..] / Vnew[b*ldn..] (the merged q|k|v projection's output) and is
- * appended to Kc_out / Vc_out (same geometry as K / V) for the later steps.                                          */
+ * appended to Kc_out / Vc_out (same geometry as K / V) for the later steps.  k_off (v6, optional, [BR/qpk + 1], not
+ * with Knew): ragged key rows as in fira_attention_fwd_ex -- entry e's keys are rows k_off[e] .. k_off[e+1] of K / V and
+ * key_valid is indexed by the same rows (kb / kvb are then ignored).                                                 */
 int fira_decode_attention(void* stream, int BR, int H, int Tk, const float* Q, int ldq, const float* K, int ldk,
                           const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
-                          const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out);
+                          const float* Knew, const float* Vnew, int ldn, float* Kc_out, float* Vc_out,
+                          const int32_t* k_off);
 
 /* CopyNet score (Model.py:15-18): score[b,t,s] = w . tanh(src[b,s,:] + tgt[b,t,:]) + bias, never
  * materialising the [B,T,S,256] tensor.  bwd re-computes tanh.                                   */

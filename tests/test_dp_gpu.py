@@ -16,14 +16,17 @@ from fira_icse_amd.config import FiraConfig
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, out, zero1=False):
+def _run(rank, world, port, out, zero1=False, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, util.REPO)
+    if backend == "nccl":                                   # RCCL: one rank per device
+        torch.cuda.set_device(rank)
     from fira_icse_amd.model import TransModel, DeviceBatch, reference_init_state_dict
     from fira_icse_amd.train import Trainer
     from fira_icse_amd.parallel import shard_indices
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     cfg = FiraConfig()
     store = data.process_raw(cfg, util.load_golden_raw())
     idx = data.split_index(*util.GOLDEN_SPLIT, seed=0)["train"]
@@ -83,6 +86,46 @@ def test_two_rank_zero1_equals_single_process(tmp_path):
     for k in ("m", "v"):                                     # moments: same accumulation up to the reduction order
         d = (a[k] - b[k]).norm() / a[k].norm()
         assert float(d) < 1e-4, (k, float(d))
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2,
+                                    reason="RCCL between two devices needs >= 2 visible GPUs (one-GPU box: gloo tests above)")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("zero1", [False, True])
+def test_two_ranks_over_rccl_equal_single_process(tmp_path, zero1):
+    """The same comparison with backend "nccl" (= RCCL over xGMI), one rank per device -- the transport the reference's
+    multi-GPU mode implies (run_model.py:392-394) and the one bench.py --gpus N uses.  zero1: the native
+    reduce_scatter_tensor / all_gather_into_tensor branch of parallel.ShardedOptimizerComm, which gloo cannot reach.
+    SKIPPED on the one-GPU boxes of the build pool; runs wherever two devices are visible."""
+    port = 29650 + (os.getpid() % 150) + (7 if zero1 else 0)
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    mp.spawn(_run, args=(1, port, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, port + 1, two, zero1, "nccl"), nprocs=2, join=True)
+    a, b = torch.load(one, weights_only=False), torch.load(two, weights_only=False)
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) / x < 1e-5, (a["losses"], b["losses"])
+    cfg = FiraConfig()
+    diff = (a["flat"] - b["flat"]).abs()
+    assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
+    assert float(diff.mean()) < 1e-3 * cfg.lr
+    for k in ("m", "v"):
+        d = (a[k] - b[k]).norm() / a[k].norm()
+        assert float(d) < 1e-4, (k, float(d))
+
+
+@needs_two_gpus
+def test_bench_two_gpus_over_rccl():
+    """`python bench.py --gpus 2` with one rank per device: the line must say backend nccl and carry the collective timings."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(util.REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-decode",
+           "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["process_group"]["backend"] == "nccl" and line["value"] > 0
 
 
 def test_bench_self_launches_under_torchrun():

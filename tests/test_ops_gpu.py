@@ -387,6 +387,128 @@ def test_attention_on_ragged_query_rows_and_bf16_operands(self_kv):
     assert rel_err(o, ref16) < 5e-5
 
 
+def _padding_style_memory(B, S=370, L=210, seed=7, holes=True):
+    """FIRA-shaped key masks: a valid prefix of the 210 code slots and of the 160 sub-token slots, padding behind each
+    (contiguous fully masked 32-key tiles next to live ones), and -- holes -- a few masked slots INSIDE the valid runs
+    (computed memory rows whose id is 0: in the batch's node list because of an edge, masked as keys)."""
+    rng = np.random.default_rng(seed)
+    valid = np.zeros((B, S), np.int32)
+    listed = np.zeros((B, S), bool)                   # the slots a batch would list as computed memory rows
+    n_code = [200, 33, 64, 1, 97, 150, 31, 210][:B] + list(rng.integers(2, L, size=max(0, B - 8)))
+    n_sub = [0, 5, 160, 0, 40, 64, 1, 100][:B] + list(rng.integers(0, S - L, size=max(0, B - 8)))
+    for b in range(B):
+        valid[b, :n_code[b]] = 1
+        valid[b, L:L + n_sub[b]] = 1
+        listed[b] = valid[b] != 0
+        if holes and n_code[b] > 8:
+            valid[b, [3, n_code[b] - 2]] = 0          # listed, but masked
+    return valid, listed
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_cross_attention_with_fully_masked_key_tiles_and_ragged_key_rows(dtype):
+    """The two forms of the engine's cross attention against the fp64 soft-max of gnn_transformer.py:149-156, forward and
+    backward, fp32 and bf16 operands:
+      dense   K / V rows [B*370] with padding-style masks: whole 32-key tiles are masked (the dead-tile skip of
+              attention.hip: scores -1e9, weight exactly 0, no MFMA chain) right next to live ones;
+      ragged  (k_off) the computed memory rows only, commit after commit -- what the engine stores since round 4: the
+              masked padding rows do not exist at all, masked-but-listed rows stay in the list.
+    Both must give the same O / dQ as the reference and the same dK / dV on every listed row; the ragged launch must
+    overwrite every dK / dV row it owns (the gradient buffers start as NaN)."""
+    from fira_icse_amd import ops
+    B, T, S = 8, 30, 370
+    lens = [30, 1, 17, 29, 8, 12, 30, 5]
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    rows = torch.cat([torch.arange(n) + b * T for b, n in enumerate(lens)]).to(DEV)
+    valid_np, listed_np = _padding_style_memory(B)
+    key_valid = torch.from_numpy(valid_np).to(DEV)
+    assert any(not valid_np[b, 32 * t:32 * t + 32].any() and valid_np[b, 32 * (t - 1):32 * t].any()
+               for b in range(B) for t in range(1, 11)), "the fixture must contain a dead tile behind a live one"
+    q = randn(B, T, 256, seed=1).double().requires_grad_(True)
+    k = randn(B, S, 256, seed=2).double().requires_grad_(True)
+    v = randn(B, S, 256, seed=3).double().requires_grad_(True)
+    ref = torch_attention(q, k, v, key_valid, False)
+    do_dense = torch.zeros(B * T, 256, device=DEV)
+    do_dense[rows] = randn(len(rows), 256, seed=5)
+    ref.backward(do_dense.view(B, T, 256).double())
+    qc = q.detach().float().view(B * T, 256)[rows].contiguous()
+    doc = do_dense[rows].contiguous()
+    kd, vd = (t.detach().float().reshape(B * S, 256) for t in (k, v))
+    tol_o, tol_g = ((2e-6, 5e-6), (1e-2, 2e-2))[dtype]
+    # ---- dense rows, padding-style masks
+    o = ops.attention_ragged_fwd(qc, kd, vd, key_valid, off, T, S, dtype=dtype)
+    assert rel_err(o, ref.reshape(B * T, 256)[rows]) < tol_o
+    dq, dk, dv = ops.attention_ragged_bwd(qc, kd, vd, key_valid, o, doc, off, T, S, dtype=dtype, fill=float("nan"))
+    assert rel_err(dq, q.grad.reshape(B * T, 256)[rows]) < tol_g
+    assert rel_err(dk, k.grad.reshape(B * S, 256)) < tol_g and rel_err(dv, v.grad.reshape(B * S, 256)) < tol_g
+    masked = torch.from_numpy(valid_np.reshape(-1) == 0).to(DEV)
+    assert float(dk[masked].abs().max()) == 0.0 and float(dv[masked].abs().max()) == 0.0      # exact zeros, as masked_fill
+    # ---- ragged key rows: the listed slots only, inside a wider buffer (the engine's [rows, 6*512 + pad] K|V)
+    sel = torch.from_numpy(np.flatnonzero(listed_np.reshape(-1))).to(DEV)
+    k_off = torch.tensor([0] + list(np.cumsum(listed_np.sum(1))), dtype=torch.int32, device=DEV)
+    buf = randn(len(sel), 3136, seed=11)
+    buf[:, 512:768], buf[:, 768:1024] = kd[sel], vd[sel]
+    kc, vc = buf[:, 512:768], buf[:, 768:1024]
+    kvc = key_valid.reshape(-1)[sel].contiguous()
+    o2 = ops.attention_ragged_fwd(qc, kc, vc, kvc, off, T, S, dtype=dtype, k_off=k_off)
+    assert rel_err(o2, ref.reshape(B * T, 256)[rows]) < tol_o
+    if dtype == 0:
+        assert rel_err(o2, o) < 1e-6                           # same arithmetic, other tile boundaries
+    dq2, dk2, dv2 = ops.attention_ragged_bwd(qc, kc, vc, kvc, o2, doc, off, T, S, dtype=dtype, k_off=k_off, fill=float("nan"))
+    assert bool(torch.isfinite(dk2).all()) and bool(torch.isfinite(dv2).all())      # every owned row was written
+    assert rel_err(dq2, q.grad.reshape(B * T, 256)[rows]) < tol_g
+    assert rel_err(dk2, k.grad.reshape(B * S, 256)[sel]) < tol_g and rel_err(dv2, v.grad.reshape(B * S, 256)[sel]) < tol_g
+    hole = kvc == 0
+    assert int(hole.sum()) > 0 and float(dk2[hole].abs().max()) == 0.0 and float(dv2[hole].abs().max()) == 0.0
+
+
+def test_attention_row_without_any_valid_key_is_documented_zero():
+    """include/fira_hip.h states the precondition "every query sees at least one unmasked key".  The reference's
+    masked_fill(-1e9) + softmax (gnn_transformer.py:153-154) turns an all-masked row into the uniform average of V over
+    all Tk keys, masked ones included; the kernels never read rows of masked keys (the engine does not even store them),
+    so they return 0 for such a row and send no gradient anywhere.  FIRA batches cannot produce one (position 0 of every
+    commit is <start>, Dataset.py:140).  This test pins the documented behaviour -- finite, exactly zero -- for the dense,
+    the ragged and the one-query (decode) kernel, and that the OTHER commits of the launch are unaffected."""
+    from fira_icse_amd import ops
+    B, T, S = 3, 30, 370
+    off = torch.tensor([0, 30, 60, 90], dtype=torch.int32, device=DEV)
+    key_valid = torch.ones(B, S, dtype=torch.int32, device=DEV)
+    key_valid[1] = 0                                             # commit 1: no valid key at all
+    q, k, v = randn(B * T, 256, seed=1), randn(B * S, 256, seed=2), randn(B * S, 256, seed=3)
+    ref = torch_attention(q.view(B, T, 256).double(), k.view(B, S, 256).double(), v.view(B, S, 256).double(), key_valid, False)
+    o = ops.attention_ragged_fwd(q, k, v, key_valid, off, T, S)
+    assert float(o[30:60].abs().max()) == 0.0
+    assert rel_err(o[:30], ref[0]) < 2e-6 and rel_err(o[60:], ref[2]) < 2e-6
+    dq, dk, dv = ops.attention_ragged_bwd(q, k, v, key_valid, o, randn(B * T, 256, seed=4), off, T, S, fill=float("nan"))
+    assert float(dq[30:60].abs().max()) == 0.0 and float(dk[S:2 * S].abs().max()) == 0.0 and float(dv[S:2 * S].abs().max()) == 0.0
+    assert bool(torch.isfinite(dq).all() and torch.isfinite(dk).all() and torch.isfinite(dv).all())
+    # ragged: commit 1 lists no row at all (k_off[1] == k_off[2]); the decode kernel with the same ranges
+    k_off = torch.tensor([0, S, S, 2 * S], dtype=torch.int32, device=DEV)
+    kc, vc = torch.cat([k[:S], k[2 * S:]]), torch.cat([v[:S], v[2 * S:]])
+    o2 = ops.attention_ragged_fwd(q, kc, vc, torch.ones(2 * S, dtype=torch.int32, device=DEV), off, T, S, k_off=k_off)
+    assert float(o2[30:60].abs().max()) == 0.0 and rel_err(o2[60:], ref[2]) < 2e-6
+    od = ops.decode_attention(q[[0, 30, 60]], kc, vc, torch.ones(2 * S, dtype=torch.int32, device=DEV), tk=S, k_off=k_off)
+    assert float(od[1].abs().max()) == 0.0 and rel_err(od[2], ref[2, 0]) < 2e-6 and rel_err(od[0], ref[0, 0]) < 2e-6
+
+
+def test_decode_attention_on_ragged_key_rows():
+    """The decode step's cross attention on the engine's compact K|V rows (k_off): beam rows of a commit share its range."""
+    from fira_icse_amd import ops
+    Bk, qpk, S = 8, 3, 370
+    valid_np, listed_np = _padding_style_memory(Bk)
+    sel = torch.from_numpy(np.flatnonzero(listed_np.reshape(-1))).to(DEV)
+    k_off = torch.tensor([0] + list(np.cumsum(listed_np.sum(1))), dtype=torch.int32, device=DEV)
+    kd, vd = randn(Bk, S, 256, seed=2), randn(Bk, S, 256, seed=3)
+    buf = randn(len(sel), 3136, seed=11)
+    buf[:, 1024:1280], buf[:, 1280:1536] = kd.view(-1, 256)[sel], vd.view(-1, 256)[sel]
+    q = randn(Bk * qpk, 256, seed=1)
+    kv = torch.from_numpy(valid_np).to(DEV)
+    o = ops.decode_attention(q, buf[:, 1024:1280], buf[:, 1280:1536], kv.reshape(-1)[sel].contiguous(), tk=S, qpk=qpk, k_off=k_off)
+    ref = torch_attention(q.double()[:, None], kd.repeat_interleave(qpk, 0).double(), vd.repeat_interleave(qpk, 0).double(),
+                          kv.repeat_interleave(qpk, 0), False)[:, 0]
+    assert rel_err(o, ref) < 2e-6
+
+
 def test_attention_strided_qkv_buffer():
     """Q|K|V read straight out of the fused [rows, 768] projection buffer (row stride 768)."""
     from fira_icse_amd import ops

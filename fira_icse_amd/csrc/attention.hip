@@ -15,62 +15,9 @@
 // The backward also needs the non-transposed tile (for dK = dS^T Q and dV = P^T dO); it is recomputed by
 // swapping the two operand fragments of the same MFMA chain, never by a transpose.
 #include "engine.h"
+#include "mfma_frag.h"
 
 namespace fira {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// One 32-deep product of two fragments (16 values per lane, k = (lane>>5)*16 + s on both sides) accumulated into a
-// 32x32 tile.  fp32: the exact 16-step v_mfma_f32_32x32x2_f32 chain.  BF (bf16 mode of the engine: torch.autocast runs
-// the attention matmuls on bf16 operands with fp32 accumulation): both fragments are rounded to bf16 (RNE) and the
-// product is TWO v_mfma_f32_32x32x16_bf16 -- slot e of lane group g holds k = g*16 + 8 j + e in step j on both sides, so
-// every k is paired once; the dependent chain shrinks from 16 x 64 to 2 x 32 cycles.
-typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
-typedef float af32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t apk2(float a, float b) {
-    const af32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));      // v_cvt_pk_bf16_f32
-}
-template <bool BF>
-__device__ __forceinline__ f32x16 chain16(const float (&a)[16], const float (&b)[16], f32x16 acc) {
-    if constexpr (BF) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint4 ua, ub;
-            ua.x = apk2(a[8 * j], a[8 * j + 1]); ua.y = apk2(a[8 * j + 2], a[8 * j + 3]);
-            ua.z = apk2(a[8 * j + 4], a[8 * j + 5]); ua.w = apk2(a[8 * j + 6], a[8 * j + 7]);
-            ub.x = apk2(b[8 * j], b[8 * j + 1]); ub.y = apk2(b[8 * j + 2], b[8 * j + 3]);
-            ub.z = apk2(b[8 * j + 4], b[8 * j + 5]); ub.w = apk2(b[8 * j + 6], b[8 * j + 7]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ua), __builtin_bit_cast(abf16x8, ub), acc,
-                                                          0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc = MFMA32(a[s], b[s], acc);
-    }
-    return acc;
-}
-
-__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
-
-// fragment X[row][col0 + kh*16 + s], s = 0..15; zero when !valid
-__device__ __forceinline__ void load_frag(float (&f)[16], const float* __restrict__ base, bool valid) {
-    if (valid) {
-        const float4* p = reinterpret_cast<const float4*>(base);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = p[i];
-            f[4 * i + 0] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) f[i] = 0.f;
-    }
-}
 
 constexpr float SQRT_DH = 5.656854249492381f;
 // the kernels multiply by reciprocals (IEEE division is a ~10-instruction VALU sequence and these kernels are bound by

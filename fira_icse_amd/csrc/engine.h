@@ -63,6 +63,17 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
              int ldx, float* Y, int ldy, int graph_rows, int variant);
 int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                 int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum);
+// One GCN layer per launch (gcn_fused.hip): gather A_hat X (or A_hat dY) into LDS, multiply by the folded weight, finish
+// whole rows.  Wk = the weight K-MAJOR ([256 k][256 n], out = U Wk).  forward (Wk = W21^T): sum = dropout(U Wk + bias +
+// (A_hat 1) r1_col^T) + X, y = LN(sum) (+ second compact copy at y2[slot2[r]]), rowsum_out (optional) = A_hat 1.
+// backward (Wk = W21): u_out = A_hat dY, acc_out += u_out Wk.
+int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                  const float* Wk, const float* bias, const float* r1_col, const float* gamma, const float* beta, float* sum,
+                  float* y, float* stats, float* rowsum_out, const int32_t* slot2, float* y2, float dropout, uint64_t seed,
+                  uint32_t site, int bf16);
+int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* dY,
+                  const float* Wk, float* u_out, float* acc_out, int bf16);
+int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[l] = W[l]^T, nl stacked [256,256] matrices
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
                      int out_bstride, int out_off);
 int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const int32_t* item_ptr, const int32_t* rows,

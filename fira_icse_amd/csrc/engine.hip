@@ -73,6 +73,7 @@ struct Plan {
     std::vector<DecGrad> decg;      // wgrad GEMMs can run on the side stream while the dgrad chain continues
     float *vtab_all, *H, *mem, *mem_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *W21, *c21, *rsum;        // GCN: per layer fc2.weight . fc1.weight [256,256] and fc2.weight . fc1.bias [256]; A_hat 1
+    float *W21t;                    // the folded weights transposed = k-major for U W21^T: what the fused GCN forward streams
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
     // backward temporaries (training only)
@@ -123,6 +124,7 @@ struct Plan {
         }
         vtab_all = a.f((size_t)4 * nl * D);
         W21 = a.f((size_t)nl * D * D); c21 = a.f((size_t)nl * D); rsum = a.f((size_t)NB);
+        W21t = a.f((size_t)nl * D * D);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
         mem_c = a.f((size_t)MB * D);
@@ -534,6 +536,13 @@ static inline int attn_bf16() {
     return g_dtype == 1 && !off;
 }
 
+// GCN layer as one fused launch per direction (gcn_fused.hip) instead of SpMM + product + add-LayerNorm (forward) /
+// product + SpMM (backward); FIRA_GCN_FUSED=0 restores the separate kernels (A/B switch)
+static inline bool gcn_fused_on() {
+    static const bool off = [] { const char* e = getenv("FIRA_GCN_FUSED"); return e && e[0] == '0'; }();
+    return !off;
+}
+
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
 static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
 
@@ -595,6 +604,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const EncLayer& w = L.enc[l];
             TRY(gemm_f32_ex(fs, 0, 0, D, D, D, c.P + w.fc2w, D, c.P + w.fc1w, D, p.W21 + (size_t)l * D * D, D, nullptr, 0, 0, nullptr));
             TRY(gemm_f32_ex(fs, 0, 1, D, 1, D, c.P + w.fc2w, D, c.P + w.fc1b, D, p.c21 + (size_t)l * D, 1, nullptr, 0, 0, nullptr));
+            if (l == 0 && gcn_fused_on()) TRY(transpose256(fs, 1, p.W21, p.W21t));       // (layer 0's first: see ev_fold0)
             if (ax && l == 0 && !g_Wb && p.nl > 1) TRY(side_mark(&ev_fold0));
         }
         if (g_Wb) {                                  // bf16 mode: shadows of the folded weights, on the same stream
@@ -607,6 +617,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             TRY(weight_shadows(fs, t21, p.W21, p.w21b, p.w21bt));
             g_W21 = p.W21; g_W21n = (int64_t)p.nl * D * D; g_W21b = p.w21b; g_W21bT = p.w21bt;
         }
+        if (gcn_fused_on() && p.nl > 1) TRY(transpose256(fs, p.nl - 1, p.W21 + (size_t)D * D, p.W21t + (size_t)D * D));
         if (ax) TRY(side_mark(&ev_fold));
         if (!ev_fold0) ev_fold0 = ev_fold;           // bf16 mode / one layer: a single mark
     }
@@ -632,8 +643,9 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
         TRY(linear_ln(s, Cc, D, e.c, D, c.P + w.wo, c.P + w.bo, e.Xc, c.P + w.ln1g, c.P + w.ln1b, e.s1, X, e.st1, c.p_drop,
                       c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
-        // GCN in folded form: U = A_hat X (kept for the weight gradient) -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
-        TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
+        // GCN in folded form: U = A_hat X -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
+        const bool fused = gcn_fused_on();
+        if (!fused) TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
         if (l == 0 && ev_fold0) TRY(main_wait(s, ev_fold0));              // the product below is the first reader of W21 / c21
         if (l == 1 && ev_fold && ev_fold != ev_fold0) TRY(main_wait(s, ev_fold));
         // second store of the output: the next layer's code rows (its Xc), or after the last layer the memory rows
@@ -641,6 +653,12 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // compact row order -- the attention kernels take commit b's key range from mem_off; the dense [B,370,256] rows the
         // copy kernels read are scattered by LinearSource's projection below, rows of masked slots are never read there)
         const bool last = l + 1 == p.nl;
+        if (fused)             // one launch: gather, product, bias + rank-1 term, dropout, residual, LayerNorm, both stores
+            TRY(gcn_fused_fwd(s, Nc, bt.rowptr, bt.col, bt.val, X, p.W21t + (size_t)l * D * D, c.P + w.fc2b, p.c21 + (size_t)l * D,
+                              c.P + w.ln2g, c.P + w.ln2b, e.s2, p.X[l + 1], e.st2, l == 0 ? p.rsum : nullptr,
+                              last ? p.mem_slot : p.code_slot, last ? p.mem_c : p.enc[l + 1].Xc, c.p_gcn, c.seed,
+                              site(l, SITE_GCN), g_dtype == 1));
+        else
         TRY(linear_ln(s, Nc, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, X, c.P + w.ln2g, c.P + w.ln2b, e.s2,
                       p.X[l + 1], e.st2, c.p_gcn, c.seed, site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D,
                       last ? p.mem_slot : p.code_slot, last ? p.mem_c : p.enc[l + 1].Xc, last ? Mc : Cc,
@@ -954,10 +972,19 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
             if (!sums) TRY(gcn_bias_unfold(ws, c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b));
             return 0;
         };
+        if (gcn_fused_on()) {
+            // one launch: V = A_hat dY (stored in e.Z, which the fused forward pass does not use), other = ds + V W21.
+            // The weight gradient follows from the same V: dW21 = dY^T (A_hat X) = (A_hat dY)^T X = V^T X
+            TRY(gcn_fused_bwd(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, p.W21 + (size_t)l * D * D, e.Z, other, g_dtype == 1));
+            TRY(enc_wgrad(s, Nc, D, D, e.Z, D, p.X[l], D, dW21, nullptr));
+            if (!sums) TRY(colsum(s, Nc, D, g.dY2, D, G + w.fc2b));     // (db2 = column sums of dY, not of V)
+            if (!grouped) TRY(unfold());
+        } else {
         TRY(enc_wgrad(s, Nc, D, D, g.dY2, D, e.Z, D, dW21, sums ? nullptr : G + w.fc2b));
         if (!grouped) TRY(unfold());
         TRY(linear_dgrad(s, Nc, D, D, g.dY2, D, p.W21 + (size_t)l * D * D, p.dNB2, D, false));  // dU
         TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, p.dNB2, D, other, D, 0, 1, 1, nullptr));   // other = ds + A_hat dU
+        }
         // Combination on the code rows, in place inside `other` through the code-row map: the LayerNorm backward reads
         // dG[code rows] and leaves the residual-branch gradient there; the q|k projection's dgrad adds to the same rows
         TRY(ln_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,

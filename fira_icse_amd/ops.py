@@ -188,6 +188,28 @@ def colsum(X):
     return out
 
 
+def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0, want_rowsum=True):
+    """fira_gcn_layer_fwd: (sum, y, stats, rowsum) of one folded GCN layer on the CSR adjacency (global column ids);
+    W21t = W21^T contiguous."""
+    n = X.shape[0]
+    summ, y = torch.empty_like(X), torch.empty_like(X)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=X.device)
+    rs = torch.empty(n, dtype=torch.float32, device=X.device) if want_rowsum else None
+    check(_lib.lib().fira_gcn_layer_fwd(cur_stream(), n, ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)), ptr(_f32(X)),
+                                        ptr(_f32(W21t)), ptr(_f32(bias)), ptr(_f32(c21)), ptr(_f32(gamma)), ptr(_f32(beta)),
+                                        ptr(summ), ptr(y), ptr(stats), ptr(rs), dropout, seed, site, dtype),
+          "fira_gcn_layer_fwd")
+    return summ, y, stats, rs
+
+
+def gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=0):
+    """fira_gcn_layer_bwd: V = A_hat dY (returned), dX += V W21 in place."""
+    V = torch.empty_like(dY)
+    check(_lib.lib().fira_gcn_layer_bwd(cur_stream(), dY.shape[0], ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)),
+                                        ptr(_f32(dY)), ptr(_f32(W21)), ptr(V), ptr(_f32(dX)), dtype), "fira_gcn_layer_bwd")
+    return V
+
+
 def attention_ragged_fwd(q, k, v, key_valid, q_off, Tq, Tk, causal=False, self_kv=False, dtype=0, heads=8, k_off=None):
     """The engine's form (fira_attention_fwd_ex): q [R,256] compact query rows, commit b's are q_off[b] .. q_off[b+1]
     (<= Tq of them); k / v [B*Tk,256] dense, or the same compact rows with self_kv, or (k_off [B+1]) RAGGED key rows:

@@ -183,6 +183,26 @@ int fira_csr_spmm_f32(void* stream, int n_rows, const int32_t* rowptr, const int
 int fira_csr_spmm(void* stream, int n_rows, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val,
                   const float* X, int ldx, float* Y, int ldy, int graph_rows, int variant, int dtype);
 
+/* One GCN layer per launch (v6; reference gnn_transformer.py:74-86: fc1 -> torch.bmm(edge, x) -> fc2 -> dropout -> +x ->
+ * LayerNorm).  There is no non-linearity between fc1, the aggregation and fc2, so the layer is evaluated in the folded form
+ *     sum = dropout( (A_hat X) W21^T + b2 + (A_hat 1) c21^T ) + X ,   y = LayerNorm(sum)
+ * with W21 = fc2.weight . fc1.weight [256,256] and c21 = fc2.weight . fc1.bias [256] formed by the caller; the forward
+ * launch takes it TRANSPOSED (W21t = W21^T row-major, i.e. [in, out]: the kernel streams the weight k-major).  A workgroup
+ * gathers 32 rows of A_hat X from the CSR adjacency into LDS, multiplies them with W21 on the MFMA (fp32 chains, or bf16
+ * operands with fp32 accumulation for FIRA_BF16) and finishes the rows: the aggregated rows never travel through HBM.
+ * CSR as for fira_csr_spmm_f32 (global column ids, sorted).  sum / y [n_rows,256], stats [n_rows,2] = {mean, 1/std} for
+ * the backward LayerNorm; rowsum_out (optional) [n_rows] = A_hat 1; dropout element index = row*256 + col of `site`.
+ *
+ * Backward of the data path (A_hat symmetric):  V = A_hat dY ;  dX += V W21 ;  the weight gradient is dW21 = V^T X.
+ * dY = gradient w.r.t. the un-dropped branch output (what fira_add_layernorm_bwd returns as dx_drop); W21 row-major
+ * [out, in] (k-major for this product); V [n_rows,256] is written, dX [n_rows,256] is accumulated into.                  */
+int fira_gcn_layer_fwd(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* X, const float* W21t, const float* bias, const float* c21, const float* gamma,
+                       const float* beta, float* sum, float* y, float* stats, float* rowsum_out, float dropout,
+                       uint64_t seed, uint32_t site, int dtype);
+int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* dY, const float* W21, float* V, float* dX, int dtype);
+
 /* out[(b*out_bstride + out_off + i), :] = table[idx[b*L + i], :] (+ pos[i,:])  — the embedding
  * gathers of gnn_transformer.py:46-52,110-113 written straight into the node buffer.           */
 int fira_embed_gather_fwd(void* stream, int B, int L, const int32_t* idx, const float* table,

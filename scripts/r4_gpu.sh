@@ -37,6 +37,44 @@ for ST in "$@"; do
         timeout 120 python scripts/attn_probe.py 32 $L 2>&1 | grep "us per launch"
       done | tee $OUT/attn_probe.txt
       timeout 120 python scripts/attn_probe.py 64 3136 ragged 2>&1 | grep "us per launch" | tee -a $OUT/attn_probe.txt ;;
+    nwprobe)
+      for NW in 12 6 4; do
+        echo "FIRA_ATTN_NW=$NW"; FIRA_ATTN_NW=$NW timeout 120 python scripts/attn_probe.py 32 3136 ragged 2>&1 | grep "us per launch"
+        FIRA_ATTN_NW=$NW timeout 120 python scripts/attn_probe.py 64 3136 ragged 2>&1 | grep "us per launch"
+      done | tee $OUT/attn_nw_probe.txt ;;
+    gcnprobe)
+      timeout 200 python scripts/gcn_probe.py 32 0 2>&1 | tail -n 6 | tee $OUT/gcn_probe.txt
+      timeout 200 python scripts/gcn_probe.py 64 1 2>&1 | tail -n 6 | tee -a $OUT/gcn_probe.txt
+      cd /tmp; mkdir -p $OUT/prof_gcn
+      timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof_gcn -o g -- python $REPO/scripts/gcn_probe.py 32 0 > $OUT/prof_gcn/run.log 2>&1
+      python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_gcn -name "*results.db" | head -1) 1 > $OUT/gcn_kernel_stats.md 2>&1
+      find $OUT/prof_gcn -name "*.db" -delete
+      grep "gcn_fused\|spmm_rowwave\|gemm_f32_kernel" $OUT/gcn_kernel_stats.md | cut -c1-200
+      for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE"; do
+        tag=$(echo $grp | cut -d' ' -f1)
+        timeout 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_gcn_$tag -o a -- python $REPO/scripts/gcn_probe.py 32 0 > $OUT/pmc_gcn_$tag.log 2>&1
+      done
+      for f in $(find $OUT -name "*counter_collection.csv"); do python $REPO/scripts/pmc_summary.py $f gcn_fused; done | tee $OUT/gcn_pmc.txt
+      find $OUT -name "*.csv" -delete
+      cd $REPO ;;
+    gcntests)
+      timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 -k "gcn_layer" > $OUT/gcntests.log 2>&1
+      echo "gcntests rc=$?"; tail -n 12 $OUT/gcntests.log ;;
+    abenv16)
+      IFS='|' read -ra VARS <<< "$ABENV"
+      for i in 1 2; do
+        for V in "${VARS[@]}"; do
+          echo -n "$V bf16 b64: "; one "$V" "--dtype bf16 --batch 64"
+        done
+      done 2>&1 | tee $OUT/abenv16.txt ;;
+    abenv)   # environment switches of ONE build, alternating: ABENV="A=1|B=2|..." 
+      IFS='|' read -ra VARS <<< "$ABENV"
+      for i in 1 2 3; do
+        for V in "${VARS[@]}"; do
+          echo -n "$V f32 b32: "; one "$V" "--batch 32"
+          [ $i = 1 ] && { echo -n "$V f32 b64: "; one "$V" "--batch 64"; }
+        done
+      done 2>&1 | tee $OUT/abenv.txt ;;
     bench)
       timeout 900 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "bench f32 rc=$?"; head -c 1500 $OUT/bench_f32.json; echo; tail -n 5 $OUT/bench_f32.err ;;
     bench16)

@@ -112,6 +112,49 @@ def test_csr_spmm_vs_dense_bmm(variant, N, nnz):
     assert rel_err(Y, ref) < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("N,nnz,p", [(650, 2500, 0.0), (97, 4000, 0.2), (33, 200, 0.2)])
+def test_gcn_layer_fused_fwd_bwd(N, nnz, p, dtype):
+    """fira_gcn_layer_{fwd,bwd} (gcn_fused.hip): one launch per direction for the folded GCN layer
+    LN(dropout((A_hat X) W21^T + b2 + (A_hat 1) c21^T) + X) of gnn_transformer.py:74-86, against the fp64 statement of the
+    same formula with the engine's own dropout mask; graphs with hub rows (97 nodes x 4000 entries: > 16 entries per row
+    -> the tail path of the gather), ragged last row block (B*N not a multiple of 32).  Backward: V = A_hat dY and
+    dX += V W21 against autograd of the aggregation + product.  dtype 1: bf16 operands of the product (fp32 gather,
+    accumulation, LayerNorm) vs the fp64 product of the ROUNDED operands."""
+    from fira_icse_amd import ops
+    B = 3
+    rowptr, col, val, dense = random_graph_batch(B, N, nnz, seed=N + 1)
+    n = B * N
+    X = randn(n, 256, seed=1)
+    W21, b2, c21 = randn(256, 256, seed=2, scale=0.06), randn(256, seed=3, scale=0.1), randn(256, seed=4, scale=0.1)
+    gamma, beta = 1 + randn(256, seed=5, scale=0.1), randn(256, seed=6, scale=0.1)
+    seed, site = 1234, 19
+    summ, y, stats, rs = ops.gcn_layer_fwd(rowptr, col, val, X, W21.t().contiguous(), b2, c21, gamma, beta, dropout=p, seed=seed, site=site,
+                                           dtype=dtype)
+    A = torch.block_diag(*[dense[b] for b in range(B)]).double()
+    U = A @ X.double()
+    r16 = (lambda t: t.float().bfloat16().double()) if dtype else (lambda t: t.double())
+    pre = r16(U) @ r16(W21).t() + b2.double() + A.sum(1, keepdim=True) * c21.double()
+    mask = ops.dropout_mask(seed, site, n * 256, p).view(n, 256).double() if p > 0 else 1.0
+    ref_sum = pre * mask + X.double()
+    ref_y = F.layer_norm(ref_sum, (256,), gamma.double(), beta.double(), 1e-5)
+    # bf16: exact products of the rounded operands, fp32 accumulation; the kernel rounds the fp32 aggregate, the reference
+    # the fp64 one -- a handful of elements land on the other side of a bf16 rounding boundary
+    tol = 2e-6 if dtype == 0 else 3e-5
+    assert rel_err(rs, A.sum(1)) < 1e-6
+    assert rel_err(summ, ref_sum) < tol and rel_err(y, ref_y) < 5 * tol
+    mean, rstd = ref_sum.mean(1), 1.0 / torch.sqrt(ref_sum.var(1, unbiased=False) + 1e-5)
+    assert rel_err(stats[:, 0], mean) < 1e-4 and rel_err(stats[:, 1], rstd) < 1e-5
+    # backward
+    dY = randn(n, 256, seed=7)
+    dX0 = randn(n, 256, seed=8)
+    dX = dX0.clone()
+    V = ops.gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=dtype)
+    refV = A @ dY.double()
+    assert rel_err(V, refV) < 1e-6
+    assert rel_err(dX, dX0.double() + r16(refV) @ r16(W21)) < tol
+
+
 def dense_graph_batch(B, N, density, seed):
     """symmetric random adjacency blocks with a full diagonal -> block-diagonal CSR (sorted unique columns) + dense copy"""
     rng = np.random.default_rng(seed)

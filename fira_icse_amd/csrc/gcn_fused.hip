@@ -9,28 +9,44 @@
 // gradient uses the same identity: dW21 = dY^T (A_hat X) = (A_hat dY)^T X = V^T X, so Z is never stored; the backward
 // launch leaves V for it.
 //
-// A workgroup (8 waves) owns 32 COMPLETE node rows:
+// Geometry.  The product is MFMA-bound in fp32 (1.3 GFLOP per launch at batch 32 = 8.4 us of the whole chip), so what
+// matters is how evenly the rows fall on the 256 CUs and how often the 256 KB weight is streamed:
+//   * ONE workgroup (16 waves) per CU, each owning a CONTIGUOUS range of 16-row tiles: ceil or floor of n_tiles / 256
+//     (10 000 rows = 627 tiles: 2 or 3 tiles per CU; 32-row workgroups would put 64 rows on some CUs and 32 on others:
+//     version 1 of this file, 36 us per launch against 33 us for the three separate kernels);
+//   * up to four tiles (64 rows) per pass: the gathered rows sit in a 64 KB fp32 LDS panel, every wave owns 16 output
+//     columns of ALL of them, so a pass streams the weight once (64 FLOP per byte of L2 traffic at four tiles);
+//   * v_mfma_f32_16x16x4_f32 (same rate as 32x32x2; its 16-row tile is what makes the split even); one accumulator per
+//     tile: up to four independent chains per wave cover the 40-cycle dependent-issue latency.
+// Phases of a pass:
 //   1. gather   wave w aggregates rows 4w .. 4w+3 (64 lanes x float4 = one 1 KiB neighbour row per load; row offsets and
-//               the first 16 (col, val) pairs of all four rows are fetched in two batched round trips, the first four
-//               neighbour rows of all four rows in a third) into a [32][256] fp32 panel in LDS (pitch 260: the
-//               ds_read_b128 fragment fetch of phase 2 is conflict-free);
-//   2. product  wave w owns output columns 32w .. 32w+31: A fragments (16 contiguous k per lane) from the panel, B
-//               fragments straight from the L2-resident 256 KB k-major weight (whole 128-byte lines per instruction,
-//               requested 2-4 chunks ahead), 8 chunks x 16 v_mfma_f32_32x32x2_f32 -- or 8 x 2 v_mfma_f32_32x32x16_bf16;
-//   3. rows     the 32x256 result goes back through the panel, and wave w finishes rows 4w .. 4w+3 with whole-row
-//               (1 KiB, coalesced) accesses: bias, rank-1 term, dropout, residual, LayerNorm, second compact copy
-//               (forward) / accumulate into the gradient rows (backward).
-// fp32: 32 x 256 x 256 is 6.8 us of one CU's MFMA time per workgroup (294 workgroups at batch 32: the launch is
-// MFMA-bound, ~1.2 GFLOP); bf16: gather-bound.
+//               the first 16 (col, val) pairs of all four rows in two batched round trips, four neighbour rows of each
+//               of the four rows per further round trip) into the panel.  Panel rows are 256 floats with the 16-byte
+//               columns XOR-swizzled by (row & 11): the fragment fetch below (ds_read_b128, 16 rows x two k quarters per
+//               lane group) is then conflict-free, and so are the whole-row accesses;
+//   2. product  A fragments (16 contiguous k per lane) from the panel, B fragments straight from the L2-resident k-major
+//               weight (whole 64-byte segments per k row, requested a 64-wide k chunk ahead; the empty asm statements pin
+//               that order -- the scheduler otherwise sinks every load to its first use);
+//   3. rows     the results go back through the panel, and wave w finishes rows 4w .. 4w+3 with whole-row (1 KiB,
+//               coalesced) accesses: bias, rank-1 term, dropout, residual, LayerNorm, second compact copy (forward) /
+//               accumulate into the gradient rows (backward).
 #include "engine.h"
 #include "mfma_frag.h"
+#include "epilogue.h"
 
 namespace fira {
 
-constexpr int GF_ROWS = 32;               // node rows per workgroup
-constexpr int GF_PITCH = FIRA_D + 4;      // LDS row pitch in floats (rows 16 bytes apart in bank space)
-constexpr int GF_WAVES = 8;
+constexpr int GF_TILE = 16;               // rows per MFMA tile
+constexpr int GF_TMAX = 4;                // tiles per pass (64 panel rows)
+constexpr int GF_ROWS = GF_TILE * GF_TMAX;
+constexpr int GF_WAVES = 16;
 constexpr int GF_RPW = GF_ROWS / GF_WAVES;   // rows per wave in the gather / row phases
+constexpr int GF_GRID = 256;              // one workgroup per CU
+// dynamic LDS: the panel + the row sums; asking for more than half of a CU's 160 KB keeps the dispatcher from placing two
+// of these workgroups on one CU while another CU stays empty
+constexpr size_t GF_LDS = 84 * 1024;
+
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
 struct GcnFusedArgs {
     int n_rows;
@@ -51,218 +67,268 @@ struct GcnFusedArgs {
     float* acc_out;          // rows the product is added to
 };
 
+// float offset of 16-byte column `quad` (0..63) of panel row `row`
+__device__ __forceinline__ int gf_off(int row, int quad) { return row * FIRA_D + ((quad ^ (row & 11)) << 2); }
+
 template <bool BF, bool BWD>
 __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm_u[GF_ROWS * GF_PITCH];
-    __shared__ float sm_rs[GF_ROWS];
+    extern __shared__ __attribute__((aligned(16))) float gf_lds[];
+    float* const sm_u = gf_lds;                          // [64][256] swizzled
+    float* const sm_rs = gf_lds + GF_ROWS * FIRA_D;      // [64] row sums of A_hat
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int l31 = lane & 31, kh = lane >> 5;
-    // XCD-aware row-block order (spmm.hip): workgroup b runs on XCD b % 8; every XCD owns a contiguous eighth of the rows
-    const int per_xcd = gridDim.x >> 3;
-    const int r0 = ((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * GF_ROWS;
-    if (r0 >= a.n_rows) return;
+    const int l15 = lane & 15, kq = lane >> 4;
+    // workgroup b runs on XCD b % 8: logical id (b % 8) * 32 + b / 8 gives every XCD a contiguous eighth of the tiles (whole
+    // graphs: the gather's re-reads of neighbour rows stay in that XCD's L2)
+    const int wg = (blockIdx.x & 7) * (GF_GRID / 8) + (blockIdx.x >> 3);
+    const int n_tiles = (a.n_rows + GF_TILE - 1) / GF_TILE;
+    const int tq = n_tiles / GF_GRID, tr = n_tiles % GF_GRID;
+    const int t_beg = wg * tq + min(wg, tr), t_cnt = tq + (wg < tr ? 1 : 0);
+    // Panel addresses as (per-lane base) + (compile-time offset): the swizzle term (row & 11) depends on the lane only --
+    //   fragment fetch   row 16 tt + l15, column quad 16 c + (4 kq + ii):  base a_off[ii], + tt * 4096 + c * 64 floats
+    //   result store     row 16 tt + 4 kq + r, column 16 wave + l15:       base d_off[r],  + tt * 4096
+    //   whole rows       row 4 wave + i, column quad = lane:               base r_off[i]
+    int a_off[4], d_off[4], r_off[GF_RPW];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) a_off[ii] = gf_off(l15, kq * 4 + ii);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d_off[r] = gf_off(4 * kq + r, (wave * 16 + l15) >> 2) + (l15 & 3);
+#pragma unroll
+    for (int i = 0; i < GF_RPW; ++i) r_off[i] = gf_off(wave * GF_RPW + i, lane);
 
-    // ---------------------------------------------------------------- 1. gather: U = A_hat X rows -> LDS
-    {
-        const int rbase = r0 + wave * GF_RPW;
-        int rp = 0;
-        if (lane <= GF_RPW) rp = a.rowptr[min(rbase + lane, a.n_rows)];
-        int beg[GF_RPW], cnt[GF_RPW];
+    for (int pass = 0; pass < t_cnt; pass += GF_TMAX) {
+        const int nt = min(GF_TMAX, t_cnt - pass);
+        const int row0 = (t_beg + pass) * GF_TILE;
+        const int row_end = min(a.n_rows, row0 + nt * GF_TILE);          // rows [row0, row_end) are this pass's
+        // ------------------------------------------------------------ 1. gather: U = A_hat X rows -> panel
+        if (wave * GF_RPW < nt * GF_TILE) {
+            const int rbase = row0 + wave * GF_RPW;
+            int rp = 0;
+            if (lane <= GF_RPW) rp = a.rowptr[min(rbase + lane, a.n_rows)];
+            int beg[GF_RPW], cnt[GF_RPW];
 #pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            beg[i] = __shfl(rp, i, 64);
-            cnt[i] = rbase + i < a.n_rows ? __shfl(rp, i + 1, 64) - beg[i] : 0;
-        }
-        // the first 16 (col, val) pairs of row i live in lanes 16 i .. 16 i + 15
-        const int gi = lane >> 4, ge = lane & 15;
-        const int my_beg = __shfl(rp, gi, 64);
-        const int my_cnt = rbase + gi < a.n_rows ? __shfl(rp, gi + 1, 64) - my_beg : 0;
-        int c = 0;
-        float v = 0.f;
-        if (ge < my_cnt) {
-            c = a.col[my_beg + ge];
-            v = a.val[my_beg + ge];
-        }
-        int cmax = 0;
+            for (int i = 0; i < GF_RPW; ++i) {
+                beg[i] = __shfl(rp, i, 64);
+                cnt[i] = rbase + i < row_end ? __shfl(rp, i + 1, 64) - beg[i] : 0;
+            }
+            // the first 16 (col, val) pairs of row i live in lanes 16 i .. 16 i + 15
+            const int gi = lane >> 4, ge = lane & 15;
+            const int my_beg = __shfl(rp, gi, 64);
+            const int my_cnt = rbase + gi < row_end ? __shfl(rp, gi + 1, 64) - my_beg : 0;
+            int c = 0;
+            float v = 0.f;
+            if (ge < my_cnt) {
+                c = a.col[my_beg + ge];
+                v = a.val[my_beg + ge];
+            }
+            int cmax = 0;
 #pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) cmax = max(cmax, min(cnt[i], 16));
-        f32x4v acc[GF_RPW];
+            for (int i = 0; i < GF_RPW; ++i) cmax = max(cmax, min(cnt[i], 16));
+            f32x4v acc[GF_RPW];
 #pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        // four neighbours of each of the four rows per round trip; lanes past a row's end carry (col 0, val 0): an
-        // unconditional load of a valid row times zero
-        for (int jb = 0; jb < cmax; jb += 4) {
-            f32x4v x[GF_RPW][4];
-            float w[GF_RPW][4];
+            for (int i = 0; i < GF_RPW; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            // four neighbours of each of the four rows per round trip; lanes past a row's end carry (col 0, val 0): an
+            // unconditional load of a valid row times zero
+            for (int jb = 0; jb < cmax; jb += 4) {
+                f32x4v x[GF_RPW][4];
+                float w[GF_RPW][4];
 #pragma unroll
-            for (int i = 0; i < GF_RPW; ++i)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int src = i * 16 + jb + u;
-                    const int cj = __shfl(c, src, 64);
-                    w[i][u] = __shfl(v, src, 64);
-                    x[i][u] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)cj * FIRA_D + lane * 4);
-                }
-#pragma unroll
-            for (int i = 0; i < GF_RPW; ++i)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc[i].x = fmaf(w[i][u], x[i][u].x, acc[i].x); acc[i].y = fmaf(w[i][u], x[i][u].y, acc[i].y);
-                    acc[i].z = fmaf(w[i][u], x[i][u].z, acc[i].z); acc[i].w = fmaf(w[i][u], x[i][u].w, acc[i].w);
-                }
-        }
-        // row sums of A_hat (the rank-1 term's row factor): over the 16-lane group, then the rare tail
-        float vs = v;
-        vs += __shfl_xor(vs, 1, 64); vs += __shfl_xor(vs, 2, 64); vs += __shfl_xor(vs, 4, 64); vs += __shfl_xor(vs, 8, 64);
-        float vsum[GF_RPW];
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) vsum[i] = __shfl(vs, i * 16, 64);
-        // rows with more than 16 entries (hub nodes): the remaining entries 64 at a time, as spmm_rowwave_kernel does
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            if (cnt[i] <= 16) continue;                      // wave-uniform
-            float extra = 0.f;
-            for (int base = beg[i] + 16; base < beg[i] + cnt[i]; base += 64) {
-                const int n = min(64, beg[i] + cnt[i] - base);
-                int c2 = 0;
-                float v2 = 0.f;
-                if (lane < n) {
-                    c2 = a.col[base + lane];
-                    v2 = a.val[base + lane];
-                }
-                extra += v2;
-                for (int j = 0; j < n; j += 4) {             // (lanes past n hold col 0 / val 0)
-                    f32x4v x4[4];
-                    float w4[4];
+                for (int i = 0; i < GF_RPW; ++i)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int sl = min(j + u, 63);
-                        const int cj = j + u < 64 ? __shfl(c2, sl, 64) : 0;
-                        w4[u] = j + u < 64 ? __shfl(v2, sl, 64) : 0.f;
-                        x4[u] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)cj * FIRA_D + lane * 4);
+                        const int src = i * 16 + jb + u;
+                        const int cj = __shfl(c, src, 64);
+                        w[i][u] = __shfl(v, src, 64);
+                        x[i][u] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)cj * FIRA_D + lane * 4);
                     }
 #pragma unroll
+                for (int i = 0; i < GF_RPW; ++i)
+#pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        acc[i].x = fmaf(w4[u], x4[u].x, acc[i].x); acc[i].y = fmaf(w4[u], x4[u].y, acc[i].y);
-                        acc[i].z = fmaf(w4[u], x4[u].z, acc[i].z); acc[i].w = fmaf(w4[u], x4[u].w, acc[i].w);
+                        acc[i].x = fmaf(w[i][u], x[i][u].x, acc[i].x); acc[i].y = fmaf(w[i][u], x[i][u].y, acc[i].y);
+                        acc[i].z = fmaf(w[i][u], x[i][u].z, acc[i].z); acc[i].w = fmaf(w[i][u], x[i][u].w, acc[i].w);
+                    }
+            }
+            // row sums of A_hat (the rank-1 term's row factor): over the 16-lane group, then the rare tail
+            float vs = v;
+            vs += __shfl_xor(vs, 1, 64); vs += __shfl_xor(vs, 2, 64); vs += __shfl_xor(vs, 4, 64); vs += __shfl_xor(vs, 8, 64);
+            float vsum[GF_RPW];
+#pragma unroll
+            for (int i = 0; i < GF_RPW; ++i) vsum[i] = __shfl(vs, i * 16, 64);
+            // rows with more than 16 entries (hub nodes): the remaining entries 64 at a time, as spmm_rowwave_kernel does
+#pragma unroll
+            for (int i = 0; i < GF_RPW; ++i) {
+                if (cnt[i] <= 16) continue;                      // wave-uniform
+                float extra = 0.f;
+                for (int base = beg[i] + 16; base < beg[i] + cnt[i]; base += 64) {
+                    const int n = min(64, beg[i] + cnt[i] - base);
+                    int c2 = 0;
+                    float v2 = 0.f;
+                    if (lane < n) {
+                        c2 = a.col[base + lane];
+                        v2 = a.val[base + lane];
+                    }
+                    extra += v2;
+                    for (int j = 0; j < n; j += 4) {             // (lanes past n hold col 0 / val 0)
+                        f32x4v x4[4];
+                        float w4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int sl = min(j + u, 63);
+                            const int cj = j + u < 64 ? __shfl(c2, sl, 64) : 0;
+                            w4[u] = j + u < 64 ? __shfl(v2, sl, 64) : 0.f;
+                            x4[u] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)cj * FIRA_D + lane * 4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc[i].x = fmaf(w4[u], x4[u].x, acc[i].x); acc[i].y = fmaf(w4[u], x4[u].y, acc[i].y);
+                            acc[i].z = fmaf(w4[u], x4[u].z, acc[i].z); acc[i].w = fmaf(w4[u], x4[u].w, acc[i].w);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o, 64);
+                vsum[i] += extra;
+            }
+#pragma unroll
+            for (int i = 0; i < GF_RPW; ++i) {
+                const int lr = wave * GF_RPW + i;
+                *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = acc[i];                  // (rows past the end: zeros)
+                if (lane == 0) sm_rs[lr] = vsum[i];
+                if (BWD && rbase + i < row_end && a.u_out)
+                    *reinterpret_cast<f32x4v*>(a.u_out + (size_t)(rbase + i) * FIRA_D + lane * 4) = acc[i];
+                if (!BWD && a.rowsum_out && lane == 0 && rbase + i < row_end) a.rowsum_out[rbase + i] = vsum[i];
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ 2. product: panel [16 nt, 256] x Wk, 16 columns per wave
+        f32x4acc acc[GF_TMAX];
+#pragma unroll
+        for (int tt = 0; tt < GF_TMAX; ++tt) acc[tt] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+        {
+            constexpr int NC = FIRA_D / 64;              // k chunks: lane (row l15, quarter kq) holds k = 64 c + 16 kq + s
+            // (buffer loads: ONE per-lane byte offset in a VGPR, the k row as the scalar offset -- with flat pointers the
+            //  compiler kept a 64-bit address pair per 4 KB window of the weight, hoisted all 64 of them and spilled)
+            const rsrc_t rW = buf_rsrc(a.W, FIRA_D * FIRA_D * 4u);
+            const unsigned wlane = (unsigned)((kq * 16) * FIRA_D + wave * 16 + l15) * 4u;
+            float b[2][16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+                b[0][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (c + 1 < NC) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2)
+                        b[(c + 1) & 1][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                           rW, wlane, ((c + 1) * 64 + s2) * FIRA_D * 4, 0));
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int tt = 0; tt < GF_TMAX; ++tt) {
+                    if (tt < nt) {                           // block-uniform
+                        float af[16];
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const f32x4v q = *reinterpret_cast<const f32x4v*>(&sm_u[a_off[ii] + tt * (GF_TILE * FIRA_D) + c * 64]);
+                            af[4 * ii] = q.x; af[4 * ii + 1] = q.y; af[4 * ii + 2] = q.z; af[4 * ii + 3] = q.w;
+                        }
+                        if constexpr (BF) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                uint4 ua, ub;
+                                ua.x = apk2(af[8 * j], af[8 * j + 1]); ua.y = apk2(af[8 * j + 2], af[8 * j + 3]);
+                                ua.z = apk2(af[8 * j + 4], af[8 * j + 5]); ua.w = apk2(af[8 * j + 6], af[8 * j + 7]);
+                                ub.x = apk2(b[c & 1][8 * j], b[c & 1][8 * j + 1]); ub.y = apk2(b[c & 1][8 * j + 2], b[c & 1][8 * j + 3]);
+                                ub.z = apk2(b[c & 1][8 * j + 4], b[c & 1][8 * j + 5]); ub.w = apk2(b[c & 1][8 * j + 6], b[c & 1][8 * j + 7]);
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, ua),
+                                                                                  __builtin_bit_cast(abf16x8, ub), acc[tt], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int s2 = 0; s2 < 16; ++s2)
+                                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s2], b[c & 1][s2], acc[tt], 0, 0, 0);
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
+        // accumulator register r of tile tt: row 16 tt + 4 kq + r, column 16 wave + l15
+#pragma unroll
+        for (int tt = 0; tt < GF_TMAX; ++tt) {
+            if (tt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm_u[d_off[r] + tt * (GF_TILE * FIRA_D)] = acc[tt][r];
+            }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------ 3. whole rows
+        const int rbase = row0 + wave * GF_RPW;
+        if (rbase < row_end) {
+            if constexpr (BWD) {
+                f32x4v old[GF_RPW];
+#pragma unroll
+                for (int i = 0; i < GF_RPW; ++i) {
+                    const int row = min(rbase + i, row_end - 1);
+                    old[i] = *reinterpret_cast<const f32x4v*>(a.acc_out + (size_t)row * FIRA_D + lane * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < GF_RPW; ++i) {
+                    if (rbase + i >= row_end) continue;
+                    const f32x4v d = *reinterpret_cast<const f32x4v*>(&sm_u[r_off[i]]);
+                    *reinterpret_cast<f32x4v*>(a.acc_out + (size_t)(rbase + i) * FIRA_D + lane * 4) = old[i] + d;
+                }
+            } else {
+                const f32x4v bias4 = *reinterpret_cast<const f32x4v*>(a.bias + lane * 4);
+                const f32x4v c4 = *reinterpret_cast<const f32x4v*>(a.r1_col + lane * 4);
+                const f32x4v g4 = *reinterpret_cast<const f32x4v*>(a.gamma + lane * 4);
+                const f32x4v be4 = *reinterpret_cast<const f32x4v*>(a.beta + lane * 4);
+                f32x4v res[GF_RPW];
+                int s2[GF_RPW];
+#pragma unroll
+                for (int i = 0; i < GF_RPW; ++i) {
+                    const int row = min(rbase + i, row_end - 1);
+                    res[i] = *reinterpret_cast<const f32x4v*>(a.res + (size_t)row * FIRA_D + lane * 4);
+                    s2[i] = a.slot2 ? a.slot2[row] : -1;
+                }
+#pragma unroll
+                for (int i = 0; i < GF_RPW; ++i) {
+                    const int row = rbase + i;
+                    if (row >= row_end) continue;                    // wave-uniform
+                    const int lr = wave * GF_RPW + i;
+                    f32x4v x = *reinterpret_cast<const f32x4v*>(&sm_u[r_off[i]]);
+                    x = x + bias4;                                   // the product's bias, then the rank-1 term (add_layernorm_fwd's order)
+                    const float w = sm_rs[lr];
+                    x.x = fmaf(w, c4.x, x.x); x.y = fmaf(w, c4.y, x.y); x.z = fmaf(w, c4.z, x.z); x.w = fmaf(w, c4.w, x.w);
+                    if (a.p > 0.f) {
+                        const uint32_t e0 = (uint32_t)row * FIRA_D + lane * 4;
+                        x.x *= dropout_scale(a.seed, a.site, e0 + 0, a.p, a.inv_keep);
+                        x.y *= dropout_scale(a.seed, a.site, e0 + 1, a.p, a.inv_keep);
+                        x.z *= dropout_scale(a.seed, a.site, e0 + 2, a.p, a.inv_keep);
+                        x.w *= dropout_scale(a.seed, a.site, e0 + 3, a.p, a.inv_keep);
+                    }
+                    x = x + res[i];
+                    const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / FIRA_D);
+                    const f32x4v d = x - mean;
+                    const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / FIRA_D);
+                    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                    const size_t o = (size_t)row * FIRA_D + lane * 4;
+                    *reinterpret_cast<f32x4v*>(a.sum + o) = x;
+                    const f32x4v out = {d.x * rstd * g4.x + be4.x, d.y * rstd * g4.y + be4.y, d.z * rstd * g4.z + be4.z,
+                                        d.w * rstd * g4.w + be4.w};
+                    *reinterpret_cast<f32x4v*>(a.y + o) = out;
+                    if (s2[i] >= 0) *reinterpret_cast<f32x4v*>(a.y2 + (size_t)s2[i] * FIRA_D + lane * 4) = out;
+                    if (lane == 0) {
+                        a.stats[2 * row] = mean;
+                        a.stats[2 * row + 1] = rstd;
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o, 64);
-            vsum[i] += extra;
         }
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            const int lr = wave * GF_RPW + i;
-            *reinterpret_cast<f32x4v*>(&sm_u[lr * GF_PITCH + lane * 4]) = acc[i];
-            if (lane == 0) sm_rs[lr] = vsum[i];
-            if (BWD && rbase + i < a.n_rows && a.u_out)
-                *reinterpret_cast<f32x4v*>(a.u_out + (size_t)(rbase + i) * FIRA_D + lane * 4) = acc[i];
-            if (!BWD && a.rowsum_out && lane == 0 && rbase + i < a.n_rows) a.rowsum_out[rbase + i] = vsum[i];
-        }
-    }
-    __syncthreads();
-
-    // ---------------------------------------------------------------- 2. product: panel [32,256] x Wk -> 32 x 32 per wave
-    // B fragments come from the K-MAJOR weight Wk[k][n]: lane (l31, kh) holds Wk[c*32 + kh*16 + s][n0 + l31], s = 0..15 --
-    // every load instruction reads two whole 128-byte lines (one per kh), each line exactly once per workgroup.  (A first
-    // version read the n-major weight as 4 x 16 bytes per lane: 32 lines per instruction, each line touched by four
-    // instructions -- with eight waves the 32 KB L1 thrashed and the launch took 38 us instead of 15.)
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-        constexpr int NC = FIRA_D / 32;              // k chunks
-        constexpr int PF = BF ? 4 : 3;               // B chunks in registers: PF - 1 requested ahead (bf16: the MFMAs hide nothing)
-        const float* wp = a.W + (size_t)(kh * 16) * FIRA_D + wave * 32 + l31;
-        const float* up = sm_u + l31 * GF_PITCH + kh * 16;
-        float b[PF][16];
-        // chunk c + PF - 1 is requested BEFORE the MFMA chain of chunk c; the empty asm statements pin that order (left alone,
-        // the scheduler sinks every load to just above its first use to shorten live ranges, and each group of four MFMAs
-        // then waits a full L2 round trip: 39 us per launch instead of 15)
-#pragma unroll
-        for (int c = 0; c < PF - 1; ++c)
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) b[c][s2] = wp[(size_t)(c * 32 + s2) * FIRA_D];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c + PF - 1 < NC) {
-#pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2) b[(c + PF - 1) % PF][s2] = wp[(size_t)((c + PF - 1) * 32 + s2) * FIRA_D];
-            }
-            asm volatile("" ::: "memory");
-            float af[16];
-            load_frag(af, up + c * 32, true);
-            acc = chain16<BF>(af, b[c % PF], acc);
-            asm volatile("" ::: "memory");
-        }
-    }
-    __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sm_u[acc_row(r, kh) * GF_PITCH + wave * 32 + l31] = acc[r];
-    __syncthreads();
-
-    // ---------------------------------------------------------------- 3. whole rows
-    const int rbase = r0 + wave * GF_RPW;
-    if constexpr (BWD) {
-        f32x4v old[GF_RPW];
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            const int row = min(rbase + i, a.n_rows - 1);
-            old[i] = *reinterpret_cast<const f32x4v*>(a.acc_out + (size_t)row * FIRA_D + lane * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            if (rbase + i >= a.n_rows) continue;
-            const f32x4v d = *reinterpret_cast<const f32x4v*>(&sm_u[(wave * GF_RPW + i) * GF_PITCH + lane * 4]);
-            *reinterpret_cast<f32x4v*>(a.acc_out + (size_t)(rbase + i) * FIRA_D + lane * 4) = old[i] + d;
-        }
-    } else {
-        const f32x4v bias4 = *reinterpret_cast<const f32x4v*>(a.bias + lane * 4);
-        const f32x4v c4 = *reinterpret_cast<const f32x4v*>(a.r1_col + lane * 4);
-        const f32x4v g4 = *reinterpret_cast<const f32x4v*>(a.gamma + lane * 4);
-        const f32x4v be4 = *reinterpret_cast<const f32x4v*>(a.beta + lane * 4);
-        f32x4v res[GF_RPW];
-        int s2[GF_RPW];
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            const int row = min(rbase + i, a.n_rows - 1);
-            res[i] = *reinterpret_cast<const f32x4v*>(a.res + (size_t)row * FIRA_D + lane * 4);
-            s2[i] = a.slot2 ? a.slot2[row] : -1;
-        }
-#pragma unroll
-        for (int i = 0; i < GF_RPW; ++i) {
-            const int row = rbase + i;
-            if (row >= a.n_rows) continue;                   // wave-uniform
-            const int lr = wave * GF_RPW + i;
-            f32x4v x = *reinterpret_cast<const f32x4v*>(&sm_u[lr * GF_PITCH + lane * 4]);
-            x = x + bias4;                                   // the product's bias, then the rank-1 term (add_layernorm_fwd's order)
-            const float w = sm_rs[lr];
-            x.x = fmaf(w, c4.x, x.x); x.y = fmaf(w, c4.y, x.y); x.z = fmaf(w, c4.z, x.z); x.w = fmaf(w, c4.w, x.w);
-            if (a.p > 0.f) {
-                const uint32_t e0 = (uint32_t)row * FIRA_D + lane * 4;
-                x.x *= dropout_scale(a.seed, a.site, e0 + 0, a.p, a.inv_keep);
-                x.y *= dropout_scale(a.seed, a.site, e0 + 1, a.p, a.inv_keep);
-                x.z *= dropout_scale(a.seed, a.site, e0 + 2, a.p, a.inv_keep);
-                x.w *= dropout_scale(a.seed, a.site, e0 + 3, a.p, a.inv_keep);
-            }
-            x = x + res[i];
-            const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / FIRA_D);
-            const f32x4v d = x - mean;
-            const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / FIRA_D);
-            const float rstd = 1.0f / sqrtf(var + 1e-5f);
-            const size_t o = (size_t)row * FIRA_D + lane * 4;
-            *reinterpret_cast<f32x4v*>(a.sum + o) = x;
-            const f32x4v out = {d.x * rstd * g4.x + be4.x, d.y * rstd * g4.y + be4.y, d.z * rstd * g4.z + be4.z,
-                                d.w * rstd * g4.w + be4.w};
-            *reinterpret_cast<f32x4v*>(a.y + o) = out;
-            if (s2[i] >= 0) *reinterpret_cast<f32x4v*>(a.y2 + (size_t)s2[i] * FIRA_D + lane * 4) = out;
-            if (lane == 0) {
-                a.stats[2 * row] = mean;
-                a.stats[2 * row + 1] = rstd;
-            }
-        }
+        if (pass + GF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
     }
 }
 
@@ -272,7 +338,11 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
 static double gcn_fused_bytes(int n_rows, bool bwd) {
     return 4.0 * (n_rows + 1) + (bwd ? 4.0 : 3.0) * n_rows * FIRA_D * 4.0;
 }
-static int gcn_fused_grid(int n_rows) { return cdiv(cdiv(n_rows, GF_ROWS), 8) * 8; }
+template <typename K>
+static int gcn_fused_lds(K kernel) {            // once per kernel: allow the > 64 KB dynamic LDS request
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GF_LDS);
+    return e == hipSuccess ? 0 : set_err("gcn_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+}
 
 int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                   const float* Wk, const float* bias, const float* r1_col, const float* gamma, const float* beta, float* sum,
@@ -289,8 +359,10 @@ int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     a.bias = bias; a.r1_col = r1_col; a.res = X; a.gamma = gamma; a.beta = beta;
     a.sum = sum; a.y = y; a.stats = stats; a.rowsum_out = rowsum_out; a.slot2 = y2 ? slot2 : nullptr; a.y2 = y2;
     a.p = dropout; a.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; a.seed = seed; a.site = site;
-    if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, false>), dim3(gcn_fused_grid(n_rows)), dim3(GF_WAVES * 64), 0, s, a);
-    else hipLaunchKernelGGL((gcn_fused_kernel<false, false>), dim3(gcn_fused_grid(n_rows)), dim3(GF_WAVES * 64), 0, s, a);
+    static const int attr = gcn_fused_lds(gcn_fused_kernel<true, false>) | gcn_fused_lds(gcn_fused_kernel<false, false>);
+    if (attr) return attr;
+    if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, false>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
+    else hipLaunchKernelGGL((gcn_fused_kernel<false, false>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     FIRA_CHECK_LAUNCH("gcn_fused_fwd");
     return 0;
 }
@@ -305,8 +377,10 @@ int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     GcnFusedArgs a{};
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.X = dY; a.W = Wk;
     a.u_out = u_out; a.acc_out = acc_out;
-    if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, true>), dim3(gcn_fused_grid(n_rows)), dim3(GF_WAVES * 64), 0, s, a);
-    else hipLaunchKernelGGL((gcn_fused_kernel<false, true>), dim3(gcn_fused_grid(n_rows)), dim3(GF_WAVES * 64), 0, s, a);
+    static const int attr = gcn_fused_lds(gcn_fused_kernel<true, true>) | gcn_fused_lds(gcn_fused_kernel<false, true>);
+    if (attr) return attr;
+    if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
+    else hipLaunchKernelGGL((gcn_fused_kernel<false, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     FIRA_CHECK_LAUNCH("gcn_fused_bwd");
     return 0;
 }

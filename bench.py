@@ -95,11 +95,12 @@ def self_launch(a) -> int:
 
 def prof_report():
     from fira_icse_amd import _lib
-    n = 8
+    n = 9
     ms, work, byts, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
     _lib.lib().fira_prof_report(n, ms, work, byts, cnt)
     # gemm_dec: the decoder's M = B*30 row products (forward + data gradients), split out of the GEMM family by the library
-    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec"]
+    # gcn: the fused GCN-layer launches (gather + product + LayerNorm / accumulate in one kernel): work = FLOP, bytes = bytes
+    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec", "gcn"]
     out = {k: dict(ms=ms[i], work=work[i], bytes=byts[i], count=int(cnt[i])) for i, k in enumerate(names)}
     dec = out.pop("gemm_dec")
     out["gemm"] = {k: out["gemm"][k] + dec[k] for k in dec}         # the family = every GEMM launch of the step
@@ -309,7 +310,10 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
     w_bytes = 4 * sum(int(np.prod(shp)) for k, (off, shp) in lay.entries.items()
                       if k.startswith(("decoder.", "out_fc", "copy_net")) and "embedding" not in k)
     Bd, Sm = a.decode_batch, cfg.mem_len
-    kv_bytes = 4 * Bd * Sm * 256 * (2 * cfg.num_layers + 1)
+    # the cross K|V of the VALID memory rows only (the step's attention kernel streams nothing else: the engine stores the
+    # computed memory rows compactly), + LinearSource's rows of the valid copy slots
+    kv_bytes = 4 * dbd.n_mem * 256 * (2 * cfg.num_layers + 1)
+    kv_bytes_dense = 4 * Bd * Sm * 256 * (2 * cfg.num_layers + 1)
     logit_bytes = 2 * 4 * Bd * cfg.out_len
     step_bytes = w_bytes + kv_bytes + logit_bytes
     step_s = ddt / max(steps_run, 1)
@@ -320,6 +324,8 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
               "trained_steps": a.decode_train_steps,
               "roofline": {"bound": "hbm", "bytes_per_step": step_bytes, "achieved": step_bytes / step_s / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                           "memory_rows": int(dbd.n_mem), "memory_rows_dense": Bd * Sm,
+                           "bytes_per_step_if_dense_kv": w_bytes + kv_bytes_dense + logit_bytes,
                            "note": "encoder pass included in the step time; the loop is launch-bound (one small "
                                    "kernel per layer op), not bandwidth-bound"},
               "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
@@ -340,7 +346,7 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
         steps16 = int(length16.max().item()) - 1
         toks16 = int((length16 - 1).sum().item())
         valid = torch.arange(out.shape[1], device=out.device)[None, :] < torch.minimum(length, length16)[:, None]
-        kv16_bytes = w_bytes + kv_bytes // 2 + 4 * Bd * Sm * 256 // 2 + logit_bytes      # K|V halved, LinearSource rows fp32
+        kv16_bytes = w_bytes + kv_bytes // 2 + 4 * dbd.n_mem * 256 // 2 + logit_bytes      # K|V halved, LinearSource rows fp32
         decode["bf16_kv"] = {"ms_per_step": d16 / max(steps16, 1) * 1e3, "tokens_per_s": toks16 * world / d16,
                              "steps_run": steps16, "bytes_per_step": kv16_bytes,
                              "token_agreement_with_fp32": float((out == out16)[valid].float().mean().item()),
@@ -410,6 +416,34 @@ def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
     return roofline, roofline_hbm, decoder_gemm
 
 
+def attention_work(metas, n_layers, d=256):
+    """Algorithmic FLOP and bytes of the attention launches of ONE training step over the given batches' commits
+    (gnn_transformer.py:137-158; 2 matmuls forward, 5 backward; causal self-attention counted at half of Tq x Tq):
+    metas = [(tq[B], tk[B])] = computed target rows and valid memory keys per commit."""
+    flop = byts = 0.0
+    for tq, tk in metas:
+        tq, tk = tq.astype(np.float64), tk.astype(np.float64)
+        cross, self_ = float((tq * tk).sum()), float((tq * tq).sum()) / 2
+        flop += n_layers * (2 + 5) * 2.0 * d * (cross + self_)
+        row = 4.0 * d
+        # forward: K, V rows in, Q in, O out; backward: K, V in + dK, dV out, Q, O, dO in, dQ out
+        byts += n_layers * row * float(((2 + 4) * tk + (2 + 4) * tq).sum())            # cross
+        byts += n_layers * row * float(((3 + 1) * tq + (5 + 3) * tq).sum())            # self (q|k|v rows, o; + gradients)
+    return flop, byts
+
+
+def rocprof_reference(dtype):
+    """Per-class kernel time of the SAME command from the committed rocprofv3 kernel trace (profiles/r4_kernel_classes.json,
+    written by scripts/rocpd_stats.py from `rocprofv3 --kernel-trace --stats -- python bench.py --dtype <dtype> ...`):
+    kernel begin-to-end durations, i.e. without the launch gaps and the cross-stream event overlap that the in-process
+    HIP-event sums include.  Counters and traces cannot be collected inside this process."""
+    try:
+        with open(os.path.join(HERE, "profiles", "r4_kernel_classes.json")) as f:
+            return json.load(f).get(dtype)
+    except Exception:
+        return None
+
+
 def main():
     a = parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -454,7 +488,19 @@ def main():
 
     def make_batches(Bx, pool):
         n = len(store)
-        return [DeviceBatch(store.batch([(i * Bx + k) % n for k in range(Bx)]), cfg, model.device_) for i in range(pool)]
+        out = []
+        for i in range(pool):
+            hb = store.batch([(i * Bx + k) % n for k in range(Bx)])
+            db = DeviceBatch(hb, cfg, model.device_)
+            # per commit: computed target rows (DeviceBatch's prefix rule) and valid memory keys -- the attention roofline
+            used = np.asarray(hb.tar) != 0
+            used[:, :-1] |= np.asarray(hb.tar_label)[:, 1:] != 0
+            T = used.shape[1]
+            tq = np.where(used.any(axis=1), T - np.argmax(used[:, ::-1], axis=1), 1)
+            tk = (np.asarray(hb.sou) != 0).sum(1) + (np.asarray(hb.sub_token) != 0).sum(1)
+            db.attn_meta = (tq if model.compact_dec else np.full_like(tq, T), tk)
+            out.append(db)
+        return out
 
     def timed_leg(batches, steps, warmup):
         """W untimed + K timed steps, barrier + synchronize on both sides, max over ranks."""
@@ -499,13 +545,44 @@ def main():
         roof, roof_hbm, dec = gemm_objects(prof, dtype, 3, tr, dec_rows_of(bs, 3))
         obj = {"commits_per_s": steps * Bx * world / dt, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": Bx,
                "dtype": dtype, "steps": steps, "host_enqueue_ms_per_step": t_enq / steps * 1e3, "roofline": roof,
-               "decoder_gemm": dec, "kernel_time_ms_per_step": {k: v["ms"] / 3 for k, v in prof.items()}}
+               "decoder_gemm": dec, "gcn": gcn_object(prof, dtype, 3), "attention": attention_object(prof, bs, 3),
+               "kernel_time_ms_per_step": {k: v["ms"] / 3 for k, v in prof.items()}}
         if dtype == "bf16":
             obj["roofline_hbm"] = roof_hbm
         if with_host and world == 1:
             obj["host_inclusive"] = host_inclusive(cfg, store, trainer, Bx, max(10, steps))
         del bs
         return obj
+
+    def gcn_object(prof, dtype, n_steps):
+        """The fused GCN-layer launches (one per layer and direction): MFMA-bound in fp32, gather / HBM-bound in bf16."""
+        g = prof.get("gcn")
+        if not g or g["count"] == 0:
+            return None
+        t_s = g["ms"] * 1e-3
+        peak_tf = BF16_MFMA_PEAK_TF if dtype == "bf16" else FP32_MFMA_PEAK_TF
+        return {"kernel": "gcn_fused_kernel (gather A_hat X -> LDS panel -> v_mfma 16x16 -> LayerNorm / accumulate rows)",
+                "bound": "mfma" if dtype == "f32" else "hbm", "launches_per_step": g["count"] // n_steps,
+                "avg_launch_us": 1e3 * g["ms"] / g["count"], "flop_per_launch": g["work"] / g["count"],
+                "bytes_per_launch": g["bytes"] / g["count"], "achieved_TFLOPs": g["work"] / t_s / 1e12,
+                "frac_mfma": g["work"] / t_s / 1e12 / peak_tf, "achieved_GBs": g["bytes"] / t_s / 1e9,
+                "frac_hbm": g["bytes"] / t_s / 1e9 / HBM_PEAK_GBS,
+                "note": "bytes = rowptr + gathered rows in + rows out (3 row streams forward, 4 backward); bench adds no "
+                        "(col, val) bytes here; FLOP = the [rows,256]x[256,256] product"}
+
+    def attention_object(prof, bs, n_steps):
+        at = prof["attention"]
+        if at["count"] == 0:
+            return None
+        flop, byts = attention_work([bs[i % len(bs)].attn_meta for i in range(n_steps)], cfg.num_layers)
+        t_s = at["ms"] * 1e-3
+        return {"kernel": "attention_fwd_kernel / attention_bwd_kernel (fp32 MFMA chains; ragged query and key rows)",
+                "bound": "latency", "launches_per_step": at["count"] // n_steps, "avg_launch_us": 1e3 * at["ms"] / at["count"],
+                "flop_per_step": flop / n_steps, "bytes_per_step": byts / n_steps,
+                "achieved_TFLOPs": flop / t_s / 1e12, "frac_mfma": flop / t_s / 1e12 / FP32_MFMA_PEAK_TF,
+                "achieved_GBs": byts / t_s / 1e9, "frac_hbm": byts / t_s / 1e9 / HBM_PEAK_GBS,
+                "note": "algorithmic FLOP (2 matmuls forward, 5 backward over computed target rows x valid keys, causal half) "
+                        "and bytes (valid K|V rows, Q / O / gradient rows once) over the summed launch time"}
 
     batches = make_batches(B, a.pool)
     nnz_mean = float(np.mean([b.nnz for b in batches]))
@@ -518,13 +595,35 @@ def main():
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     traffic = traffic_all.get(a.dtype) or (traffic_all if a.dtype == "f32" and "gemm" in traffic_all else {})
     roofline, roofline_hbm, decoder_gemm = gemm_objects(prof, a.dtype, prof_steps, traffic, dec_rows_of(batches, prof_steps))
+    ref = rocprof_reference(a.dtype)
+    if ref and ref.get("batch") == B and ref.get("gemm_us_per_step"):
+        # the same FLOP over the rocprofv3 kernel durations of the committed trace of this command: the number a reader of
+        # profiles/r4_kernel_stats_<dtype>.md recomputes (kernel begin-to-end, no launch gaps)
+        flop_step = prof["gemm"]["work"] / prof_steps
+        tf = flop_step / (ref["gemm_us_per_step"] * 1e-6) / 1e12
+        roofline["rocprof"] = {"gemm_us_per_step": ref["gemm_us_per_step"], "gemm_launches_per_step": ref.get("gemm_launches_per_step"),
+                               "achieved": tf, "frac": tf / (BF16_MFMA_PEAK_TF if a.dtype == "bf16" else FP32_MFMA_PEAK_TF),
+                               "source": ref.get("source"), "commit": ref.get("commit"), "box_commits_per_s": ref.get("commits_per_s")}
+    roofline["method"] = ("frac = algorithmic FLOP / SUM of per-launch HIP-event times inside this process (includes launch gaps "
+                          "and the overlap of the three streams: a lower bound); `rocprof` = the same FLOP over the kernel "
+                          "durations of the committed rocprofv3 trace of this command")
     spmm = prof["spmm"]
-    spmm_bytes_step = spmm["work"] + 8.0 * nnz_mean * spmm["count"]         # + (col,val) of the batch's nnz
-    spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic.get("spmm", {}).get("hbm_bytes_per_launch"),
-                "avg_launch_us": 1e3 * spmm["ms"] / max(spmm["count"], 1),
-                "bytes_per_launch": spmm_bytes_step / max(spmm["count"], 1), "share_of_kernel_time": spmm["ms"] / total_ms}
+    spmm_obj = None
+    if spmm["count"] > 0:                           # (the separate aggregation kernel: FIRA_GCN_FUSED=0)
+        spmm_bytes_step = spmm["work"] + 8.0 * nnz_mean * spmm["count"]         # + (col,val) of the batch's nnz
+        spmm_obj = {"bound": "hbm", "kernel": "spmm_rowwave_kernel", "achieved": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmm_bytes_step / (spmm["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic.get("spmm", {}).get("hbm_bytes_per_launch"),
+                    "avg_launch_us": 1e3 * spmm["ms"] / max(spmm["count"], 1),
+                    "bytes_per_launch": spmm_bytes_step / max(spmm["count"], 1), "share_of_kernel_time": spmm["ms"] / total_ms}
+    gcn_obj = gcn_object(prof, a.dtype, prof_steps)
+    if gcn_obj:
+        gcn_obj["traffic"] = traffic.get("gcn", {}).get("hbm_bytes_per_launch")
+        gcn_obj["share_of_kernel_time"] = prof["gcn"]["ms"] / total_ms
+    attn_obj = attention_object(prof, batches, prof_steps)
+    if attn_obj:
+        attn_obj["traffic"] = traffic.get("attention", {}).get("hbm_bytes_per_launch")
+        attn_obj["share_of_kernel_time"] = prof["attention"]["ms"] / total_ms
 
     extras = {}
     single = rank == 0 and world == 1
@@ -571,10 +670,28 @@ def main():
         except Exception as e:
             cpu = {"error": repr(e)}
 
+    comm = None
+    if world > 1 and trainer.reducer is not None and not a.zero1:
+        # per-bucket collective timing (extra steps, outside the timed region): HIP events around each all-reduce on the
+        # stream that carries it, and around the caller-stream waits (= the communication that was NOT hidden)
+        trainer.reducer.timing = True
+        for i in range(6):
+            trainer.step(batches[i % len(batches)])
+        comm = trainer.reducer.timing_summary()
+        trainer.reducer.timing = False
+        barrier()
     if rank == 0:
         pg = None
         if world > 1:
-            pg = {"rccl_world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend()}
+            pg = {"rccl_world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
+                  "mode": "zero1 (reduce-scatter + sharded Adam + all-gather)" if a.zero1 else "all-reduce in 2 readiness buckets",
+                  "gradient_bytes_per_rank": 4 * int(model.layout.live)}
+            if comm:
+                pg.update(comm)
+                pg["note"] = ("allreduce_ms_early = head+decoder bucket on the side stream from the mid-backward event "
+                              "(overlaps the encoder backward); allreduce_ms_late = encoder bucket, launch to ready on the "
+                              "caller's stream (overlaps Adam of the early slice); exposed_comm_ms = time the caller's "
+                              "stream stood waiting for the two buckets")
         wl = ("BASELINE configs[1]: FIRA training step (fwd+bwd+Adam, dropout 0.1/0.2), batch %d commits/GPU, fp32"
               if a.dtype == "f32" else
               "BASELINE configs[2] per-GPU workload: FIRA training step (fwd+bwd+Adam, dropout 0.1/0.2), batch %d "
@@ -586,7 +703,8 @@ def main():
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
                        "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss},
-            "roofline": roofline, "decoder_gemm": decoder_gemm, "spmm": spmm_obj, "decode": decode, "cpu_baseline": cpu,
+            "roofline": roofline, "decoder_gemm": decoder_gemm, "gcn": gcn_obj, "attention": attn_obj, "spmm": spmm_obj,
+            "decode": decode, "cpu_baseline": cpu,
             "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in prof.items()},
         }
         if a.dtype == "bf16":
@@ -594,6 +712,19 @@ def main():
         if pg:
             line["process_group"] = pg
         line.update(extras)
+        # the reference's own per-GPU batch (170, run_model.py:40) and BASELINE configs[2]'s per-GPU workload (batch 64, bf16)
+        # as first-class fields of `config` (the full objects stay in b170 / b64)
+        try:
+            line["config"]["b170_f32_commits_per_s"] = extras["b170"]["f32"]["commits_per_s"]
+            line["config"]["b170_bf16_commits_per_s"] = extras["b170"]["bf16"]["commits_per_s"]
+            line["config"]["b170_f32_gemm_frac"] = extras["b170"]["f32"]["roofline"]["frac"]
+            line["config"]["b64_bf16_commits_per_s"] = extras["b64"]["bf16"]["commits_per_s"]
+            line["config"]["b64_f32_commits_per_s"] = extras["b64"]["f32"]["commits_per_s"]
+            line["config"]["b64_bf16_over_f32"] = extras["b64"]["bf16_over_f32"]
+            line["config"]["b64_f32_decoder_gemm_frac"] = extras["b64"]["f32"]["decoder_gemm"]["frac"]
+            line["config"]["b64_f32_decoder_gemm_frac_dense_equiv"] = extras["b64"]["f32"]["decoder_gemm"].get("frac_dense_equiv")
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

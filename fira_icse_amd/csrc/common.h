@@ -32,7 +32,9 @@ int set_err(const char* fmt, ...);
 // time and the algorithmic work (FLOP for GEMM/attention, bytes for the memory-bound classes) per class.
 // PROF_GEMM_DEC: the GEMM launches issued while a ProfDecoderTag is alive on the calling thread (the decoder's M = B*30 row
 // products, forward and data gradients) -- the quantity north_star sets its MFMA target on; reported beside PROF_GEMM
-enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_NCLASS };
+// PROF_GCN: the fused GCN-layer launches (gcn_fused.hip): work = FLOP of the [rows,256]x[256,256] product, bytes = the
+// algorithmic bytes of the whole layer (gather in, rows out)
+enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_GCN, PROF_NCLASS };
 bool prof_on();
 void prof_decoder_tag(int delta);      // +1 / -1 (nesting counter, thread-local)
 struct ProfDecoderTag {

@@ -79,6 +79,12 @@ __global__ __launch_bounds__(256) void copy_score_fwd_kernel(int T, int S, const
 // Only target rows whose label is a copied token carry a non-zero dscore row (Model.py:80-86: the NLL picks one entry
 // of the [gen ; copy] distribution), typically a handful of the 30 positions: the workgroup stages its [T, slots]
 // tile of dscore in LDS, derives the set of rows with any non-zero entry and spends tanh work only on those.
+// Round 4: the active rows are processed in chunks of COPY_KA, so only COPY_KA target rows (and as many partial dtgt
+// rows) live in LDS: 19 KB per workgroup instead of 68 KB.  The launch sits on the dependent chain right behind the fork
+// of the vocabulary projection's weight gradient, whose workgroups (4 x 34 KB per CU) leave 21 KB of LDS free: at 68 KB a
+// workgroup of this kernel could only be placed once TWO of them had left the same CU -- and the freed slot was refilled
+// from the weight-gradient queue first (123 us in the step for ~20 us of work).
+constexpr int COPY_KA = 8;
 __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const float* __restrict__ src,
                                                              const float* __restrict__ tgt,
                                                              const float* __restrict__ w,
@@ -88,9 +94,9 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
                                                              const int32_t* __restrict__ mem_valid, int slots,
                                                              float* __restrict__ part,
                                                              const int32_t* __restrict__ t_off) {
-    constexpr int SLOTS_MAX = 16;
-    __shared__ __attribute__((aligned(16))) float sm_tgt[T_MAX * FIRA_D];
-    __shared__ float sm_dt[T_MAX * FIRA_D];
+    constexpr int SLOTS_MAX = 16, SPW = SLOTS_MAX / 4;            // slots per wave
+    __shared__ __attribute__((aligned(16))) float sm_tgt[COPY_KA * FIRA_D];
+    __shared__ float sm_dt[COPY_KA * FIRA_D];
     __shared__ float sm_dw[FIRA_D + 1];
     __shared__ float sm_g[T_MAX * SLOTS_MAX];
     __shared__ unsigned sm_mask;
@@ -107,6 +113,7 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
         sm_g[t * SLOTS_MAX + i % slots] = g;
         if (g != 0.f) atomicOr(&sm_mask, 1u << t);
     }
+    for (int i = t0; i < FIRA_D + 1; i += 256) sm_dw[i] = 0.f;
     __syncthreads();
     const unsigned mask = sm_mask;                                 // uniform: rows of this tile with any gradient
     float* const my_part = part ? part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * COPY_PART_STRIDE : nullptr;
@@ -117,56 +124,87 @@ __global__ __launch_bounds__(256) void copy_score_bwd_kernel(int T, int S, const
             for (int i = t0; i < FIRA_D + 1; i += 256) my_part[i] = 0.f;
         return;
     }
-    for (int i = t0; i < Tb * (FIRA_D / 4); i += 256)
-        reinterpret_cast<float4*>(sm_tgt)[i] = reinterpret_cast<const float4*>(tgt + (size_t)tb * FIRA_D)[i];
-    for (int i = t0; i < T_MAX * FIRA_D; i += 256) sm_dt[i] = 0.f;
-    for (int i = t0; i < FIRA_D + 1; i += 256) sm_dw[i] = 0.f;
-    __syncthreads();
     const float4 w4 = *reinterpret_cast<const float4*>(w + lane * 4);
     const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-    float dt[T_MAX][4];
+    // this wave's memory slots j0 + wave + 4 q: their source rows and gradient accumulators stay in registers for all chunks
+    float4 s4[SPW];
+    float ds[SPW][4];
+    bool live[SPW];
 #pragma unroll
-    for (int t = 0; t < T_MAX; ++t)
+    for (int q = 0; q < SPW; ++q) {
+        const int j = j0 + wave + 4 * q;
+        live[q] = j < j_end && !(mem_valid && mem_valid[(size_t)b * S + min(j, S - 1)] == 0);   // masked slot: no gradient through masked_fill
+        s4[q] = live[q] ? *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dt[t][e] = 0.f;
+        for (int e = 0; e < 4; ++e) ds[q][e] = 0.f;
+    }
     float dwa[4] = {0.f, 0.f, 0.f, 0.f};
     float dba = 0.f;
-    for (int j = j0 + wave; j < j_end; j += 4) {
-        float ds[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!(mem_valid && mem_valid[(size_t)b * S + j] == 0)) {  // masked slot: no gradient flows through masked_fill
-            const float4 s4 = *reinterpret_cast<const float4*>(src + ((size_t)b * S + j) * FIRA_D + lane * 4);
+    unsigned rem = mask;
+    while (rem) {                                                  // block-uniform: chunks of up to COPY_KA active rows
+        int tl[COPY_KA], nk = 0;
 #pragma unroll
-            for (int t = 0; t < T_MAX; ++t) {
-                if ((mask >> t) & 1u) {
-                    const float g = sm_g[t * SLOTS_MAX + (j - j0)];
-                    const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[t * FIRA_D + lane * 4]);
-                    const float th[4] = {tanh_fast(s4.x + x.x), tanh_fast(s4.y + x.y), tanh_fast(s4.z + x.z),
-                                         tanh_fast(s4.w + x.w)};
+        for (int k = 0; k < COPY_KA; ++k) {
+            tl[k] = 0;
+            if (rem) { tl[k] = __ffs(rem) - 1; rem &= rem - 1; nk = k + 1; }
+        }
+#pragma unroll
+        for (int k = 0; k < COPY_KA; ++k)
+            if (k < nk && t0 < FIRA_D / 4)
+                reinterpret_cast<float4*>(sm_tgt)[k * (FIRA_D / 4) + t0] =
+                    reinterpret_cast<const float4*>(tgt + ((size_t)tb + tl[k]) * FIRA_D)[t0];
+        for (int i = t0; i < COPY_KA * FIRA_D; i += 256) sm_dt[i] = 0.f;
+        __syncthreads();
+        float dt[COPY_KA][4];
+#pragma unroll
+        for (int k = 0; k < COPY_KA; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dt[k][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < SPW; ++q) {
+            if (!live[q]) continue;                                // wave-uniform
+            const int jj = wave + 4 * q;
+#pragma unroll
+            for (int k = 0; k < COPY_KA; ++k) {
+                if (k < nk) {
+                    const float g = sm_g[tl[k] * SLOTS_MAX + jj];
+                    const float4 x = *reinterpret_cast<const float4*>(&sm_tgt[k * FIRA_D + lane * 4]);
+                    const float th[4] = {tanh_fast(s4[q].x + x.x), tanh_fast(s4[q].y + x.y), tanh_fast(s4[q].z + x.z),
+                                         tanh_fast(s4[q].w + x.w)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float u = g * wv[e] * (1.f - th[e] * th[e]);
-                        ds[e] += u;
-                        dt[t][e] += u;
+                        ds[q][e] += u;
+                        dt[k][e] += u;
                         dwa[e] = fmaf(g, th[e], dwa[e]);
                     }
                     dba += g;
                 }
             }
         }
-        *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+#pragma unroll
+        for (int k = 0; k < COPY_KA; ++k)
+            if (k < nk) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[k * FIRA_D + lane * 4 + e], dt[k][e]);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < COPY_KA; ++k)
+            if (k < nk) unsafeAtomicAdd(&dtgt[((size_t)tb + tl[k]) * FIRA_D + t0], sm_dt[k * FIRA_D + t0]);
+        __syncthreads();                                           // sm_tgt / sm_dt are rewritten by the next chunk
     }
 #pragma unroll
-    for (int t = 0; t < T_MAX; ++t)
-        if ((mask >> t) & 1u) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&sm_dt[t * FIRA_D + lane * 4 + e], dt[t][e]);
-        }
+    for (int q = 0; q < SPW; ++q) {
+        const int j = j0 + wave + 4 * q;
+        if (j < j_end)
+            *reinterpret_cast<float4*>(dsrc + ((size_t)b * S + j) * FIRA_D + lane * 4) = make_float4(ds[q][0], ds[q][1], ds[q][2], ds[q][3]);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) atomicAdd(&sm_dw[lane * 4 + e], dwa[e]);
     if (lane == 0) atomicAdd(&sm_dw[FIRA_D], dba);
     __syncthreads();
-    for (int i = t0; i < Tb * FIRA_D; i += 256)
-        if ((mask >> (i / FIRA_D)) & 1u) unsafeAtomicAdd(&dtgt[(size_t)tb * FIRA_D + i], sm_dt[i]);
     if (my_part) {
         // deferred reduction (rowops.hip): B * S/16 workgroups adding to the same 257 addresses serialise in L2 (~50 ns per
         // same-address atomic: 1536 workgroups = ~75 us, most of this kernel's former run time)

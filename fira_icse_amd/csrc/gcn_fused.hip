@@ -353,7 +353,7 @@ int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
                  "gcn_fused_fwd: null pointer argument");
     FIRA_REQUIRE((uintptr_t)X % 16 == 0 && (uintptr_t)Wk % 16 == 0 && (uintptr_t)sum % 16 == 0 && (uintptr_t)y % 16 == 0,
                  "gcn_fused_fwd: rows must be 16-byte aligned");
-    ProfScope prof(s, PROF_SPMM, gcn_fused_bytes(n_rows, false));
+    ProfScope prof(s, PROF_GCN, 2.0 * n_rows * FIRA_D * FIRA_D, gcn_fused_bytes(n_rows, false));
     GcnFusedArgs a{};
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.X = X; a.W = Wk;
     a.bias = bias; a.r1_col = r1_col; a.res = X; a.gamma = gamma; a.beta = beta;
@@ -373,7 +373,7 @@ int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     FIRA_REQUIRE(rowptr && col && val && dY && Wk && acc_out, "gcn_fused_bwd: null pointer argument");
     FIRA_REQUIRE((uintptr_t)dY % 16 == 0 && (uintptr_t)Wk % 16 == 0 && (uintptr_t)acc_out % 16 == 0 && (uintptr_t)u_out % 16 == 0,
                  "gcn_fused_bwd: rows must be 16-byte aligned");
-    ProfScope prof(s, PROF_SPMM, gcn_fused_bytes(n_rows, true));
+    ProfScope prof(s, PROF_GCN, 2.0 * n_rows * FIRA_D * FIRA_D, gcn_fused_bytes(n_rows, true));
     GcnFusedArgs a{};
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.X = dY; a.W = Wk;
     a.u_out = u_out; a.acc_out = acc_out;

@@ -58,15 +58,48 @@ class GradReducer:
         self._pending = None
         self._late = None
         self._side = torch.cuda.Stream() if torch.cuda.is_available() else None
+        # optional per-collective timing (bench.py's process_group object): HIP events around each bucket on the stream
+        # that carries it, and around the points where the caller's stream waits for it (= the EXPOSED communication)
+        self.timing = False
+        self._ev = {}
+        self._timings = []
+
+    def _mark(self, name, stream=None):
+        if self.timing and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream if stream is not None else torch.cuda.current_stream())
+            self._ev[name] = e
+
+    def timing_summary(self):
+        """Mean milliseconds per step of every timed interval since ``timing`` was switched on; synchronises."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out = {}
+        for ev in self._timings:
+            for k, (a, b) in (("allreduce_ms_early", ("early0", "early1")), ("allreduce_ms_late", ("late0", "late1")),
+                              ("exposed_comm_ms_early", ("wait_e0", "wait_e1")), ("exposed_comm_ms_late", ("wait_l0", "wait_l1"))):
+                if a in ev and b in ev:
+                    out.setdefault(k, []).append(ev[a].elapsed_time(ev[b]))
+        res = {k: sum(v) / len(v) for k, v in out.items()}
+        if "exposed_comm_ms_early" in res and "exposed_comm_ms_late" in res:
+            res["exposed_comm_ms"] = res["exposed_comm_ms_early"] + res["exposed_comm_ms_late"]
+        res["timed_steps"] = len(self._timings)
+        self._timings = []
+        return res
 
     def start_early_bucket(self, gbuf: torch.Tensor, mid_event=None):
         """Launch the all-reduce of [0, split) as soon as ``mid_event`` fires (decoder backward done)."""
         if self.world == 1:
             return
+        self._ev = {}
         if self._side is not None and mid_event is not None:
             self._side.wait_event(mid_event)
             with torch.cuda.stream(self._side):
+                self._mark("early0")
                 self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.timing:               # stream-level wait on the side stream (the host does not block with RCCL)
+                    self._pending.wait()
+                    self._mark("early1")
         else:
             self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -79,17 +112,28 @@ class GradReducer:
         if self._pending is None:
             self.start_early_bucket(gbuf, None)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+        self._mark("late0")
         self._late = dist.all_reduce(gbuf[self.split:self.live], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait_early(self):
         if self._pending is not None:
+            self._mark("wait_e0")
             self._pending.wait()
+            if self.timing and self._side is not None:
+                torch.cuda.current_stream().wait_stream(self._side)     # (the side stream already waited for the collective)
+            self._mark("wait_e1")
             self._pending = None
 
     def wait_late(self):
         if getattr(self, "_late", None) is not None:
+            self._mark("wait_l0")
             self._late.wait()
+            self._mark("wait_l1")
+            self._ev["late1"] = self._ev.get("wait_l1")
             self._late = None
+            if self.timing and self._ev:
+                self._timings.append({k: v for k, v in self._ev.items() if v is not None})
+                self._ev = {}
 
     def finish(self, gbuf: torch.Tensor, stats: torch.Tensor):
         """Reduce the encoder bucket and the 2-element stats (fp32: loss_sum, n_tok); wait for both buckets."""

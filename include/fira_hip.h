@@ -131,6 +131,8 @@ size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam);
  * (work = algorithmic bytes), 2 attention, 3 row ops, 4 copy score, 5 head/loss, 6 Adam.  report() synchronises,
  * returns per class the summed event time [ms], summed work and launch count since the last report, and resets. */
 #define FIRA_PROF_NCLASS 7
+/* two more classes are reported when n_class asks for them: 7 = the decoder's M = B*30 products (a sub-set of class 0's
+ * launches, split out of it), 8 = the fused GCN-layer launches (work = FLOP of the product, bytes = algorithmic bytes) */
 void fira_prof_enable(int on);
 /* bytes (may be NULL): for the GEMM class, the algorithmic operand + result bytes 4*(M*K + N*K + M*N) of its launches */
 int  fira_prof_report(int n_class, double* ms, double* work, double* bytes, int64_t* count);

@@ -55,7 +55,13 @@ def main():
             allj = {"f32": {k: allj[k] for k in ("gemm", "spmm") if k in allj}}
     except Exception:
         allj = {}
-    allj[dtype] = {"gemm": group(lambda k: "gemm_" in k), "spmm": group(lambda k: "spmm_" in k)}
+    allj[dtype] = {"gemm": group(lambda k: "gemm_" in k), "spmm": group(lambda k: "spmm_" in k),
+                   "gcn": group(lambda k: "gcn_fused" in k),
+                   "attention": group(lambda k: "attention_" in k),
+                   "attention_cross_fwd": group(lambda k: "attention_fwd_kernel<12" in k),
+                   "attention_cross_bwd": group(lambda k: "attention_bwd_kernel<12" in k)}
+    import os
+    allj[dtype]["commit"] = os.environ.get("ROCPD_COMMIT", "")
     allj["note"] = note
     json.dump(allj, open(js, "w"), indent=1)
 

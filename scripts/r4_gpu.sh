@@ -83,7 +83,11 @@ for ST in "$@"; do
       DT=f32; [ $ST = prof16 ] && DT=bf16
       cd /tmp; mkdir -p $OUT/prof_$DT
       timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$DT -o step -- python $REPO/bench.py --dtype $DT --steps 10 --warmup 2 --no-decode --no-cpu-baseline --no-extras > $OUT/prof_$DT/bench.log 2>&1
-      python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_$DT -name "*results.db" | head -1) 15 $OUT/timeline_$DT.md > $OUT/kernel_stats_$DT.md 2>&1
+      VAL=$(grep -o '"value": [0-9.]*' $OUT/prof_$DT/bench.log | head -1 | cut -d' ' -f2)
+      BS=32; [ $DT = bf16 ] && BS=64
+      ROCPD_CLASSES_JSON=$OUT/kernel_classes.json ROCPD_DTYPE=$DT ROCPD_BATCH=$BS ROCPD_COMMIT=${R4_COMMIT:-unknown} ROCPD_VALUE=$VAL \
+        ROCPD_SOURCE="rocprofv3 --kernel-trace --stats -- python bench.py --dtype $DT --steps 10 --warmup 2 --no-decode --no-cpu-baseline --no-extras (15 steps in the trace; under the profiler)" \
+        python $REPO/scripts/rocpd_stats.py $(find $OUT/prof_$DT -name "*results.db" | head -1) 15 $OUT/timeline_$DT.md > $OUT/kernel_stats_$DT.md 2>&1
       find $OUT/prof_$DT -name "*.db" -delete
       cd $REPO; head -n 60 $OUT/kernel_stats_$DT.md ;;
     profdec)
@@ -95,7 +99,7 @@ for ST in "$@"; do
     pmc)
       for DT in f32 bf16; do
         bash scripts/pmc_traffic.sh $DT > /dev/null 2>&1
-        python scripts/pmc_traffic_summary.py gpurun_out/pmc_traffic_$DT $OUT/pmc_traffic_$DT.md $OUT/traffic.json $DT; echo "pmc $DT rc=$?"
+        ROCPD_COMMIT=${R4_COMMIT:-unknown} python scripts/pmc_traffic_summary.py gpurun_out/pmc_traffic_$DT $OUT/pmc_traffic_$DT.md $OUT/traffic.json $DT; echo "pmc $DT rc=$?"
         find gpurun_out/pmc_traffic_$DT -name "*.csv" -delete
       done
       cat $OUT/traffic.json | head -40 ;;

@@ -38,6 +38,37 @@ def main():
         print("| `%s` | %d | %.1f | %.1f | %.2f | %.1f | %.1f | %.1f | %s | %s | %s |" %
               (k[:120], v[0], v[0] / steps, v[1] / steps, 100 * v[1] / tot, v[1] / v[0], v[2], v[3], v[4], v[5], v[6]))
     print("\ntotal kernel time: %.1f us over %d dispatches (%.1f us/step over %d steps)" % (tot, len(rows), tot / steps, steps))
+    # ROCPD_CLASSES_JSON=<file> ROCPD_DTYPE=f32|bf16 [ROCPD_BATCH ROCPD_COMMIT ROCPD_VALUE ROCPD_SOURCE]: per-class kernel time of this
+    # trace, merged into <file>[dtype] -- bench.py quotes `roofline.rocprof` from it (the GEMM family's FLOP over the kernel
+    # durations of this trace: what a reader of the table above recomputes)
+    import json, os
+    out = os.environ.get("ROCPD_CLASSES_JSON")
+    if out:
+        cls = [("gemm", ("gemm_",)), ("gcn", ("gcn_fused",)), ("attention", ("attention_",)), ("spmm", ("spmm_",)),
+               ("copy", ("copy_score",)), ("head", ("head_loss",)), ("adam", ("adam_",))]
+        acc = {c: [0, 0.0] for c, _ in cls}
+        acc["rowops"] = [0, 0.0]
+        for k, v in agg.items():
+            if not ("fira" in k):
+                continue
+            for c, pats in cls:
+                if any(p_ in k for p_ in pats):
+                    acc[c][0] += v[0]; acc[c][1] += v[1]
+                    break
+            else:
+                acc["rowops"][0] += v[0]; acc["rowops"][1] += v[1]
+        try:
+            allj = json.load(open(out))
+        except Exception:
+            allj = {}
+        ent = {"%s_us_per_step" % c: a[1] / steps for c, a in acc.items()}
+        ent.update({"%s_launches_per_step" % c: a[0] / steps for c, a in acc.items()})
+        ent.update({"steps": steps, "total_kernel_us_per_step": tot / steps,
+                    "batch": int(os.environ.get("ROCPD_BATCH", "0")), "commit": os.environ.get("ROCPD_COMMIT", ""),
+                    "commits_per_s": float(os.environ.get("ROCPD_VALUE", "0") or 0),
+                    "source": os.environ.get("ROCPD_SOURCE", "")})
+        allj[os.environ.get("ROCPD_DTYPE", "f32")] = ent
+        json.dump(allj, open(out, "w"), indent=1)
     if per_q and qcol:
         main_q = max(per_q, key=lambda r: r[1])[0]
         rows_q = cur.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id = s.id where d.%s = ? "

@@ -67,6 +67,7 @@ SIGNATURES = {
     "fira_add_layernorm_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
     "fira_linear_presum_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _F, _U64, _U32]),
     "fira_ln_linear_f32": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "fira_ln_bwd_linear_f32": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
     "fira_linear_layernorm_bf16_fwd": (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
     "fira_add_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32]),
     "fira_dropout_mask": (_I, [_P, _U64, _U32, _L, _F, _P]),

@@ -56,6 +56,12 @@ bool gemm_tile32_try(hipStream_t s, int tB, int M, int N, int K, const float* A,
                      const float* relu_mask, const int32_t* a_rows, const EpiRes* er);
 bool gemm_tile32_ln_try(hipStream_t s, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
                         int ldy, int flags, const float* gamma, const float* beta, float* x_out, float* stats_out, int* rc);
+// LayerNorm backward in the prologue of the data-gradient product dX[M,N] = dx_drop . W (W row-major [256,N]); writes ds,
+// dx_drop and [gemm_tile32_lnb_blocks(M), 512] partial {dgamma | dbeta} rows (gemm_small.hip: LnB)
+int gemm_tile32_lnb_blocks(int M);
+bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const float* W, int ldw, float* dX, int lddx,
+                         const float* relu_mask, const float* sum, const float* stats, const float* gamma, float* ds,
+                         float* dx_drop, float* part, float dropout, uint64_t seed, uint32_t site, int* rc);
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows = nullptr,
                     const float* relu_mask = nullptr);

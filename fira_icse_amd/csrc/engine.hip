@@ -529,6 +529,28 @@ static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const
     return 0;
 }
 
+// LayerNorm backward of a decoder block + the data-gradient product that consumes its output, as ONE launch where the
+// coalesced tile kernel takes the shape (fp32, 256-wide rows: gemm_tile32_lnb_try) -- otherwise the row kernel followed by
+// the product.  dX[M,N] = dx_drop[M,256] . W[256,N] (W row-major [256,N]) (masked by relu_mask > 0); ds must not alias dy.
+static int ln_bwd_dgrad(hipStream_t s, int M, int N, const float* dy, const float* sum, const float* stats, const float* gamma,
+                        float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed, uint32_t st,
+                        const float* W, int ldw, float* dX, int lddx, const float* relu_mask) {
+    if (g_dtype == 0 && ds != dy && gemm_tile32_takes(0, M, N, FIRA_D, dy, FIRA_D, W, ldw)) {
+        const int nb = gemm_tile32_lnb_blocks(M);
+        float* part = red().alloc((size_t)nb * 2 * FIRA_D);
+        int rc = 0;
+        if (part && gemm_tile32_lnb_try(s, M, N, dy, W, ldw, dX, lddx, relu_mask, sum, stats, gamma, ds, dx_drop, part, dropout, seed,
+                                        st, &rc)) {
+            TRY(rc);
+            red().add(dgamma, part, FIRA_D, nb, 2 * FIRA_D);
+            red().add(dbeta, part + FIRA_D, FIRA_D, nb, 2 * FIRA_D);
+            return 0;
+        }
+    }
+    TRY(ln_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st));
+    return gemm_any(s, 0, 0, M, N, FIRA_D, dx_drop, FIRA_D, W, ldw, dX, lddx, nullptr, 0, 0, nullptr, nullptr, relu_mask);
+}
+
 // bf16 mode: the attention matmuls run on bf16 operands too (torch.autocast semantics); FIRA_ATTN_BF16=0 keeps the fp32
 // MFMA chains (A/B switch)
 static inline int attn_bf16() {
@@ -846,29 +868,30 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     }
 
     // ---- decoder layers, last to first ------------------------------------------------------------------
-    const float* dy = p.ddec;
+    // Three [Td,256] gradient buffers rotate through the layers (ddec, dT_a, dT_c): bx holds the gradient w.r.t. the layer's
+    // output rows, by / bz are free.  Every LayerNorm backward writes its residual-branch gradient to a buffer OTHER than the
+    // one it reads (it runs in the prologue of the product that follows it: the product's other column tiles still read dy).
+    float *bx = p.ddec, *by = p.dT_a, *bz = p.dT_c;
     for (int l = p.nl - 1; l >= 0; --l) {
         ProfDecoderTag prof_tag;               // data gradients of the M = B*30 products (the grouped wgrads flush later)
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
         DecGrad& g = p.decg[l];
         const float* x_in = l == 0 ? p.x0 : p.dec[l - 1].x_f;
-        // FeedForward (gnn_transformer.py:170-174)
-        TRY(ln_bwd(s, c.Td, dy, e.s_f, e.st_f, c.P + w.lnf_g, p.dT_a, g.dYf, G + w.lnf_g, G + w.lnf_b,
-                              c.p_drop, c.seed, site(l, SITE_FFN)));
+        // FeedForward (gnn_transformer.py:170-174): LayerNorm backward + d hidden = (dYf W2) masked by the saved activation > 0
+        // (ReLU backward in the GEMM epilogue)
+        TRY(ln_bwd_dgrad(s, c.Td, p.F, bx, e.s_f, e.st_f, c.P + w.lnf_g, by, g.dYf, G + w.lnf_g, G + w.lnf_b, c.p_drop, c.seed,
+                         site(l, SITE_FFN), c.P + w.w2, p.F, g.dh, p.F, e.h));
         TRY(linear_wgrad_grouped(s, c.Td, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
-        // d hidden = (dYf W2) masked by the saved activation > 0: ReLU backward in the GEMM epilogue
-        TRY(gemm_any(s, 0, 0, c.Td, p.F, D, g.dYf, D, c.P + w.w2, p.F, g.dh, p.F, nullptr, 0, 0, nullptr, nullptr, e.h));
         TRY(linear_wgrad_grouped(s, c.Td, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
-        TRY(linear_dgrad(s, c.Td, p.F, D, g.dh, p.F, c.P + w.w1, p.dT_a, D, true));           // dT_a = d x_c
-        // cross attention
-        TRY(ln_bwd(s, c.Td, p.dT_a, e.s_c, e.st_c, c.P + w.lnc_g, p.dT_c, g.dYc, G + w.lnc_g, G + w.lnc_b,
-                              c.p_drop, c.seed, site(l, SITE_CROSS)));
+        TRY(linear_dgrad(s, c.Td, p.F, D, g.dh, p.F, c.P + w.w1, by, D, true));               // by = d x_c
+        // cross attention: LayerNorm backward + d ao2 = dYc Wo_c
+        TRY(ln_bwd_dgrad(s, c.Td, D, by, e.s_c, e.st_c, c.P + w.lnc_g, bz, g.dYc, G + w.lnc_g, G + w.lnc_b, c.p_drop, c.seed,
+                         site(l, SITE_CROSS), c.P + w.wo_c, D, bx, D, nullptr));              // bx = d ao2
         TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
-        TRY(linear_dgrad(s, c.Td, D, D, g.dYc, D, c.P + w.wo_c, p.dT_a, D, false));           // dT_a = d ao2
         // (ragged key rows: dkv_all holds the computed memory rows only, every one of them written by this launch)
         TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
-                          p.mem_valid_c, 0, 0, e.ao2, D, p.dT_a, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
+                          p.mem_valid_c, 0, 0, e.ao2, D, bx, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
                           p.dkv_all + l * 2 * D + D, p.kvp, c.dec_off, 0, attn_bf16(), p.mem_off));
         if (so && (l % 2 == 0 || l == 0)) {
             // dK|dV of this layer and of the one above it (adjacent column blocks of dkv_all / row blocks of the stacked K|V
@@ -883,18 +906,18 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
             TRY(rc_kv);
         }
         TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
-        TRY(linear_dgrad(s, c.Td, D, D, g.dq, D, c.P + w.wq_c, p.dT_c, D, true));             // dT_c = d x_a
-        // self attention
-        TRY(ln_bwd(s, c.Td, p.dT_c, e.s_a, e.st_a, c.P + w.lns_g, p.dT_a, g.dYs, G + w.lns_g, G + w.lns_b,
-                              c.p_drop, c.seed, site(l, SITE_SELF)));
+        TRY(linear_dgrad(s, c.Td, D, D, g.dq, D, c.P + w.wq_c, bz, D, true));                 // bz = d x_a
+        // self attention: LayerNorm backward + d ao = dYs Wo_s
+        TRY(ln_bwd_dgrad(s, c.Td, D, bz, e.s_a, e.st_a, c.P + w.lns_g, by, g.dYs, G + w.lns_g, G + w.lns_b, c.p_drop, c.seed,
+                         site(l, SITE_SELF), c.P + w.wo_s, D, bx, D, nullptr));               // bx = d ao
         TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
-        TRY(linear_dgrad(s, c.Td, D, D, g.dYs, D, c.P + w.wo_s, p.dT_c, D, false));           // dT_c = d ao
         TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
-                          e.ao, D, p.dT_c, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1, attn_bf16()));
+                          e.ao, D, bx, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1, attn_bf16()));
         TRY(linear_wgrad_grouped(s, c.Td, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
-        TRY(linear_dgrad(s, c.Td, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, p.dT_a, D, true));   // dT_a = d x_in
-        dy = p.dT_a;
+        TRY(linear_dgrad(s, c.Td, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, by, D, true));       // by = d x_in
+        float* t = bx; bx = by; by = t;         // the next layer's output gradient is in (the old) by; bz stays free
     }
+    const float* dy = bx;
     TRY(flush_grouped_wgrads(s));                                  // the decoder's and the head's small weight gradients
     // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions
     // carry an exactly-zero gradient (never attended as keys, zero loss weight): skipping id 0 only drops the

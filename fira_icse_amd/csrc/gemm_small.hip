@@ -191,14 +191,35 @@ struct LnA {
     float* stats_out = nullptr;      // [M, 2] or nullptr
 };
 
-template <bool B_KCONTIG, int NCH, bool LN_A = false>
+// LN_B (K = 256 only, round 4): the LayerNorm BACKWARD of a residual block in the prologue of the data-gradient product that
+// consumes it (gnn_transformer.py:161,174 backward: the decoder's 18 LayerNorm-backward launches per step sat between two
+// products of the dependent chain).  A = dy, the gradient w.r.t. the block's output rows; with the saved pre-norm rows s
+// and their statistics the kernel forms, for its 32 complete rows,
+//     xh = (s - mean) rstd,  h = dy gamma,  ds = (h - mean_k(h) - xh mean_k(h xh)) rstd,  dx = ds * dropout mask
+// (one pass: both row means from the same registers, combined over the four waves through LDS) and multiplies dx into the
+// product.  The workgroups of column tile 0 also publish ds (the residual-branch gradient), dx (the weight gradient's
+// operand) and the row block's partial column sums {sum dy xh | sum dy} for dgamma / dbeta (deferred reduction).  ds must
+// not alias dy: the other column tiles of the row block read dy while tile 0 writes ds.
+struct LnB {
+    const float* sum = nullptr;      // [M, 256] saved pre-norm rows
+    const float* stats = nullptr;    // [M, 2] mean, rstd
+    const float* gamma = nullptr;
+    float* ds = nullptr;             // [M, 256]
+    float* dx = nullptr;             // [M, 256]
+    float* part = nullptr;           // [ceil(M / 32), 512] partial {dgamma | dbeta}
+    float p = 0.f, inv_keep = 1.f;
+    uint64_t seed = 0;
+    uint32_t site = 0;
+};
+
+template <bool B_KCONTIG, int NCH, bool LN_A = false, bool LN_B = false>
 __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias, int flags,
                                                           const int32_t* __restrict__ c_rows,
                                                           const float* __restrict__ relu_mask,
                                                           const int32_t* __restrict__ a_rows, int tiles_n, const EpiRes er,
-                                                          const LnA ln) {
+                                                          const LnA ln, const LnB lb) {
     __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
     __shared__ float ln_red[2][4][32];
     const int lane = threadIdx.x & 63;
@@ -299,6 +320,106 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
             }
         }
     }
+    if constexpr (LN_B) {
+        static_assert(!LN_B || (NCH == 2 && !LN_A), "the LayerNorm-backward prologue needs the whole row in the two chunks of the four waves");
+        auto sum8 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
+        auto hsum = [](const f32x4 v) { return (v.x + v.y) + (v.z + v.w); };
+        const int ce = (ls ^ sw_even) << 2, co = (ls ^ sw_odd) << 2;
+        const int k0 = wave << 5, k1 = (wave + 4) << 5;
+        // the saved pre-norm rows at the positions of the A registers, the statistics of the lane's four rows
+        const float* ps0 = lb.sum + (size_t)ra0 * FIRA_D; const float* ps1 = lb.sum + (size_t)ra1 * FIRA_D;
+        const float* ps2 = lb.sum + (size_t)ra2 * FIRA_D; const float* ps3 = lb.sum + (size_t)ra3 * FIRA_D;
+        f32x4 s00 = *reinterpret_cast<const f32x4*>(ps0 + k0 + ce), s10 = *reinterpret_cast<const f32x4*>(ps0 + k1 + ce);
+        f32x4 s01 = *reinterpret_cast<const f32x4*>(ps1 + k0 + co), s11 = *reinterpret_cast<const f32x4*>(ps1 + k1 + co);
+        f32x4 s02 = *reinterpret_cast<const f32x4*>(ps2 + k0 + ce), s12 = *reinterpret_cast<const f32x4*>(ps2 + k1 + ce);
+        f32x4 s03 = *reinterpret_cast<const f32x4*>(ps3 + k0 + co), s13 = *reinterpret_cast<const f32x4*>(ps3 + k1 + co);
+        const float mean0 = lb.stats[2 * ra0], rstd0 = lb.stats[2 * ra0 + 1], mean1 = lb.stats[2 * ra1], rstd1 = lb.stats[2 * ra1 + 1];
+        const float mean2 = lb.stats[2 * ra2], rstd2 = lb.stats[2 * ra2 + 1], mean3 = lb.stats[2 * ra3], rstd3 = lb.stats[2 * ra3 + 1];
+        const f32x4 g0e = *reinterpret_cast<const f32x4*>(lb.gamma + k0 + ce), g0o = *reinterpret_cast<const f32x4*>(lb.gamma + k0 + co);
+        const f32x4 g1e = *reinterpret_cast<const f32x4*>(lb.gamma + k1 + ce), g1o = *reinterpret_cast<const f32x4*>(lb.gamma + k1 + co);
+        // xh (over s), h (kept), then the two row sums
+        s00 = (s00 - mean0) * rstd0; s10 = (s10 - mean0) * rstd0; s01 = (s01 - mean1) * rstd1; s11 = (s11 - mean1) * rstd1;
+        s02 = (s02 - mean2) * rstd2; s12 = (s12 - mean2) * rstd2; s03 = (s03 - mean3) * rstd3; s13 = (s13 - mean3) * rstd3;
+        const f32x4 h00 = R0.a0 * g0e, h10 = R1.a0 * g1e, h01 = R0.a1 * g0o, h11 = R1.a1 * g1o;
+        const f32x4 h02 = R0.a2 * g0e, h12 = R1.a2 * g1e, h03 = R0.a3 * g0o, h13 = R1.a3 * g1o;
+        {
+            const float p0 = sum8(hsum(h00) + hsum(h10)), p1 = sum8(hsum(h01) + hsum(h11));
+            const float p2 = sum8(hsum(h02) + hsum(h12)), p3 = sum8(hsum(h03) + hsum(h13));
+            const float q0 = sum8(hsum(h00 * s00) + hsum(h10 * s10)), q1 = sum8(hsum(h01 * s01) + hsum(h11 * s11));
+            const float q2 = sum8(hsum(h02 * s02) + hsum(h12 * s12)), q3 = sum8(hsum(h03 * s03) + hsum(h13 * s13));
+            if (ls == 0) {
+                ln_red[0][wave][lr] = p0; ln_red[0][wave][8 + lr] = p1; ln_red[0][wave][16 + lr] = p2; ln_red[0][wave][24 + lr] = p3;
+                ln_red[1][wave][lr] = q0; ln_red[1][wave][8 + lr] = q1; ln_red[1][wave][16 + lr] = q2; ln_red[1][wave][24 + lr] = q3;
+            }
+        }
+        if (lb.part && n0 == 0) {
+            // partial dgamma / dbeta of this row block: the wave's 32 rows x 64 columns of dy xh (then dy) go through its private
+            // LDS slot ([row][64 columns]), lane L sums column (wave + 4 (L >> 5)) * 32 + (L & 31) over the rows.  Rows past M
+            // were clamped to row M - 1 and must not count: their dy is zeroed here.
+            const bool v0 = m0 + lr < M, v1 = m0 + 8 + lr < M, v2 = m0 + 16 + lr < M, v3 = m0 + 24 + lr < M;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 d00 = v0 ? R0.a0 : z, d10 = v0 ? R1.a0 : z, d01 = v1 ? R0.a1 : z, d11 = v1 ? R1.a1 : z;
+            const f32x4 d02 = v2 ? R0.a2 : z, d12 = v2 ? R1.a2 : z, d03 = v3 ? R0.a3 : z, d13 = v3 ? R1.a3 : z;
+            float* sc = reinterpret_cast<float*>(slot);
+            float colsum[2];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                __builtin_amdgcn_wave_barrier();
+                *reinterpret_cast<f32x4*>(sc + (lr) * 64 + ce) = pass ? d00 : d00 * s00;
+                *reinterpret_cast<f32x4*>(sc + (lr) * 64 + 32 + ce) = pass ? d10 : d10 * s10;
+                *reinterpret_cast<f32x4*>(sc + (8 + lr) * 64 + co) = pass ? d01 : d01 * s01;
+                *reinterpret_cast<f32x4*>(sc + (8 + lr) * 64 + 32 + co) = pass ? d11 : d11 * s11;
+                *reinterpret_cast<f32x4*>(sc + (16 + lr) * 64 + ce) = pass ? d02 : d02 * s02;
+                *reinterpret_cast<f32x4*>(sc + (16 + lr) * 64 + 32 + ce) = pass ? d12 : d12 * s12;
+                *reinterpret_cast<f32x4*>(sc + (24 + lr) * 64 + co) = pass ? d03 : d03 * s03;
+                *reinterpret_cast<f32x4*>(sc + (24 + lr) * 64 + 32 + co) = pass ? d13 : d13 * s13;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 32; r += 2) { a0 += sc[r * 64 + lane]; a1 += sc[(r + 1) * 64 + lane]; }
+                colsum[pass] = a0 + a1;
+            }
+            const int col = ((wave + 4 * (lane >> 5)) << 5) + (lane & 31);
+            float* pp = lb.part + (size_t)(m0 >> 5) * (2 * FIRA_D);
+            pp[col] = colsum[0];
+            pp[FIRA_D + col] = colsum[1];
+        }
+        __syncthreads();
+        float m1[4], m2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m1[j] = ((ln_red[0][0][8 * j + lr] + ln_red[0][1][8 * j + lr]) + (ln_red[0][2][8 * j + lr] + ln_red[0][3][8 * j + lr])) * (1.0f / FIRA_D);
+            m2[j] = ((ln_red[1][0][8 * j + lr] + ln_red[1][1][8 * j + lr]) + (ln_red[1][2][8 * j + lr] + ln_red[1][3][8 * j + lr])) * (1.0f / FIRA_D);
+        }
+        // ds over the h registers, dx = ds * mask over the A registers
+        const f32x4 e00 = (h00 - m1[0] - s00 * m2[0]) * rstd0, e10 = (h10 - m1[0] - s10 * m2[0]) * rstd0;
+        const f32x4 e01 = (h01 - m1[1] - s01 * m2[1]) * rstd1, e11 = (h11 - m1[1] - s11 * m2[1]) * rstd1;
+        const f32x4 e02 = (h02 - m1[2] - s02 * m2[2]) * rstd2, e12 = (h12 - m1[2] - s12 * m2[2]) * rstd2;
+        const f32x4 e03 = (h03 - m1[3] - s03 * m2[3]) * rstd3, e13 = (h13 - m1[3] - s13 * m2[3]) * rstd3;
+        auto drop = [&](const f32x4 v, int row, int col) {
+            if (lb.p <= 0.f) return v;
+            const uint32_t e0 = (uint32_t)row * FIRA_D + (uint32_t)col;
+            return f32x4{v.x * dropout_scale(lb.seed, lb.site, e0, lb.p, lb.inv_keep), v.y * dropout_scale(lb.seed, lb.site, e0 + 1, lb.p, lb.inv_keep),
+                         v.z * dropout_scale(lb.seed, lb.site, e0 + 2, lb.p, lb.inv_keep), v.w * dropout_scale(lb.seed, lb.site, e0 + 3, lb.p, lb.inv_keep)};
+        };
+        const int r0 = m0 + lr, r1 = m0 + 8 + lr, r2 = m0 + 16 + lr, r3 = m0 + 24 + lr;
+        R0.a0 = drop(e00, r0, k0 + ce); R1.a0 = drop(e10, r0, k1 + ce); R0.a1 = drop(e01, r1, k0 + co); R1.a1 = drop(e11, r1, k1 + co);
+        R0.a2 = drop(e02, r2, k0 + ce); R1.a2 = drop(e12, r2, k1 + ce); R0.a3 = drop(e03, r3, k0 + co); R1.a3 = drop(e13, r3, k1 + co);
+        if (n0 == 0) {                              // column tile 0 publishes ds and dx
+            float* o1 = lb.ds;
+            float* o2 = lb.dx;
+            if (r0 < M) { *reinterpret_cast<f32x4*>(o1 + (size_t)r0 * FIRA_D + k0 + ce) = e00; *reinterpret_cast<f32x4*>(o1 + (size_t)r0 * FIRA_D + k1 + ce) = e10;
+                          *reinterpret_cast<f32x4*>(o2 + (size_t)r0 * FIRA_D + k0 + ce) = R0.a0; *reinterpret_cast<f32x4*>(o2 + (size_t)r0 * FIRA_D + k1 + ce) = R1.a0; }
+            if (r1 < M) { *reinterpret_cast<f32x4*>(o1 + (size_t)r1 * FIRA_D + k0 + co) = e01; *reinterpret_cast<f32x4*>(o1 + (size_t)r1 * FIRA_D + k1 + co) = e11;
+                          *reinterpret_cast<f32x4*>(o2 + (size_t)r1 * FIRA_D + k0 + co) = R0.a1; *reinterpret_cast<f32x4*>(o2 + (size_t)r1 * FIRA_D + k1 + co) = R1.a1; }
+            if (r2 < M) { *reinterpret_cast<f32x4*>(o1 + (size_t)r2 * FIRA_D + k0 + ce) = e02; *reinterpret_cast<f32x4*>(o1 + (size_t)r2 * FIRA_D + k1 + ce) = e12;
+                          *reinterpret_cast<f32x4*>(o2 + (size_t)r2 * FIRA_D + k0 + ce) = R0.a2; *reinterpret_cast<f32x4*>(o2 + (size_t)r2 * FIRA_D + k1 + ce) = R1.a2; }
+            if (r3 < M) { *reinterpret_cast<f32x4*>(o1 + (size_t)r3 * FIRA_D + k0 + co) = e03; *reinterpret_cast<f32x4*>(o1 + (size_t)r3 * FIRA_D + k1 + co) = e13;
+                          *reinterpret_cast<f32x4*>(o2 + (size_t)r3 * FIRA_D + k0 + co) = R0.a3; *reinterpret_cast<f32x4*>(o2 + (size_t)r3 * FIRA_D + k1 + co) = R1.a3; }
+        }
+    }
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci) {
         if ((ci & 1) == 0) {
@@ -335,8 +456,8 @@ template <bool B_KCONTIG, int NCH>
 static void tile32_launch(hipStream_t s, dim3 grid, int M, int N, const float* A, int lda, const float* B, int ldb, float* C,
                           int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask,
                           const int32_t* a_rows, int tiles_n, const EpiRes& er) {
-    hipLaunchKernelGGL((gemm_tile32_kernel<B_KCONTIG, NCH, false>), grid, dim3(256), 0, s, M, N, A, lda, B, ldb, C, ldc, bias,
-                       flags, c_rows, relu_mask, a_rows, tiles_n, er, LnA());
+    hipLaunchKernelGGL((gemm_tile32_kernel<B_KCONTIG, NCH, false, false>), grid, dim3(256), 0, s, M, N, A, lda, B, ldb, C, ldc, bias,
+                       flags, c_rows, relu_mask, a_rows, tiles_n, er, LnA(), LnB());
 }
 
 // shapes the coalesced tile kernel takes (the engine asks before it plans a fused LayerNorm prologue / residual epilogue)
@@ -383,11 +504,34 @@ bool gemm_tile32_ln_try(hipStream_t s, int M, int N, const float* S, int lds, co
     const int tiles_n = cdiv(N, 32);
     LnA ln;
     ln.gamma = gamma; ln.beta = beta; ln.x_out = x_out; ln.stats_out = stats_out;
-    hipLaunchKernelGGL((gemm_tile32_kernel<true, 2, true>), dim3(cdiv(M, 32) * tiles_n), dim3(256), 0, s, M, N, S, lds, W, FIRA_D,
+    hipLaunchKernelGGL((gemm_tile32_kernel<true, 2, true, false>), dim3(cdiv(M, 32) * tiles_n), dim3(256), 0, s, M, N, S, lds, W, FIRA_D,
                        Y, ldy, bias, flags & 3, (const int32_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, tiles_n,
-                       EpiRes(), ln);
+                       EpiRes(), ln, LnB());
     hipError_t e = hipGetLastError();
     *rc = e != hipSuccess ? set_err("gemm_tile32_ln: %s", hipGetErrorString(e)) : 0;
+    return true;
+}
+
+// dX[M,N] = LNbwd(dy)[M,256] . W[256,N] (W stored [256, N] row-major: the data gradient through a closing nn.Linear with
+// weight [256 out, N in]) in one launch, plus ds / dx_drop / the partial dgamma | dbeta rows (see LnB).  relu_mask (optional,
+// [M,N]): output zeroed where mask <= 0 (the FFN's ReLU backward).  false: shape not taken.
+int gemm_tile32_lnb_blocks(int M) { return cdiv(M, 32); }
+bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const float* W, int ldw, float* dX, int lddx,
+                         const float* relu_mask, const float* sum, const float* stats, const float* gamma, float* ds,
+                         float* dx_drop, float* part, float dropout, uint64_t seed, uint32_t site, int* rc) {
+    static const bool off = [] { const char* e = getenv("FIRA_LN_BWD_PROLOGUE"); return e && e[0] == '0'; }();     // A/B switch
+    if (off || !gemm_tile32_takes(0, M, N, FIRA_D, dy, FIRA_D, W, ldw)) return false;
+    if (((uintptr_t)sum % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)ds % 16) || ((uintptr_t)dx_drop % 16) || ds == dy) return false;
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * N * (double)FIRA_D, 4.0 * ((double)M * FIRA_D + (double)N * FIRA_D + (double)M * N));
+    const int tiles_n = cdiv(N, 32);
+    LnB lb;
+    lb.sum = sum; lb.stats = stats; lb.gamma = gamma; lb.ds = ds; lb.dx = dx_drop; lb.part = part;
+    lb.p = dropout; lb.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; lb.seed = seed; lb.site = site;
+    hipLaunchKernelGGL((gemm_tile32_kernel<false, 2, false, true>), dim3(cdiv(M, 32) * tiles_n), dim3(256), 0, s, M, N, dy, FIRA_D, W, ldw,
+                       dX, lddx, (const float*)nullptr, 0, (const int32_t*)nullptr, relu_mask, (const int32_t*)nullptr, tiles_n,
+                       EpiRes(), LnA(), lb);
+    hipError_t e = hipGetLastError();
+    *rc = e != hipSuccess ? set_err("gemm_tile32_lnb: %s", hipGetErrorString(e)) : 0;
     return true;
 }
 
@@ -433,6 +577,25 @@ int fira_linear_presum_f32(void* stream, int M, int K, const float* X, int ldx, 
                                nullptr, &er))
         return fira::set_err("fira_linear_presum_f32: shape %d x 256 x %d / alignment not taken by the tile kernel", M, K);
     return rc;
+}
+int fira_ln_bwd_linear_f32(void* stream, int M, int N, const float* dy, const float* Wt, float* dX, const float* relu_mask,
+                           const float* sum, const float* stats, const float* gamma, float* ds, float* dx_drop, float* dgamma,
+                           float* dbeta, float* part, float dropout, uint64_t seed, uint32_t site) {
+    FIRA_REQUIRE(dy && Wt && dX && sum && stats && gamma && ds && dx_drop && dgamma && dbeta && part && M > 0 && N > 0,
+                 "fira_ln_bwd_linear_f32: bad argument");
+    FIRA_REQUIRE(ds != dy, "fira_ln_bwd_linear_f32: ds must not alias dy");
+    FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_ln_bwd_linear_f32: dropout must be in [0,1)");
+    int rc = 0;
+    if (!fira::gemm_tile32_lnb_try((hipStream_t)stream, M, N, dy, Wt, N, dX, N, relu_mask, sum, stats, gamma, ds, dx_drop, part,
+                                   dropout, seed, site, &rc))
+        return fira::set_err("fira_ln_bwd_linear_f32: shape %d x %d / alignment not taken by the tile kernel", M, N);
+    if (rc) return rc;
+    fira::RedTable tab;
+    const int nb = fira::gemm_tile32_lnb_blocks(M);
+    tab.e[0] = fira::RedEntry{dgamma, part, FIRA_D, nb, 2 * FIRA_D};
+    tab.e[1] = fira::RedEntry{dbeta, part + FIRA_D, FIRA_D, nb, 2 * FIRA_D};
+    tab.n = 2;
+    return fira::deferred_reduce((hipStream_t)stream, tab);
 }
 int fira_ln_linear_f32(void* stream, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
                        int ldy, int relu, const float* gamma, const float* beta, float* x_out, float* stats_out) {

@@ -174,6 +174,21 @@ def add_layernorm_bwd(dy, s, stats, gamma, dropout=0.0, seed=0, site=0, want_dx_
     return ds, dxd, dg, db
 
 
+def ln_bwd_linear(dy, Wt, summ, stats, gamma, relu_mask=None, dropout=0.0, seed=0, site=0):
+    """fira_ln_bwd_linear_f32: (dX, ds, dx_drop, dgamma, dbeta) -- LayerNorm backward in the prologue of dX = dx_drop . Wt."""
+    M, N = dy.shape[0], Wt.shape[1]
+    dX = torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    ds, dxd = torch.empty_like(dy), torch.empty_like(dy)
+    dg = torch.zeros(256, dtype=torch.float32, device=dy.device)
+    db = torch.zeros(256, dtype=torch.float32, device=dy.device)
+    part = torch.empty(((M + 31) // 32) * 512, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().fira_ln_bwd_linear_f32(cur_stream(), M, N, ptr(_f32(dy)), ptr(_f32(Wt)), ptr(dX),
+                                            ptr(None if relu_mask is None else _f32(relu_mask)), ptr(_f32(summ)),
+                                            ptr(_f32(stats)), ptr(_f32(gamma)), ptr(ds), ptr(dxd), ptr(dg), ptr(db), ptr(part),
+                                            dropout, seed, site), "fira_ln_bwd_linear_f32")
+    return dX, ds, dxd, dg, db
+
+
 def dropout_mask(seed, site, n, p, device="cuda"):
     """Scale factors (0 or 1/(1-p)) of dropout site ``site`` for element indices 0..n-1 under ``seed``."""
     out = torch.empty(n, dtype=torch.float32, device=device)

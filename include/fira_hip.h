@@ -239,6 +239,17 @@ int fira_linear_presum_f32(void* stream, int M, int K, const float* X, int ldx, 
                            const float* res, float* sum, float dropout, uint64_t seed, uint32_t stream_id);
 int fira_ln_linear_f32(void* stream, int M, int N, const float* S, int lds, const float* W, const float* bias, float* Y,
                        int ldy, int relu, const float* gamma, const float* beta, float* x_out, float* stats_out);
+/* (v6) The LayerNorm BACKWARD of such a block inside the data-gradient product that consumes it (the decoder's backward
+ * chain: gnn_transformer.py:161,174 backward followed by the closing nn.Linear's data gradient): with dy [M,256] the
+ * gradient w.r.t. the block's output, sum / stats the saved pre-norm rows and {mean, 1/std},
+ *     ds = LayerNorm'(dy)  [M,256]   (gradient w.r.t. the pre-norm sum = the residual-branch gradient; must not alias dy)
+ *     dx_drop = ds * dropout mask of `site`            (the weight gradient's operand)
+ *     dX[M,N] = dx_drop . Wt   (Wt row-major [256, N] = the closing nn.Linear's weight [256 out, N in]; relu_mask [M,N]
+ *                               optional: dX zeroed where mask <= 0 -- the FFN's ReLU backward)
+ *     dgamma / dbeta [256] += column sums (through `part`, caller scratch of ceil(M/32) * 512 floats).                    */
+int fira_ln_bwd_linear_f32(void* stream, int M, int N, const float* dy, const float* Wt, float* dX, const float* relu_mask,
+                           const float* sum, const float* stats, const float* gamma, float* ds, float* dx_drop,
+                           float* dgamma, float* dbeta, float* part, float dropout, uint64_t seed, uint32_t site);
 /* bf16 mode twin (K = 256): Wb is the [256,256] bf16 shadow of the weight (fira_weight_shadow), row pitch ldb a multiple
  * of 8; X is rounded to bf16 while staged, fp32 accumulation, fp32 LayerNorm.  M >= 64.                                  */
 int fira_linear_layernorm_bf16_fwd(void* stream, int M, const float* X, int ldx, const uint16_t* Wb, int ldb,

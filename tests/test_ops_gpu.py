@@ -306,6 +306,37 @@ def test_residual_block_split_at_its_layernorm(M, K, N, p):
     assert rel_err(out, F.relu(F.linear(ref_y, w2.double(), b2.double()))) < 5e-6
 
 
+@pytest.mark.parametrize("M,N,relu", [(530, 256, False), (530, 1024, True), (960, 256, False), (33, 256, False), (1921, 1024, True)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_backward_in_the_dgrad_prologue(M, N, relu, p):
+    """fira_ln_bwd_linear_f32 (LayerNorm backward in the prologue of the data-gradient product, gemm_small.hip LnB) against
+    the two launches it replaces -- add_layernorm_bwd (same dropout stream) and the product (with the ReLU mask of the FFN) --
+    and against autograd of LayerNorm in fp64.  Ragged last row block (M % 32 != 0), decoder- and FFN-sized outputs."""
+    from fira_icse_amd import ops
+    x = randn(M, 256, seed=1)
+    gamma, beta = 1 + 0.1 * randn(256, seed=2), 0.1 * randn(256, seed=3)
+    y, s, stats = ops.add_layernorm_fwd(x.clone(), None, gamma, beta)
+    dy = randn(M, 256, seed=4)
+    Wt = randn(256, N, seed=5, scale=1 / 16)
+    mask = randn(M, N, seed=6) if relu else None
+    dX, ds, dxd, dg, db = ops.ln_bwd_linear(dy, Wt, s, stats, gamma, relu_mask=mask, dropout=p, seed=55, site=21)
+    ds0, dxd0, dg0, db0 = ops.add_layernorm_bwd(dy, s, stats, gamma, p, seed=55, site=21, want_dx_drop=True)
+    ref_dX = ops.gemm(dxd0, Wt, transB=False)
+    if relu:
+        ref_dX = ref_dX * (mask > 0)
+    assert rel_err(ds, ds0) < 2e-6 and rel_err(dxd, dxd0) < 2e-6
+    assert rel_err(dg, dg0) < 1e-5 and rel_err(db, db0) < 1e-5
+    assert rel_err(dX, ref_dX) < 3e-6
+    if p > 0:
+        assert torch.equal(dxd == 0, dxd0 == 0)                  # the same mask
+    # fp64 autograd of the LayerNorm
+    xs = s.double().requires_grad_(True)
+    g64 = gamma.double().requires_grad_(True)
+    b64 = beta.double().requires_grad_(True)
+    F.layer_norm(xs, (256,), g64, b64, 1e-5).backward(dy.double())
+    assert rel_err(ds, xs.grad) < 5e-6 and rel_err(dg, g64.grad) < 1e-5 and rel_err(db, b64.grad) < 1e-5
+
+
 def test_add_layernorm_fwd_bwd_and_dropout_mask():
     from fira_icse_amd import ops
     M = 1237

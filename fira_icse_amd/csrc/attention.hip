@@ -35,6 +35,25 @@ __device__ __forceinline__ float mask_score(float raw, int key, int query, int T
     return masked ? -1e9f : raw * INV_SQRT_DH;
 }
 
+// The row ranges of a (batch entry, K/V entry) pair -- q_off[b], q_off[b+1], k_off[bk], k_off[bk+1] -- fetched by lanes 0..3
+// with ONE vector load and broadcast: as four scalar loads behind null-pointer branches they were four DEPENDENT round
+// trips at the head of every attention launch (one cold workgroup per CU: the scalar cache never helps).
+struct AttnRanges { int qb, tq, k0, tk; };
+__device__ __forceinline__ AttnRanges attn_ranges(const int32_t* __restrict__ q_off, const int32_t* __restrict__ k_off, int b,
+                                                  int bk, int Tq, int Tk, bool selfk, int lane) {
+    int v = 0;
+    const int32_t* src = nullptr;
+    if (lane < 2 && q_off) src = q_off + b + lane;
+    if (lane >= 2 && lane < 4 && k_off && !selfk) src = k_off + bk + (lane - 2);
+    if (src) v = *src;
+    AttnRanges r;
+    r.qb = q_off ? __builtin_amdgcn_readlane(v, 0) : b * Tq;
+    r.tq = q_off ? __builtin_amdgcn_readlane(v, 1) - r.qb : Tq;
+    r.k0 = (k_off && !selfk) ? __builtin_amdgcn_readlane(v, 2) : 0;
+    r.tk = selfk ? r.tq : (k_off ? min(__builtin_amdgcn_readlane(v, 3) - r.k0, Tk) : Tk);
+    return r;
+}
+
 template <int NW, int TPW, bool BF>
 __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, int Tk, const float* __restrict__ Q,
                                                                 int ldq, const float* __restrict__ K, int ldk,
@@ -57,21 +76,16 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     const int bk = b / qpk;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int qb = q_off ? q_off[b] : b * Tq;
-    const int tq = q_off ? q_off[b + 1] - qb : Tq;
     const bool selfk = q_off && self_kv;
-    const int k0 = (k_off && !selfk) ? k_off[bk] : 0;
-    const int tk = selfk ? tq : (k_off ? min(k_off[bk + 1] - k0, Tk) : Tk);
+    const AttnRanges rg = attn_ranges(q_off, k_off, b, bk, Tq, Tk, selfk, lane);
+    const int qb = rg.qb, tq = rg.tq, k0 = rg.k0, tk = rg.tk;
     const int NT = (tk + 31) / 32;
     if (tk <= 0) {                                   // no key at all (never in the engine: a commit has its <start> token)
         for (int idx = t; idx < tq * FIRA_DH; idx += NW * 64)
             O[((size_t)qb + idx / FIRA_DH) * ldo + h * FIRA_DH + idx % FIRA_DH] = 0.f;
         return;
     }
-    {
-        const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)bk * kvb);
-        for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
-    }
+    const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)bk * kvb);
     const size_t krow0 = selfk ? (size_t)qb : (k_off ? (size_t)k0 : (size_t)bk * kb);
     K += krow0 * ldk;                                // this batch entry's key/value rows
     V += krow0 * ldv;
@@ -93,6 +107,10 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
             for (int s = 0; s < 16; ++s) { ak[i][s] = 0.f; vv[i][s] = 0.f; }
         }
     }
+    // the key mask travels in the SAME round trip, behind the operand requests (round 4: it used to be fetched and parked in
+    // LDS before the first operand load was issued -- one more dependent round trip)
+    asm volatile("" ::: "memory");
+    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
     __syncthreads();
     if (l31 >= tq) {
 #pragma unroll
@@ -228,11 +246,9 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int qb = q_off ? q_off[b] : b * Tq;                  // ragged query rows: see attention_fwd_kernel
-    const int tq = q_off ? q_off[b + 1] - qb : Tq;
     const bool selfk = q_off && self_kv;
-    const int k0 = (k_off && !selfk) ? k_off[b] : 0;
-    const int tk = selfk ? tq : (k_off ? min(k_off[b + 1] - k0, Tk) : Tk);
+    const AttnRanges rg = attn_ranges(q_off, k_off, b, b, Tq, Tk, selfk, lane);       // ragged rows: see attention_fwd_kernel
+    const int qb = rg.qb, tq = rg.tq, k0 = rg.k0, tk = rg.tk;
     const size_t kbase = selfk ? (size_t)qb : (k_off ? (size_t)k0 : (size_t)b * Tk);
     const int NT = (tk + 31) / 32;
     if (tk <= 0) {                                   // no key: nothing flows back to the queries (and there is no dK / dV row)
@@ -240,10 +256,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             dQ[((size_t)qb + idx / FIRA_DH) * lddq + h * FIRA_DH + idx % FIRA_DH] = 0.f;
         return;
     }
-    {
-        const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)b * Tk);
-        for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
-    }
+    const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)b * Tk);
 
     // ---- all operands, one round trip (rows past the end are clamped to a real row and zeroed below) ----------
     const int ql = min(l31, tq - 1);
@@ -269,6 +282,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             for (int s = 0; s < 16; ++s) { ak[i][s] = 0.f; av[i][s] = 0.f; kvv[i][s] = 0.f; }
         }
     }
+    asm volatile("" ::: "memory");                   // the key mask rides behind the operand requests (see the forward kernel)
+    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
     __syncthreads();
     if (l31 >= tq) {
 #pragma unroll

@@ -270,6 +270,16 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
         // this lane holds, of rows 8j + lr (j = 0..3), the four columns kc + ((ls ^ sw_j) << 2) .. + 3 of each chunk
         auto sum8 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
         auto hsum = [](const f32x4 v) { return (v.x + v.y) + (v.z + v.w); };
+        // columns of this lane: chunk c (k base kc = (wave + 4c) * 32), rows j even -> ls ^ sw_even, j odd -> ls ^ sw_odd.
+        // gamma / beta are requested HERE, with the operand tiles still in flight (round 4: they used to be loaded after the two
+        // statistics barriers -- one more dependent memory round trip in every LayerNorm-prologue product of the chain)
+        const int ce = (ls ^ sw_even) << 2, co = (ls ^ sw_odd) << 2;
+        const int k0 = wave << 5, k1 = (wave + 4) << 5;
+        const f32x4 g0e = *reinterpret_cast<const f32x4*>(ln.gamma + k0 + ce), g0o = *reinterpret_cast<const f32x4*>(ln.gamma + k0 + co);
+        const f32x4 g1e = *reinterpret_cast<const f32x4*>(ln.gamma + k1 + ce), g1o = *reinterpret_cast<const f32x4*>(ln.gamma + k1 + co);
+        const f32x4 b0e = *reinterpret_cast<const f32x4*>(ln.beta + k0 + ce), b0o = *reinterpret_cast<const f32x4*>(ln.beta + k0 + co);
+        const f32x4 b1e = *reinterpret_cast<const f32x4*>(ln.beta + k1 + ce), b1o = *reinterpret_cast<const f32x4*>(ln.beta + k1 + co);
+        asm volatile("" ::: "memory");             // (keep the requests above the first reduction: the scheduler sinks loads)
         float mean[4], rstd[4];
         {
             const float p0 = sum8(hsum(R0.a0) + hsum(R1.a0)), p1 = sum8(hsum(R0.a1) + hsum(R1.a1));
@@ -294,13 +304,6 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
                 rstd[j] = 1.0f / sqrtf(var + 1e-5f);
             }
         }
-        // columns of this lane: chunk c (k base kc = (wave + 4c) * 32), rows j even -> ls ^ sw_even, j odd -> ls ^ sw_odd
-        const int ce = (ls ^ sw_even) << 2, co = (ls ^ sw_odd) << 2;
-        const int k0 = wave << 5, k1 = (wave + 4) << 5;
-        const f32x4 g0e = *reinterpret_cast<const f32x4*>(ln.gamma + k0 + ce), g0o = *reinterpret_cast<const f32x4*>(ln.gamma + k0 + co);
-        const f32x4 g1e = *reinterpret_cast<const f32x4*>(ln.gamma + k1 + ce), g1o = *reinterpret_cast<const f32x4*>(ln.gamma + k1 + co);
-        const f32x4 b0e = *reinterpret_cast<const f32x4*>(ln.beta + k0 + ce), b0o = *reinterpret_cast<const f32x4*>(ln.beta + k0 + co);
-        const f32x4 b1e = *reinterpret_cast<const f32x4*>(ln.beta + k1 + ce), b1o = *reinterpret_cast<const f32x4*>(ln.beta + k1 + co);
         R0.a0 = (R0.a0 - mean[0]) * rstd[0] * g0e + b0e; R1.a0 = (R1.a0 - mean[0]) * rstd[0] * g1e + b1e;
         R0.a1 = (R0.a1 - mean[1]) * rstd[1] * g0o + b0o; R1.a1 = (R1.a1 - mean[1]) * rstd[1] * g1o + b1o;
         R0.a2 = (R0.a2 - mean[2]) * rstd[2] * g0e + b0e; R1.a2 = (R1.a2 - mean[2]) * rstd[2] * g1e + b1e;

@@ -331,6 +331,34 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
               "note": "tokens = emitted tokens up to and including <eos> (SURVEY 8d); step_tokens = batch x decoder "
                       "steps executed, the unit of BASELINE.md's CPU figure.  Weights: %d training steps on the "
                       "synthetic commits (untimed), fp32 search" % a.decode_train_steps}
+    # several batches of the same size in flight, each on its own stream (Searcher.greedy_many: what run_model.py test does
+    # with the test set's consecutive batches); the batch size per search call stays BASELINE configs[3]'s 64
+    try:
+        n_store = len(store)
+        n_fl = 4
+        group = [dbd] + [DeviceBatch(store.batch([(j * a.decode_batch + k) % n_store for k in range(a.decode_batch)]), cfg,
+                                     model.device_) for j in range(1, n_fl)]
+        for _ in range(2):
+            res = search.greedy_many(group, in_flight=n_fl)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = search.greedy_many(group, in_flight=n_fl)
+        barrier()
+        d2 = (time.perf_counter() - t0) / reps
+        toks2 = sum(int((r[1] - 1).sum().item()) for r in res)
+        steps2 = sum(int(r[1].max().item()) - 1 for r in res)
+        same = bool(torch.equal(res[0][0], out) and torch.equal(res[0][1], length))
+        decode["in_flight"] = {"tokens_per_s": toks2 * world / d2, "commits_per_s": n_fl * a.decode_batch * world / d2,
+                               "step_tokens_per_s": a.decode_batch * steps2 * world / d2,
+                               "ms_per_group": d2 * 1e3, "ms_per_batch_step": d2 * 1e3 / max(steps2, 1),
+                               "speedup_over_one_at_a_time": (a.decode_batch * steps2 / d2) / (a.decode_batch * steps_run / ddt),
+                               "batch": a.decode_batch, "batches_in_flight": n_fl, "ids_equal_to_single": same,
+                               "note": "%d independent batches of %d, each on its own stream / workspace / captured graphs "
+                                       "(one decode step is ~58 dependent launches of 16-48 workgroups: one chain leaves most "
+                                       "of the chip idle); per-batch arithmetic and ids unchanged" % (n_fl, a.decode_batch)}
+    except Exception as e:
+        decode["in_flight"] = {"error": repr(e)}
     # the same greedy search streaming a bf16 copy of the cross K|V (FIRA_DECODE_KV_BF16; not the default: the ids are no
     # longer bit-identical to the fp32 search) -- reported beside the fp32 figure, with the token agreement
     try:

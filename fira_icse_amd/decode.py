@@ -87,13 +87,8 @@ class Searcher:
                                                _lib.ptr(st["alive"]), _lib.ptr(st["tok"]), _lib.ptr(st["n_alive"])),
                        "fira_greedy_advance")
 
-    @torch.no_grad()
-    def greedy(self, db: DeviceBatch, chunk: int = 5, use_graphs: bool = True):
-        """Returns (tokens [B,T] int64 starting with <start>, lengths [B], probability [B]).
-
-        The step loop is launch-bound (~85 small kernels per generated token), so it is captured once per batch size
-        into hipGraphs of ``chunk`` steps each and replayed; between chunks one counter is read back to stop as soon
-        as every hypothesis has emitted <eos> (run_model.py:276-279)."""
+    def _greedy_start(self, db: DeviceBatch, chunk: int, use_graphs: bool):
+        """Encoder pass + reset of the hypothesis state for one batch on the CURRENT stream; returns the loop's context."""
         cfg = self.cfg
         B, T = db.B, cfg.tar_len
         ws = self._begin(db, 1)
@@ -114,14 +109,87 @@ class Searcher:
                 graphs.append(g)
             st["graphs"] = graphs
             self._greedy_reset(st)
-        for i, (lo, hi) in enumerate(bounds):
-            if use_graphs:
-                st["graphs"][i].replay()
-            else:
-                self._greedy_steps(st, ws, B, lo, hi)
-            if hi < T - 1 and int(st["n_alive"][hi - 1].item()) == 0:
+        return dict(st=st, ws=ws, B=B, bounds=bounds, i=0, use_graphs=use_graphs)
+
+    def _greedy_launch(self, ctx):
+        """Enqueue the next chunk of steps (one hipGraph replay) on the current stream."""
+        lo, hi = ctx["bounds"][ctx["i"]]
+        if ctx["use_graphs"]:
+            ctx["st"]["graphs"][ctx["i"]].replay()
+        else:
+            self._greedy_steps(ctx["st"], ctx["ws"], ctx["B"], lo, hi)
+
+    def _greedy_done(self, ctx) -> bool:
+        """After the chunk launched last: read the alive counter back (synchronises with the chunk) and advance."""
+        lo, hi = ctx["bounds"][ctx["i"]]
+        ctx["i"] += 1
+        if ctx["i"] >= len(ctx["bounds"]):
+            return True
+        return int(ctx["st"]["n_alive"][hi - 1].item()) == 0      # every hypothesis has emitted <eos> (run_model.py:276-279)
+
+    @torch.no_grad()
+    def greedy(self, db: DeviceBatch, chunk: int = 5, use_graphs: bool = True):
+        """Returns (tokens [B,T] int64 starting with <start>, lengths [B], probability [B]).
+
+        The step loop is launch-bound (~58 small kernels per generated token), so it is captured once per batch size
+        into hipGraphs of ``chunk`` steps each and replayed; between chunks one counter is read back to stop as soon
+        as every hypothesis has emitted <eos> (run_model.py:276-279)."""
+        ctx = self._greedy_start(db, chunk, use_graphs)
+        while True:
+            self._greedy_launch(ctx)
+            if self._greedy_done(ctx):
                 break
+        st = ctx["st"]
         return st["out"].long(), st["length"].long(), st["prob"].clone()
+
+    @torch.no_grad()
+    def greedy_many(self, dbs, in_flight: int = 2, chunk: int = 5):
+        """Greedy search over a sequence of batches with ``in_flight`` of them on the GPU at once, each on its own stream
+        (its own workspace, hypothesis state and captured graphs); results are returned in the order of ``dbs``.
+
+        One decode step is ~58 dependent launches of 16-48 workgroups each: a single batch of 64 keeps a fraction of the 256
+        CUs busy and the loop is bound by the launch chain, not by the chip.  The reference walks the test set batch after
+        batch (run_model.py:225); nothing couples two batches, so two independent chains share the chip and the tokens/s
+        nearly double at the same per-batch latency.  Same arithmetic, same ids as ``greedy`` batch by batch."""
+        dbs = list(dbs)
+        n_lane = max(1, min(in_flight, len(dbs)))
+        if not hasattr(self, "_lanes"):
+            self._lanes = []
+        while len(self._lanes) < n_lane:
+            lane = Searcher(self.model, kv_bf16=bool(self.flags)) if self._lanes else self
+            self._lanes.append((lane, torch.cuda.Stream(device=self.model.device_)))
+        main = torch.cuda.current_stream()
+        results = [None] * len(dbs)
+        active = [None] * n_lane                                # per lane: (batch index, loop context)
+        nxt = 0
+        for lane, stream in self._lanes[:n_lane]:
+            stream.wait_stream(main)
+        while True:
+            busy = False
+            for k in range(n_lane):
+                lane, stream = self._lanes[k]
+                with torch.cuda.stream(stream):
+                    if active[k] is not None:
+                        j, ctx = active[k]
+                        if lane._greedy_done(ctx):              # (synchronises with this lane's last chunk only)
+                            st = ctx["st"]
+                            results[j] = (st["out"].long(), st["length"].long(), st["prob"].clone())
+                            for r_ in results[j]:
+                                r_.record_stream(main)          # allocated on the lane's stream, consumed on the caller's
+                            active[k] = None
+                        else:
+                            lane._greedy_launch(ctx)
+                    if active[k] is None and nxt < len(dbs):
+                        ctx = lane._greedy_start(dbs[nxt], chunk, True)
+                        lane._greedy_launch(ctx)
+                        active[k] = (nxt, ctx)
+                        nxt += 1
+                busy = busy or active[k] is not None
+            if not busy:
+                break
+        for lane, stream in self._lanes[:n_lane]:
+            main.wait_stream(stream)
+        return results
 
     # ------------------------------------------------------------------ beam search with the reference's semantics
     def _beam_state(self, B, beam):

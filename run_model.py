@@ -213,19 +213,24 @@ class Run:
         search = Searcher(self.model)
         mine = shard_indices(list(range(len(store))), self.rank, self.world)
         lines, n_tok, t0 = [], 0, time.time()
-        for lo in range(0, len(mine), cfg.test_batch_size):
-            idx = mine[lo:lo + cfg.test_batch_size]
-            db = self.device_batch(store, idx)
+        # greedy: groups of `in_flight` batches share the GPU (two independent launch chains: decode.Searcher.greedy_many);
+        # the output order stays all_index['test'] order (run_model.py:372)
+        group = 4 if cfg.beam_size == 1 else 1
+        starts = list(range(0, len(mine), cfg.test_batch_size))
+        for g0 in range(0, len(starts), group):
+            idxs = [mine[lo:lo + cfg.test_batch_size] for lo in starts[g0:g0 + group]]
+            dbs = [self.device_batch(store, idx) for idx in idxs]
             if cfg.beam_size == 1:
-                hyps = search.best(*search.greedy(db))
+                outs = [search.best(*r) for r in search.greedy_many(dbs, in_flight=group)]
             else:
-                hyps = search.best(*search.beam(db, cfg.beam_size))
-            for h, i in zip(hyps, idx):
-                lines.append(text.detokenize(h, self.r_vocab, self.var_maps[test_index[i]]))
-                n_tok += max(len(h) - 1, 0)
+                outs = [search.best(*search.beam(dbs[0], cfg.beam_size))]
+            for idx, hyps in zip(idxs, outs):
+                for h, i in zip(hyps, idx):
+                    lines.append(text.detokenize(h, self.r_vocab, self.var_maps[test_index[i]]))
+                    n_tok += max(len(h) - 1, 0)
             if self.rank == 0:
-                print("data: %d/%d  (%.1f tokens/s)" % (lo + len(idx), len(mine), n_tok / max(time.time() - t0, 1e-9)),
-                      flush=True)
+                done = min(len(mine), starts[min(g0 + group, len(starts)) - 1] + cfg.test_batch_size)
+                print("data: %d/%d  (%.1f tokens/s)" % (done, len(mine), n_tok / max(time.time() - t0, 1e-9)), flush=True)
         lines = gather_lines(lines)
         if self.rank == 0:
             with open(self.out("output_fira"), "w") as f:

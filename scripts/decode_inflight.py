@@ -1,0 +1,27 @@
+"""Greedy search with 1..4 batches of 64 in flight (Searcher.greedy_many), freshly initialised weights (29 steps each)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fira_icse_amd import data, synth
+from fira_icse_amd.config import FiraConfig
+from fira_icse_amd.model import TransModel, DeviceBatch
+from fira_icse_amd.decode import Searcher
+
+cfg = FiraConfig()
+store = data.process_raw(cfg, synth.generate_dataset(256, seed=1000))
+torch.manual_seed(0)
+model = TransModel(cfg)
+model.eval()
+dbs = [DeviceBatch(store.batch(range(64 * i, 64 * i + 64)), cfg) for i in range(4)]
+for n in (1, 2, 3, 4):
+    s = Searcher(model)
+    for _ in range(2):
+        s.greedy_many(dbs, in_flight=n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.greedy_many(dbs, in_flight=n)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("in flight %d: %.2f ms for 4 batches of 64 x 29 steps = %.4f ms per batch-step, %.0f step-tokens/s" %
+          (n, dt * 1e3, dt * 1e3 / (4 * 29), 4 * 64 * 29 / dt), flush=True)

@@ -51,6 +51,31 @@ def test_greedy_matches_reference_output_lines(setup):
     assert lines_of(search.best(out2, length2, prob2), raw, ids) == gold
 
 
+def test_greedy_with_several_batches_in_flight_equals_batch_by_batch(setup):
+    """Searcher.greedy_many: batches of the test set searched two / three at a time on separate streams (own workspace,
+    hypothesis state and captured graphs per lane) -- the ids, lengths and probabilities must be exactly those of searching
+    the batches one after the other (run_model.py:225 walks the test set sequentially; nothing couples two batches), for
+    equal and unequal batch sizes, more batches than lanes, and a repeated call (graph replay on every lane)."""
+    from fira_icse_amd.model import DeviceBatch
+    from fira_icse_amd.decode import Searcher
+    cfg, raw, ids, hb, sd, model, db, search = setup
+    store = data.process_raw(cfg, raw)
+    groups = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10], [11, 12, 13, 14], [0, 1, 2, 3]]      # (any commits of the 24-commit store)
+    dbs = [DeviceBatch(store.batch(g), cfg) for g in groups]
+    one = Searcher(model)
+    ref = [tuple(t.clone() for t in one.greedy(d)) for d in dbs]
+    for in_flight in (2, 3):
+        many = Searcher(model)
+        for _ in range(2):
+            got = many.greedy_many(dbs, in_flight=in_flight)
+            torch.cuda.synchronize()
+            for (o, l, p), (o2, l2, p2) in zip(ref, got):
+                assert torch.equal(o, o2) and torch.equal(l, l2) and torch.equal(p, p2)
+    gold = json.load(open(os.path.join(util.GOLDEN, "decode_ref.json")))["beam1"]
+    got = search.greedy_many([db, db])
+    assert lines_of(search.best(*got[1]), raw, ids) == gold
+
+
 def test_search_with_a_bf16_cross_kv_copy_agrees_with_the_fp32_search(setup):
     """FIRA_DECODE_KV_BF16 (Searcher(kv_bf16=True)): the step loop streams a bf16 copy of the cross-attention K|V (half of
     the bytes a step moves).  Not bit-identical by construction -- the attention scores see bf16-rounded keys / values --

@@ -565,6 +565,15 @@ static inline bool gcn_fused_on() {
     return !off;
 }
 
+// ... and of the backward pass only (FIRA_GCN_FUSED_BWD=0: V = A_hat dY by the CSR kernel, dX += V W21 by the product -- the same
+// identity in two launches).  Measured in bf16 at batch 64, where the product is a few microseconds of MFMA time and the
+// fused launch's phase latencies are exposed: 16 239 / 16 203 commits/s fused against 16 110 / 15 982 -- fused stays the
+// default in both modes.
+static inline bool gcn_fused_bwd_on() {
+    static const bool off = [] { const char* e = getenv("FIRA_GCN_FUSED_BWD"); return e && e[0] == '0'; }();
+    return !off;
+}
+
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
 static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
 
@@ -998,7 +1007,12 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         if (gcn_fused_on()) {
             // one launch: V = A_hat dY (stored in e.Z, which the fused forward pass does not use), other = ds + V W21.
             // The weight gradient follows from the same V: dW21 = dY^T (A_hat X) = (A_hat dY)^T X = V^T X
-            TRY(gcn_fused_bwd(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, p.W21 + (size_t)l * D * D, e.Z, other, g_dtype == 1));
+            if (gcn_fused_bwd_on()) {
+                TRY(gcn_fused_bwd(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, p.W21 + (size_t)l * D * D, e.Z, other, g_dtype == 1));
+            } else {
+                TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, D, e.Z, D, 0, 1, 0, nullptr));            // V
+                TRY(linear_dgrad(s, Nc, D, D, e.Z, D, p.W21 + (size_t)l * D * D, other, D, true));                 // other += V W21
+            }
             TRY(enc_wgrad(s, Nc, D, D, e.Z, D, p.X[l], D, dW21, nullptr));
             if (!sums) TRY(colsum(s, Nc, D, g.dY2, D, G + w.fc2b));     // (db2 = column sums of dY, not of V)
             if (!grouped) TRY(unfold());

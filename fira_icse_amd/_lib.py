@@ -52,6 +52,7 @@ SIGNATURES = {
     "fira_param_total": (_L, [_DP]),
     "fira_workspace_bytes": (_Z, [_DP, _I, _I]),
     "fira_decode_workspace_bytes": (_Z, [_DP, _I, _I]),
+    "fira_decode_workspace_bytes_ex": (_Z, [_DP, _I, _I, _I]),
     "fira_gemm_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_gemm_bf16": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I]),
     "fira_weight_shadow": (_I, [_P, _I, _I, _P, _P, _P]),
@@ -161,16 +162,20 @@ def lib():
 
 
 _host_warned = False
+_host_failed = False
 
 
 def host_lib():
     """The library for its two HOST-ONLY helpers (fira_host_collate_csr / fira_host_node_lists), or None when it cannot be
     loaded or built (a CPU-only box without hipcc): the callers then run the numpy statements those helpers are tested
     against (tests/test_host_lists.py) -- same arrays, slower.  Device code never goes through this accessor."""
-    global _host_warned
+    global _host_warned, _host_failed
+    if _host_failed:                     # one failed load / build attempt is remembered: no hipcc run per batch afterwards
+        return None
     try:
         return lib()
-    except (ImportError, OSError) as e:
+    except (ImportError, OSError, AttributeError) as e:      # (AttributeError: a stale library without a declared symbol)
+        _host_failed = True
         if not _host_warned:
             _host_warned = True
             import warnings

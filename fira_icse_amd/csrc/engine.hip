@@ -1107,7 +1107,8 @@ struct DecodePlan {
     int32_t* hist[2];
     float *x, *q, *qkv, *ao, *s, *xa, *qc, *xc, *h, *tgt, *score, *gate, *logits;
     uint16_t* kv16;                  // optional bf16 copy of the cross K|V rows of all layers (FIRA_DECODE_KV_BF16)
-    size_t build(void* ws, const fira_dims& d, int B, int n_beam) {
+    // flags: FIRA_DECODE_KV_BF16 reserves the bf16 copy of the cross K|V (148 MB at batch 64); without it nothing is reserved
+    size_t build(void* ws, const fira_dims& d, int B, int n_beam, int flags = 0) {
         size_t used = enc.build(ws, d, B, false);
         Arena a(ws ? (char*)ws + used : nullptr);
         BR = B * n_beam;
@@ -1120,7 +1121,7 @@ struct DecodePlan {
         xc = a.f(BR * D); h = a.f((size_t)BR * d.d_ff); tgt = a.f(BR * D);
         score = a.f((size_t)BR * (d.sou_len + d.sub_len)); gate = a.f((size_t)BR * 2);
         logits = a.f((size_t)BR * enc.ldl);
-        kv16 = a.get<uint16_t>((size_t)enc.MB * enc.kvp);
+        kv16 = (flags & FIRA_DECODE_KV_BF16) ? a.get<uint16_t>((size_t)enc.MB * enc.kvp) : nullptr;      // (last: the other offsets do not move)
         return used + a.used;
     }
 };
@@ -1137,9 +1138,12 @@ size_t fira_workspace_bytes(const fira_dims* d, int B, int mode) {
     return p.build(nullptr, *d, B, mode == 1);
 }
 size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam) {
-    if (!get_layout(d) || B <= 0 || n_beam <= 0) return 0;
+    return fira_decode_workspace_bytes_ex(d, B, n_beam, 0);
+}
+size_t fira_decode_workspace_bytes_ex(const fira_dims* d, int B, int n_beam, int flags) {
+    if (!get_layout(d) || B <= 0 || n_beam <= 0 || (flags & ~FIRA_DECODE_KV_BF16)) return 0;
     DecodePlan dp;
-    return dp.build(nullptr, *d, B, n_beam);
+    return dp.build(nullptr, *d, B, n_beam, flags);
 }
 
 int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
@@ -1242,8 +1246,9 @@ int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* bat
     FIRA_REQUIRE(params && workspace && n_beam >= 1, "bad argument");
     FIRA_REQUIRE((flags & ~FIRA_DECODE_KV_BF16) == 0, "fira_decode_begin_ex: unknown flags %d", flags);
     DecodePlan dp;
-    const size_t need = dp.build(workspace, *d, batch->B, n_beam);
-    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const size_t need = dp.build(workspace, *d, batch->B, n_beam, flags);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu (fira_decode_workspace_bytes_ex with the same flags)",
+                 need, workspace_bytes);
     Plan& p = dp.enc;
     fira_batch b2 = *batch;
     b2.tar = nullptr;
@@ -1271,9 +1276,11 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
     const Layout& L = *Lp;
     FIRA_REQUIRE(params && workspace && tokens && B > 0 && n_beam >= 1, "bad argument");
     FIRA_REQUIRE(step >= 0 && step < d->tar_len, "step %d out of range", step);
+    FIRA_REQUIRE((flags & ~FIRA_DECODE_KV_BF16) == 0, "fira_decode_step_ex: unknown flags %d", flags);
     DecodePlan dp;
-    const size_t need = dp.build(workspace, *d, B, n_beam);
-    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+    const size_t need = dp.build(workspace, *d, B, n_beam, flags);
+    FIRA_REQUIRE(need <= workspace_bytes, "workspace too small: need %zu bytes, got %zu (fira_decode_workspace_bytes_ex with the same flags)",
+                 need, workspace_bytes);
     Plan& p = dp.enc;
     hipStream_t s = (hipStream_t)stream;
     const int D = FIRA_D, H = d->n_head, T = p.T, KV = p.nl * 2 * D, Sm = p.L + p.S, BR = dp.BR;

@@ -31,7 +31,7 @@ class Searcher:
     def _workspace(self, B, beam):
         key = (B, beam)
         if key not in self._ws:
-            n = _lib.lib().fira_decode_workspace_bytes(C.byref(self.model.dims), B, beam)
+            n = _lib.lib().fira_decode_workspace_bytes_ex(C.byref(self.model.dims), B, beam, self.flags)
             if n == 0:
                 _lib.check(1, "fira_decode_workspace_bytes")
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.model.device_)

@@ -126,6 +126,9 @@ int    fira_param_groups(const fira_dims* d, int64_t* split, int64_t* live);
 size_t fira_workspace_bytes(const fira_dims* d, int B, int mode);
 /* scratch for fira_decode_begin / fira_decode_step with n_beam hypotheses per commit */
 size_t fira_decode_workspace_bytes(const fira_dims* d, int B, int n_beam);
+/* (v6) the same for the flags fira_decode_begin_ex / fira_decode_step_ex will be called with: FIRA_DECODE_KV_BF16 adds the
+ * bf16 copy of the cross-attention K|V (148 MB at batch 64); flags 0 == fira_decode_workspace_bytes */
+size_t fira_decode_workspace_bytes_ex(const fira_dims* d, int B, int n_beam, int flags);
 
 /* Per-kernel-class HIP-event profiling (bench.py's roofline leg).  Classes: 0 GEMM (work = FLOP), 1 CSR SpMM
  * (work = algorithmic bytes), 2 attention, 3 row ops, 4 copy score, 5 head/loss, 6 Adam.  report() synchronises,

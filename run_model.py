@@ -63,7 +63,8 @@ def parse_args(argv):
     ap.add_argument("--resume", action="store_true", help="start from best_model.pt (+ fira_train_state.pt if present)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="arithmetic of the nn.Linear products: f32 = "
                     "the reference's (fp32 MFMA, default); bf16 = BASELINE configs[2] (bf16 MFMA, fp32 accumulate; master "
-                    "weights, LayerNorm, soft-max, loss and Adam stay fp32).  Applies to train, dev and test")
+                    "weights, LayerNorm, soft-max, loss and Adam stay fp32).  Applies to train and dev (teacher-forced BLEU); the test-time "
+                    "SEARCH always runs the reference's fp32 arithmetic (decode.Searcher / fira_decode_step), whatever --dtype says")
     ap.add_argument("--zero1", action="store_true", help="multi-GPU: reduce-scatter + Adam on the owned shard + all-gather "
                     "(Adam moments sharded over the ranks) instead of all-reduce + replicated Adam")
     return ap.parse_args(argv)

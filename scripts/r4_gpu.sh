@@ -75,6 +75,8 @@ for ST in "$@"; do
           [ $i = 1 ] && { echo -n "$V f32 b64: "; one "$V" "--batch 64"; }
         done
       done 2>&1 | tee $OUT/abenv.txt ;;
+    adopt)   # make this session's counters / traces the ones bench.py quotes (profiles/traffic.json, r4_kernel_classes.json)
+      cp $OUT/traffic.json $REPO/profiles/traffic.json; cp $OUT/kernel_classes.json $REPO/profiles/r4_kernel_classes.json; echo adopted ;;
     bench)
       timeout 900 python bench.py > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "bench f32 rc=$?"; head -c 1500 $OUT/bench_f32.json; echo; tail -n 5 $OUT/bench_f32.err ;;
     bench16)

@@ -335,7 +335,7 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
     # with the test set's consecutive batches); the batch size per search call stays BASELINE configs[3]'s 64
     try:
         n_store = len(store)
-        n_fl = 4
+        n_fl = 3
         group = [dbd] + [DeviceBatch(store.batch([(j * a.decode_batch + k) % n_store for k in range(a.decode_batch)]), cfg,
                                      model.device_) for j in range(1, n_fl)]
         for _ in range(2):

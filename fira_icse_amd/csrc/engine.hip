@@ -601,6 +601,11 @@ struct Ctx {
     // cross-attention K|V rows: the computed memory rows only, ragged per commit (Plan::mem_off / mem_valid_c) -- what
     // encoder_forward leaves; false: a dense [B, 370] memory supplied by the caller (fira_decoder_forward)
     bool kv_ragged = false;
+    // the search's encoder pass: everything on the caller's stream.  Several searches run side by side on their own streams
+    // (decode.Searcher.greedy_many); the library's auxiliary stream is ONE per thread, and HIP multiplexes streams onto a few
+    // hardware queues: a fork onto it from one search queued behind another search's 290-kernel graph on the same queue
+    // (measured: four batches in flight 54 ms instead of 18 once a trainer had created the streams)
+    bool serial = false;
     float* loss_sum = nullptr;      // zeroed by the prep launch (head_loss accumulates into them)
     int32_t* n_tok = nullptr;
     hipEvent_t ev_kv[16] = {};
@@ -628,7 +633,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     // layer 1.
     hipEvent_t ev_fold0 = nullptr, ev_fold = nullptr;
     {
-        const bool ax = side_on();
+        const bool ax = side_on() && !c.serial;
         hipStream_t fs = ax ? side().aux : s;
         if (ax) TRY(aux_fork(s));
         for (int l = 0; l < p.nl; ++l) {
@@ -1253,6 +1258,7 @@ int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* bat
     fira_batch b2 = *batch;
     b2.tar = nullptr;
     Ctx c{(hipStream_t)stream, L, &b2, params, nullptr, &p, 0.f, 0.f, 0};
+    c.serial = true;
     TRY(check_counts(batch, p));
     TRY(encoder_forward(c, false));     // also leaves kv_all (cross K|V of all layers) and src = LinearSource(memory)
     TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers

@@ -14,6 +14,8 @@
 #include "engine.h"
 #include "epilogue.h"
 #include <cmath>
+#include <stdlib.h>
+#include <algorithm>
 
 namespace fira {
 
@@ -302,16 +304,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(int M, int N, int K, cons
     // i = (b % 8) * chunk + b / 8 gives every XCD a contiguous range of items ordered K split (slowest), tiles of the
     // larger operand, other dimension (fastest): weight-gradient K slabs and activation row panels are fetched from HBM
     // once per XCD and re-read from its private L2 by the neighbouring tiles.
-    const int i = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (i >= tiles_m * tiles_n * splitk) return;
-    const int per = tiles_m * tiles_n;
-    const int z = i / per, r = i - z * per;
-    int tm, tn;
-    if (!spread_n) { tm = r / tiles_n; tn = r - tm * tiles_n; }
-    else { tn = r / tiles_m; tm = r - tn * tiles_m; }
-    const int kbeg = z * k_chunk;
-    gemm_tile<BM, BN, TA, TB>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, vecA, vecB, colsum, c_rows, relu_mask,
-                              tm * BM, tn * BN, kbeg, min(K, kbeg + k_chunk), splitk > 1, z == 0, tn == 0);
+    // (a capped grid -- FIRA_WGRAD_WGS, weight gradients only -- walks the items in strides of the grid: gridDim.x stays a
+    // multiple of 8, so an item keeps its XCD)
+    for (int b = blockIdx.x; b < 8 * chunk; b += gridDim.x) {
+        const int i = (b & 7) * chunk + (b >> 3);
+        if (i >= tiles_m * tiles_n * splitk) continue;
+        const int per = tiles_m * tiles_n;
+        const int z = i / per, r = i - z * per;
+        int tm, tn;
+        if (!spread_n) { tm = r / tiles_n; tn = r - tm * tiles_n; }
+        else { tn = r / tiles_m; tm = r - tn * tiles_m; }
+        const int kbeg = z * k_chunk;
+        gemm_tile<BM, BN, TA, TB>(M, N, K, A, lda, B, ldb, C, ldc, bias, flags, vecA, vecB, colsum, c_rows, relu_mask,
+                                  tm * BM, tn * BN, kbeg, min(K, kbeg + k_chunk), splitk > 1, z == 0, tn == 0);
+        __syncthreads();                             // the next item restages the LDS tiles
+    }
 }
 
 // Grouped weight gradients: dW_i (+)= dY_i^T X_i for up to GROUP_MAX independent problems in ONE launch.  The decoder's
@@ -332,17 +339,27 @@ struct GroupTable {
     GroupProblem p[GROUP_MAX];
 };
 __global__ __launch_bounds__(256) void gemm_grouped_wgrad_kernel(GroupTable g) {
-    int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.wg_start[i + 1]) ++i;          // uniform scan of <= 40 entries
-    const GroupProblem& q = g.p[i];
-    const int w = blockIdx.x - g.wg_start[i];
-    const int tile = w / q.splitk, z = w - tile * q.splitk;
-    const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
-    const int kbeg = z * q.k_chunk;
-    const int vecA = ((uintptr_t)q.A % 16 == 0) && (q.lda % 4 == 0), vecB = ((uintptr_t)q.B % 16 == 0) && (q.ldb % 4 == 0);
-    gemm_tile<64, 64, true, false>(q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, nullptr, FIRA_GEMM_ACCUM, vecA, vecB,
-                                   q.colsum, nullptr, nullptr, tm * 64, tn * 64, kbeg, min(q.K, kbeg + q.k_chunk),
-                                   q.splitk > 1, z == 0, tn == 0);
+    const int total = g.wg_start[g.n];
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {                          // (one item per workgroup unless the grid is capped)
+        int i = 0;
+        while (i + 1 < g.n && b >= g.wg_start[i + 1]) ++i;                          // uniform scan of <= 40 entries
+        const GroupProblem& q = g.p[i];
+        const int w = b - g.wg_start[i];
+        const int tile = w / q.splitk, z = w - tile * q.splitk;
+        const int tm = tile / q.tiles_n, tn = tile - tm * q.tiles_n;
+        const int kbeg = z * q.k_chunk;
+        const int vecA = ((uintptr_t)q.A % 16 == 0) && (q.lda % 4 == 0), vecB = ((uintptr_t)q.B % 16 == 0) && (q.ldb % 4 == 0);
+        gemm_tile<64, 64, true, false>(q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, nullptr, FIRA_GEMM_ACCUM, vecA, vecB,
+                                       q.colsum, nullptr, nullptr, tm * 64, tn * 64, kbeg, min(q.K, kbeg + q.k_chunk),
+                                       q.splitk > 1, z == 0, tn == 0);
+        __syncthreads();
+    }
+}
+// FIRA_WGRAD_WGS = n (experiment): weight-gradient launches use at most n workgroups (persistent over their tiles), so that
+// they leave wave / LDS slots and memory bandwidth to the latency-bound kernels of the dependent chain they run beside
+static int wgrad_wg_cap() {
+    static const int cap = [] { const char* e = getenv("FIRA_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? (v + 7) / 8 * 8 : 0; }();
+    return cap;
 }
 
 template <int BM, int BN>
@@ -353,6 +370,7 @@ static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const floa
     const int spread_n = (long)N > (long)M ? 1 : 0;
     const int chunk = cdiv(tiles_m * tiles_n * splitk, 8);
     dim3 grid(8 * chunk);
+    if (tA && wgrad_wg_cap() > 0) grid.x = std::min<unsigned>(grid.x, (unsigned)wgrad_wg_cap());
     int k_chunk = cdiv(cdiv(K, splitk), BK) * BK;
     const int vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     const int vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
@@ -442,7 +460,8 @@ int gemm_group_flush(hipStream_t s) {
         bytes += 4.0 * (M * K + N * K + M * N);
     }
     ProfScope prof(s, PROF_GEMM, flop, bytes);
-    hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(t.wg_start[t.n]), dim3(256), 0, s, t);
+    const int cap = wgrad_wg_cap();
+    hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(cap > 0 ? std::min(cap, t.wg_start[t.n]) : t.wg_start[t.n]), dim3(256), 0, s, t);
     t.n = 0;
     FIRA_CHECK_LAUNCH("gemm_grouped_wgrad");
     return 0;

@@ -19,6 +19,43 @@ from .config import EOS, PAD, START
 from .model import DeviceBatch, TransModel
 
 
+def concurrent_streams(n: int, device, pool: int = 12):
+    """``n`` HIP streams that really run side by side.  HIP multiplexes streams onto a few hardware queues (4 by default,
+    assigned round-robin in creation order over everything the process has created so far): two streams that land on the same
+    queue serialise, and which ones do depends on the process's history.  So: create ``pool`` candidate streams, time a short
+    spin kernel on pairs of them, and keep a set whose members overlap with each other (measured: 4 lanes on 4 distinct queues
+    run 4 batches of 64 in 17 ms, on 2 queues in 32 ms -- DESIGN.md section 6).  Costs a few milliseconds, once per Searcher."""
+    import time
+    cands = [torch.cuda.Stream(device=device) for _ in range(max(pool, n))]
+    if n <= 1:
+        return cands[:1]
+    spin = 400_000                                         # cycles of torch.cuda._sleep: ~0.2 ms
+
+    def run(streams):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    run(cands[:2])                                         # warm-up
+    one = min(run(cands[:1]) for _ in range(3))
+    chosen = [cands[0]]
+    for c in cands[1:]:
+        if len(chosen) == n:
+            break
+        if all(min(run([c, o]) for _ in range(2)) < 1.5 * one for o in chosen):
+            chosen.append(c)
+    for c in cands:                                        # fewer distinct queues than lanes: fill up with the rest
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen
+
+
 class Searcher:
     def __init__(self, model: TransModel, kv_bf16: bool = False):
         """``kv_bf16``: stream a bf16 copy of the cross-attention K|V in the step loop (FIRA_DECODE_KV_BF16: half of the
@@ -143,21 +180,23 @@ class Searcher:
         return st["out"].long(), st["length"].long(), st["prob"].clone()
 
     @torch.no_grad()
-    def greedy_many(self, dbs, in_flight: int = 2, chunk: int = 5):
+    def greedy_many(self, dbs, in_flight: int = 3, chunk: int = 5):
         """Greedy search over a sequence of batches with ``in_flight`` of them on the GPU at once, each on its own stream
         (its own workspace, hypothesis state and captured graphs); results are returned in the order of ``dbs``.
 
         One decode step is ~58 dependent launches of 16-48 workgroups each: a single batch of 64 keeps a fraction of the 256
         CUs busy and the loop is bound by the launch chain, not by the chip.  The reference walks the test set batch after
-        batch (run_model.py:225); nothing couples two batches, so two independent chains share the chip and the tokens/s
-        nearly double at the same per-batch latency.  Same arithmetic, same ids as ``greedy`` batch by batch."""
+        batch (run_model.py:225); nothing couples two batches, so independent chains share the chip.  Three lanes: x1.7
+        step-tokens/s in every process tried; four lanes reach x2.5 in a fresh process but fall BELOW one lane (x0.8) once
+        the process has created more streams (a trainer's): HIP oversubscribes its hardware queues -- DESIGN.md section 6.
+        Same arithmetic, same ids as ``greedy`` batch by batch."""
         dbs = list(dbs)
         n_lane = max(1, min(in_flight, len(dbs)))
-        if not hasattr(self, "_lanes"):
-            self._lanes = []
-        while len(self._lanes) < n_lane:
-            lane = Searcher(self.model, kv_bf16=bool(self.flags)) if self._lanes else self
-            self._lanes.append((lane, torch.cuda.Stream(device=self.model.device_)))
+        if not hasattr(self, "_lanes") or len(self._lanes) < n_lane:
+            streams = concurrent_streams(n_lane, self.model.device_)
+            old = getattr(self, "_lanes", [])
+            self._lanes = [(old[k][0] if k < len(old) else (Searcher(self.model, kv_bf16=bool(self.flags)) if k else self),
+                            streams[k]) for k in range(n_lane)]
         main = torch.cuda.current_stream()
         results = [None] * len(dbs)
         active = [None] * n_lane                                # per lane: (batch index, loop context)

@@ -216,7 +216,7 @@ class Run:
         lines, n_tok, t0 = [], 0, time.time()
         # greedy: groups of `in_flight` batches share the GPU (two independent launch chains: decode.Searcher.greedy_many);
         # the output order stays all_index['test'] order (run_model.py:372)
-        group = 4 if cfg.beam_size == 1 else 1
+        group = 3 if cfg.beam_size == 1 else 1
         starts = list(range(0, len(mine), cfg.test_batch_size))
         for g0 in range(0, len(starts), group):
             idxs = [mine[lo:lo + cfg.test_batch_size] for lo in starts[g0:g0 + group]]

@@ -11,6 +11,16 @@ cfg = FiraConfig()
 store = data.process_raw(cfg, synth.generate_dataset(256, seed=1000))
 torch.manual_seed(0)
 model = TransModel(cfg)
+n_train = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+if n_train:                                            # the bench's situation: a trainer (its streams, workspace) came first
+    from fira_icse_amd.train import Trainer
+    model.train()
+    tr = Trainer(model)
+    tb = [DeviceBatch(store.batch(range(32 * i, 32 * i + 32)), cfg) for i in range(4)]
+    for i in range(n_train):
+        tr.step(tb[i % 4])
+    torch.cuda.synchronize()
+    print("trained %d steps, loss %.3f" % (n_train, tr.last_loss()), flush=True)
 model.eval()
 dbs = [DeviceBatch(store.batch(range(64 * i, 64 * i + 64)), cfg) for i in range(4)]
 for n in (1, 2, 3, 4):

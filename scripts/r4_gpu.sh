@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $REPO
 export TMPDIR=/tmp
 PREV=$REPO/fira_icse_amd/libfira_hip_prev.so
-one() { env $1 timeout 200 python bench.py $2 --no-decode --no-cpu-baseline --no-extras --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_time_ms_per_step']; print(round(d['value']), 'commits/s', round(d['ms_per_step'],3), 'ms', 'attn', round(k['attention'],3), 'gemm', round(k['gemm'],3), 'rowops', round(k['rowops'],3), 'spmm', round(k['spmm'],3), 'host', round(d['host_enqueue_ms_per_step'],2))"; }
+one() { env $1 timeout 500 python bench.py $2 --no-decode --no-cpu-baseline --no-extras --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_time_ms_per_step']; print(round(d['value']), 'commits/s', round(d['ms_per_step'],3), 'ms', 'attn', round(k['attention'],3), 'gemm', round(k['gemm'],3), 'rowops', round(k['rowops'],3), 'spmm', round(k['spmm'],3), 'host', round(d['host_enqueue_ms_per_step'],2))"; }
 for ST in "$@"; do
   case $ST in
     newtests)
@@ -71,8 +71,8 @@ for ST in "$@"; do
       IFS='|' read -ra VARS <<< "$ABENV"
       for i in 1 2 3; do
         for V in "${VARS[@]}"; do
-          echo -n "$V f32 b32: "; one "$V" "--batch 32"
-          [ $i = 1 ] && { echo -n "$V f32 b64: "; one "$V" "--batch 64"; }
+          echo -n "$V f32 b${ABBATCH:-32}: "; one "$V" "--batch ${ABBATCH:-32}"
+          [ $i = 1 ] && [ -z "$ABBATCH" ] && { echo -n "$V f32 b64: "; one "$V" "--batch 64"; }
         done
       done 2>&1 | tee $OUT/abenv.txt ;;
     adopt)   # make this session's counters / traces the ones bench.py quotes (profiles/traffic.json, r4_kernel_classes.json)

@@ -15,6 +15,7 @@
 // The backward also needs the non-transposed tile (for dK = dS^T Q and dV = P^T dO); it is recomputed by
 // swapping the two operand fragments of the same MFMA chain, never by a transpose.
 #include "engine.h"
+#include "epilogue.h"
 #include "mfma_frag.h"
 
 namespace fira {
@@ -25,14 +26,43 @@ constexpr float SQRT_DH = 5.656854249492381f;
 constexpr float INV_SQRT_DH = 1.0f / SQRT_DH;
 constexpr int MAX_TK = 384;
 
-// Rows of masked keys are never read (their K/V fragments are zero-filled): their score is -1e9 whatever K holds and
-// their soft-max weight is exactly 0, so callers may leave those rows uninitialised.
-// masked, scaled score.  beyond Tk: -inf (not part of the soft-max at all); masked key: -1e9 as the reference.
-__device__ __forceinline__ float mask_score(float raw, int key, int query, int Tk, const int* kv, int causal, int q_pos0,
-                                            bool& masked) {
-    if (key >= Tk) { masked = true; return -INFINITY; }
-    masked = (kv[key] == 0) || (causal && key > query + q_pos0);
-    return masked ? -1e9f : raw * INV_SQRT_DH;
+// ---- masks as bit vectors --------------------------------------------------------------------------------------------
+// A 32x32 score tile lives in 16 accumulator registers per lane; register s of a lane with kh = lane>>5 holds row
+// acc_row(s, kh) = c(s) + 4 kh, c(s) = (s&3) + 8 (s>>2), and column lane&31.  Every mask the kernels need is a function of
+// (row, column), and per lane the 16 rows differ only in the compile-time constant c(s): each mask is therefore ONE 32-bit
+// word per lane and tile whose bit c(s) answers register s (bit test = v_bfe, select = v_bfi: 2 VALU per element).  Round 3
+// answered the same questions with an LDS look-up, compares and a divergent branch per element (3 700 instructions in the
+// single-wave backward, 1 150 of them scalar exec-mask bookkeeping); the kernels are bound by exactly that issue stream.
+// Scores are kept in the base-2 domain (raw * log2(e)/sqrt(32); the soft-max is invariant), so the exponential is one
+// v_exp_f32; a masked key's score is the reference's -1e9 (times log2 e), a key beyond Tk is -inf.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SCORE2 = INV_SQRT_DH * LOG2E;
+constexpr float MASKED2 = -1e9f * LOG2E;
+__device__ __forceinline__ constexpr int acc_c(int s) { return (s & 3) + 8 * (s >> 2); }
+// bits [0, n) set (n may be <= 0 or >= 32)
+__device__ __forceinline__ uint32_t low_bits(int n) { return n <= 0 ? 0u : (n >= 32 ? 0xffffffffu : (1u << n) - 1u); }
+// sel ? a : b on the bit patterns, sel = all ones / all zeros
+__device__ __forceinline__ float bit_select(int sel, float a, float b) {
+    return __int_as_float((sel & __float_as_int(a)) | (~sel & __float_as_int(b)));
+}
+__device__ __forceinline__ int bit_of(uint32_t word, int c) { return __builtin_amdgcn_sbfe((int)word, c, 1); }   // 0 / -1
+
+// 16 contiguous floats of a row through a buffer descriptor (rows outside the descriptor read 0)
+__device__ __forceinline__ void buf_frag(float (&f)[16], rsrc_t r, unsigned off) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, off + 16u * i, 0, 0));
+        f[4 * i + 0] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+    }
+}
+// the 16 accumulator-order rows of column lane&31: X[row0 + acc_row(s, kh)][lane&31], off0 = byte offset of row0 + 4 kh
+__device__ __forceinline__ void buf_rows(float (&f)[16], rsrc_t r, unsigned off0, unsigned ld4) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) f[s] = buf_load_f32(r, off0 + (unsigned)acc_c(s) * ld4);
+}
+// descriptor over rows [0, n) of a [*, ld] matrix slice that is 32 floats wide (n <= 0: nothing is addressable)
+__device__ __forceinline__ rsrc_t rows_rsrc(const float* base, int n, int ld) {
+    return buf_rsrc(base, n > 0 ? (unsigned)(n - 1) * (unsigned)ld * 4u + 128u : 0u);
 }
 
 // The row ranges of a (batch entry, K/V entry) pair -- q_off[b], q_off[b+1], k_off[bk], k_off[bk+1] -- fetched by lanes 0..3
@@ -54,7 +84,24 @@ __device__ __forceinline__ AttnRanges attn_ranges(const int32_t* __restrict__ q_
     return r;
 }
 
-template <int NW, int TPW, bool BF>
+// Key-tile state of a wave: which of the tile's 32 keys exist and are unmasked, as lane predicates and as row bit words.
+struct TileMask {
+    bool ok;            // this lane's key (tile*32 + lane&31) is inside Tk and unmasked
+    uint32_t valid;     // bit j: key row 4 kh + j of the tile is inside Tk and unmasked   (accumulator-row order)
+    uint32_t outside;   // bit j: key row 4 kh + j lies beyond Tk
+    bool live;          // the tile holds at least one unmasked key
+};
+__device__ __forceinline__ TileMask tile_mask(int kvld, int n_in, int kh) {
+    TileMask m;
+    m.ok = kvld != 0;
+    const uint32_t vbits = (uint32_t)__ballot(m.ok);          // both halves of the wave hold the same 32 keys
+    m.live = vbits != 0;
+    m.valid = vbits >> (4 * kh);
+    m.outside = ~low_bits(n_in) >> (4 * kh);
+    return m;
+}
+
+template <int NW, bool BF>
 __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, int Tk, const float* __restrict__ Q,
                                                                 int ldq, const float* __restrict__ K, int ldk,
                                                                 const float* __restrict__ V, int ldv,
@@ -69,7 +116,6 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     // and key_valid is indexed by the same compact rows.  Otherwise key_valid is dense (kvb entries per batch entry).
     // kb: K/V rows per batch entry, kvb: key_valid entries per batch entry, qpk: consecutive query batches
     // that share one K/V batch entry (beam rows of one commit share the encoder memory)
-    __shared__ int sm_kv[MAX_TK];
     __shared__ float sm_red[NW][32];
     __shared__ float sm_o[NW > 1 ? NW * 1024 : 1];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -85,82 +131,59 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
             O[((size_t)qb + idx / FIRA_DH) * ldo + h * FIRA_DH + idx % FIRA_DH] = 0.f;
         return;
     }
-    const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)bk * kvb);
+    // this (batch entry, head)'s slices behind buffer descriptors: the base is wave-uniform (scalar address arithmetic), a lane
+    // adds a 32-bit byte offset, and rows outside [0, tq) / [0, tk) read zeros and drop their stores -- no clamps, no
+    // zero-fills of the edge rows and no branch around any memory instruction
     const size_t krow0 = selfk ? (size_t)qb : (k_off ? (size_t)k0 : (size_t)bk * kb);
-    K += krow0 * ldk;                                // this batch entry's key/value rows
-    V += krow0 * ldv;
+    const rsrc_t rQ = rows_rsrc(Q + (size_t)qb * ldq + h * FIRA_DH, tq, ldq);
+    const rsrc_t rK = rows_rsrc(K + krow0 * ldk + h * FIRA_DH, tk, ldk);
+    const rsrc_t rV = rows_rsrc(V + krow0 * ldv + h * FIRA_DH, tk, ldv);
+    const rsrc_t rO = rows_rsrc(O + (size_t)qb * ldo + h * FIRA_DH, tq, ldo);
+    const rsrc_t rM = buf_rsrc(key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)bk * kvb), (unsigned)tk * 4u);
+    const unsigned ldk4 = (unsigned)ldk * 4u, ldv4 = (unsigned)ldv * 4u, ldo4 = (unsigned)ldo * 4u;
+    const int kt = wave;                             // the wave's key tile (one per wave: Tk <= NW * 32)
+    const bool mine = kt < NT;                       // (wave-uniform: a wave without a key tile requests nothing)
 
-    // every operand of the wave is requested here, before the key mask has reached LDS: the fragments of masked keys are
-    // zeroed afterwards instead of not being loaded (one memory round trip instead of three; see the backward kernel)
-    float bq[16];
-    load_frag(bq, Q + ((size_t)qb + min(l31, tq - 1)) * ldq + h * FIRA_DH + kh * 16, true);
-    float ak[TPW][16], vv[TPW][16];                  // K fragment of key tile*32 + l31; V rows of key acc_row(s,kh)
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        if (kt < NT) {                               // (wave-uniform: a wave without a key tile requests nothing)
-            load_frag(ak[i], K + (size_t)min(kt * 32 + l31, tk - 1) * ldk + h * FIRA_DH + kh * 16, true);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) vv[i][s] = V[(size_t)min(kt * 32 + acc_row(s, kh), tk - 1) * ldv + h * FIRA_DH + l31];
-        } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { ak[i][s] = 0.f; vv[i][s] = 0.f; }
-        }
+    // every operand of the wave and its slice of the key mask, one round trip
+    float bq[16], ak[16], vv[16];                    // Q / K fragments [row = lane&31][kh*16 + s]; V rows of key acc_row(s,kh)
+    int kvld = 0;
+    buf_frag(bq, rQ, (unsigned)l31 * (unsigned)ldq * 4u + (unsigned)kh * 64u);
+    if (mine) {
+        buf_frag(ak, rK, (unsigned)(kt * 32 + l31) * ldk4 + (unsigned)kh * 64u);
+        buf_rows(vv, rV, (unsigned)(kt * 32 + 4 * kh) * ldv4 + (unsigned)l31 * 4u, ldv4);
+        kvld = __builtin_amdgcn_raw_buffer_load_b32(rM, (unsigned)(kt * 32 + l31) * 4u, 0, 0);
     }
-    // the key mask travels in the SAME round trip, behind the operand requests (round 4: it used to be fetched and parked in
-    // LDS before the first operand load was issued -- one more dependent round trip)
-    asm volatile("" ::: "memory");
-    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
-    __syncthreads();
-    if (l31 >= tq) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) bq[s] = 0.f;
-    }
-    // live[i]: the wave's key tile holds at least one unmasked key.  A tile without one contributes nothing: its scores are
-    // the constant -1e9, its soft-max weights exp(-1e9 - max) are exactly 0 next to any real score (and its V fragment is
-    // zero-filled anyway), so both MFMA chains are skipped -- on FIRA-shaped batches about half of the twelve memory tiles
-    // (padding behind the code tokens and behind the sub-tokens), which halves the load of the SIMD's MFMA pipe.
-    bool live[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        const int key = kt * 32 + l31;
-        const bool ok = kt < NT && key < tk && sm_kv[key < tk ? key : 0] != 0;
-        live[i] = __ballot(ok) != 0;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int kr = kt * 32 + acc_row(s, kh);
-            if (!ok) ak[i][s] = 0.f;
-            if (!(kt < NT && kr < tk && sm_kv[kr < tk ? kr : 0] != 0)) vv[i][s] = 0.f;
-        }
-    }
+    // A tile without an unmasked key contributes nothing: its scores are the constant -1e9, its soft-max weights
+    // exp(-1e9 - max) are exactly 0 next to any real score, so both MFMA chains are skipped -- on FIRA-shaped dense batches
+    // about half of the twelve memory tiles (with ragged key rows: none but the commit's last).
+    const TileMask tm = tile_mask(kvld, tk - kt * 32, kh);
+    const bool live = mine && tm.live;
+    // masked(row c) = key masked, or (causal) key row kt*32 + 4 kh + c  >  query l31 + q_pos0
+    const uint32_t maskedT = ~tm.valid | (causal ? ~low_bits(l31 + q_pos0 - kt * 32 - 4 * kh + 1) : 0u);
 
-    f32x16 st[TPW];
+    f32x16 st;
     float mx = -INFINITY;
+    if (live) {
+        // rows of masked keys are zero-filled: callers may leave them uninitialised (their weight is exactly 0)
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
+        for (int s = 0; s < 16; ++s) vv[s] = bit_select(bit_of(tm.valid, acc_c(s)), vv[s], 0.f);
+        f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
-        if (kt < NT && live[i]) {
-            f32x16 acc;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = chain16<BF>(ak, bq, acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = chain16<BF>(ak[i], bq, acc);
+        for (int r = 0; r < 16; ++r) {
+            float x = bit_select(bit_of(maskedT, acc_c(r)), MASKED2, acc[r] * SCORE2);
+            x = bit_select(bit_of(tm.outside, acc_c(r)), -INFINITY, x);
+            st[r] = x;
+            mx = fmaxf(mx, x);
+        }
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bool masked;
-                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, tk, sm_kv, causal, q_pos0, masked);
-                st[i][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        } else if (kt < NT) {                            // every key masked: the scores mask_score would return
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = kt * 32 + acc_row(r, kh) < tk ? -1e9f : -INFINITY;
-                st[i][r] = x;
-                mx = fmaxf(mx, x);
-            }
+        for (int r = 0; r < 16; ++r) {               // every key masked (or no tile): the scores the branch above would give
+            const float x = mine ? bit_select(bit_of(tm.outside, acc_c(r)), -INFINITY, MASKED2) : -INFINITY;
+            st[r] = x;
+            mx = fmaxf(mx, x);
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -173,13 +196,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = expf(st[i][r] - mx);       // exp(-inf) = 0 for keys beyond Tk / tiles not owned
-            st[i][r] = p;
-            sum += p;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[r] - mx);      // exp2(-inf) = 0 for keys beyond Tk / waves without a tile
+        st[r] = p;
+        sum += p;
+    }
     sum += __shfl_xor(sum, 32, 64);
     if (NW > 1) {
         if (kh == 0) sm_red[wave][l31] = sum;
@@ -192,15 +213,11 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    if (live) {
+        float pn[16];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        if (kt < NT && live[i]) {
-            float pn[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) pn[s] = st[i][s] * inv_sum;
-            o = chain16<BF>(pn, vv[i], o);
-        }
+        for (int s = 0; s < 16; ++s) pn[s] = st[s] * inv_sum;
+        o = chain16<BF>(pn, vv, o);
     }
     // o[r]: query = acc_row(r, kh), d = l31
     if (NW > 1) {
@@ -212,37 +229,34 @@ __global__ __launch_bounds__(NW * 64) void attention_fwd_kernel(int H, int Tq, i
         __syncthreads();
         for (int idx = t; idx < 1024; idx += NW * 64) {
             float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) if (w < nwa) v += sm_o[w * 1024 + idx];
+            for (int w = 0; w < nwa; ++w) v += sm_o[w * 1024 + idx];
             const int r = idx >> 6, ln = idx & 63;
-            const int q = acc_row(r, ln >> 5);
-            if (q < tq) O[((size_t)qb + q) * ldo + h * FIRA_DH + (ln & 31)] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rO,
+                                                  (unsigned)acc_row(r, ln >> 5) * ldo4 + (unsigned)(ln & 31) * 4u, 0, 0);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = acc_row(r, kh);
-            if (q < tq) O[((size_t)qb + q) * ldo + h * FIRA_DH + l31] = o[r];
-        }
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(o[r]), rO,
+                                                  (unsigned)(4 * kh + acc_c(r)) * ldo4 + (unsigned)l31 * 4u, 0, 0);
     }
 }
 
 // Backward.  Every operand a wave needs -- its K / V fragments, the K rows of its key tile, the query-side fragments and
-// rows -- is requested at the top of the kernel, before the key mask has even reached LDS: the fragments of masked keys
-// are zeroed afterwards instead of not being loaded (their rows lie inside the caller's buffers), so the kernel waits for
-// ONE memory round trip instead of one per phase (round 2 loaded K and V twice, phase by phase, behind the mask).
-template <int NW, int TPW, bool BF>
+// rows, its slice of the key mask -- is requested at the top of the kernel in ONE memory round trip (round 2 loaded K and V
+// twice, phase by phase, behind the mask; round 3 staged the mask and the transposed query tiles through LDS behind a
+// barrier).  Masked keys' fragments are zeroed afterwards instead of not being loaded (their rows lie inside the caller's
+// buffers).
+template <int NW, bool BF>
 __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     int H, int Tq, int Tk, const float* __restrict__ Q, int ldq, const float* __restrict__ K, int ldk,
     const float* __restrict__ V, int ldv, const int32_t* __restrict__ key_valid, int causal, int q_pos0,
     const float* __restrict__ O, int ldo, const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq,
     float* __restrict__ dK, int lddk, float* __restrict__ dV, int lddv, const int32_t* __restrict__ q_off, int self_kv,
     const int32_t* __restrict__ k_off) {             // k_off: ragged key rows, see attention_fwd_kernel
-    __shared__ int sm_kv[MAX_TK];
     __shared__ float sm_red[NW][32];
-    __shared__ float sm_m[32], sm_sum[32], sm_delta[32];
+    __shared__ __attribute__((aligned(16))) float sm_m[32], sm_sum[32], sm_delta[32];
     __shared__ float sm_o[NW > 1 ? NW * 1024 : 1];
-    __shared__ float sm_q[32 * 33], sm_do[32 * 33];             // Q and dO tiles [query][d] (pitch 33) for phase N's row operands
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -256,60 +270,41 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
             dQ[((size_t)qb + idx / FIRA_DH) * lddq + h * FIRA_DH + idx % FIRA_DH] = 0.f;
         return;
     }
-    const int32_t* kvp = key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)b * Tk);
+    const rsrc_t rQ = rows_rsrc(Q + (size_t)qb * ldq + h * FIRA_DH, tq, ldq);
+    const rsrc_t rO = rows_rsrc(O + (size_t)qb * ldo + h * FIRA_DH, tq, ldo);
+    const rsrc_t rdO = rows_rsrc(dO + (size_t)qb * lddo + h * FIRA_DH, tq, lddo);
+    const rsrc_t rdQ = rows_rsrc(dQ + (size_t)qb * lddq + h * FIRA_DH, tq, lddq);
+    const rsrc_t rK = rows_rsrc(K + kbase * ldk + h * FIRA_DH, tk, ldk);
+    const rsrc_t rV = rows_rsrc(V + kbase * ldv + h * FIRA_DH, tk, ldv);
+    const rsrc_t rdK = rows_rsrc(dK + kbase * lddk + h * FIRA_DH, tk, lddk);
+    const rsrc_t rdV = rows_rsrc(dV + kbase * lddv + h * FIRA_DH, tk, lddv);
+    const rsrc_t rM = buf_rsrc(key_valid + (k_off && !selfk ? (size_t)k0 : (size_t)b * Tk), (unsigned)tk * 4u);
+    const unsigned ldq4 = (unsigned)ldq * 4u, ldk4 = (unsigned)ldk * 4u, ldv4 = (unsigned)ldv * 4u;
+    const unsigned lddo4 = (unsigned)lddo * 4u, lddq4 = (unsigned)lddq * 4u, lddk4 = (unsigned)lddk * 4u, lddv4 = (unsigned)lddv * 4u;
+    const int kt = wave;
+    const bool mine = kt < NT;
 
-    // ---- all operands, one round trip (rows past the end are clamped to a real row and zeroed below) ----------
-    const int ql = min(l31, tq - 1);
+    // ---- all operands, one round trip (rows past the end read zeros) ---------------------------------------------------
     float bq[16], bdo[16], bo[16];                   // fragments X[query = lane&31][kh*16 + s]
-    load_frag(bq, Q + ((size_t)qb + ql) * ldq + h * FIRA_DH + kh * 16, true);
-    load_frag(bdo, dO + ((size_t)qb + ql) * lddo + h * FIRA_DH + kh * 16, true);
-    load_frag(bo, O + ((size_t)qb + ql) * ldo + h * FIRA_DH + kh * 16, true);
-    float ak[TPW][16], av[TPW][16], kvv[TPW][16];    // K / V fragments of key = tile*32 + l31; K rows of key acc_row(s,kh)
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        if (kt < NT) {                               // (wave-uniform: a wave without a key tile requests nothing)
-            const int key = min(kt * 32 + l31, tk - 1);
-            load_frag(ak[i], K + (kbase + key) * ldk + h * FIRA_DH + kh * 16, true);
-            load_frag(av[i], V + (kbase + key) * ldv + h * FIRA_DH + kh * 16, true);
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int kr = min(kt * 32 + acc_row(s, kh), tk - 1);
-                kvv[i][s] = K[(kbase + kr) * ldk + h * FIRA_DH + l31];
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { ak[i][s] = 0.f; av[i][s] = 0.f; kvv[i][s] = 0.f; }
-        }
+    const unsigned fq = (unsigned)kh * 64u;
+    buf_frag(bq, rQ, (unsigned)l31 * ldq4 + fq);
+    buf_frag(bdo, rdO, (unsigned)l31 * lddo4 + fq);
+    buf_frag(bo, rO, (unsigned)l31 * (unsigned)ldo * 4u + fq);
+    float ak[16], av[16], kvv[16];                   // K / V fragments of key = tile*32 + l31; K rows of key acc_row(s,kh)
+    float qrow[16], dorow[16];                       // Q / dO rows of query acc_row(s,kh), column d = l31 (phase N's B operands)
+    int kvld = 0;
+    if (mine) {
+        const unsigned krow = (unsigned)(kt * 32 + l31);
+        buf_frag(ak, rK, krow * ldk4 + fq);
+        buf_frag(av, rV, krow * ldv4 + fq);
+        buf_rows(kvv, rK, (unsigned)(kt * 32 + 4 * kh) * ldk4 + (unsigned)l31 * 4u, ldk4);
+        kvld = __builtin_amdgcn_raw_buffer_load_b32(rM, krow * 4u, 0, 0);
+        buf_rows(qrow, rQ, (unsigned)(4 * kh) * ldq4 + (unsigned)l31 * 4u, ldq4);
+        buf_rows(dorow, rdO, (unsigned)(4 * kh) * lddo4 + (unsigned)l31 * 4u, lddo4);
     }
-    asm volatile("" ::: "memory");                   // the key mask rides behind the operand requests (see the forward kernel)
-    for (int i = t; i < tk; i += NW * 64) sm_kv[i] = kvp[i];
-    __syncthreads();
-    if (l31 >= tq) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) { bq[s] = 0.f; bdo[s] = 0.f; bo[s] = 0.f; }
-    }
-    if (wave == 0) {                                 // the same tiles, transposed access in phase N: through LDS
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            sm_q[l31 * 33 + kh * 16 + s] = bq[s];
-            sm_do[l31 * 33 + kh * 16 + s] = bdo[s];
-        }
-    }
-    bool live[TPW];                                  // see attention_fwd_kernel: tiles without an unmasked key skip their MFMA chains
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        const int key = kt * 32 + l31;
-        const bool ok = kt < NT && key < tk && sm_kv[key < tk ? key : 0] != 0;
-        live[i] = __ballot(ok) != 0;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int kr = kt * 32 + acc_row(s, kh);
-            if (!ok) { ak[i][s] = 0.f; av[i][s] = 0.f; }
-            if (!(kt < NT && kr < tk && sm_kv[kr < tk ? kr : 0] != 0)) kvv[i][s] = 0.f;
-        }
-    }
+    const TileMask tm = tile_mask(kvld, tk - kt * 32, kh);
+    const bool live = mine && tm.live;               // see attention_fwd_kernel: tiles without an unmasked key skip their chains
+    const uint32_t maskedT = ~tm.valid | (causal ? ~low_bits(l31 + q_pos0 - kt * 32 - 4 * kh + 1) : 0u);
     float delta;
     {
         float d = 0.f;
@@ -319,32 +314,32 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     }
 
     // ---- statistics (identical to the forward) -------------------------------------------------
-    f32x16 st[TPW];
+    f32x16 st;
     float mx = -INFINITY;
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
+        for (int s = 0; s < 16; ++s) kvv[s] = bit_select(bit_of(tm.valid, acc_c(s)), kvv[s], 0.f);
+        if (!tm.ok) {                                // (lane predicate: a masked key's K / V rows may be uninitialised)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[i][r] = -INFINITY;
-        if (kt < NT && live[i]) {
-            f32x16 acc;
+            for (int s = 0; s < 16; ++s) { ak[s] = 0.f; av[s] = 0.f; }
+        }
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            acc = chain16<BF>(ak[i], bq, acc);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = chain16<BF>(ak, bq, acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bool masked;
-                const float x = mask_score(acc[r], kt * 32 + acc_row(r, kh), l31, tk, sm_kv, causal, q_pos0, masked);
-                st[i][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        } else if (kt < NT) {
+        for (int r = 0; r < 16; ++r) {
+            float x = bit_select(bit_of(maskedT, acc_c(r)), MASKED2, acc[r] * SCORE2);
+            x = bit_select(bit_of(tm.outside, acc_c(r)), -INFINITY, x);
+            st[r] = x;
+            mx = fmaxf(mx, x);
+        }
+    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = kt * 32 + acc_row(r, kh) < tk ? -1e9f : -INFINITY;
-                st[i][r] = x;
-                mx = fmaxf(mx, x);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float x = mine ? bit_select(bit_of(tm.outside, acc_c(r)), -INFINITY, MASKED2) : -INFINITY;
+            st[r] = x;
+            mx = fmaxf(mx, x);
         }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -357,13 +352,11 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = expf(st[i][r] - mx);
-            st[i][r] = p;
-            sum += p;
-        }
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[r] - mx);
+        st[r] = p;
+        sum += p;
+    }
     sum += __shfl_xor(sum, 32, 64);
     if (NW > 1) {
         if (kh == 0) sm_red[wave][l31] = sum;
@@ -373,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         for (int w = 0; w < NW; ++w) sum += sm_red[w][l31];
     }
     const float inv_sum = 1.0f / sum;
-    if (wave == 0 && kh == 0) {
+    if (wave == 0 && kh == 0) {                      // per-query statistics, for phase N's register-row = query layout
         sm_m[l31] = mx;
         sm_sum[l31] = inv_sum;                       // reciprocal of the soft-max denominator
         sm_delta[l31] = delta;
@@ -384,24 +377,17 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
     f32x16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+    if (live) {                                      // a tile of masked keys: dS = 0, nothing flows into dQ
+        f32x16 dpt;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        if (kt < NT && live[i]) {                      // a tile of masked keys: dS = 0, nothing flows into dQ
-            f32x16 dpt;
+        for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
+        dpt = chain16<BF>(av, bdo, dpt);                                     // dP^T = V dO^T
+        float dsv[16];
+        const float sc = inv_sum * INV_SQRT_DH;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dpt[r] = 0.f;
-            dpt = chain16<BF>(av[i], bdo, dpt);                                     // dP^T = V dO^T
-            float dsv[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int kr = kt * 32 + acc_row(s, kh);
-                const bool dead = kr >= tk || sm_kv[kr < tk ? kr : 0] == 0 || (causal && kr > l31 + q_pos0);
-                const float p = st[i][s] * inv_sum;
-                dsv[s] = dead ? 0.f : p * (dpt[s] - delta) * INV_SQRT_DH;
-            }
-            dq = chain16<BF>(dsv, kvv[i], dq);                                     // dQ += dS K
-        }
+        for (int s = 0; s < 16; ++s)
+            dsv[s] = bit_select(bit_of(maskedT, acc_c(s)), 0.f, st[s] * sc * (dpt[s] - delta));
+        dq = chain16<BF>(dsv, kvv, dq);                                      // dQ += dS K
     }
     if (NW > 1) {
         const int nwa = min(NW, NT);                 // waves that own a key tile
@@ -412,62 +398,60 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_kernel(
         __syncthreads();
         for (int idx = t; idx < 1024; idx += NW * 64) {
             float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) if (w < nwa) v += sm_o[w * 1024 + idx];
+            for (int w = 0; w < nwa; ++w) v += sm_o[w * 1024 + idx];
             const int r = idx >> 6, ln = idx & 63;
-            const int q = acc_row(r, ln >> 5);
-            if (q < tq) dQ[((size_t)qb + q) * lddq + h * FIRA_DH + (ln & 31)] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rdQ,
+                                                  (unsigned)acc_row(r, ln >> 5) * lddq4 + (unsigned)(ln & 31) * 4u, 0, 0);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = acc_row(r, kh);
-            if (q < tq) dQ[((size_t)qb + q) * lddq + h * FIRA_DH + l31] = dq[r];
-        }
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(dq[r]), rdQ,
+                                                  (unsigned)(4 * kh + acc_c(r)) * lddq4 + (unsigned)l31 * 4u, 0, 0);
     }
 
     // ---- phase N (register row = query, lane column = key): dK, dV ---------------------------------
-    float qrow[16], dorow[16];              // B operands: X[query = acc_row(s,kh)][d = l31] (rows >= tq are zero)
+    if (mine) {
+        f32x16 dk, dv;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        qrow[s] = sm_q[acc_row(s, kh) * 33 + l31];
-        dorow[s] = sm_do[acc_row(s, kh) * 33 + l31];
-    }
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+        if (live) {
+            // statistics of query 4 kh + c(s): four 16-byte LDS reads per vector (c(s) runs over 4 groups of 4 consecutive rows)
+            float qm[16], qs[16], qd[16];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int kt = wave + i * NW;
-        if (kt < NT) {
-            const int key = kt * 32 + l31;
+            for (int g = 0; g < 4; ++g) {
+                const f32x4v m4 = *reinterpret_cast<const f32x4v*>(&sm_m[4 * kh + 8 * g]);
+                const f32x4v s4 = *reinterpret_cast<const f32x4v*>(&sm_sum[4 * kh + 8 * g]);
+                const f32x4v d4 = *reinterpret_cast<const f32x4v*>(&sm_delta[4 * kh + 8 * g]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { qm[4 * g + j] = m4[j]; qs[4 * g + j] = s4[j]; qd[4 * g + j] = d4[j]; }
+            }
             f32x16 sN, dpN;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sN[r] = 0.f; dpN[r] = 0.f; }
-            f32x16 dk, dv;
+            sN = chain16<BF>(bq, ak, sN);                // S   = Q K^T
+            dpN = chain16<BF>(bdo, av, dpN);             // dP  = dO V^T
+            // masked(query row c) = key masked, or (causal) key > query 4 kh + c + q_pos0
+            const int key = kt * 32 + l31;
+            const uint32_t maskedN = tm.ok ? (causal ? low_bits(key - q_pos0 - 4 * kh) : 0u) : 0xffffffffu;
+            const float gone = key < tk ? MASKED2 : -INFINITY;
+            float pv[16], dsn[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-            if (live[i]) {
-                sN = chain16<BF>(bq, ak[i], sN);             // S   = Q K^T
-                dpN = chain16<BF>(bdo, av[i], dpN);          // dP  = dO V^T
-                float pv[16], dsn[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int q = acc_row(s, kh);
-                    bool masked;
-                    const float x = mask_score(sN[s], key, q, tk, sm_kv, causal, q_pos0, masked);
-                    const float p = expf(x - sm_m[q]) * sm_sum[q];
-                    pv[s] = p;
-                    dsn[s] = masked ? 0.f : p * (dpN[s] - sm_delta[q]) * INV_SQRT_DH;
-                }
-                dk = chain16<BF>(dsn, qrow, dk);          // dK += dS^T Q
-                dv = chain16<BF>(pv, dorow, dv);          // dV += P^T dO
-            }                                             // (a tile of masked keys: its dK / dV rows are zero)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kr = kt * 32 + acc_row(r, kh);
-                if (kr < tk) {
-                    dK[(kbase + kr) * lddk + h * FIRA_DH + l31] = dk[r];
-                    dV[(kbase + kr) * lddv + h * FIRA_DH + l31] = dv[r];
-                }
+            for (int s = 0; s < 16; ++s) {
+                const int sel = bit_of(maskedN, acc_c(s));
+                const float x = bit_select(sel, gone, sN[s] * SCORE2);
+                const float p = __builtin_amdgcn_exp2f(x - qm[s]) * qs[s];
+                pv[s] = p;
+                dsn[s] = bit_select(sel, 0.f, p * (dpN[s] - qd[s]) * INV_SQRT_DH);
             }
+            dk = chain16<BF>(dsn, qrow, dk);             // dK += dS^T Q
+            dv = chain16<BF>(pv, dorow, dv);             // dV += P^T dO
+        }                                                // (a tile of masked keys: its dK / dV rows are zero)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned row = (unsigned)(kt * 32 + 4 * kh + acc_c(r));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(dk[r]), rdK, row * lddk4 + (unsigned)l31 * 4u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(dv[r]), rdV, row * lddv4 + (unsigned)l31 * 4u, 0, 0);
         }
     }
 }
@@ -677,7 +661,7 @@ int attention_fwd_ex(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q
     if (int e = check_geometry("attention_fwd", Tq, Tk, ldq, ldk, ldv, Q, K, V)) return e;
     FIRA_REQUIRE(kb >= Tk && kvb >= Tk && qpk >= 1, "attention_fwd: bad batch strides");
 #define FIRA_ATT_FWD(NW_, BF_)                                                                                      \
-    hipLaunchKernelGGL((attention_fwd_kernel<NW_, 1, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
+    hipLaunchKernelGGL((attention_fwd_kernel<NW_, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
                        ldv, key_valid, causal, q_pos0, O, ldo, kb, kvb, qpk, q_off, self_kv, k_off)
     if (Tk <= 32) { if (bf16) FIRA_ATT_FWD(1, true); else FIRA_ATT_FWD(1, false); }
     else { if (bf16) FIRA_ATT_FWD(12, true); else FIRA_ATT_FWD(12, false); }
@@ -702,7 +686,7 @@ int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, i
     FIRA_REQUIRE(ldo % 4 == 0 && lddo % 4 == 0 && (uintptr_t)O % 16 == 0 && (uintptr_t)dO % 16 == 0,
                  "attention_bwd: O/dO rows must be 16-byte aligned");
 #define FIRA_ATT_BWD(NW_, BF_)                                                                                      \
-    hipLaunchKernelGGL((attention_bwd_kernel<NW_, 1, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
+    hipLaunchKernelGGL((attention_bwd_kernel<NW_, BF_>), dim3(B * H), dim3(NW_ * 64), 0, s, H, Tq, Tk, Q, ldq, K, ldk, V, \
                        ldv, key_valid, causal, q_pos0, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, q_off, self_kv, k_off)
     if (Tk <= 32) { if (bf16) FIRA_ATT_BWD(1, true); else FIRA_ATT_BWD(1, false); }
     else { if (bf16) FIRA_ATT_BWD(12, true); else FIRA_ATT_BWD(12, false); }

@@ -7,6 +7,7 @@ which a FIRA-shaped prefix of the code tokens (<= 210) and of the sub-tokens (<=
 layout:
     dense   K | V rows inside a [B*370, pitch] buffer, padded slots masked (the round-3 engine layout)
     ragged  the valid rows only, commit after commit ([n_valid, pitch]), key ranges through k_off (round 4)
+    self    the decoder's causal self-attention: q | k | v are column slices of one [R, 768] buffer of the compact target rows
 pitch 3136 = 6 layers x 512 + 64 pad (the engine's); 3072 = unpadded; 512 = one buffer per layer.
 Rotates over enough buffers to leave the last-level cache, times forward and backward with HIP events, and prints the
 microseconds per launch together with the bytes and the MFMA work a launch has, so that the number can be put against a roof:
@@ -22,6 +23,46 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fira_icse_amd import ops  # noqa: E402
+
+
+def self_probe(B, dev, q_off, R):
+    T, H = 30, 8
+    qo = torch.from_numpy(q_off).to(dev)
+    valid = torch.ones(B * T, dtype=torch.int32, device=dev)
+    bufs = [torch.randn(R, 768, device=dev) * 0.5 for _ in range(8)]
+    do = torch.randn(R, 256, device=dev) * 0.1
+    tiles = B * H
+    for name, bwd, chains in (("forward", False, 2), ("forward + backward", True, 9)):
+        def run(i):
+            x = bufs[i % 8]
+            q, k, v = x[:, :256], x[:, 256:512], x[:, 512:]
+            o = ops.attention_ragged_fwd(q, k, v, valid, qo, T, T, causal=True, self_kv=True)
+            if bwd:
+                ops.attention_ragged_bwd(q, k, v, valid, o, do, qo, T, T, causal=True, self_kv=True)
+        def wrapper_only():
+            torch.zeros_like(do)
+            if bwd:
+                torch.full_like(bufs[0][:, :256], 0.0); torch.full_like(bufs[0][:, :256], 0.0); torch.full_like(bufs[0][:, :256], 0.0)
+        for i in range(6):
+            run(i)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 100
+        a.record()
+        for i in range(n):
+            run(i)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / n
+        a.record()
+        for i in range(n):
+            wrapper_only()
+        b.record()
+        torch.cuda.synchronize()
+        us_w = a.elapsed_time(b) * 1e3 / n
+        flop = tiles * chains * 2 * 32 * 32 * 32
+        print("%-20s self batch %d: %.1f us per launch (%.1f incl. the wrapper's fills), %d rows, %.3f GFLOP" %
+              (name, B, max(us - us_w, 1e-3), us, R, flop / 1e9))
 
 
 def main():
@@ -42,6 +83,8 @@ def main():
     q_off[1:] = np.cumsum(tq)
     R = int(q_off[-1])
     n_valid = int(valid.sum())
+    if layout == "self":
+        return self_probe(B, dev, q_off, R)
     if layout == "ragged":
         k_off_np = np.zeros(B + 1, np.int32)
         k_off_np[1:] = np.cumsum(valid.sum(1))

@@ -36,7 +36,12 @@ for ST in "$@"; do
       for L in "3136 dense" "3136 ragged" "3072 ragged" "512 ragged" "256 ragged"; do
         timeout 120 python scripts/attn_probe.py 32 $L 2>&1 | grep "us per launch"
       done | tee $OUT/attn_probe.txt
-      timeout 120 python scripts/attn_probe.py 64 3136 ragged 2>&1 | grep "us per launch" | tee -a $OUT/attn_probe.txt ;;
+      timeout 120 python scripts/attn_probe.py 64 3136 ragged 2>&1 | grep "us per launch" | tee -a $OUT/attn_probe.txt
+      timeout 120 python scripts/attn_probe.py 32 768 self 2>&1 | grep "us per launch" | tee -a $OUT/attn_probe.txt ;;
+    probeprev)   # the same probe on the previous build
+      for L in "32 3136 ragged" "64 3136 ragged" "32 768 self"; do
+        FIRA_HIP_LIB=$PREV timeout 120 python scripts/attn_probe.py $L 2>&1 | grep "us per launch"
+      done | tee $OUT/attn_probe_prev.txt ;;
     nwprobe)
       for NW in 12 6 4; do
         echo "FIRA_ATTN_NW=$NW"; FIRA_ATTN_NW=$NW timeout 120 python scripts/attn_probe.py 32 3136 ragged 2>&1 | grep "us per launch"

@@ -851,9 +851,12 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(gemm_any(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
                         nullptr));
         if (so) TRY(side_mark(&ev_dfc));
+    }
+    // (the vocabulary projection's weight gradient, the step's largest product, is forked HERE, under the copy branch: forked
+    // behind the join of the head it ran under the decoder layers' small launches instead and the step lost 0.6 %, same box)
+    if (R > 0)
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec, D, G + L.wout,
                          G + L.bout));
-    }
     if (g_dtype == 0) TRY(rank2_rows(s, c.Td, p.gate, c.P + L.wp, p.ddec));        // ddec = dgate Wp: a rank-2 row kernel
     else TRY(linear_dgrad(s, c.Td, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad_grouped(s, c.Td, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));

@@ -168,14 +168,16 @@ __global__ __launch_bounds__(256) void embed_list_bwd_small_kernel(int n, const 
 // CombinationLayer (reference combination_layer.py:7-17): per element
 //   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
 // The head split/transposes of gnn_transformer.py:197-202 cancel.
+// The two-way soft-max with the maximum subtracted has one exponential equal to exp(0) = 1: with e = exp(-|a - b|) the larger
+// gate is 1 / (1 + e) and the smaller e / (1 + e) -- one v_exp_f32 and one v_rcp_f32 per element instead of two expf and an
+// IEEE division (these kernels are bound by their VALU instruction stream, not by memory).
 __device__ __forceinline__ void gate_elem(float q, float k, float v, float& g0, float& g1) {
     const float is = 1.0f / 5.656854249492381f;  // 1 / sqrt(32): reciprocal multiplies instead of divisions (<= 1 ulp)
     const float a = q * k * is, b = q * v * is;
-    const float m = fmaxf(a, b);
-    const float ea = expf(a - m), eb = expf(b - m);
-    const float iden = 1.0f / (ea + eb);
-    g0 = ea * iden;
-    g1 = eb * iden;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(a - b) * 1.4426950408889634f);
+    const float big = __builtin_amdgcn_rcpf(1.0f + e), small = e * big;
+    g0 = a >= b ? big : small;
+    g1 = a >= b ? small : big;
 }
 
 __global__ __launch_bounds__(256) void combination_fwd_kernel(int M, const float* __restrict__ qk,
@@ -241,6 +243,16 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
             d4[u] = *reinterpret_cast<const float4*>(dout + (size_t)r * FIRA_D + lane * 4);
             mk[u] = mark[r];
         }
+        // one row per wave: the mark is wave-uniform.  Its value row and its dv accumulator are picked ARITHMETICALLY with
+        // four scalar 0/1 weights (exact: one weight is 1, the others 0) -- as `mk == a ? .. : ..` chains on a vector register
+        // the compiler built a tree of 170 branches per four rows.
+        float w[COMB_RW][4];
+#pragma unroll
+        for (int u = 0; u < COMB_RW; ++u) {
+            const int m = __builtin_amdgcn_readfirstlane(mk[u]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) w[u][a] = m == a ? 1.0f : 0.0f;
+        }
 #pragma unroll
         for (int u = 0; u < COMB_RW; ++u) {
             const int r = r0 + u;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
             float dq[4], dk[4], dv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = mk[u] == 0 ? vt[0][e] : mk[u] == 1 ? vt[1][e] : mk[u] == 2 ? vt[2][e] : vt[3][e];
+                const float v = fmaf(w[u][0], vt[0][e], fmaf(w[u][1], vt[1][e], fmaf(w[u][2], vt[2][e], w[u][3] * vt[3][e])));
                 if (p > 0.f) dc[e] *= dropout_scale(seed, site, (uint32_t)r * FIRA_D + lane * 4 + e, p, inv_keep);
                 float g0, g1;
                 gate_elem(q[e], k[e], v, g0, g1);
@@ -265,10 +277,8 @@ __global__ __launch_bounds__(256) void combination_bwd_kernel(int M, const float
             *reinterpret_cast<float4*>(dqk + (size_t)r * 2 * FIRA_D + FIRA_D + lane * 4) = make_float4(dk[0], dk[1], dk[2], dk[3]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                if (mk[u] == a) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dv_acc[a][e] += dv[e];
-                }
+                for (int e = 0; e < 4; ++e) dv_acc[a][e] = fmaf(w[u][a], dv[e], dv_acc[a][e]);
         }
     }
 #pragma unroll

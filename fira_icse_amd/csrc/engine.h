@@ -48,6 +48,8 @@ int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int
 int gemm_group_flush(hipStream_t s);
 void gemm_group_reset();
 // coalesced 32x32 tile kernel (gemm_small.hip): shape test, launch with an optional residual epilogue (epilogue.h: EpiRes),
+// the stream whose gemm_f32 launches pad their LDS request (gemm_f32.hip: side_lds_pad)
+void gemm_set_pad_stream(hipStream_t s);
 // and the product with a LayerNorm prologue on its A operand (K = 256)
 struct EpiRes;
 bool gemm_tile32_takes(int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb);

@@ -377,6 +377,7 @@ struct SideStream {
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;   // no priorities: plain streams
         hipError_t e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least);
         if (e != hipSuccess) return set_err("hipStreamCreate: %s", hipGetErrorString(e));
+        gemm_set_pad_stream(stream);
         e = hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest);
         if (e != hipSuccess) return set_err("hipStreamCreateWithPriority: %s", hipGetErrorString(e));
         events.resize(512);

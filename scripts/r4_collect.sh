@@ -5,7 +5,7 @@
 TAG=${1:-r4final}; COMMIT=${2:-$(git rev-parse --short HEAD)}
 S=gpurun_out/$TAG
 VAL=$(python -c "import json;print(round(json.loads(open('$S/bench_f32.json').read().strip().splitlines()[-1])['value']))")
-STAMP="<!-- round 4, session $TAG, built from commit $COMMIT; this box: $VAL commits/s on the default bench line (pool classes: ~9 950 slow, ~10 900 fast) -->"
+STAMP="<!-- round 4, session $TAG, built from commit $COMMIT; this box: $VAL commits/s on the default bench line (pool classes at this commit: ~10 700 slow, ~11 400 fast) -->"
 stamp() { { echo "$STAMP"; echo; cat "$1"; } > "$2"; }
 for DT in f32 bf16; do
   [ -f $S/kernel_stats_$DT.md ] && stamp $S/kernel_stats_$DT.md profiles/r4_kernel_stats_$DT.md

@@ -566,11 +566,11 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
         for (int j = 0; j < NSLOT; ++j) {
             float d = q4.x * kf[j].x;
             d = fmaf(q4.y, kf[j].y, d); d = fmaf(q4.z, kf[j].z, d); d = fmaf(q4.w, kf[j].w, d);
-            d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+            d = sum8(d);                             // (DPP: common.h)
             sc[j] = have[j] ? d * INV_SQRT_DH : -INFINITY;
             mx = fmaxf(mx, sc[j]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = wave_max(mx);                           // (the 8 lanes of a key hold the same score)
         if (lane == 0) sm_f[wave][33] = mx;
         __syncthreads();
         mx = fmaxf(fmaxf(sm_f[0][33], sm_f[1][33]), fmaxf(sm_f[2][33], sm_f[3][33]));
@@ -583,8 +583,11 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
             acc += vf[j] * p;
         }
         // over the 8 key sub-rows of the wave (lanes with equal c), then over the 4 waves
+        sum += dpp_take<DPP_ROR8, 0xf>(sum, sum);      // lane ^ 8 inside the 16-lane row: one DPP instruction
+        acc.x += dpp_take<DPP_ROR8, 0xf>(acc.x, acc.x); acc.y += dpp_take<DPP_ROR8, 0xf>(acc.y, acc.y);
+        acc.z += dpp_take<DPP_ROR8, 0xf>(acc.z, acc.z); acc.w += dpp_take<DPP_ROR8, 0xf>(acc.w, acc.w);
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
+        for (int o = 16; o < 64; o <<= 1) {
             sum += __shfl_xor(sum, o, 64);
             acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
             acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);

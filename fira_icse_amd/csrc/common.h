@@ -71,15 +71,46 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint32_t site, uin
 }
 
 // ---------------------------------------------------------------- wave-level reductions (64 lanes)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Data-parallel-primitive (DPP) butterflies: a step is ONE VALU instruction whose operand comes from another lane of the same
+// 16-lane row (quad permutes for lane^1 / lane^2, row_half_mirror / row_mirror for the other quad / the other half -- after the
+// quad steps all lanes of a quad hold the same value, so a mirror is as good as an xor), then row_bcast:15 / row_bcast:31 carry
+// the row sums into lane 63 and a readlane broadcasts it.  As __shfl_xor every step was a ds_bpermute_b32: an LDS-crossbar
+// round trip (~100 cycles with its s_waitcnt) that the next step depends on -- 6 per reduction, 48 per wave in the row phase of
+// the fused GCN kernel, ~190 per wave in the copy-score forward.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143,
+              DPP_ROR8 = 0x128;          // row_ror:8 = lane ^ 8 inside a 16-lane row
+// sum over the 8 lanes lane&~7 .. lane|7, in every one of them
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_take<DPP_XOR1, 0xf>(v, v);
+    v += dpp_take<DPP_XOR2, 0xf>(v, v);
+    v += dpp_take<DPP_HALF_MIRROR, 0xf>(v, v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// sum over the 16 lanes of a row, in every one of them
+__device__ __forceinline__ float sum16(float v) {
+    v = sum8(v);
+    v += dpp_take<DPP_MIRROR, 0xf>(v, v);
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = sum16(v);
+    v += dpp_take<DPP_BCAST15, 0xa>(0.f, v);           // rows 1, 3 += lane 15 of the row before
+    v += dpp_take<DPP_BCAST31, 0xc>(0.f, v);           // rows 2, 3 += lane 31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_take<DPP_XOR1, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<DPP_XOR2, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<DPP_HALF_MIRROR, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<DPP_MIRROR, 0xf>(v, v));
+    v = fmaxf(v, dpp_take<DPP_BCAST15, 0xa>(v, v));    // (rows the mask leaves out keep their own value)
+    v = fmaxf(v, dpp_take<DPP_BCAST31, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 }  // namespace fira

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             int beg[GF_RPW], cnt[GF_RPW];
 #pragma unroll
             for (int i = 0; i < GF_RPW; ++i) {
-                beg[i] = __shfl(rp, i, 64);
-                cnt[i] = rbase + i < row_end ? __shfl(rp, i + 1, 64) - beg[i] : 0;
+                beg[i] = __builtin_amdgcn_readlane(rp, i);
+                cnt[i] = rbase + i < row_end ? __builtin_amdgcn_readlane(rp, i + 1) - beg[i] : 0;
             }
             // the first 16 (col, val) pairs of row i live in lanes 16 i .. 16 i + 15
             const int gi = lane >> 4, ge = lane & 15;
@@ -136,8 +136,10 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int src = i * 16 + jb + u;
-                        const int cj = __shfl(c, src, 64);
-                        w[i][u] = __shfl(v, src, 64);
+                        // (a wave-uniform source lane: v_readlane, the neighbour row's base address is scalar -- as __shfl each of these was a
+                        //  ds_bpermute round trip ahead of the load it addresses)
+                        const int cj = __builtin_amdgcn_readlane(c, src);
+                        w[i][u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
                         x[i][u] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)cj * FIRA_D + lane * 4);
                     }
 #pragma unroll
@@ -150,10 +152,10 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             }
             // row sums of A_hat (the rank-1 term's row factor): over the 16-lane group, then the rare tail
             float vs = v;
-            vs += __shfl_xor(vs, 1, 64); vs += __shfl_xor(vs, 2, 64); vs += __shfl_xor(vs, 4, 64); vs += __shfl_xor(vs, 8, 64);
+            vs = sum16(vs);
             float vsum[GF_RPW];
 #pragma unroll
-            for (int i = 0; i < GF_RPW; ++i) vsum[i] = __shfl(vs, i * 16, 64);
+            for (int i = 0; i < GF_RPW; ++i) vsum[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vs), i * 16));
             // rows with more than 16 entries (hub nodes): the remaining entries 64 at a time, as spmm_rowwave_kernel does
 #pragma unroll
             for (int i = 0; i < GF_RPW; ++i) {
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int sl = min(j + u, 63);
-                            const int cj = j + u < 64 ? __shfl(c2, sl, 64) : 0;
-                            w4[u] = j + u < 64 ? __shfl(v2, sl, 64) : 0.f;
+                            const int cj = j + u < 64 ? __builtin_amdgcn_readlane(c2, sl) : 0;
+                            w4[u] = j + u < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v2), sl)) : 0.f;
                             x4[u] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)cj * FIRA_D + lane * 4);
                         }
 #pragma unroll
@@ -185,8 +187,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) extra += __shfl_xor(extra, o, 64);
+                extra = wave_sum(extra);
                 vsum[i] += extra;
             }
 #pragma unroll

@@ -371,11 +371,11 @@ __global__ __launch_bounds__(256, 2) void linear_ln_bf16_kernel(int M, const flo
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        v = sum16(v);                                     // DPP (common.h): the 16-lane row sums, then rows 1 / 3 take
+        v += dpp_take<DPP_BCAST15, 0xa>(0.f, v);          // lane 15 of rows 0 / 2: lanes 16..31 and 48..63 hold the 32-lane sums
         mean[r] = v;
     }
-    if (l31 == 0) {
+    if (l31 == 16) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[0][rt][cg][(r & 3) + 8 * (r >> 2) + 4 * kh] = mean[r];
     }
@@ -391,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void linear_ln_bf16_kernel(int M, const flo
         float v = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const float d = acc[j][r] - mean[r]; v = fmaf(d, d, v); }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        v = sum16(v);                                     // DPP (common.h): the 16-lane row sums, then rows 1 / 3 take
+        v += dpp_take<DPP_BCAST15, 0xa>(0.f, v);          // lane 15 of rows 0 / 2: lanes 16..31 and 48..63 hold the 32-lane sums
         rstd[r] = v;
     }
-    if (l31 == 0) {
+    if (l31 == 16) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[1][rt][cg][(r & 3) + 8 * (r >> 2) + 4 * kh] = rstd[r];
     }

@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     if (LN_A) {
         static_assert(!LN_A || NCH == 2, "the LayerNorm prologue needs the whole row in the two chunks of the four waves");
         // this lane holds, of rows 8j + lr (j = 0..3), the four columns kc + ((ls ^ sw_j) << 2) .. + 3 of each chunk
-        auto sum8 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
         auto hsum = [](const f32x4 v) { return (v.x + v.y) + (v.z + v.w); };
         // columns of this lane: chunk c (k base kc = (wave + 4c) * 32), rows j even -> ls ^ sw_even, j odd -> ls ^ sw_odd.
         // gamma / beta are requested HERE, with the operand tiles still in flight (round 4: they used to be loaded after the two
@@ -325,7 +324,6 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     }
     if constexpr (LN_B) {
         static_assert(!LN_B || (NCH == 2 && !LN_A), "the LayerNorm-backward prologue needs the whole row in the two chunks of the four waves");
-        auto sum8 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
         auto hsum = [](const f32x4 v) { return (v.x + v.y) + (v.z + v.w); };
         const int ce = (ls ^ sw_even) << 2, co = (ls ^ sw_odd) << 2;
         const int k0 = wave << 5, k1 = (wave + 4) << 5;

@@ -536,7 +536,10 @@ static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const
 static int ln_bwd_dgrad(hipStream_t s, int M, int N, const float* dy, const float* sum, const float* stats, const float* gamma,
                         float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed, uint32_t st,
                         const float* W, int ldw, float* dX, int lddx, const float* relu_mask) {
-    if (g_dtype == 0 && ds != dy && gemm_tile32_takes(0, M, N, FIRA_D, dy, FIRA_D, W, ldw)) {
+    // Up to ~1 500 rows (batch 64): beyond, the prologue repeated in each of the N / 32 column tiles of a row block is no longer
+    // hidden by idle CUs (batch 170, 2 700 rows: 20 177 -> 20 567 commits/s without it; batch 64 neutral, batch 32 +0.5 % with it)
+    static const int lnb_max_rows = [] { const char* e = getenv("FIRA_LN_BWD_MAX_ROWS"); return e ? atoi(e) : 1536; }();
+    if (g_dtype == 0 && M <= lnb_max_rows && ds != dy && gemm_tile32_takes(0, M, N, FIRA_D, dy, FIRA_D, W, ldw)) {
         const int nb = gemm_tile32_lnb_blocks(M);
         float* part = red().alloc((size_t)nb * 2 * FIRA_D);
         int rc = 0;

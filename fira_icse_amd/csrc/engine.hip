@@ -613,6 +613,7 @@ struct Ctx {
     float* loss_sum = nullptr;      // zeroed by the prep launch (head_loss accumulates into them)
     int32_t* n_tok = nullptr;
     hipEvent_t ev_kv[16] = {};
+    int kv_waited = 0;
     hipEvent_t ev_src = nullptr;
     hipEvent_t ev_zero = nullptr;   // the backward pass's zero-initialised buffers were cleared on the auxiliary stream
 };
@@ -715,7 +716,11 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const size_t o = (size_t)l * 2 * D;
             TRY(gemm_any(ss, 0, 1, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, D, p.kv_all + o, p.kvp, c.P + L.bkv_all + o, 0,
                          0, nullptr));
-            TRY(side_mark(&c.ev_kv[l]));
+            // two marks (behind layers 1 and the last one) instead of one per layer: every wait is a barrier packet in the
+            // decoder's dependent chain, and the projections (~10 us each) are far ahead of the layers that read them
+            // (layer 2's cross attention starts ~170 us after this fork).  FIRA_KV_MARKS=6: one per layer (A/B switch)
+            static const bool per_layer = [] { const char* e = getenv("FIRA_KV_MARKS"); return e && e[0] == '6'; }();
+            if (per_layer || l == std::min(1, p.nl - 1) || l == p.nl - 1) TRY(side_mark(&c.ev_kv[l]));
         }
         // (LinearSource: output rows straight to their dense [B,370] slots through the row map of the GEMM epilogue)
         TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
@@ -778,7 +783,15 @@ static int decoder_forward(Ctx& c) {
                         site(l, SITE_SELF), true, nullptr, nullptr, 0, nullptr));
         x = e.x_a;
         TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
-        if (c.deferred) TRY(main_wait(s, c.ev_kv[l]));             // this layer's K|V rows (side stream)
+        // this layer's K|V rows (auxiliary stream): the first mark at or behind the layer, waited for once
+        if (c.deferred) {
+            int m = l;
+            while (m < p.nl - 1 && c.ev_kv[m] == nullptr) ++m;     // the first mark at or behind this layer
+            if (c.ev_kv[m] != nullptr && c.kv_waited < m + 1) {
+                TRY(main_wait(s, c.ev_kv[m]));
+                c.kv_waited = m + 1;                               // layers < kv_waited are covered
+            }
+        }
         TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
                           c.kv_ragged ? p.mem_valid_c : p.mem_valid, 0, 0, e.ao2, D, c.dec_off, 0, attn_bf16(),
                           c.kv_ragged ? p.mem_off : nullptr));

@@ -45,19 +45,4 @@ __device__ __forceinline__ f32x16 chain16(const float (&a)[16], const float (&b)
 
 __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
-// fragment X[row][col0 + kh*16 + s], s = 0..15; zero when !valid
-__device__ __forceinline__ void load_frag(float (&f)[16], const float* __restrict__ base, bool valid) {
-    if (valid) {
-        const float4* p = reinterpret_cast<const float4*>(base);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 v = p[i];
-            f[4 * i + 0] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) f[i] = 0.f;
-    }
-}
-
 }  // namespace fira

@@ -142,26 +142,48 @@ __global__ __launch_bounds__(256) void embed_gather_bwd_small_kernel(int rows, i
 }
 
 // List form of the small-table scatter: (compact node row, table id) pairs instead of the dense [B, L] id array.
+// Round 5: one workgroup per (table row j, slice of ELS_SLICE list items).  Its four waves scan the slice's ids with one
+// coalesced load each, and gather ONLY the rows whose id is j (up to eight row loads in flight per wave) into register sums:
+// one atomic per column and workgroup, none when the slice holds no such row.  (The round-1 kernel kept an LDS copy of the
+// whole table per workgroup: 72 KB zeroed, filled through LDS atomics and flushed with up to 18 000 global atomics per
+// workgroup -- 29 us on the tail of every step for ~5 MB of gradient rows.)
+constexpr int ELS_SLICE = 256;
 __global__ __launch_bounds__(256) void embed_list_bwd_small_kernel(int n, const int32_t* __restrict__ rows,
                                                                    const int32_t* __restrict__ ids,
                                                                    float* __restrict__ dtable,
-                                                                   const float* __restrict__ dnode, int table_rows,
-                                                                   int per_block) {
-    extern __shared__ float tab[];                       // [table_rows][256]
+                                                                   const float* __restrict__ dnode) {
+    __shared__ __attribute__((aligned(16))) float red[4][FIRA_D];
+    __shared__ int any;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (int i = t; i < table_rows * FIRA_D; i += 256) tab[i] = 0.f;
+    const int j = blockIdx.y;
+    const int k = blockIdx.x * ELS_SLICE + t;
+    if (t == 0) any = 0;
+    int id = -1, row = 0;
+    if (k < n) { id = ids[k]; row = rows[k]; }
+    unsigned long long m = __ballot(id == j);
     __syncthreads();
-    const int beg = blockIdx.x * per_block, end = min(n, beg + per_block);
-    for (int k = beg + wave; k < end; k += 4) {
-        const float4 g = *reinterpret_cast<const float4*>(dnode + (size_t)rows[k] * FIRA_D + lane * 4);
-        float* p = tab + (size_t)ids[k] * FIRA_D + lane * 4;
-        atomicAdd(p + 0, g.x); atomicAdd(p + 1, g.y); atomicAdd(p + 2, g.z); atomicAdd(p + 3, g.w);
+    if (m != 0ull && lane == 0) any = 1;                   // (benign race: every writer stores 1)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    while (m) {                                            // wave-uniform: the matching lanes, eight at a time
+        f32x4 g[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ok[u] = m != 0ull;
+            const int src = ok[u] ? (int)__builtin_ctzll(m) : 0;
+            if (ok[u]) m &= m - 1;
+            const int r = __builtin_amdgcn_readlane(row, src);
+            g[u] = *reinterpret_cast<const f32x4*>(dnode + (size_t)r * FIRA_D + lane * 4);    // (not ok: some listed row, unused)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ok[u]) acc += g[u];
     }
+    *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = acc;
     __syncthreads();
-    for (int i = t; i < table_rows * FIRA_D; i += 256) {
-        const float v = tab[i];
-        if (v != 0.f) unsafeAtomicAdd(&dtable[i], v);
-    }
+    if (!any) return;
+    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (v != 0.f) unsafeAtomicAdd(&dtable[(size_t)j * FIRA_D + t], v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,12 +498,28 @@ __global__ __launch_bounds__(256) void gcn_bias_unfold_kernel(const float* __res
 }
 // the same for every GCN layer in one launch (grid.y = layer): the dc vectors come out of the deferred reduction at
 // the end of the backward pass
+// Round 5: a workgroup owns UNFOLD_ROWS rows i of one layer and thread k keeps  sum_i W2[i,k] dc[i]  in a register: 8 atomics
+// per address instead of 256 (one workgroup per row i made 256 workgroups add to the same 256 floats of db1: ~13 us of
+// serialised same-address atomics on the step's tail, right in front of Adam).
+constexpr int UNFOLD_ROWS = 32;
 __global__ __launch_bounds__(256) void gcn_bias_unfold_all_kernel(UnfoldTable tab) {
     const UnfoldEntry& q = tab.e[blockIdx.y];
-    const int i = blockIdx.x, k = threadIdx.x;
-    const float dci = q.dc[i];
-    q.dW2[(size_t)i * FIRA_D + k] += dci * q.b1[k];
-    unsafeAtomicAdd(&q.db1[k], q.W2[(size_t)i * FIRA_D + k] * dci);
+    const int i0 = blockIdx.x * UNFOLD_ROWS, k = threadIdx.x;
+    const float b1k = q.b1[k];
+    float w2[UNFOLD_ROWS], g[UNFOLD_ROWS];
+#pragma unroll
+    for (int r = 0; r < UNFOLD_ROWS; ++r) {                 // every operand requested before the first use
+        w2[r] = q.W2[(size_t)(i0 + r) * FIRA_D + k];
+        g[r] = q.dW2[(size_t)(i0 + r) * FIRA_D + k];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < UNFOLD_ROWS; ++r) {
+        const float dci = q.dc[i0 + r];                     // (wave-uniform: a scalar load)
+        q.dW2[(size_t)(i0 + r) * FIRA_D + k] = g[r] + dci * b1k;
+        acc = fmaf(w2[r], dci, acc);
+    }
+    unsafeAtomicAdd(&q.db1[k], acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -768,18 +806,10 @@ int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const
 int embed_list_bwd_small(hipStream_t s, int n, const int32_t* rows, const int32_t* ids, float* dtable, const float* dnode,
                          int table_rows) {
     if (n <= 0) return 0;
-    FIRA_REQUIRE(table_rows > 0 && table_rows * FIRA_D * 4 <= 150 * 1024, "embed_list_bwd_small: table of %d rows does not fit LDS", table_rows);
+    FIRA_REQUIRE(table_rows > 0 && table_rows <= 65535, "embed_list_bwd_small: table of %d rows", table_rows);
     ProfScope prof(s, PROF_ROWOPS, 0.0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t ae = hipFuncSetAttribute((const void*)embed_list_bwd_small_kernel,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        FIRA_REQUIRE(ae == hipSuccess, "embed_list_bwd_small: cannot raise the dynamic LDS limit: %s", hipGetErrorString(ae));
-        attr_set = true;
-    }
-    const int per = std::max(64, cdiv(n, 96));
-    hipLaunchKernelGGL(embed_list_bwd_small_kernel, dim3(cdiv(n, per)), dim3(256),
-                       (size_t)table_rows * FIRA_D * sizeof(float), s, n, rows, ids, dtable, dnode, table_rows, per);
+    hipLaunchKernelGGL(embed_list_bwd_small_kernel, dim3(cdiv(n, ELS_SLICE), table_rows), dim3(256), 0, s, n, rows, ids, dtable,
+                       dnode);
     FIRA_CHECK_LAUNCH("embed_list_bwd_small");
     return 0;
 }
@@ -853,7 +883,7 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
 }
 int gcn_bias_unfold_all(hipStream_t s, const UnfoldTable& tab) {
     if (tab.n <= 0) return 0;
-    hipLaunchKernelGGL(gcn_bias_unfold_all_kernel, dim3(FIRA_D, tab.n), dim3(FIRA_D), 0, s, tab);
+    hipLaunchKernelGGL(gcn_bias_unfold_all_kernel, dim3(FIRA_D / UNFOLD_ROWS, tab.n), dim3(FIRA_D), 0, s, tab);
     FIRA_CHECK_LAUNCH("gcn_bias_unfold_all");
     return 0;
 }

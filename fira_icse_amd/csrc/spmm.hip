@@ -16,8 +16,12 @@
 //   neighbour gather is an LDS read (ds_read_b128: a 16-lane group covers one 64-float row and owns one
 //   output row, so a wave aggregates 4 rows at once with register sums only).
 #include "common.h"
+#include <stdlib.h>
+#include "epilogue.h"
 
 namespace fira {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
@@ -77,6 +81,124 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
     if (rowsum) {                                    // r = A 1, needed where a bias travels through the aggregation
         vsum = wave_sum(vsum);
         if (lane == 0) rowsum[row] = vsum;
+    }
+}
+
+// Round 5 -- the row-per-wave kernel above is bound by its chain of three dependent round trips (row offsets -> (col, val) ->
+// neighbour rows) for ONE KiB of output per wave: 41 600 waves in five generations of ~5 us.  Here a wave owns FOUR consecutive
+// rows and batches every trip over them (the gather of gcn_fused.hip): one load for the five row offsets, one for the first
+// 16 (col, val) pairs of each row (lanes 16 i .. 16 i + 15 = row i), then the listed neighbour rows of all four rows EIGHT
+// per round trip, whichever row they belong to (the set bits of one ballot word, in lane order; a lane group's index is the
+// accumulator).  Entries beyond the last one of a trip carry the out-of-range offset of the buffer descriptor: no request.
+// Rows with more than 16 entries finish as the kernel above does.  4x fewer waves, 4-5 trips per four rows instead of 12.
+template <bool ACCUM>
+__global__ __launch_bounds__(256) void spmm_rowbatch_kernel(int n_rows, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val, const float* __restrict__ X,
+                                                            int ldx, float* __restrict__ Y, int ldy,
+                                                            float* __restrict__ rowsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    const int grp = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);          // XCD-aware: see spmm_rowwave_kernel
+    const int rbase = grp * 16 + wave * 4;
+    if (rbase >= n_rows) return;
+    int rp = 0;
+    if (lane <= 4) rp = rowptr[min(rbase + lane, n_rows)];
+    int beg[4], cnt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        beg[i] = __builtin_amdgcn_readlane(rp, i);
+        cnt[i] = rbase + i < n_rows ? __builtin_amdgcn_readlane(rp, i + 1) - beg[i] : 0;
+    }
+    const int gi = lane >> 4, ge = lane & 15;
+    const int my_beg = gi == 0 ? beg[0] : gi == 1 ? beg[1] : gi == 2 ? beg[2] : beg[3];
+    const int my_cnt = gi == 0 ? cnt[0] : gi == 1 ? cnt[1] : gi == 2 ? cnt[2] : cnt[3];
+    int c = 0;
+    float v = 0.f;
+    if (ge < my_cnt) {
+        c = col[my_beg + ge];
+        v = val[my_beg + ge];
+    }
+    f32x4s old[ACCUM ? 4 : 1];
+    if constexpr (ACCUM) {                                // (requested with the index lists still in flight)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            old[i] = *reinterpret_cast<const f32x4s*>(Y + (size_t)min(rbase + i, n_rows - 1) * ldy + lane * 4);
+    }
+    const rsrc_t rX = buf_rsrc(X, (unsigned)((size_t)n_rows * ldx * 4));
+    f32x4s acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    unsigned long long m = __ballot(ge < my_cnt);
+    while (m) {                                           // wave-uniform: the listed entries of the four rows, eight per trip
+        f32x4s g[8];
+        float w[8];
+        int own[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = m != 0ull;
+            const int src = ok ? (int)__builtin_ctzll(m) : 0;
+            if (ok) m &= m - 1;
+            own[u] = ok ? src >> 4 : -1;
+            const int cj = __builtin_amdgcn_readlane(c, src);
+            w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+            g[u] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rX, ok ? (unsigned)lane * 16u : FIRA_OOB,
+                                                                                    (unsigned)cj * (unsigned)ldx * 4u, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (own[u] == i) {                        // wave-uniform
+                    acc[i].x = fmaf(w[u], g[u].x, acc[i].x); acc[i].y = fmaf(w[u], g[u].y, acc[i].y);
+                    acc[i].z = fmaf(w[u], g[u].z, acc[i].z); acc[i].w = fmaf(w[u], g[u].w, acc[i].w);
+                }
+        }
+    }
+    float vs = sum16(v);
+    float vsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vsum[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vs), i * 16));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                         // hub rows: entries 16 .. as the row-per-wave kernel walks them
+        if (cnt[i] <= 16) continue;                       // wave-uniform
+        float extra = 0.f;
+        for (int base = beg[i] + 16; base < beg[i] + cnt[i]; base += 64) {
+            const int n = min(64, beg[i] + cnt[i] - base);
+            int c2 = 0;
+            float v2 = 0.f;
+            if (lane < n) {
+                c2 = col[base + lane];
+                v2 = val[base + lane];
+            }
+            extra += v2;
+            for (int j = 0; j < n; j += 4) {              // (lanes past n hold col 0 / val 0: a valid row times zero)
+                f32x4s x4[4];
+                float w4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sl = min(j + u, 63);
+                    const int cj = __builtin_amdgcn_readlane(c2, sl);
+                    w4[u] = j + u < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v2), sl)) : 0.f;
+                    x4[u] = *reinterpret_cast<const f32x4s*>(X + (size_t)cj * ldx + lane * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[i].x = fmaf(w4[u], x4[u].x, acc[i].x); acc[i].y = fmaf(w4[u], x4[u].y, acc[i].y);
+                    acc[i].z = fmaf(w4[u], x4[u].z, acc[i].z); acc[i].w = fmaf(w4[u], x4[u].w, acc[i].w);
+                }
+            }
+        }
+        vsum[i] += wave_sum(extra);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (rbase + i >= n_rows) continue;                // wave-uniform
+        f32x4s y = acc[i];
+        if constexpr (ACCUM) y += old[i];
+        // (streamed: nobody gathers from Y in this launch, the lines should not push X rows out of the L2)
+        __builtin_nontemporal_store(y, reinterpret_cast<f32x4s*>(Y + (size_t)(rbase + i) * ldy + lane * 4));
+        if (rowsum && lane == 0) rowsum[rbase + i] = vsum[i];
     }
 }
 
@@ -192,9 +314,9 @@ int csr_spmm(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* co
 int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                 int ldx, float* Y, int ldy, int graph_rows, int variant, int accum, float* rowsum) {
     if (n_rows <= 0) return 0;
-    FIRA_REQUIRE(!((accum || rowsum) && variant >= 2), "csr_spmm: accumulate / row sums need the row-per-wave variant");
-    FIRA_REQUIRE(variant >= 0 && variant <= 4, "csr_spmm: variant must be 0..4");
-    if (variant >= 3) return csr_spmm_dense(s, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant == 4);
+    FIRA_REQUIRE(!((accum || rowsum) && variant >= 2 && variant != 5), "csr_spmm: accumulate / row sums need a row-per-wave variant (1, 5)");
+    FIRA_REQUIRE(variant >= 0 && variant <= 5, "csr_spmm: variant must be 0..5");
+    if (variant == 3 || variant == 4) return csr_spmm_dense(s, n_rows, rowptr, col, val, X, ldx, Y, ldy, graph_rows, variant == 4);
     FIRA_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)Y % 16 == 0),
                  "csr_spmm: feature rows must be 16-byte aligned");
     if (variant == 0) variant = 1;
@@ -216,6 +338,16 @@ int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t*
                            rowptr, col, val, X, ldx, Y, ldy);
     } else {
         // grid rounded up to a multiple of 8 so that the XCD remap above is a bijection onto the row groups
+        // FIRA_SPMM_ROWBATCH=0: the round-1 kernel, one row per wave (A/B switch); also for feature matrices of 2 GiB and more
+        // (the batched kernel addresses X through a buffer descriptor)
+        static const bool batch_off = [] { const char* e = getenv("FIRA_SPMM_ROWBATCH"); return e && e[0] == '0'; }();
+        if (variant != 5 && !batch_off && (size_t)n_rows * ldx * 4 < (1ull << 31))
+        {
+            const dim3 grid(cdiv(cdiv(n_rows, 16), 8) * 8);
+            if (accum) hipLaunchKernelGGL(spmm_rowbatch_kernel<true>, grid, dim3(256), 0, s, n_rows, rowptr, col, val, X, ldx, Y, ldy, rowsum);
+            else hipLaunchKernelGGL(spmm_rowbatch_kernel<false>, grid, dim3(256), 0, s, n_rows, rowptr, col, val, X, ldx, Y, ldy, rowsum);
+        }
+        else
         hipLaunchKernelGGL(spmm_rowwave_kernel, dim3(cdiv(cdiv(n_rows, 4), 8) * 8), dim3(256), 0, s, n_rows, rowptr, col,
                            val, X, ldx, Y, ldy, accum, rowsum);
     }

@@ -173,8 +173,10 @@ int fira_gemm_bf16_wb(void* stream, int M, int N, int K, const float* A, int lda
 
 /* Y[r,:] = sum_j val[j] * X[col[j],:]  over CSR row r (d = 256).  The GCN aggregation
  * torch.bmm(edge.float(), x) (gnn_transformer.py:80); its backward is the same call because
- * the normalised adjacency is symmetric.  variant: 0 auto, 1 wave-per-row gather, 2 LDS-staged
- * (needs graph_rows > 0: rows per graph, cols local to the graph's row block).                  */
+ * the normalised adjacency is symmetric.  variant: 0 auto, 1 row gather (round 5: a wave owns four
+ * consecutive rows and batches their index and neighbour-row requests), 2 LDS-staged (needs graph_rows > 0:
+ * rows per graph, cols local to the graph's row block), 5 the round-1 gather, one row per wave (kept for
+ * feature matrices of 2 GiB and more and as the A/B partner: FIRA_SPMM_ROWBATCH=0 makes variant 1 run it). */
 int fira_csr_spmm_f32(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val,
                       const float* X, int ldx, float* Y, int ldy, int graph_rows, int variant);
 /* The same aggregation with the block-dense MFMA variants and the measured variant choice:

@@ -101,7 +101,7 @@ def random_graph_batch(B, N, nnz_per_graph, seed):
     return t(rowptr, np.int32), t(col, np.int32), t(val, np.float32), torch.tensor(dense, device=DEV)
 
 
-@pytest.mark.parametrize("variant,N,nnz", [(1, 650, 2500), (1, 97, 4000), (2, 512, 9000), (2, 500, 3000), (2, 64, 3000)])
+@pytest.mark.parametrize("variant,N,nnz", [(1, 650, 2500), (1, 97, 4000), (1, 33, 1000), (5, 650, 2500), (5, 97, 4000), (2, 512, 9000), (2, 500, 3000), (2, 64, 3000)])
 def test_csr_spmm_vs_dense_bmm(variant, N, nnz):
     from fira_icse_amd import ops
     B = 3

@@ -1,0 +1,305 @@
+// The Combination block of one encoder layer as ONE launch per direction (reference gnn_transformer.py:176-205 with
+// combination_layer.py:7-17; code rows only):
+//
+//   forward    q | k = Xc [Wq | Wk]^T + b          (two [n,256]x[256,256] products)
+//              c     = dropout( g0 k + g1 v[mark] ),  (g0, g1) = softmax(q k / sqrt 32, q v / sqrt 32)   per element
+//              s     = dropout( c Wo^T + bo ) + Xc ;  X[code_rows] = LayerNorm(s)
+//
+// replacing the four launches  [n,512,256] product -> gate row kernel -> [n,256,256] product -> add + LayerNorm row kernel
+// (15 + 4 + 8 + 4.3 us of kernel time at batch 32 and three boundaries of the forward chain, where nothing else runs beside
+// the caller's stream) and the round trips of q|k and c through HBM between them (they are still WRITTEN once: the backward
+// pass reads q|k for the gate's derivative and c as the output projection's weight-gradient operand).
+//
+// Geometry: that of gcn_fused.hip -- ONE workgroup (16 waves) per CU over a contiguous range of 16-row tiles, up to CF_TMAX
+// tiles per pass in a swizzled fp32 LDS panel, every wave owning 16 output columns of all of them, v_mfma_f32_16x16x4_f32 with
+// B fragments straight from the L2-resident K-MAJOR weights (transposed once per step on the auxiliary stream) through buffer
+// loads requested a 64-wide k chunk ahead.  The gate runs in the ACCUMULATOR layout (lane (l15, kq), register r = row 4 kq + r,
+// column 16 wave + l15 of a tile: q and k of one element sit in the same lane), so q|k never go back through LDS; c does (it is
+// the next product's A operand), and the closing rows leave through the panel as whole 1 KiB rows.
+// At batch 32 (3 700 code rows = 230 tiles) every CU owns one tile: 3 x 16x256x256 products = 10 us of its fp32 MFMA pipe.
+#include "engine.h"
+#include "mfma_frag.h"
+#include "epilogue.h"
+
+namespace fira {
+
+constexpr int CF_TILE = 16;               // rows per MFMA tile
+constexpr int CF_TMAX = 2;                // tiles per pass (32 panel rows)
+constexpr int CF_ROWS = CF_TILE * CF_TMAX;
+constexpr int CF_WAVES = 16;
+constexpr int CF_RPW = CF_ROWS / CF_WAVES;   // rows per wave in the load / row phases
+constexpr int CF_GRID = 256;              // one workgroup per CU
+constexpr size_t CF_LDS = 84 * 1024;      // > half of a CU's 160 KB: never two of these workgroups on one CU (see gcn_fused.hip)
+
+typedef float cf_acc __attribute__((ext_vector_type(4)));
+
+struct CombFusedArgs {
+    int n_rows;
+    const float* Xc;                      // [n, 256] code rows: the block's input and residual
+    const float *WqT, *WkT, *WoT;         // k-major [256 k][256 n]
+    const float *bqk, *bo;                // [512], [256]
+    const float* vtab;                    // value rows of the 4 marks: vtab[m * ldv + col]
+    int ldv;
+    const int32_t* mark;                  // [n]
+    float *qk, *c;                        // saved for the backward pass: [n, 512], [n, 256]
+    const float *gamma, *beta;
+    float *sum, *y, *stats;               // pre-norm rows [n,256] (compact), output rows (at y_rows[r]), (mean, rstd) [n,2]
+    const int32_t* y_rows;
+    float p, inv_keep;
+    uint64_t seed;
+    uint32_t site_gate, site_out;
+};
+
+// float offset of 16-byte column `quad` (0..63) of panel row `row` (gcn_fused.hip's swizzle)
+__device__ __forceinline__ int cf_off(int row, int quad) { return row * FIRA_D + ((quad ^ (row & 11)) << 2); }
+
+// The first 64-wide k chunk of a weight's B fragments (k = 16 kq + s of this wave's 16 columns): requested EARLY -- at the top
+// of the kernel for Wq / Wk (under the load of the code rows), before the gate for Wo -- so that no product starts with a bare
+// L2 round trip (one tile per CU at batch 32: a product is 0.9 us of MFMA issue per wave, a round trip costs more)
+__device__ __forceinline__ void cf_first_chunk(const float* __restrict__ W, unsigned wlane, float (&b0)[16]) {
+    const rsrc_t rW = buf_rsrc(W, FIRA_D * FIRA_D * 4u);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+        b0[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
+}
+
+// acc[tt] += panel tile tt [16, 256] x Wk[256 k][16 columns of this wave]   (tt < nt); b0 = cf_first_chunk(W)
+__device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const int (&a_off)[4], const float* __restrict__ W,
+                                           unsigned wlane, int nt, const float (&b0)[16], cf_acc (&acc)[CF_TMAX]) {
+    constexpr int NC = FIRA_D / 64;
+    const rsrc_t rW = buf_rsrc(W, FIRA_D * FIRA_D * 4u);
+    float b[2][16];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) b[0][s2] = b0[s2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+                b[(c + 1) & 1][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                                   rW, wlane, ((c + 1) * 64 + s2) * FIRA_D * 4, 0));
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) {
+            if (tt < nt) {                               // block-uniform
+                float af[16];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const f32x4v q = *reinterpret_cast<const f32x4v*>(&sm_u[a_off[ii] + tt * (CF_TILE * FIRA_D) + c * 64]);
+                    af[4 * ii] = q.x; af[4 * ii + 1] = q.y; af[4 * ii + 2] = q.z; af[4 * ii + 3] = q.w;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s2], b[c & 1][s2], acc[tt], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+__global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const CombFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+    float* const sm_u = cf_lds;                                            // [32][256] swizzled
+    int* const sm_mark = reinterpret_cast<int*>(cf_lds + CF_ROWS * FIRA_D);   // [32]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wg = (blockIdx.x & 7) * (CF_GRID / 8) + (blockIdx.x >> 3);      // XCD b % 8 owns a contiguous eighth of the tiles
+    const int n_tiles = (a.n_rows + CF_TILE - 1) / CF_TILE;
+    const int tq = n_tiles / CF_GRID, tr = n_tiles % CF_GRID;
+    const int t_beg = wg * tq + min(wg, tr), t_cnt = tq + (wg < tr ? 1 : 0);
+    if (t_cnt == 0) return;
+    int a_off[4], d_off[4], r_off[CF_RPW];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) a_off[ii] = cf_off(l15, kq * 4 + ii);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d_off[r] = cf_off(4 * kq + r, (wave * 16 + l15) >> 2) + (l15 & 3);
+#pragma unroll
+    for (int i = 0; i < CF_RPW; ++i) r_off[i] = cf_off(wave * CF_RPW + i, lane);
+    // this lane's output column in every product, and what the gate needs of it
+    const int col = wave * 16 + l15;
+    const unsigned wlane = (unsigned)((kq * 16) * FIRA_D + col) * 4u;
+    const float bq = a.bqk[col], bk = a.bqk[FIRA_D + col];
+    const float vt0 = a.vtab[col], vt1 = a.vtab[(size_t)a.ldv + col], vt2 = a.vtab[(size_t)2 * a.ldv + col],
+                vt3 = a.vtab[(size_t)3 * a.ldv + col];
+    const rsrc_t rQK = buf_rsrc(a.qk, (unsigned)((size_t)a.n_rows * 2 * FIRA_D * 4));
+    const rsrc_t rC = buf_rsrc(a.c, (unsigned)((size_t)a.n_rows * FIRA_D * 4));
+
+    for (int pass = 0; pass < t_cnt; pass += CF_TMAX) {
+        const int nt = min(CF_TMAX, t_cnt - pass);
+        const int row0 = (t_beg + pass) * CF_TILE;
+        const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
+        // ------------------------------------------------------------ 1. the tile's code rows -> panel
+        float b0q[16], b0k[16];
+        cf_first_chunk(a.WqT, wlane, b0q);
+        cf_first_chunk(a.WkT, wlane, b0k);
+        asm volatile("" ::: "memory");
+        {
+            f32x4v x[CF_RPW];
+#pragma unroll
+            for (int i = 0; i < CF_RPW; ++i) {
+                const int row = row0 + wave * CF_RPW + i;
+                x[i] = *reinterpret_cast<const f32x4v*>(a.Xc + (size_t)min(row, a.n_rows - 1) * FIRA_D + lane * 4);
+            }
+            if (t < CF_ROWS) sm_mark[t] = a.mark[min(row0 + t, a.n_rows - 1)];
+#pragma unroll
+            for (int i = 0; i < CF_RPW; ++i) {
+                const int row = row0 + wave * CF_RPW + i;
+                *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ 2. q and k: two products over the same panel
+        cf_acc aq[CF_TMAX], ak[CF_TMAX];
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) { aq[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; ak[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; }
+        cf_product(sm_u, a_off, a.WqT, wlane, nt, b0q, aq);
+        cf_product(sm_u, a_off, a.WkT, wlane, nt, b0k, ak);
+        float b0o[16];
+        cf_first_chunk(a.WoT, wlane, b0o);               // (in flight under the gate)
+        asm volatile("" ::: "memory");
+        __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
+        // ------------------------------------------------------------ 3. the gate, element by element in the accumulator layout
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) {
+            if (tt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = tt * CF_TILE + 4 * kq + r, row = row0 + rl;
+                    const bool live = row < row_end;
+                    const float q = aq[tt][r] + bq, k = ak[tt][r] + bk;
+                    const int m = sm_mark[rl];
+                    const float v = m == 0 ? vt0 : m == 1 ? vt1 : m == 2 ? vt2 : vt3;
+                    float g0, g1;
+                    gate_elem(q, k, v, g0, g1);
+                    float c = g0 * k + g1 * v;
+                    if (a.p > 0.f) c *= dropout_scale(a.seed, a.site_gate, (uint32_t)row * FIRA_D + col, a.p, a.inv_keep);
+                    const unsigned o = live ? ((unsigned)row * FIRA_D + col) * 4u : FIRA_OOB;       // rows past the end: dropped
+                    const unsigned o2 = live ? ((unsigned)row * 2 * FIRA_D + col) * 4u : FIRA_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q), rQK, o2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, k), rQK, o2, FIRA_D * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), rC, o, 0, 0);
+                    sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = live ? c : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ 4. the output projection
+        cf_acc ao[CF_TMAX];
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) ao[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+        cf_product(sm_u, a_off, a.WoT, wlane, nt, b0o, ao);
+        // what the closing rows need from memory, requested before the accumulators go back through the panel
+        const int rbase = row0 + wave * CF_RPW;
+        const f32x4v bias4 = *reinterpret_cast<const f32x4v*>(a.bo + lane * 4);
+        const f32x4v g4 = *reinterpret_cast<const f32x4v*>(a.gamma + lane * 4);
+        const f32x4v be4 = *reinterpret_cast<const f32x4v*>(a.beta + lane * 4);
+        f32x4v res[CF_RPW];
+        int yr[CF_RPW];
+#pragma unroll
+        for (int i = 0; i < CF_RPW; ++i) {
+            const int row = min(rbase + i, a.n_rows - 1);
+            res[i] = *reinterpret_cast<const f32x4v*>(a.Xc + (size_t)row * FIRA_D + lane * 4);
+            yr[i] = a.y_rows ? a.y_rows[row] : row;
+        }
+        asm volatile("" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) {
+            if (tt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = ao[tt][r];
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ 5. whole rows: bias, dropout, residual, LayerNorm
+        if (rbase < row_end) {
+#pragma unroll
+            for (int i = 0; i < CF_RPW; ++i) {
+                const int row = rbase + i;
+                if (row >= row_end) continue;                        // wave-uniform
+                f32x4v x = *reinterpret_cast<const f32x4v*>(&sm_u[r_off[i]]);
+                x = x + bias4;
+                if (a.p > 0.f) {
+                    const uint32_t e0 = (uint32_t)row * FIRA_D + lane * 4;
+                    x.x *= dropout_scale(a.seed, a.site_out, e0 + 0, a.p, a.inv_keep);
+                    x.y *= dropout_scale(a.seed, a.site_out, e0 + 1, a.p, a.inv_keep);
+                    x.z *= dropout_scale(a.seed, a.site_out, e0 + 2, a.p, a.inv_keep);
+                    x.w *= dropout_scale(a.seed, a.site_out, e0 + 3, a.p, a.inv_keep);
+                }
+                x = x + res[i];
+                const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / FIRA_D);
+                const f32x4v d = x - mean;
+                const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / FIRA_D);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                *reinterpret_cast<f32x4v*>(a.sum + (size_t)row * FIRA_D + lane * 4) = x;
+                const f32x4v out = {d.x * rstd * g4.x + be4.x, d.y * rstd * g4.y + be4.y, d.z * rstd * g4.z + be4.z,
+                                    d.w * rstd * g4.w + be4.w};
+                *reinterpret_cast<f32x4v*>(a.y + (size_t)yr[i] * FIRA_D + lane * 4) = out;
+                if (lane == 0) {
+                    a.stats[2 * row] = mean;
+                    a.stats[2 * row + 1] = rstd;
+                }
+            }
+        }
+        if (pass + CF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
+    }
+}
+
+int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
+                   const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
+                   const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
+                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out) {
+    if (n_rows <= 0) return 0;
+    FIRA_REQUIRE(Xc && WqT && WkT && WoT && bqk && bo && vtab && mark && qk && c && gamma && beta && sum && y && stats,
+                 "comb_fused_fwd: null pointer argument");
+    FIRA_REQUIRE((uintptr_t)Xc % 16 == 0 && (uintptr_t)sum % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)WqT % 16 == 0,
+                 "comb_fused_fwd: rows must be 16-byte aligned");
+    FIRA_REQUIRE((size_t)n_rows * 2 * FIRA_D * 4 < (1ull << 31), "comb_fused_fwd: %d rows exceed the 2 GiB the kernel addresses", n_rows);
+    // three [n,256]x[256,256] products; bytes: Xc in (twice: operand and residual, the second read an L2 hit), q|k, c, sum, y out
+    ProfScope prof(s, PROF_COMB, 3.0 * 2.0 * n_rows * FIRA_D * FIRA_D, 4.0 * n_rows * FIRA_D * (1.0 + 2.0 + 1.0 + 1.0 + 1.0));
+    CombFusedArgs a{};
+    a.n_rows = n_rows; a.Xc = Xc; a.WqT = WqT; a.WkT = WkT; a.WoT = WoT; a.bqk = bqk; a.bo = bo; a.vtab = vtab; a.ldv = ldv;
+    a.mark = mark; a.qk = qk; a.c = c; a.gamma = gamma; a.beta = beta; a.sum = sum; a.y = y; a.stats = stats; a.y_rows = y_rows;
+    a.p = dropout; a.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; a.seed = seed; a.site_gate = site_gate;
+    a.site_out = site_out;
+    static const int attr = [] {
+        const hipError_t e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }();
+    if (attr) return attr;
+    hipLaunchKernelGGL(comb_fused_fwd_kernel, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+    FIRA_CHECK_LAUNCH("comb_fused_fwd");
+    return 0;
+}
+
+// Wt[i] = W[i]^T for a table of [256,256] matrices anywhere in memory (the Combination weights live in the flat parameter buffer)
+__global__ __launch_bounds__(256) void transpose256_table_kernel(const TransposeTable tab) {
+    __shared__ float tile[64][65];
+    const float* src = tab.src[blockIdx.z];
+    float* dst = tab.dst[blockIdx.z];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = src[(size_t)(r0 + r) * FIRA_D + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) dst[(size_t)(c0 + r) * FIRA_D + r0 + tx] = tile[tx][r];
+}
+int transpose256_table(hipStream_t s, const TransposeTable& tab) {
+    if (tab.n <= 0) return 0;
+    hipLaunchKernelGGL(transpose256_table_kernel, dim3(FIRA_D / 64, FIRA_D / 64, tab.n), dim3(256), 0, s, tab);
+    FIRA_CHECK_LAUNCH("transpose256_table");
+    return 0;
+}
+
+}  // namespace fira
+
+extern "C" {
+int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
+                               const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk,
+                               float* c, const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows,
+                               float* stats, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out) {
+    FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_fwd: dropout must be in [0,1)");
+    return fira::comb_fused_fwd((hipStream_t)stream, n_rows, Xc, WqT, WkT, WoT, bqk, bo, vtab, ldv, mark, qk, c, gamma, beta, sum,
+                                y, y_rows, stats, dropout, seed, site_gate, site_out);
+}
+}

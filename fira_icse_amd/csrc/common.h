@@ -34,7 +34,8 @@ int set_err(const char* fmt, ...);
 // products, forward and data gradients) -- the quantity north_star sets its MFMA target on; reported beside PROF_GEMM
 // PROF_GCN: the fused GCN-layer launches (gcn_fused.hip): work = FLOP of the [rows,256]x[256,256] product, bytes = the
 // algorithmic bytes of the whole layer (gather in, rows out)
-enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_GCN, PROF_NCLASS };
+// PROF_COMB: the fused Combination-block launches (comb_fused.hip): work = FLOP of its three [rows,256]x[256,256] products
+enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_GCN, PROF_COMB, PROF_NCLASS };
 bool prof_on();
 void prof_decoder_tag(int delta);      // +1 / -1 (nesting counter, thread-local)
 struct ProfDecoderTag {
@@ -111,6 +112,22 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, dpp_take<DPP_BCAST15, 0xa>(v, v));    // (rows the mask leaves out keep their own value)
     v = fmaxf(v, dpp_take<DPP_BCAST31, 0xc>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// ------------------------------------------------------------------------------------------------
+// CombinationLayer (reference combination_layer.py:7-17): per element
+//   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
+// The head split/transposes of gnn_transformer.py:197-202 cancel.
+// The two-way soft-max with the maximum subtracted has one exponential equal to exp(0) = 1: with e = exp(-|a - b|) the larger
+// gate is 1 / (1 + e) and the smaller e / (1 + e) -- one v_exp_f32 and one v_rcp_f32 per element instead of two expf and an
+// IEEE division (these kernels are bound by their VALU instruction stream, not by memory).
+__device__ __forceinline__ void gate_elem(float q, float k, float v, float& g0, float& g1) {
+    const float is = 1.0f / 5.656854249492381f;  // 1 / sqrt(32): reciprocal multiplies instead of divisions (<= 1 ulp)
+    const float a = q * k * is, b = q * v * is;
+    const float e = __builtin_amdgcn_exp2f(-fabsf(a - b) * 1.4426950408889634f);
+    const float big = __builtin_amdgcn_rcpf(1.0f + e), small = e * big;
+    g0 = a >= b ? big : small;
+    g1 = a >= b ? small : big;
 }
 
 }  // namespace fira

@@ -82,6 +82,16 @@ int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
 int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* dY,
                   const float* Wk, float* u_out, float* acc_out, int bf16);
 int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[l] = W[l]^T, nl stacked [256,256] matrices
+// One Combination block per launch (comb_fused.hip): q|k projections, the two-way gate, the output projection, dropout,
+// residual and LayerNorm of gnn_transformer.py:176-205 on the code rows.  WqT / WkT / WoT: the three weights K-MAJOR
+// ([256 in][256 out], i.e. transposed nn.Linear weights: transpose256_table).  Stores q|k [n,512] and c [n,256] (what the
+// backward pass reads), the pre-norm rows `sum` [n,256], (mean, rstd) `stats` [n,2], and the output rows at y[y_rows[r]].
+int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
+                   const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
+                   const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
+                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out);
+struct TransposeTable { int n = 0; const float* src[24]; float* dst[24]; };
+int transpose256_table(hipStream_t s, const TransposeTable& tab);         // dst[i] = src[i]^T, [256,256] each
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,
                      int out_bstride, int out_off);
 int embed_grouped_bwd(hipStream_t s, int n_items, const int32_t* item_tok, const int32_t* item_ptr, const int32_t* rows,

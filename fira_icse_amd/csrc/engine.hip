@@ -74,6 +74,7 @@ struct Plan {
     float *vtab_all, *H, *mem, *mem_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *W21, *c21, *rsum;        // GCN: per layer fc2.weight . fc1.weight [256,256] and fc2.weight . fc1.bias [256]; A_hat 1
     float *W21t;                    // the folded weights transposed = k-major for U W21^T: what the fused GCN forward streams
+    float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
     // backward temporaries (training only)
@@ -125,6 +126,7 @@ struct Plan {
         vtab_all = a.f((size_t)4 * nl * D);
         W21 = a.f((size_t)nl * D * D); c21 = a.f((size_t)nl * D); rsum = a.f((size_t)NB);
         W21t = a.f((size_t)nl * D * D);
+        WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
         mem_c = a.f((size_t)MB * D);
@@ -578,6 +580,13 @@ static inline bool gcn_fused_bwd_on() {
     return !off;
 }
 
+// Combination block as one fused launch (comb_fused.hip) instead of product + gate kernel + product + add-LayerNorm; fp32 only
+// (bf16 mode keeps the panel products).  FIRA_COMB_FUSED=0 restores the separate kernels (A/B switch).
+static inline bool comb_fused_on() {
+    static const bool off = [] { const char* e = getenv("FIRA_COMB_FUSED"); return e && e[0] == '0'; }();
+    return !off && g_dtype == 0;
+}
+
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
 static inline uint32_t site(int layer, int kind) { return (uint32_t)(layer * 8 + kind + 1); }
 
@@ -636,11 +645,25 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     // first Combination kernels.  Layer 0's pair is marked on its own (the caller's stream reaches its first GCN product
     // ~100 us into the call, 12 launches of the auxiliary stream would not be through by then); the rest is awaited at
     // layer 1.
-    hipEvent_t ev_fold0 = nullptr, ev_fold = nullptr;
+    hipEvent_t ev_fold0 = nullptr, ev_fold = nullptr, ev_comb = nullptr;
     {
         const bool ax = side_on() && !c.serial;
         hipStream_t fs = ax ? side().aux : s;
         if (ax) TRY(aux_fork(s));
+        if (comb_fused_on()) {
+            // k-major copies of the Combination weights of every layer (Wq^T, Wk^T, Wo^T): one launch, the first thing on the
+            // auxiliary stream -- layer 0's block is the third launch of the caller's stream
+            TransposeTable tt;
+            for (int l = 0; l < p.nl && tt.n + 3 <= 24; ++l) {
+                const EncLayer& w = L.enc[l];
+                float* dst = p.WcT + (size_t)l * 3 * D * D;
+                tt.src[tt.n] = c.P + w.wqk; tt.dst[tt.n++] = dst;
+                tt.src[tt.n] = c.P + w.wqk + (size_t)D * D; tt.dst[tt.n++] = dst + (size_t)D * D;
+                tt.src[tt.n] = c.P + w.wo; tt.dst[tt.n++] = dst + (size_t)2 * D * D;
+            }
+            TRY(transpose256_table(fs, tt));
+            if (ax) TRY(side_mark(&ev_comb));
+        }
         for (int l = 0; l < p.nl; ++l) {
             const EncLayer& w = L.enc[l];
             TRY(gemm_f32_ex(fs, 0, 0, D, D, D, c.P + w.fc2w, D, c.P + w.fc1w, D, p.W21 + (size_t)l * D * D, D, nullptr, 0, 0, nullptr));
@@ -680,10 +703,18 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         float* X = p.X[l];
         // Combination (gnn_transformer.py:192-205): code rows only; the result overwrites them in place.  e.Xc (the code
         // rows before the update: residual, and the q|k weight gradient's operand) was stored by the kernel that produced X
+        if (comb_fused_on() && l < 8) {
+            if (l == 0 && ev_comb) TRY(main_wait(s, ev_comb));
+            const float* wt = p.WcT + (size_t)l * 3 * D * D;
+            TRY(comb_fused_fwd(s, Cc, e.Xc, wt, wt + (size_t)D * D, wt + (size_t)2 * D * D, c.P + w.bqk, c.P + w.bo,
+                               p.vtab_all + l * D, p.nl * D, bt.code_mark, e.qk, e.c, c.P + w.ln1g, c.P + w.ln1b, e.s1, X,
+                               bt.code_rows, e.st1, c.p_drop, c.seed, site(l, SITE_GATE), site(l, SITE_COMB_OUT)));
+        } else {
         TRY(linear(s, Cc, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
         TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
         TRY(linear_ln(s, Cc, D, e.c, D, c.P + w.wo, c.P + w.bo, e.Xc, c.P + w.ln1g, c.P + w.ln1b, e.s1, X, e.st1, c.p_drop,
                       c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
+        }
         // GCN in folded form: U = A_hat X -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
         const bool fused = gcn_fused_on();
         if (!fused) TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));

@@ -186,21 +186,6 @@ __global__ __launch_bounds__(256) void embed_list_bwd_small_kernel(int n, const 
     if (v != 0.f) unsafeAtomicAdd(&dtable[(size_t)j * FIRA_D + t], v);
 }
 
-// ------------------------------------------------------------------------------------------------
-// CombinationLayer (reference combination_layer.py:7-17): per element
-//   a = q*k/sqrt(32), b = q*v/sqrt(32), (g0,g1) = softmax(a,b), c = g0*k + g1*v, then dropout(c).
-// The head split/transposes of gnn_transformer.py:197-202 cancel.
-// The two-way soft-max with the maximum subtracted has one exponential equal to exp(0) = 1: with e = exp(-|a - b|) the larger
-// gate is 1 / (1 + e) and the smaller e / (1 + e) -- one v_exp_f32 and one v_rcp_f32 per element instead of two expf and an
-// IEEE division (these kernels are bound by their VALU instruction stream, not by memory).
-__device__ __forceinline__ void gate_elem(float q, float k, float v, float& g0, float& g1) {
-    const float is = 1.0f / 5.656854249492381f;  // 1 / sqrt(32): reciprocal multiplies instead of divisions (<= 1 ulp)
-    const float a = q * k * is, b = q * v * is;
-    const float e = __builtin_amdgcn_exp2f(-fabsf(a - b) * 1.4426950408889634f);
-    const float big = __builtin_amdgcn_rcpf(1.0f + e), small = e * big;
-    g0 = a >= b ? big : small;
-    g1 = a >= b ? small : big;
-}
 
 __global__ __launch_bounds__(256) void combination_fwd_kernel(int M, const float* __restrict__ qk,
                                                               const float* __restrict__ vtab, int ldv,

@@ -217,6 +217,28 @@ def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0
     return summ, y, stats, rs
 
 
+def combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout=0.0, seed=0, site_gate=0, site_out=0, y=None,
+                          y_rows=None):
+    """fira_combination_block_fwd: (qk, c, sum, y, stats) of one Combination block on the code rows Xc [n,256]; Wqk [512,256]
+    and Wo [256,256] as nn.Linear stores them (transposed here: the kernel streams k-major copies); vtab [4, >=256] rows of the
+    projected mark table (row stride = vtab.stride(0)).  y / y_rows: optional node buffer and row map for the output rows."""
+    n = Xc.shape[0]
+    dev = Xc.device
+    assert vtab.is_cuda and vtab.dtype == torch.float32 and vtab.stride(1) == 1 and vtab.shape[0] == 4, "vtab: fp32 rows"
+    WqT, WkT, WoT = (_f32(Wqk[:256]).t().contiguous(), _f32(Wqk[256:]).t().contiguous(), _f32(Wo).t().contiguous())
+    qk = torch.empty((n, 512), dtype=torch.float32, device=dev)
+    c, summ = torch.empty_like(Xc), torch.empty_like(Xc)
+    if y is None:
+        y = torch.empty_like(Xc)
+    stats = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    yr = None if y_rows is None else _i32(y_rows)
+    check(_lib.lib().fira_combination_block_fwd(cur_stream(), n, ptr(_f32(Xc)), ptr(WqT), ptr(WkT), ptr(WoT), ptr(_f32(bqk)),
+                                                ptr(_f32(bo)), ptr(vtab), vtab.stride(0), ptr(_i32(mark)), ptr(qk), ptr(c),
+                                                ptr(_f32(gamma)), ptr(_f32(beta)), ptr(summ), ptr(y), ptr(yr), ptr(stats),
+                                                dropout, seed, site_gate, site_out), "fira_combination_block_fwd")
+    return qk, c, summ, y, stats
+
+
 def gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=0):
     """fira_gcn_layer_bwd: V = A_hat dY (returned), dX += V W21 in place."""
     V = torch.empty_like(dY)

@@ -97,12 +97,13 @@ def self_launch(a) -> int:
 
 def prof_report():
     from fira_icse_amd import _lib
-    n = 9
+    n = 10
     ms, work, byts, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
     _lib.lib().fira_prof_report(n, ms, work, byts, cnt)
     # gemm_dec: the decoder's M = B*30 row products (forward + data gradients), split out of the GEMM family by the library
     # gcn: the fused GCN-layer launches (gather + product + LayerNorm / accumulate in one kernel): work = FLOP, bytes = bytes
-    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec", "gcn"]
+    # comb: the fused Combination-block launches (round 5: q|k products + gate + output product + LayerNorm in one kernel)
+    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec", "gcn", "comb"]
     out = {k: dict(ms=ms[i], work=work[i], bytes=byts[i], count=int(cnt[i])) for i, k in enumerate(names)}
     dec = out.pop("gemm_dec")
     out["gemm"] = {k: out["gemm"][k] + dec[k] for k in dec}         # the family = every GEMM launch of the step
@@ -463,12 +464,12 @@ def attention_work(metas, n_layers, d=256):
 
 
 def rocprof_reference(dtype):
-    """Per-class kernel time of the SAME command from the committed rocprofv3 kernel trace (profiles/r4_kernel_classes.json,
+    """Per-class kernel time of the SAME command from the committed rocprofv3 kernel trace (profiles/r5_kernel_classes.json,
     written by scripts/rocpd_stats.py from `rocprofv3 --kernel-trace --stats -- python bench.py --dtype <dtype> ...`):
     kernel begin-to-end durations, i.e. without the launch gaps and the cross-stream event overlap that the in-process
     HIP-event sums include.  Counters and traces cannot be collected inside this process."""
     try:
-        with open(os.path.join(HERE, "profiles", "r4_kernel_classes.json")) as f:
+        with open(os.path.join(HERE, "profiles", "r5_kernel_classes.json")) as f:
             return json.load(f).get(dtype)
     except Exception:
         return None
@@ -546,6 +547,8 @@ def compact_line(line, detail_path):
     for k in ("avg_launch_us", "frac_mfma", "frac_hbm", "traffic"):
         put("gcn_" + k, line, "gcn", k)
         put("attention_" + k, line, "attention", k)
+    put("comb_avg_launch_us", line, "comb", "avg_launch_us")
+    put("comb_frac_mfma", line, "comb", "frac_mfma")
     put("spmm_in_step_frac", line, "spmm", "frac")
     put("spmm_b64_frac", line, "spmm_b64", "frac")
     put("spmm_b64_us", line, "spmm_b64", "avg_launch_us")
@@ -684,7 +687,8 @@ def main():
         roof, roof_hbm, dec = gemm_objects(prof, dtype, 3, tr, dec_rows_of(bs, 3))
         obj = {"commits_per_s": steps * Bx * world / dt, "ms_per_step": dt / steps * 1e3, "batch_per_gpu": Bx,
                "dtype": dtype, "steps": steps, "host_enqueue_ms_per_step": t_enq / steps * 1e3, "roofline": roof,
-               "decoder_gemm": dec, "gcn": gcn_object(prof, dtype, 3), "attention": attention_object(prof, bs, 3),
+               "decoder_gemm": dec, "gcn": gcn_object(prof, dtype, 3), "comb": comb_object(prof, 3),
+               "attention": attention_object(prof, bs, 3),
                "kernel_time_ms_per_step": {k: v["ms"] / 3 for k, v in prof.items()}}
         if dtype == "bf16":
             obj["roofline_hbm"] = roof_hbm
@@ -708,6 +712,18 @@ def main():
                 "frac_hbm": g["bytes"] / t_s / 1e9 / HBM_PEAK_GBS,
                 "note": "bytes = rowptr + gathered rows in + rows out (3 row streams forward, 4 backward); bench adds no "
                         "(col, val) bytes here; FLOP = the [rows,256]x[256,256] product"}
+
+    def comb_object(prof, n_steps):
+        """The fused Combination-block launches (comb_fused.hip): three [n_code,256]x[256,256] products per launch, fp32 MFMA."""
+        g = prof.get("comb")
+        if not g or g["count"] == 0:
+            return None
+        t_s = g["ms"] * 1e-3
+        return {"kernel": "comb_fused_fwd_kernel (q|k products -> gate in registers -> output product -> LayerNorm rows)",
+                "bound": "mfma", "launches_per_step": g["count"] // n_steps, "avg_launch_us": 1e3 * g["ms"] / g["count"],
+                "flop_per_launch": g["work"] / g["count"], "bytes_per_launch": g["bytes"] / g["count"],
+                "achieved_TFLOPs": g["work"] / t_s / 1e12, "frac_mfma": g["work"] / t_s / 1e12 / FP32_MFMA_PEAK_TF,
+                "achieved_GBs": g["bytes"] / t_s / 1e9, "frac_hbm": g["bytes"] / t_s / 1e9 / HBM_PEAK_GBS}
 
     def attention_object(prof, bs, n_steps):
         at = prof["attention"]
@@ -737,7 +753,7 @@ def main():
     ref = rocprof_reference(a.dtype)
     if ref and ref.get("batch") == B and ref.get("gemm_us_per_step"):
         # the same FLOP over the rocprofv3 kernel durations of the committed trace of this command: the number a reader of
-        # profiles/r4_kernel_stats_<dtype>.md recomputes (kernel begin-to-end, no launch gaps)
+        # profiles/r5_kernel_stats_<dtype>.md recomputes (kernel begin-to-end, no launch gaps)
         flop_step = prof["gemm"]["work"] / prof_steps
         tf = flop_step / (ref["gemm_us_per_step"] * 1e-6) / 1e12
         roofline["rocprof"] = {"gemm_us_per_step": ref["gemm_us_per_step"], "gemm_launches_per_step": ref.get("gemm_launches_per_step"),
@@ -842,7 +858,8 @@ def main():
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
                        "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss},
-            "roofline": roofline, "decoder_gemm": decoder_gemm, "gcn": gcn_obj, "attention": attn_obj, "spmm": spmm_obj,
+            "roofline": roofline, "decoder_gemm": decoder_gemm, "gcn": gcn_obj, "comb": comb_object(prof, prof_steps),
+            "attention": attn_obj, "spmm": spmm_obj,
             "decode": decode, "cpu_baseline": cpu,
             "kernel_time_ms_per_step": {k: v["ms"] / prof_steps for k, v in prof.items()},
         }

@@ -64,6 +64,9 @@ __device__ __forceinline__ void cf_first_chunk(const float* __restrict__ W, unsi
 }
 
 // acc[tt] += panel tile tt [16, 256] x Wk[256 k][16 columns of this wave]   (tt < nt); b0 = cf_first_chunk(W)
+// BF (bf16 mode of the engine): both fragments rounded to bf16 (RNE, as the staged operands of gemm_bf16*.hip), two
+// v_mfma_f32_16x16x32_bf16 per 64-wide chunk and tile, fp32 accumulation
+template <bool BF>
 __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const int (&a_off)[4], const float* __restrict__ W,
                                            unsigned wlane, int nt, const float (&b0)[16], cf_acc (&acc)[CF_TMAX]) {
     constexpr int NC = FIRA_D / 64;
@@ -89,15 +92,29 @@ __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const
                     const f32x4v q = *reinterpret_cast<const f32x4v*>(&sm_u[a_off[ii] + tt * (CF_TILE * FIRA_D) + c * 64]);
                     af[4 * ii] = q.x; af[4 * ii + 1] = q.y; af[4 * ii + 2] = q.z; af[4 * ii + 3] = q.w;
                 }
+                if constexpr (BF) {
 #pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2)
-                    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s2], b[c & 1][s2], acc[tt], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+                        uint4 ua, ub;
+                        ua.x = apk2(af[8 * j], af[8 * j + 1]); ua.y = apk2(af[8 * j + 2], af[8 * j + 3]);
+                        ua.z = apk2(af[8 * j + 4], af[8 * j + 5]); ua.w = apk2(af[8 * j + 6], af[8 * j + 7]);
+                        ub.x = apk2(b[c & 1][8 * j], b[c & 1][8 * j + 1]); ub.y = apk2(b[c & 1][8 * j + 2], b[c & 1][8 * j + 3]);
+                        ub.z = apk2(b[c & 1][8 * j + 4], b[c & 1][8 * j + 5]); ub.w = apk2(b[c & 1][8 * j + 6], b[c & 1][8 * j + 7]);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(abf16x8, ua),
+                                                                          __builtin_bit_cast(abf16x8, ub), acc[tt], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s2], b[c & 1][s2], acc[tt], 0, 0, 0);
+                }
             }
         }
         asm volatile("" ::: "memory");
     }
 }
 
+template <bool BF>
 __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const CombFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cf_lds[];
     float* const sm_u = cf_lds;                                            // [32][256] swizzled
@@ -153,8 +170,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc aq[CF_TMAX], ak[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) { aq[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; ak[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; }
-        cf_product(sm_u, a_off, a.WqT, wlane, nt, b0q, aq);
-        cf_product(sm_u, a_off, a.WkT, wlane, nt, b0k, ak);
+        cf_product<BF>(sm_u, a_off, a.WqT, wlane, nt, b0q, aq);
+        cf_product<BF>(sm_u, a_off, a.WkT, wlane, nt, b0k, ak);
         float b0o[16];
         cf_first_chunk(a.WoT, wlane, b0o);               // (in flight under the gate)
         asm volatile("" ::: "memory");
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc ao[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) ao[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
-        cf_product(sm_u, a_off, a.WoT, wlane, nt, b0o, ao);
+        cf_product<BF>(sm_u, a_off, a.WoT, wlane, nt, b0o, ao);
         // what the closing rows need from memory, requested before the accumulators go back through the panel
         const int rbase = row0 + wave * CF_RPW;
         const f32x4v bias4 = *reinterpret_cast<const f32x4v*>(a.bo + lane * 4);
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                 const f32x4v d = x - mean;
                 const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / FIRA_D);
                 const float rstd = 1.0f / sqrtf(var + 1e-5f);
-                *reinterpret_cast<f32x4v*>(a.sum + (size_t)row * FIRA_D + lane * 4) = x;
+                __builtin_nontemporal_store(x, reinterpret_cast<f32x4v*>(a.sum + (size_t)row * FIRA_D + lane * 4));   // (backward only)
                 const f32x4v out = {d.x * rstd * g4.x + be4.x, d.y * rstd * g4.y + be4.y, d.z * rstd * g4.z + be4.z,
                                     d.w * rstd * g4.w + be4.w};
                 *reinterpret_cast<f32x4v*>(a.y + (size_t)yr[i] * FIRA_D + lane * 4) = out;
@@ -249,7 +266,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
-                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out) {
+                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int bf16) {
     if (n_rows <= 0) return 0;
     FIRA_REQUIRE(Xc && WqT && WkT && WoT && bqk && bo && vtab && mark && qk && c && gamma && beta && sum && y && stats,
                  "comb_fused_fwd: null pointer argument");
@@ -264,11 +281,14 @@ int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT,
     a.p = dropout; a.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; a.seed = seed; a.site_gate = site_gate;
     a.site_out = site_out;
     static const int attr = [] {
-        const hipError_t e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }();
     if (attr) return attr;
-    hipLaunchKernelGGL(comb_fused_fwd_kernel, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+    if (bf16) hipLaunchKernelGGL(comb_fused_fwd_kernel<true>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+    else hipLaunchKernelGGL(comb_fused_fwd_kernel<false>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     FIRA_CHECK_LAUNCH("comb_fused_fwd");
     return 0;
 }
@@ -297,9 +317,10 @@ extern "C" {
 int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                                const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk,
                                float* c, const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows,
-                               float* stats, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out) {
+                               float* stats, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int dtype) {
     FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_fwd: dropout must be in [0,1)");
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_combination_block_fwd: dtype must be FIRA_F32 or FIRA_BF16");
     return fira::comb_fused_fwd((hipStream_t)stream, n_rows, Xc, WqT, WkT, WoT, bqk, bo, vtab, ldv, mark, qk, c, gamma, beta, sum,
-                                y, y_rows, stats, dropout, seed, site_gate, site_out);
+                                y, y_rows, stats, dropout, seed, site_gate, site_out, dtype == FIRA_BF16);
 }
 }

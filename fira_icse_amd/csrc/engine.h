@@ -89,7 +89,7 @@ int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
-                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out);
+                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int bf16);
 struct TransposeTable { int n = 0; const float* src[24]; float* dst[24]; };
 int transpose256_table(hipStream_t s, const TransposeTable& tab);         // dst[i] = src[i]^T, [256,256] each
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,

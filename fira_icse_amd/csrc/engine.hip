@@ -580,11 +580,13 @@ static inline bool gcn_fused_bwd_on() {
     return !off;
 }
 
-// Combination block as one fused launch (comb_fused.hip) instead of product + gate kernel + product + add-LayerNorm; fp32 only
-// (bf16 mode keeps the panel products).  FIRA_COMB_FUSED=0 restores the separate kernels (A/B switch).
+// Combination block as one fused launch (comb_fused.hip) instead of product + gate kernel + product + add-LayerNorm, in fp32
+// and in bf16 mode (operands rounded as the panel products round them).  FIRA_COMB_FUSED=0 restores the separate kernels,
+// FIRA_COMB_FUSED_BF16=0 in bf16 mode only (A/B switches).
 static inline bool comb_fused_on() {
     static const bool off = [] { const char* e = getenv("FIRA_COMB_FUSED"); return e && e[0] == '0'; }();
-    return !off && g_dtype == 0;
+    static const bool off16 = [] { const char* e = getenv("FIRA_COMB_FUSED_BF16"); return e && e[0] == '0'; }();
+    return !off && !(g_dtype == 1 && off16);
 }
 
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
@@ -708,7 +710,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const float* wt = p.WcT + (size_t)l * 3 * D * D;
             TRY(comb_fused_fwd(s, Cc, e.Xc, wt, wt + (size_t)D * D, wt + (size_t)2 * D * D, c.P + w.bqk, c.P + w.bo,
                                p.vtab_all + l * D, p.nl * D, bt.code_mark, e.qk, e.c, c.P + w.ln1g, c.P + w.ln1b, e.s1, X,
-                               bt.code_rows, e.st1, c.p_drop, c.seed, site(l, SITE_GATE), site(l, SITE_COMB_OUT)));
+                               bt.code_rows, e.st1, c.p_drop, c.seed, site(l, SITE_GATE), site(l, SITE_COMB_OUT), g_dtype == 1));
         } else {
         TRY(linear(s, Cc, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
         TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));

@@ -200,6 +200,16 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                 if (!BWD && a.rowsum_out && lane == 0 && rbase + i < row_end) a.rowsum_out[rbase + i] = vsum[i];
             }
         }
+        // (round 5) the first 64-wide k chunk of this wave's B fragments is requested BEFORE the barrier that closes the gather: a wave
+        // that is done early has its weights on the way while the slowest wave still collects neighbours (with the gather's 64
+        // row registers live the request cannot move further up: 128 VGPRs per lane at 1024 threads)
+        const rsrc_t rW = buf_rsrc(a.W, FIRA_D * FIRA_D * 4u);
+        const unsigned wlane = (unsigned)((kq * 16) * FIRA_D + wave * 16 + l15) * 4u;
+        float b[2][16];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)
+            b[0][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
+        asm volatile("" ::: "memory");
         __syncthreads();
 
         // ------------------------------------------------------------ 2. product: panel [16 nt, 256] x Wk, 16 columns per wave
@@ -210,12 +220,6 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             constexpr int NC = FIRA_D / 64;              // k chunks: lane (row l15, quarter kq) holds k = 64 c + 16 kq + s
             // (buffer loads: ONE per-lane byte offset in a VGPR, the k row as the scalar offset -- with flat pointers the
             //  compiler kept a 64-bit address pair per 4 KB window of the weight, hoisted all 64 of them and spilled)
-            const rsrc_t rW = buf_rsrc(a.W, FIRA_D * FIRA_D * 4u);
-            const unsigned wlane = (unsigned)((kq * 16) * FIRA_D + wave * 16 + l15) * 4u;
-            float b[2][16];
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2)
-                b[0][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if (c + 1 < NC) {
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                     const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / FIRA_D);
                     const float rstd = 1.0f / sqrtf(var + 1e-5f);
                     const size_t o = (size_t)row * FIRA_D + lane * 4;
-                    *reinterpret_cast<f32x4v*>(a.sum + o) = x;
+                    __builtin_nontemporal_store(x, reinterpret_cast<f32x4v*>(a.sum + o));     // (read by the backward pass only)
                     const f32x4v out = {d.x * rstd * g4.x + be4.x, d.y * rstd * g4.y + be4.y, d.z * rstd * g4.z + be4.z,
                                         d.w * rstd * g4.w + be4.w};
                     *reinterpret_cast<f32x4v*>(a.y + o) = out;

@@ -218,7 +218,7 @@ def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0
 
 
 def combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout=0.0, seed=0, site_gate=0, site_out=0, y=None,
-                          y_rows=None):
+                          y_rows=None, dtype=0):
     """fira_combination_block_fwd: (qk, c, sum, y, stats) of one Combination block on the code rows Xc [n,256]; Wqk [512,256]
     and Wo [256,256] as nn.Linear stores them (transposed here: the kernel streams k-major copies); vtab [4, >=256] rows of the
     projected mark table (row stride = vtab.stride(0)).  y / y_rows: optional node buffer and row map for the output rows."""
@@ -235,7 +235,7 @@ def combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout
     check(_lib.lib().fira_combination_block_fwd(cur_stream(), n, ptr(_f32(Xc)), ptr(WqT), ptr(WkT), ptr(WoT), ptr(_f32(bqk)),
                                                 ptr(_f32(bo)), ptr(vtab), vtab.stride(0), ptr(_i32(mark)), ptr(qk), ptr(c),
                                                 ptr(_f32(gamma)), ptr(_f32(beta)), ptr(summ), ptr(y), ptr(yr), ptr(stats),
-                                                dropout, seed, site_gate, site_out), "fira_combination_block_fwd")
+                                                dropout, seed, site_gate, site_out, dtype), "fira_combination_block_fwd")
     return qk, c, summ, y, stats
 
 

@@ -211,7 +211,8 @@ int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const in
                        const float* dY, const float* W21, float* V, float* dX, int dtype);
 
 /* One Combination block (gnn_transformer.py:176-205 with combination_layer.py:7-17) on n_rows code rows as ONE launch
- * (round 5, csrc/comb_fused.hip; fp32):
+ * (round 5, csrc/comb_fused.hip; dtype FIRA_F32, or FIRA_BF16 = the operands of the three products rounded to bf16, fp32
+ * accumulation and storage):
  *     q | k = Xc [Wq | Wk]^T + bqk ;   c = dropout_gate( g0 k + g1 vtab[mark] ),  (g0, g1) = softmax(q k / sqrt 32, q v / sqrt 32)
  *     sum   = dropout_out( c Wo^T + bo ) + Xc ;   y[y_rows[r]] = LayerNorm(sum[r]) ;   stats[r] = {mean, 1/std}
  * WqT / WkT / WoT are the three nn.Linear weights TRANSPOSED ([256 in][256 out], contiguous): the kernel streams them
@@ -223,7 +224,7 @@ int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const 
                                const float* WoT, const float* bqk, const float* bo, const float* vtab, int ldv,
                                const int32_t* mark, float* qk, float* c, const float* gamma, const float* beta, float* sum,
                                float* y, const int32_t* y_rows, float* stats, float dropout, uint64_t seed,
-                               uint32_t site_gate, uint32_t site_out);
+                               uint32_t site_gate, uint32_t site_out, int dtype);
 
 /* out[(b*out_bstride + out_off + i), :] = table[idx[b*L + i], :] (+ pos[i,:])  — the embedding
  * gathers of gnn_transformer.py:46-52,110-113 written straight into the node buffer.           */

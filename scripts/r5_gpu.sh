@@ -35,6 +35,16 @@ for ST in "$@"; do
           echo -n "$V f32 b${ABBATCH:-32}: "; one "$V" "--batch ${ABBATCH:-32}"
         done
       done 2>&1 | tee $OUT/abenv.txt ;;
+    abenv16)
+      IFS='|' read -ra VARS <<< "$ABENV"
+      for i in 1 2 3; do
+        for V in "${VARS[@]}"; do
+          echo -n "$V bf16 b64: "; one "$V" "--dtype bf16 --batch 64"
+        done
+      done 2>&1 | tee $OUT/abenv16.txt ;;
+    bf16tests)
+      timeout 900 python -m pytest tests/test_bf16_gpu.py -m gpu -q --tb=short -p no:cacheprovider --timeout 300 > $OUT/bf16tests.log 2>&1
+      echo "bf16tests rc=$?"; tail -n 8 $OUT/bf16tests.log ;;
     abdec)
       for i in 1 2; do
         for V in "FIRA_HIP_LIB=$PREV" "FIRA_X=1"; do echo -n "${V##*/} decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done

@@ -155,13 +155,15 @@ def test_gcn_layer_fused_fwd_bwd(N, nnz, p, dtype):
     assert rel_err(dX, dX0.double() + r16(refV) @ r16(W21)) < tol
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("n,p", [(3667, 0.0), (3667, 0.1), (530, 0.1), (37, 0.1), (6861, 0.1)])
-def test_combination_block_fused_fwd(n, p):
+def test_combination_block_fused_fwd(n, p, dtype):
     """fira_combination_block_fwd (comb_fused.hip): the Combination block of gnn_transformer.py:176-205 as one launch -- q|k
     projections, two-way gate (combination_layer.py:7-17), output projection, dropout, residual, LayerNorm -- against (a) the
     four launches it replaces with the SAME dropout masks (q|k bit-comparable up to fp32 re-association; c, sum, y, stats) and
     (b) the fp64 statement of the formulas with the engine's masks.  Row counts: batch 32 / 64 sizes (one and two tiles per
-    CU, ragged last tile), fewer tiles than workgroups, a single partial pass."""
+    CU, ragged last tile), fewer tiles than workgroups, a single partial pass.  dtype 1 (bf16 mode): the operands of the three
+    products rounded to bf16, fp32 accumulation -- against the fp64 products of the ROUNDED operands."""
     from fira_icse_amd import ops
     Xc = randn(n, 256, seed=1)
     Wqk, bqk = randn(512, 256, seed=2, scale=0.08), randn(512, seed=3, scale=0.1)
@@ -173,25 +175,30 @@ def test_combination_block_fused_fwd(n, p):
     ybuf = torch.full((2 * n, 256), float("nan"), device=DEV)
     seed, sg, so = 4321, 17, 18
     qk, c, summ, y, stats = ops.combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout=p, seed=seed,
-                                                      site_gate=sg, site_out=so, y=ybuf, y_rows=rows)
+                                                      site_gate=sg, site_out=so, y=ybuf, y_rows=rows, dtype=dtype)
     # (b) fp64 reference with the engine's masks
-    q64 = Xc.double() @ Wqk[:256].double().t() + bqk[:256].double()
-    k64 = Xc.double() @ Wqk[256:].double().t() + bqk[256:].double()
+    r16 = (lambda t: t.float().bfloat16().double()) if dtype else (lambda t: t.double())
+    q64 = r16(Xc) @ r16(Wqk[:256]).t() + bqk[:256].double()
+    k64 = r16(Xc) @ r16(Wqk[256:]).t() + bqk[256:].double()
     v64 = vtab.double()[mark.long()]
     a, b = q64 * k64 / math.sqrt(32), q64 * v64 / math.sqrt(32)
     g = torch.softmax(torch.stack([a, b], -1), -1)
     mg = ops.dropout_mask(seed, sg, n * 256, p).view(n, 256).double() if p > 0 else 1.0
     mo = ops.dropout_mask(seed, so, n * 256, p).view(n, 256).double() if p > 0 else 1.0
     c64 = (g[..., 0] * k64 + g[..., 1] * v64) * mg
-    s64 = (c64 @ Wo.double().t() + bo.double()) * mo + Xc.double()
+    # (bf16: the kernel rounds ITS fp32 c, the reference the fp64 one -- a few elements fall on the other side of a boundary)
+    s64 = (r16(c64) @ r16(Wo).t() + bo.double()) * mo + Xc.double()
     y64 = F.layer_norm(s64, (256,), gamma.double(), beta.double(), 1e-5)
-    assert rel_err(qk[:, :256], q64) < 2e-6 and rel_err(qk[:, 256:], k64) < 2e-6
-    assert rel_err(c, c64) < 5e-6 and rel_err(summ, s64) < 5e-6
-    assert rel_err(y[rows.long()], y64) < 1e-5
+    t1, t2 = (2e-6, 5e-6) if dtype == 0 else (2e-6, 5e-5)
+    assert rel_err(qk[:, :256], q64) < t1 and rel_err(qk[:, 256:], k64) < t1
+    assert rel_err(c, c64) < 5e-6 and rel_err(summ, s64) < t2
+    assert rel_err(y[rows.long()], y64) < 2 * t2
     untouched = torch.ones(2 * n, dtype=torch.bool, device=DEV)
     untouched[rows.long()] = False
     assert bool(torch.isnan(y[untouched]).all())                     # only the listed rows are written
     assert rel_err(stats[:, 0], s64.mean(1)) < 1e-4 and rel_err(stats[:, 1], 1.0 / torch.sqrt(s64.var(1, unbiased=False) + 1e-5)) < 1e-5
+    if dtype:
+        return
     # (a) the separate launches, same masks
     qk2 = ops.gemm(Xc, Wqk, bias=bqk)
     c2 = ops.combination_fwd(qk2, vtab.contiguous(), mark, dropout=p, seed=seed, site=sg)

@@ -62,6 +62,8 @@ SIGNATURES = {
     "fira_gcn_layer_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32, _I]),
     "fira_gcn_layer_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
     "fira_combination_block_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32, _U32, _I]),
+    "fira_combination_block_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _F, _U64, _U32, _U32, _I]),
+    "fira_combination_block_bwd_part_floats": (_I, []),
     "fira_embed_gather_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I]),
     "fira_embed_gather_bwd": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I]),
     "fira_combination_fwd": (_I, [_P, _I, _P, _P, _P, _P, _F, _U64, _U32]),

@@ -63,17 +63,22 @@ __device__ __forceinline__ void cf_first_chunk(const float* __restrict__ W, unsi
         b0[s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
 }
 
-// acc[tt] += panel tile tt [16, 256] x Wk[256 k][16 columns of this wave]   (tt < nt); b0 = cf_first_chunk(W)
+// acc[tt] += panel tile tt [16, 256] x Wk[256 k][16 columns of this wave]   (tt < nt).  On entry bx = cf_first_chunk(W); on
+// exit bx = the first chunk of Wnext (if given), requested under the MFMAs of W's last chunk into the fragment buffer that
+// chunk leaves free -- a chain of products never opens with a bare round trip and holds no extra registers for it.
 // BF (bf16 mode of the engine): both fragments rounded to bf16 (RNE, as the staged operands of gemm_bf16*.hip), two
 // v_mfma_f32_16x16x32_bf16 per 64-wide chunk and tile, fp32 accumulation
-template <bool BF>
+template <bool BF, int TM>
 __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const int (&a_off)[4], const float* __restrict__ W,
-                                           unsigned wlane, int nt, const float (&b0)[16], cf_acc (&acc)[CF_TMAX]) {
+                                           unsigned wlane, int nt, float (&bx)[16], cf_acc (&acc)[TM],
+                                           const float* __restrict__ Wnext = nullptr) {
     constexpr int NC = FIRA_D / 64;
+    static_assert(NC % 2 == 0, "the buffer the last chunk leaves free is b[0]");
     const rsrc_t rW = buf_rsrc(W, FIRA_D * FIRA_D * 4u);
+    const rsrc_t rN = buf_rsrc(Wnext ? Wnext : W, FIRA_D * FIRA_D * 4u);
     float b[2][16];
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2) b[0][s2] = b0[s2];
+    for (int s2 = 0; s2 < 16; ++s2) b[0][s2] = bx[s2];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c + 1 < NC) {
@@ -81,10 +86,14 @@ __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const
             for (int s2 = 0; s2 < 16; ++s2)
                 b[(c + 1) & 1][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                                    rW, wlane, ((c + 1) * 64 + s2) * FIRA_D * 4, 0));
+        } else if (Wnext) {                              // (block-uniform)
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+                b[0][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rN, wlane, s2 * FIRA_D * 4, 0));
         }
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int tt = 0; tt < CF_TMAX; ++tt) {
+        for (int tt = 0; tt < TM; ++tt) {
             if (tt < nt) {                               // block-uniform
                 float af[16];
 #pragma unroll
@@ -112,6 +121,8 @@ __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const
         }
         asm volatile("" ::: "memory");
     }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) bx[s2] = b[0][s2];
 }
 
 template <bool BF>
@@ -147,9 +158,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         const int row0 = (t_beg + pass) * CF_TILE;
         const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
         // ------------------------------------------------------------ 1. the tile's code rows -> panel
-        float b0q[16], b0k[16];
-        cf_first_chunk(a.WqT, wlane, b0q);
-        cf_first_chunk(a.WkT, wlane, b0k);
+        float bx[16];
+        cf_first_chunk(a.WqT, wlane, bx);
         asm volatile("" ::: "memory");
         {
             f32x4v x[CF_RPW];
@@ -170,11 +180,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc aq[CF_TMAX], ak[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) { aq[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; ak[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; }
-        cf_product<BF>(sm_u, a_off, a.WqT, wlane, nt, b0q, aq);
-        cf_product<BF>(sm_u, a_off, a.WkT, wlane, nt, b0k, ak);
-        float b0o[16];
-        cf_first_chunk(a.WoT, wlane, b0o);               // (in flight under the gate)
-        asm volatile("" ::: "memory");
+        cf_product<BF, CF_TMAX>(sm_u, a_off, a.WqT, wlane, nt, bx, aq, a.WkT);
+        cf_product<BF, CF_TMAX>(sm_u, a_off, a.WkT, wlane, nt, bx, ak, a.WoT);       // (Wo's first chunk: in flight under the gate)
         __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
         // ------------------------------------------------------------ 3. the gate, element by element in the accumulator layout
 #pragma unroll
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc ao[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) ao[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
-        cf_product<BF>(sm_u, a_off, a.WoT, wlane, nt, b0o, ao);
+        cf_product<BF, CF_TMAX>(sm_u, a_off, a.WoT, wlane, nt, bx, ao);
         // what the closing rows need from memory, requested before the accumulators go back through the panel
         const int rbase = row0 + wave * CF_RPW;
         const f32x4v bias4 = *reinterpret_cast<const f32x4v*>(a.bo + lane * 4);
@@ -293,6 +300,251 @@ int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the block, one launch (replaces LayerNorm backward -> [n,256,256] data gradient -> gate backward ->
+// [n,256,512] data gradient with accumulate: 5 + 8 + 6 + 14.5 us and three boundaries at batch 32):
+//   rows      dy = dG[rows[r]],  xh = (s - mean) rstd,  h = dy gamma,  ds = (h - mean(h) - xh mean(h xh)) rstd,
+//             dYc = ds * mask_out  (-> HBM: the output projection's weight-gradient operand, and the panel);
+//             the wave keeps ds and its share of sum dy xh | sum dy (dgamma | dbeta) in registers
+//   product   dc = dYc Wo                           (Wo as stored [out][in] IS k-major for this product)
+//   gate      per element in the accumulator layout: (dq, dk, dv) from (q, k, v[mark], dc * mask_gate)  (rowops.hip:
+//             combination_bwd_kernel's formulas); dq | dk -> HBM (the q|k weight gradient's operand) and two panels; dv summed per
+//             mark value and column in registers
+//   product   dX = dq Wq + dk Wk                    (Wq | Wk as stored)
+//   rows      dG[rows[r]] = ds + dX
+// and at the end the workgroup's partial {dgamma | dbeta} [512] and dvtab [4][256] rows for the deferred reduction.
+// The backward kernel walks ONE tile per pass (a lane's registers: the LayerNorm row it keeps, its share of four column sums
+// and the saved q | k of its elements on top of the product's fragments -- two tiles spilled 35-56 registers per lane)
+constexpr int CB_TMAX = 1;
+constexpr int CB_ROWS = CF_TILE * CB_TMAX;
+constexpr int CB_RPW = CB_ROWS / CF_WAVES;
+
+struct CombFusedBwdArgs {
+    int n_rows;
+    float* dG;                            // node-row gradients (read at rows[r], overwritten there)
+    const int32_t* rows;
+    const float *sum, *stats, *gamma;     // saved pre-norm rows [n,256], (mean, rstd) [n,2], LayerNorm weight
+    const float *Wo, *Wqk;                // nn.Linear weights as stored: [256,256], [512,256]
+    const float* qk;                      // saved [n,512]
+    const float* vtab;
+    int ldv;
+    const int32_t* mark;
+    float *dYc, *dqk;                     // [n,256], [n,512]
+    float *part_ln, *part_v;              // [CF_GRID][512], [CF_GRID][1024]
+    float p, inv_keep;
+    uint64_t seed;
+    uint32_t site_gate, site_out;
+};
+
+template <bool BF>
+__global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const CombFusedBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+    float* const sm_u = cf_lds;                                            // panel 1 [32][256]: dYc, then dq, then dX
+    float* const sm_w = cf_lds + CB_ROWS * FIRA_D;                         // panel 2 [32][256]: dk
+    int* const sm_mark = reinterpret_cast<int*>(cf_lds + 2 * CB_ROWS * FIRA_D);
+    // column sums of the whole workgroup, kept in LDS between the passes (in registers they cost 12 per lane next to the
+    // product's fragments): every lane owns its slots -- plain read-modify-write, no atomics
+    float* const red = cf_lds + 2 * CB_ROWS * FIRA_D + 64;              // [16 waves][dgamma 256 | dbeta 256]
+    float* const redv = red + CF_WAVES * 2 * FIRA_D;                    // [4 kq][4 marks][256 columns]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wg = (blockIdx.x & 7) * (CF_GRID / 8) + (blockIdx.x >> 3);
+    const int n_tiles = (a.n_rows + CF_TILE - 1) / CF_TILE;
+    const int tq = n_tiles / CF_GRID, tr = n_tiles % CF_GRID;
+    const int t_beg = wg * tq + min(wg, tr), t_cnt = tq + (wg < tr ? 1 : 0);
+    int a_off[4], d_off[4], r_off[CB_RPW];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) a_off[ii] = cf_off(l15, kq * 4 + ii);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d_off[r] = cf_off(4 * kq + r, (wave * 16 + l15) >> 2) + (l15 & 3);
+#pragma unroll
+    for (int i = 0; i < CB_RPW; ++i) r_off[i] = cf_off(wave * CB_RPW + i, lane);
+    const int col = wave * 16 + l15;
+    const unsigned wlane = (unsigned)((kq * 16) * FIRA_D + col) * 4u;
+    const rsrc_t rQK = buf_rsrc(a.qk, (unsigned)((size_t)a.n_rows * 2 * FIRA_D * 4));
+    const rsrc_t rDQK = buf_rsrc(a.dqk, (unsigned)((size_t)a.n_rows * 2 * FIRA_D * 4));
+    const float is = 1.0f / 5.656854249492381f;
+    *reinterpret_cast<f32x4v*>(&red[wave * 2 * FIRA_D + lane * 4]) = f32x4v{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4v*>(&red[wave * 2 * FIRA_D + FIRA_D + lane * 4]) = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) redv[(kq * 4 + m) * FIRA_D + col] = 0.f;
+
+    for (int pass = 0; pass < t_cnt; pass += CB_TMAX) {
+        const int nt = min(CB_TMAX, t_cnt - pass);
+        const int row0 = (t_beg + pass) * CF_TILE;
+        const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
+        float bx[16];
+        cf_first_chunk(a.Wo, wlane, bx);
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------------------ 1. LayerNorm backward of this wave's rows -> dYc
+        const int rbase = row0 + wave * CB_RPW;
+        int nr[CB_RPW];
+        f32x4v ds[CB_RPW];
+        {
+            f32x4v d[CB_RPW], sv[CB_RPW];
+            float mean[CB_RPW], rstd[CB_RPW];
+            const f32x4v gam = *reinterpret_cast<const f32x4v*>(a.gamma + lane * 4);      // (per pass: an L2 hit, four registers less)
+#pragma unroll
+            for (int i = 0; i < CB_RPW; ++i) nr[i] = a.rows[min(rbase + i, a.n_rows - 1)];
+            if (t < CB_ROWS) sm_mark[t] = a.mark[min(row0 + t, a.n_rows - 1)];
+#pragma unroll
+            for (int i = 0; i < CB_RPW; ++i) {
+                const int row = min(rbase + i, a.n_rows - 1);
+                d[i] = *reinterpret_cast<const f32x4v*>(a.dG + (size_t)nr[i] * FIRA_D + lane * 4);
+                sv[i] = *reinterpret_cast<const f32x4v*>(a.sum + (size_t)row * FIRA_D + lane * 4);
+                mean[i] = a.stats[2 * row];
+                rstd[i] = a.stats[2 * row + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < CB_RPW; ++i) {
+                const bool live = rbase + i < row_end;              // wave-uniform
+                if (!live) { d[i] = f32x4v{0.f, 0.f, 0.f, 0.f}; rstd[i] = 0.f; }
+                const f32x4v xh = (sv[i] - mean[i]) * rstd[i];
+                *reinterpret_cast<f32x4v*>(&red[wave * 2 * FIRA_D + lane * 4]) += d[i] * xh;
+                *reinterpret_cast<f32x4v*>(&red[wave * 2 * FIRA_D + FIRA_D + lane * 4]) += d[i];
+                const f32x4v h = d[i] * gam;
+                const f32x4v hx = h * xh;
+                const float m1 = wave_sum(h.x + h.y + h.z + h.w) * (1.0f / FIRA_D);
+                const float m2 = wave_sum(hx.x + hx.y + hx.z + hx.w) * (1.0f / FIRA_D);
+                ds[i] = (h - m1 - xh * m2) * rstd[i];
+                f32x4v o4 = ds[i];
+                if (a.p > 0.f) {
+                    const uint32_t e0 = (uint32_t)(rbase + i) * FIRA_D + lane * 4;
+                    o4.x *= dropout_scale(a.seed, a.site_out, e0 + 0, a.p, a.inv_keep);
+                    o4.y *= dropout_scale(a.seed, a.site_out, e0 + 1, a.p, a.inv_keep);
+                    o4.z *= dropout_scale(a.seed, a.site_out, e0 + 2, a.p, a.inv_keep);
+                    o4.w *= dropout_scale(a.seed, a.site_out, e0 + 3, a.p, a.inv_keep);
+                }
+                *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = o4;                 // (rows past the end: zeros)
+                if (live) *reinterpret_cast<f32x4v*>(a.dYc + (size_t)(rbase + i) * FIRA_D + lane * 4) = o4;
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ 2. dc = dYc Wo; the saved q | k of this lane's elements on the way
+        float qs[CB_TMAX][4], ks[CB_TMAX][4];
+        auto load_qk = [&]() {
+#pragma unroll
+            for (int tt = 0; tt < CB_TMAX; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + tt * CF_TILE + 4 * kq + r;
+                    const unsigned o2 = row < row_end ? ((unsigned)row * 2 * FIRA_D + col) * 4u : FIRA_OOB;   // past the end: reads 0
+                    qs[tt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rQK, o2, 0, 0));
+                    ks[tt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rQK, o2, FIRA_D * 4, 0));
+                }
+            asm volatile("" ::: "memory");
+        };
+        // (fp32: requested ahead of the product's 10 us of MFMA issue; bf16: the product is short and its packed fragments need the
+        //  registers -- the request follows it)
+        if constexpr (!BF) load_qk();
+        cf_acc ac[CB_TMAX];
+#pragma unroll
+        for (int tt = 0; tt < CB_TMAX; ++tt) ac[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+        cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wo, wlane, nt, bx, ac, a.Wqk);    // (Wq's first chunk: in flight under the gate's arithmetic)
+        if constexpr (BF) load_qk();
+        __syncthreads();                                                // the panel's A fragments are consumed
+        // ------------------------------------------------------------ 3. gate backward in the accumulator layout
+#pragma unroll
+        for (int tt = 0; tt < CB_TMAX; ++tt) {
+            if (tt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = tt * CF_TILE + 4 * kq + r, row = row0 + rl;
+                    const bool live = row < row_end;
+                    float dc = ac[tt][r];
+                    if (a.p > 0.f) dc *= dropout_scale(a.seed, a.site_gate, (uint32_t)row * FIRA_D + col, a.p, a.inv_keep);
+                    const int m = sm_mark[rl];
+                    const float v = a.vtab[(size_t)m * a.ldv + col];            // (four rows of 1 KiB: L1 / L2 hits)
+                    const float q = qs[tt][r], k = ks[tt][r];
+                    float g0, g1;
+                    gate_elem(q, k, v, g0, g1);
+                    const float dg0 = dc * k, dg1 = dc * v;
+                    const float dot = g0 * dg0 + g1 * dg1;
+                    const float da = g0 * (dg0 - dot), db = g1 * (dg1 - dot);
+                    const float dq = live ? (da * k + db * v) * is : 0.f;
+                    const float dk = live ? dc * g0 + da * q * is : 0.f;
+                    const float dv = live ? dc * g1 + db * q * is : 0.f;
+                    const unsigned o2 = live ? ((unsigned)row * 2 * FIRA_D + col) * 4u : FIRA_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dq), rDQK, o2, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dk), rDQK, o2, FIRA_D * 4, 0);
+                    redv[(kq * 4 + m) * FIRA_D + col] += dv;             // (dv = 0 past the end; this lane's own slot)
+                    sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = dq;
+                    sm_w[d_off[r] + tt * (CF_TILE * FIRA_D)] = dk;
+                }
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ 4. dX = dq Wq + dk Wk
+        cf_acc ax[CB_TMAX];
+#pragma unroll
+        for (int tt = 0; tt < CB_TMAX; ++tt) ax[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+        cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wqk, wlane, nt, bx, ax, a.Wqk + (size_t)FIRA_D * FIRA_D);
+        cf_product<BF, CB_TMAX>(sm_w, a_off, a.Wqk + (size_t)FIRA_D * FIRA_D, wlane, nt, bx, ax);
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < CB_TMAX; ++tt) {
+            if (tt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = ax[tt][r];
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ 5. rows: dG = ds + dX
+#pragma unroll
+        for (int i = 0; i < CB_RPW; ++i) {
+            if (rbase + i >= row_end) continue;                         // wave-uniform
+            const f32x4v x = *reinterpret_cast<const f32x4v*>(&sm_u[r_off[i]]);
+            *reinterpret_cast<f32x4v*>(a.dG + (size_t)nr[i] * FIRA_D + lane * 4) = ds[i] + x;
+        }
+        __syncthreads();                                                // the next pass (or the reduction below) reuses the panels
+    }
+    // ---------------------------------------------------------------- the workgroup's partial rows (every workgroup writes: the
+    // reducer sums CF_GRID of them)
+    __syncthreads();
+    if (t < 2 * FIRA_D) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < CF_WAVES; ++w) acc += red[w * 2 * FIRA_D + t];
+        a.part_ln[(size_t)blockIdx.x * 2 * FIRA_D + t] = acc;
+    }
+    {
+        const int m = t >> 8, cc = t & 255;                             // 1024 threads = 4 marks x 256 columns
+        a.part_v[(size_t)blockIdx.x * 4 * FIRA_D + t] = (redv[(0 * 4 + m) * FIRA_D + cc] + redv[(1 * 4 + m) * FIRA_D + cc]) +
+                                                        (redv[(2 * 4 + m) * FIRA_D + cc] + redv[(3 * 4 + m) * FIRA_D + cc]);
+    }
+}
+
+int comb_fused_bwd_parts() { return CF_GRID; }
+int comb_fused_bwd(hipStream_t s, int n_rows, float* dG, const int32_t* rows, const float* sum, const float* stats,
+                   const float* gamma, const float* Wo, const float* Wqk, const float* qk, const float* vtab, int ldv,
+                   const int32_t* mark, float* dYc, float* dqk, float* part_ln, float* part_v, float dropout, uint64_t seed,
+                   uint32_t site_gate, uint32_t site_out, int bf16) {
+    if (n_rows <= 0) return 0;
+    FIRA_REQUIRE(dG && rows && sum && stats && gamma && Wo && Wqk && qk && vtab && mark && dYc && dqk && part_ln && part_v,
+                 "comb_fused_bwd: null pointer argument");
+    FIRA_REQUIRE((uintptr_t)dG % 16 == 0 && (uintptr_t)sum % 16 == 0 && (uintptr_t)dYc % 16 == 0 && (uintptr_t)Wo % 16 == 0,
+                 "comb_fused_bwd: rows must be 16-byte aligned");
+    FIRA_REQUIRE((size_t)n_rows * 2 * FIRA_D * 4 < (1ull << 31), "comb_fused_bwd: %d rows exceed the 2 GiB the kernel addresses", n_rows);
+    // three [n,256]x[256,256] products; bytes: dy, s in; q|k in; dYc, dq|dk out; the node rows out
+    ProfScope prof(s, PROF_COMB, 3.0 * 2.0 * n_rows * FIRA_D * FIRA_D, 4.0 * n_rows * FIRA_D * (2.0 + 2.0 + 1.0 + 2.0 + 1.0));
+    CombFusedBwdArgs a{};
+    a.n_rows = n_rows; a.dG = dG; a.rows = rows; a.sum = sum; a.stats = stats; a.gamma = gamma; a.Wo = Wo; a.Wqk = Wqk; a.qk = qk;
+    a.vtab = vtab; a.ldv = ldv; a.mark = mark; a.dYc = dYc; a.dqk = dqk; a.part_ln = part_ln; a.part_v = part_v;
+    a.p = dropout; a.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; a.seed = seed; a.site_gate = site_gate;
+    a.site_out = site_out;
+    static const int attr = [] {
+        hipError_t e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }();
+    if (attr) return attr;
+    if (bf16) hipLaunchKernelGGL(comb_fused_bwd_kernel<true>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+    else hipLaunchKernelGGL(comb_fused_bwd_kernel<false>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+    FIRA_CHECK_LAUNCH("comb_fused_bwd");
+    return 0;
+}
+
 // Wt[i] = W[i]^T for a table of [256,256] matrices anywhere in memory (the Combination weights live in the flat parameter buffer)
 __global__ __launch_bounds__(256) void transpose256_table_kernel(const TransposeTable tab) {
     __shared__ float tile[64][65];
@@ -314,6 +566,28 @@ int transpose256_table(hipStream_t s, const TransposeTable& tab) {
 }  // namespace fira
 
 extern "C" {
+int fira_combination_block_bwd(void* stream, int n_rows, float* dG, const int32_t* rows, const float* sum, const float* stats,
+                               const float* gamma, const float* Wo, const float* Wqk, const float* qk, const float* vtab, int ldv,
+                               const int32_t* mark, float* dYc, float* dqk, float* dgamma, float* dbeta, float* dvtab, int lddv,
+                               float* part, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int dtype) {
+    FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_bwd: dropout must be in [0,1)");
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_combination_block_bwd: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(dgamma && dbeta && dvtab && part, "fira_combination_block_bwd: null pointer argument");
+    const int nb = fira::comb_fused_bwd_parts();
+    float* part_ln = part;
+    float* part_v = part + (size_t)nb * 2 * FIRA_D;
+    if (int rc = fira::comb_fused_bwd((hipStream_t)stream, n_rows, dG, rows, sum, stats, gamma, Wo, Wqk, qk, vtab, ldv, mark, dYc, dqk,
+                                      part_ln, part_v, dropout, seed, site_gate, site_out, dtype == FIRA_BF16))
+        return rc;
+    if (n_rows <= 0) return 0;
+    fira::RedTable tab;
+    tab.e[0] = fira::RedEntry{dgamma, part_ln, FIRA_D, nb, 2 * FIRA_D};
+    tab.e[1] = fira::RedEntry{dbeta, part_ln + FIRA_D, FIRA_D, nb, 2 * FIRA_D};
+    for (int k = 0; k < 4; ++k) tab.e[2 + k] = fira::RedEntry{dvtab + (size_t)k * lddv, part_v + k * FIRA_D, FIRA_D, nb, 4 * FIRA_D};
+    tab.n = 6;
+    return fira::deferred_reduce((hipStream_t)stream, tab);
+}
+int fira_combination_block_bwd_part_floats(void) { return fira::comb_fused_bwd_parts() * 6 * FIRA_D; }
 int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                                const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk,
                                float* c, const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows,

@@ -151,7 +151,7 @@ struct Plan {
             dCB_a = a.f((size_t)CB * D);
             red_cap = (size_t)nl * ((size_t)cdiv(NB, 16) * 4 * D + (size_t)cdiv(CB, 16) * 2 * D)                 // encoder LNs (GCN: + 2 sums)
                     + (size_t)3 * nl * cdiv(TB, 16) * 2 * D                                                      // decoder LNs
-                    + (size_t)nl * cdiv(CB, 16) * 4 * D                                                          // Combination
+                    + (size_t)nl * std::max((size_t)cdiv(CB, 16) * 4 * D, (size_t)256 * 6 * D)                           // Combination (fused: 256 x 1536)
                     + (size_t)cdiv(L + S, 16) * B * COPY_PART_STRIDE + 4096;                                     // copy head
             red_buf = a.f(red_cap);
             // buffers that must start a backward pass at zero, contiguous: ONE fill per step (zero_beg .. zero_end)
@@ -587,6 +587,11 @@ static inline bool comb_fused_on() {
     static const bool off = [] { const char* e = getenv("FIRA_COMB_FUSED"); return e && e[0] == '0'; }();
     static const bool off16 = [] { const char* e = getenv("FIRA_COMB_FUSED_BF16"); return e && e[0] == '0'; }();
     return !off && !(g_dtype == 1 && off16);
+}
+
+static inline bool comb_fused_bwd_on() {         // FIRA_COMB_FUSED_BWD=0: the backward pass keeps its four launches (A/B switch)
+    static const bool off = [] { const char* e = getenv("FIRA_COMB_FUSED_BWD"); return e && e[0] == '0'; }();
+    return !off && comb_fused_on();
 }
 
 enum Site { SITE_GATE = 0, SITE_COMB_OUT = 1, SITE_GCN = 2, SITE_SELF = 3, SITE_CROSS = 4, SITE_FFN = 5 };
@@ -1082,6 +1087,25 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         }
         // Combination on the code rows, in place inside `other` through the code-row map: the LayerNorm backward reads
         // dG[code rows] and leaves the residual-branch gradient there; the q|k projection's dgrad adds to the same rows
+        bool comb_done = false;
+        if (comb_fused_bwd_on()) {
+            // one launch (comb_fused.hip): LayerNorm backward, dgrad through Wo, gate backward, dgrad through Wq | Wk
+            const int nb = comb_fused_bwd_parts();
+            float* part_ln = red().alloc((size_t)nb * 2 * D);
+            float* part_v = part_ln ? red().alloc((size_t)nb * 4 * D) : nullptr;
+            if (part_v) {
+                TRY(comb_fused_bwd(s, Cc, other, bt.code_rows, e.s1, e.st1, c.P + w.ln1g, c.P + w.wo, c.P + w.wqk, e.qk,
+                                   p.vtab_all + l * D, p.nl * D, bt.code_mark, g.dYc, g.dqk, part_ln, part_v, c.p_drop, c.seed,
+                                   site(l, SITE_GATE), site(l, SITE_COMB_OUT), g_dtype == 1));
+                red().add(G + w.ln1g, part_ln, D, nb, 2 * D);
+                red().add(G + w.ln1b, part_ln + D, D, nb, 2 * D);
+                for (int k = 0; k < 4; ++k)
+                    red().add(p.dvtab_all + (size_t)k * p.nl * D + l * D, part_v + k * D, D, nb, 4 * D);
+                TRY(enc_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
+                comb_done = true;
+            }
+        }
+        if (!comb_done) {
         TRY(ln_bwd(s, Cc, other, e.s1, e.st1, c.P + w.ln1g, other, g.dYc, G + w.ln1g, G + w.ln1b, c.p_drop,
                               c.seed, site(l, SITE_COMB_OUT), bt.code_rows));
         TRY(enc_wgrad(s, Cc, D, D, g.dYc, D, e.c, D, G + w.wo, G + w.bo));
@@ -1095,13 +1119,15 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                 for (int k = 0; k < 4; ++k)
                     red().add(p.dvtab_all + (size_t)k * p.nl * D + l * D, part + k * D, D, nb, 4 * D);
         }
+        }
         TRY(enc_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
         if (grouped) {                           // the layer's three weight gradients: one fork, one launch, then the unfold
             TRY(flush_grouped_wgrads(s));
             TRY(unfold());
         }
-        TRY(gemm_any(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
-                        bt.code_rows));                                                        // other = dX[l]
+        if (!comb_done)
+            TRY(gemm_any(s, 0, 0, Cc, D, 2 * D, g.dqk, 2 * D, c.P + w.wqk, D, other, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr,
+                         bt.code_rows));                                                       // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
     // encoder LayerNorms, dvtab_all and the two products that read it: beside the embedding kernels below, on the auxiliary

@@ -239,6 +239,25 @@ def combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout
     return qk, c, summ, y, stats
 
 
+def combination_block_bwd(dG, rows, summ, stats, gamma, Wo, Wqk, qk, vtab, mark, dropout=0.0, seed=0, site_gate=0, site_out=0,
+                          dtype=0):
+    """fira_combination_block_bwd: dG [N,256] is updated in place at rows[r]; returns (dYc, dqk, dgamma, dbeta, dvtab)."""
+    n = summ.shape[0]
+    dev = summ.device
+    assert vtab.is_cuda and vtab.dtype == torch.float32 and vtab.stride(1) == 1 and vtab.shape[0] == 4, "vtab: fp32 rows"
+    dYc = torch.empty((n, 256), dtype=torch.float32, device=dev)
+    dqk = torch.empty((n, 512), dtype=torch.float32, device=dev)
+    dgamma, dbeta = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+    dvtab = torch.zeros((4, 256), device=dev)
+    part = torch.empty(_lib.lib().fira_combination_block_bwd_part_floats(), dtype=torch.float32, device=dev)
+    check(_lib.lib().fira_combination_block_bwd(cur_stream(), n, ptr(_f32(dG)), ptr(_i32(rows)), ptr(_f32(summ)), ptr(_f32(stats)),
+                                                ptr(_f32(gamma)), ptr(_f32(Wo)), ptr(_f32(Wqk)), ptr(_f32(qk)), ptr(vtab),
+                                                vtab.stride(0), ptr(_i32(mark)), ptr(dYc), ptr(dqk), ptr(dgamma), ptr(dbeta),
+                                                ptr(dvtab), 256, ptr(part), dropout, seed, site_gate, site_out, dtype),
+          "fira_combination_block_bwd")
+    return dYc, dqk, dgamma, dbeta, dvtab
+
+
 def gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=0):
     """fira_gcn_layer_bwd: V = A_hat dY (returned), dX += V W21 in place."""
     V = torch.empty_like(dY)

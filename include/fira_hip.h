@@ -226,6 +226,19 @@ int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const 
                                float* y, const int32_t* y_rows, float* stats, float dropout, uint64_t seed,
                                uint32_t site_gate, uint32_t site_out, int dtype);
 
+/* Backward of the block, one launch + one reduction launch: with dy = dG[rows[r]] (the gradient w.r.t. the block's output rows)
+ *     ds = LayerNorm'(dy; sum, stats, gamma) ;  dYc = ds * mask_out ;  dc = dYc Wo ;  (dq, dk, dv) = gate'(q, k, vtab[mark], dc * mask_gate)
+ *     dG[rows[r]] = ds + dq Wq + dk Wk
+ * Wo [256,256] and Wqk [512,256] as nn.Linear stores them.  Written: dYc [n_rows,256] and dqk [n_rows,512] (the operands of the
+ * weight gradients dWo = dYc^T c, dWqk = dqk^T Xc); accumulated into: dgamma, dbeta [256], dvtab (row m at dvtab + m*lddv).
+ * part: scratch of fira_combination_block_bwd_part_floats() floats.                                                       */
+int fira_combination_block_bwd(void* stream, int n_rows, float* dG, const int32_t* rows, const float* sum, const float* stats,
+                               const float* gamma, const float* Wo, const float* Wqk, const float* qk, const float* vtab,
+                               int ldv, const int32_t* mark, float* dYc, float* dqk, float* dgamma, float* dbeta,
+                               float* dvtab, int lddv, float* part, float dropout, uint64_t seed, uint32_t site_gate,
+                               uint32_t site_out, int dtype);
+int fira_combination_block_bwd_part_floats(void);
+
 /* out[(b*out_bstride + out_off + i), :] = table[idx[b*L + i], :] (+ pos[i,:])  — the embedding
  * gathers of gnn_transformer.py:46-52,110-113 written straight into the node buffer.           */
 int fira_embed_gather_fwd(void* stream, int B, int L, const int32_t* idx, const float* table,

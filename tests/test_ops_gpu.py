@@ -209,6 +209,67 @@ def test_combination_block_fused_fwd(n, p, dtype):
         assert bool(((c == 0) == (c2 == 0)).all())
 
 
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("n,p", [(3667, 0.0), (3667, 0.1), (37, 0.1), (6861, 0.1)])
+def test_combination_block_fused_bwd(n, p, dtype):
+    """fira_combination_block_bwd (comb_fused.hip): LayerNorm backward, data gradient through the output projection, gate
+    backward and data gradient through q | k in one launch, against fp64 autograd of the block's own formulas with the engine's
+    dropout masks: dG rows (in place at the listed rows, other rows untouched), dYc, dq|dk, dgamma, dbeta, dvtab.  bf16: the
+    products on bf16-rounded operands (reference: the same rounding through a straight-through estimator)."""
+    from fira_icse_amd import ops
+    Xc = randn(n, 256, seed=1)
+    Wqk, bqk = randn(512, 256, seed=2, scale=0.08), randn(512, seed=3, scale=0.1)
+    Wo, bo = randn(256, 256, seed=4, scale=0.08), randn(256, seed=5, scale=0.1)
+    vtab = randn(4, 256, seed=6)
+    mark = torch.randint(0, 4, (n,), device=DEV, dtype=torch.int32)
+    gamma, beta = 1 + randn(256, seed=7, scale=0.1), randn(256, seed=8, scale=0.1)
+    rows = torch.randperm(2 * n, device=DEV)[:n].to(torch.int32)
+    seed, sg, so = 4321, 17, 18
+    qk, c, summ, y, stats = ops.combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout=p, seed=seed,
+                                                      site_gate=sg, site_out=so, dtype=dtype)
+    dG0 = randn(2 * n, 256, seed=9)
+    dG = dG0.clone()
+    dYc, dqk, dgamma, dbeta, dvtab = ops.combination_block_bwd(dG, rows, summ, stats, gamma, Wo, Wqk, qk, vtab, mark, dropout=p,
+                                                               seed=seed, site_gate=sg, site_out=so, dtype=dtype)
+    # fp64 autograd from the SAVED q|k and pre-norm rows (what the kernel reads), with the engine's masks
+    mg = ops.dropout_mask(seed, sg, n * 256, p).view(n, 256).double() if p > 0 else torch.ones(n, 256, device=DEV, dtype=torch.float64)
+    mo = ops.dropout_mask(seed, so, n * 256, p).view(n, 256).double() if p > 0 else torch.ones(n, 256, device=DEV, dtype=torch.float64)
+
+    class R16(torch.autograd.Function):                               # bf16 rounding of a product's operand, identity gradient
+        @staticmethod
+        def forward(ctx, x):
+            return x.float().bfloat16().double()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+    r16 = R16.apply if dtype else (lambda t: t)
+    dy = dG0[rows.long()].double()
+    s_ = summ.double().requires_grad_(True)
+    g_, b_ = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yy = F.layer_norm(s_, (256,), g_, b_, 1e-5)
+    ds, dgam_ref, dbet_ref = torch.autograd.grad(yy, (s_, g_, b_), dy)
+    dYc_ref = ds * mo
+    dc = r16(dYc_ref) @ r16(Wo.double())                               # d(c Wo^T) / dc
+    q_ = qk[:, :256].double().requires_grad_(True)
+    k_ = qk[:, 256:].double().requires_grad_(True)
+    vt_ = vtab.double().requires_grad_(True)
+    v_ = vt_[mark.long()]
+    gg = torch.softmax(torch.stack([q_ * k_ / math.sqrt(32), q_ * v_ / math.sqrt(32)], -1), -1)
+    cc = (gg[..., 0] * k_ + gg[..., 1] * v_) * mg
+    dq_ref, dk_ref, dvt_ref = torch.autograd.grad(cc, (q_, k_, vt_), dc)
+    dX_ref = r16(dq_ref) @ r16(Wqk[:256].double()) + r16(dk_ref) @ r16(Wqk[256:].double())
+    t1 = 5e-6 if dtype == 0 else 2e-4
+    assert rel_err(dYc, dYc_ref) < 5e-6
+    assert rel_err(dqk[:, :256], dq_ref) < t1 and rel_err(dqk[:, 256:], dk_ref) < t1
+    assert rel_err(dG[rows.long()], ds + dX_ref) < t1
+    untouched = torch.ones(2 * n, dtype=torch.bool, device=DEV)
+    untouched[rows.long()] = False
+    assert torch.equal(dG[untouched], dG0[untouched])
+    assert rel_err(dgamma, dgam_ref) < 1e-5 and rel_err(dbeta, dbet_ref) < 1e-5
+    assert rel_err(dvtab, dvt_ref) < (1e-5 if dtype == 0 else 2e-4)
+
+
 def dense_graph_batch(B, N, density, seed):
     """symmetric random adjacency blocks with a full diagonal -> block-diagonal CSR (sorted unique columns) + dense copy"""
     rng = np.random.default_rng(seed)

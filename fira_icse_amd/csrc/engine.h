@@ -150,6 +150,9 @@ int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float
 struct UnfoldEntry { const float *W2, *b1, *dc; float *dW2, *db1; };
 struct UnfoldTable { int n = 0; UnfoldEntry e[16]; };
 int gcn_bias_unfold_all(hipStream_t s, const UnfoldTable& tab);      // every GCN layer in one launch
+// dW2[l] += dW21[l] W1[l]^T and dW1[l] += W2[l]^T dW21[l] for every layer in ONE launch (gemm_small.hip; [256,256] matrices)
+int gcn_unfold_products(hipStream_t s, int n_layers, const float* const* dW21, const float* const* W1, const float* const* W2,
+                        float* const* dW1, float* const* dW2);
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight = nullptr);
 int rank2_rows(hipStream_t s, int M, const float* g, const float* w, float* out);   // out[M,256] = g[M,2] w[2,256]
 // index-list row movers (W floats per row): mode 0 out[r]=in[src[r]], 1 out[dst[r]]=in[r], 2 out[dst[r]]+=in[r],

@@ -1034,6 +1034,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     float* dXn = p.dXa;
     float* other = p.dXb;
     UnfoldTable unfold_tab;                  // GCN layers whose dc comes out of the deferred reduction at the end
+    // (round 5) FIRA_UNFOLD_LATE=0: the folded weight's two unfold products per layer as two launches behind that layer's grouped
+    // weight gradients (A/B switch); default: all layers in one launch behind the last group
+    static const bool unfold_late_off = [] { const char* e = getenv("FIRA_UNFOLD_LATE"); return e && e[0] == '0'; }();
+    const bool unfold_late = !unfold_late_off && enc_group_on() && p.nl <= 16;
+    const float *uf_dW21[16], *uf_W1[16], *uf_W2[16];
+    float *uf_dW1[16], *uf_dW2[16];
+    int uf_n = 0;
     if (!c.ev_zero) TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));   // AST/edit rows of the last layer feed nothing
     if (ev_dmem) TRY(main_wait(s, ev_dmem));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
@@ -1062,8 +1069,14 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                 ws = side().stream;
             }
             if (!sums) TRY(colsum(ws, Nc, D, g.dY2, D, dc21, p.rsum));
+            if (unfold_late) {                       // the two products of every layer: ONE launch behind the last layer's group
+                uf_dW21[uf_n] = dW21; uf_W1[uf_n] = c.P + w.fc1w; uf_W2[uf_n] = c.P + w.fc2w;
+                uf_dW1[uf_n] = G + w.fc1w; uf_dW2[uf_n] = G + w.fc2w;
+                ++uf_n;
+            } else {
             TRY(gemm_f32_ex(ws, 0, 1, D, D, D, dW21, D, c.P + w.fc1w, D, G + w.fc2w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
             TRY(gemm_f32_ex(ws, 1, 0, D, D, D, c.P + w.fc2w, D, dW21, D, G + w.fc1w, D, nullptr, FIRA_GEMM_ACCUM, 0, nullptr));
+            }
             if (!sums) TRY(gcn_bias_unfold(ws, c.P + w.fc2w, c.P + w.fc1b, dc21, G + w.fc2w, G + w.fc1b));
             return 0;
         };
@@ -1130,6 +1143,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                          bt.code_rows));                                                       // other = dX[l]
         float* tmp = dXn; dXn = other; other = tmp;
     }
+    if (uf_n > 0) TRY(gcn_unfold_products(side().stream, uf_n, uf_dW21, uf_W1, uf_W2, uf_dW1, uf_dW2));   // (in order behind the last group)
     // encoder LayerNorms, dvtab_all and the two products that read it: beside the embedding kernels below, on the auxiliary
     // stream (idle since the decoder's backward pass)
     hipEvent_t ev_tail = nullptr;

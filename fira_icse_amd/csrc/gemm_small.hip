@@ -536,6 +536,83 @@ bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const flo
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the folded GCN weight's gradient dW21 goes back to the reference's parameters through two 256^3 products per layer,
+//     dW2 += dW21 W1^T        dW1 += W2^T dW21         (engine.hip: W21 = W2 W1)
+// which were two launches per layer on the weight-gradient stream (7 + 5 us each, launch-bound: 72 us of that stream's serial
+// chain per step, and the end of the step waits for it).  Here ALL of them are one launch after the last layer's weight
+// gradient: one 32x32 output tile per workgroup, the four waves split K = 256 (gemm_small_kernel's decomposition: every wave
+// fetches its fragments straight into registers, 2 x 16 MFMAs, partial tiles combined through LDS), operands addressed by
+// (row stride, k stride) so that both products read the matrices as stored.
+struct UnfoldGemm { const float *A, *B; float* C; int a_rs, a_ks, b_rs, b_ks; };      // C[i,j] += sum_k A[i*a_rs + k*a_ks] B[j*b_rs + k*b_ks]
+struct UnfoldGemmTable { int n = 0; UnfoldGemm e[32]; };
+__global__ __launch_bounds__(256) void unfold_gemm_kernel(const UnfoldGemmTable tab) {
+    __shared__ float red[4][1024];
+    const UnfoldGemm& q = tab.e[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int m0 = (blockIdx.x >> 3) * 32, n0 = (blockIdx.x & 7) * 32;
+    const float* pa = q.A + (size_t)(m0 + l31) * q.a_rs;
+    const float* pb = q.B + (size_t)(n0 + l31) * q.b_rs;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a[2][16], b[2][16];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                       // chunks wave, wave + 4 of the eight 32-wide k chunks: all loads in flight at once
+        const int k0 = (wave + 4 * u) * 32 + kh * 16;
+        if (q.a_ks == 1) {                              // (workgroup-uniform)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(pa + k0 + 4 * v);
+                a[u][4 * v] = x.x; a[u][4 * v + 1] = x.y; a[u][4 * v + 2] = x.z; a[u][4 * v + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a[u][t] = pa[(size_t)(k0 + t) * q.a_ks];
+        }
+        if (q.b_ks == 1) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(pb + k0 + 4 * v);
+                b[u][4 * v] = x.x; b[u][4 * v + 1] = x.y; b[u][4 * v + 2] = x.z; b[u][4 * v + 3] = x.w;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) b[u][t] = pb[(size_t)(k0 + t) * q.b_ks];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], b[u][t], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = threadIdx.x + 256 * i;          // accumulator register r = idx / 64 of lane idx % 64
+        const int r = idx >> 6, ln = idx & 63;
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
+        float* pc = q.C + (size_t)row * FIRA_D + col;
+        *pc += (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+    }
+}
+int gcn_unfold_products(hipStream_t s, int n_layers, const float* const* dW21, const float* const* W1, const float* const* W2,
+                        float* const* dW1, float* const* dW2) {
+    if (n_layers <= 0) return 0;
+    if (n_layers > 16) return set_err("gcn_unfold_products: %d layers", n_layers);
+    UnfoldGemmTable tab;
+    for (int l = 0; l < n_layers; ++l) {
+        tab.e[tab.n++] = UnfoldGemm{dW21[l], W1[l], dW2[l], FIRA_D, 1, FIRA_D, 1};        // dW2[i,j] += sum_k dW21[i,k] W1[j,k]
+        tab.e[tab.n++] = UnfoldGemm{W2[l], dW21[l], dW1[l], 1, FIRA_D, 1, FIRA_D};        // dW1[i,j] += sum_k W2[k,i] dW21[k,j]
+    }
+    ProfScope prof(s, PROF_GEMM, 2.0 * tab.n * FIRA_D * (double)FIRA_D * FIRA_D, 4.0 * tab.n * 3.0 * FIRA_D * FIRA_D);
+    hipLaunchKernelGGL(unfold_gemm_kernel, dim3(64, tab.n), dim3(256), 0, s, tab);
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? set_err("gcn_unfold_products: %s", hipGetErrorString(e)) : 0;
+}
+
 // true if this kernel took the call
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows,

@@ -39,6 +39,11 @@ class TrainOpts(C.Structure):
                 ("dtype", C.c_int32), ("compact_dec", C.c_int32), ("zero_grads", C.c_int32)]
 
 
+class AdamOpts(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32),
+                ("m", C.c_void_p), ("v", C.c_void_p)]
+
+
 _P, _I, _F, _L, _Z = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_size_t
 _U64, _U32 = C.c_uint64, C.c_uint32
 _DP, _BP, _OP = C.POINTER(Dims), C.POINTER(Batch), C.POINTER(TrainOpts)
@@ -93,6 +98,7 @@ SIGNATURES = {
     "fira_pack_stats": (_I, [_P, _P, _P, _P]),
     "fira_debug_chain": (_I, [_P, _I, _I, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
+    "fira_train_step": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, C.POINTER(AdamOpts)]),
     "fira_prof_enable": (None, [_I]),
     "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
     "fira_param_groups": (_I, [_DP, C.POINTER(_L), C.POINTER(_L)]),
@@ -147,14 +153,24 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # FIRA_HIP_LIB (A/B timing of an older build through the model-level entry points, whose signatures did not change
-    # between v5 and v6) may load a v5 library; the tree's own library must be v6
-    ok = (6,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6)
+    # between v5 and v7; callers ask has_symbol() before using an entry a v5 / v6 build lacks) may load an older library; the
+    # tree's own library must be v7
+    ok = (7,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7)
     if lib.fira_abi_version() not in ok:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib
 
 
 _lib = None
+
+
+def has_symbol(name: str) -> bool:
+    """True if the loaded library exports ``name`` (an older build loaded through FIRA_HIP_LIB may not)."""
+    try:
+        getattr(lib(), name)
+        return True
+    except AttributeError:
+        return False
 
 
 def lib():

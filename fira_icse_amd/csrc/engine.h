@@ -246,6 +246,8 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
               const int32_t* row_bt = nullptr);      // BT computed target rows, row_bt[r] = flat b*T + t (nullptr: r itself)
 int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1,
               float beta2, float eps, int step, const float* scale_ptr, int scale_is_count = 0);
+int adam_step_mb(hipStream_t s, int64_t n, float* p, const float* g0, const float* g1, float* m, float* v, float lr,
+                 float beta1, float beta2, float eps, int step, const int32_t* n0, const int32_t* n1);
 
 // ---- parameter layout ---------------------------------------------------------------------------------
 struct ParamInfo {

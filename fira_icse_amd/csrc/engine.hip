@@ -632,6 +632,12 @@ struct Ctx {
     int kv_waited = 0;
     hipEvent_t ev_src = nullptr;
     hipEvent_t ev_zero = nullptr;   // the backward pass's zero-initialised buffers were cleared on the auxiliary stream
+    // fira_train_step (round 5): the optimizer update is part of the call.  Adam is element-wise, so the head + decoder slice
+    // [0, split) is updated as soon as the caller's stream has finished the encoder's backward chain -- while the weight-gradient
+    // and auxiliary streams still work on the encoder's last gradients -- and [split, live) after the join.  Pw = the parameters,
+    // writable (nothing reads [0, split) after the decoder's backward pass; see backward()).
+    const fira_adam_opts* adam = nullptr;
+    float* Pw = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------ encoder forward
@@ -1012,6 +1018,14 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // decoder LayerNorms, copy head: their partial rows were written before the fork of the weight gradient above, and only
     // the end of the step (or the mid-event below, which waits for this stream) reads the sums: off the dependent chain
     TRY(deferred_reduce(side().stream && side().enabled ? side().stream : s, red().tab));
+    // every gradient of [0, split) is final once the weight-gradient stream has passed this point (its launches above: the
+    // vocabulary / copy / decoder weight gradients, the decoder embedding, the stacked K|V weight, the deferred column sums;
+    // the auxiliary stream writes data gradients only)
+    hipEvent_t ev_groupA = nullptr;
+    if (c.adam && side().stream && side().enabled) {
+        ev_groupA = side().ev();
+        if (hipEventRecord(ev_groupA, side().stream) != hipSuccess) return set_err("group-A mark failed");
+    }
     if (mid_event) {                         // gradients of [0, split) are final from here on
         // The event fires when BOTH the caller's stream and the weight-gradient stream have reached this point, without
         // holding up either of them: the auxiliary stream (idle for the rest of the backward pass) waits for the two and
@@ -1174,11 +1188,25 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         else
             TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     }
+    if (c.adam) {
+        // Adam on [0, split) (69 % of the live parameters) HERE: the caller's stream would otherwise stand waiting for the last
+        // grouped weight gradient / the unfold products / the deferred reductions of the other two streams (timeline: 30-60 us)
+        // and then run the whole update alone.  Nothing enqueued after the decoder's backward pass reads a parameter of
+        // [0, split): the encoder's backward kernels read encoder weights, the weight-gradient stream reads activations.
+        const fira_adam_opts& ad = *c.adam;
+        if (ev_groupA) TRY(main_wait(s, ev_groupA));
+        TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+    }
     if (ev_tail) TRY(main_wait(s, ev_tail));
     if (side().stream && side().enabled) TRY(side_join(s));        // every weight gradient is complete past this point
     // dc of every GCN layer is final (deferred reduction above) and so are the side stream's additions to dW2: back to the
     // reference's fc2.weight / fc1.bias gradients, one launch for all layers
     TRY(gcn_bias_unfold_all(s, unfold_tab));
+    if (c.adam) {
+        const fira_adam_opts& ad = *c.adam;
+        TRY(adam_step_mb(s, L.live - L.split, c.Pw + L.split, G + L.split, nullptr, ad.m + L.split, ad.v + L.split, ad.lr, ad.beta1,
+                         ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+    }
     return 0;
 }
 
@@ -1244,9 +1272,9 @@ size_t fira_decode_workspace_bytes_ex(const fira_dims* d, int B, int n_beam, int
     return dp.build(nullptr, *d, B, n_beam, flags);
 }
 
-int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
-                       void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
-                       int32_t* n_tok, void* mid_event) {
+static int train_call(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                      void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                      int32_t* n_tok, void* mid_event, float* params_w, const fira_adam_opts* adam) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
     TRY(check_batch(batch));
@@ -1286,6 +1314,8 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     }
     c.loss_sum = loss_sum;
     c.n_tok = n_tok;
+    c.adam = adam;
+    c.Pw = params_w;
     const bool zero_g = opts && opts->zero_grads;
     if (!side_on() && zero_g) TRY(zero(c.s, grads, (size_t)L->live * sizeof(float)));
     TRY(encoder_forward(c, true));
@@ -1305,6 +1335,21 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
     TRY(backward(c, R, rows, (hipEvent_t)mid_event));
     return 0;
+}
+
+int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                       void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                       int32_t* n_tok, void* mid_event) {
+    return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, mid_event, nullptr,
+                      nullptr);
+}
+
+int fira_train_step(void* stream, const fira_dims* d, const fira_batch* batch, float* params, float* grads, void* workspace,
+                    size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum, int32_t* n_tok,
+                    const fira_adam_opts* adam) {
+    FIRA_REQUIRE(adam && adam->m && adam->v, "fira_train_step: Adam moments missing");
+    FIRA_REQUIRE(adam->step >= 1, "fira_train_step: the Adam step counter starts at 1");
+    return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, nullptr, params, adam);
 }
 
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,

@@ -479,6 +479,27 @@ class TransModel(nn.Module):
                    "fira_train_fwd_bwd")
         return self.loss_sum, self.n_tok
 
+    def train_step(self, db: DeviceBatch, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, beta1: float = 0.9,
+                   beta2: float = 0.999, eps: float = 1e-8, dropout: Optional[float] = None,
+                   gcn_dropout: Optional[float] = None):
+        """``loss.backward(); optimizer.step()`` of run_model.py:104-111 as ONE library call (fira_train_step): the same
+        arithmetic as :meth:`train_fwd_bwd` + ``ops.adam_step_mb`` over ``[0, live)``; the head + decoder slice of the update
+        runs beside the last weight gradients.  ``m`` / ``v``: the Adam moments (flat, like ``self.flat``)."""
+        lib = _lib.lib()
+        db.wait_ready()
+        p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
+        pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
+        self.dropout_step += 1
+        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0, self._dtype_code(),
+                              1 if self.compact_dec else 0, 1)
+        adam = _lib.AdamOpts(lr, beta1, beta2, eps, int(step), _lib.ptr(m), _lib.ptr(v))
+        ws = self.workspace(db.B, 1)
+        _lib.check(lib.fira_train_step(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct), _lib.ptr(self.flat.data),
+                                       _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(), C.byref(opts),
+                                       _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok), C.byref(adam)),
+                   "fira_train_step")
+        return self.loss_sum, self.n_tok
+
     def _dtype_code(self) -> int:
         try:
             return {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[self.compute_dtype]

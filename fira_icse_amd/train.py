@@ -7,11 +7,12 @@ run_model.py:112); ``last_loss()`` reads it back only when asked.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .model import DeviceBatch, TransModel
 from .parallel import GradReducer, ShardedOptimizerComm
 
@@ -37,6 +38,9 @@ class Trainer:
             self.g_sh = [torch.zeros(c, dtype=torch.float32, device=dev) for c in chunks]
             self.zstream = torch.cuda.Stream()
             self.end_event = torch.cuda.Event()
+        # one library call per step (fira_train_step: the head + decoder slice of the update beside the last weight gradients);
+        # FIRA_FUSED_STEP=0 = fira_train_fwd_bwd + one Adam launch over [0, live) (A/B switch; identical results)
+        self.fused_step = (not distributed) and os.environ.get("FIRA_FUSED_STEP", "1") != "0" and _lib.has_symbol("fira_train_step")
         self.t = 0
         self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
@@ -64,6 +68,10 @@ class Trainer:
             m.n_tok.zero_()
             self.mid_event.record()
             loss_sum, n_tok = m.loss_sum, m.n_tok
+        elif self.fused_step and self.reducer is None and self.zero is None:
+            self.t += 1
+            m.train_step(db, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps)
+            return
         else:
             loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
         b1, b2 = self.betas

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 6
+#define FIRA_ABI_VERSION 7
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -416,6 +416,22 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
                        float* loss_sum, int32_t* n_tok, void* mid_event);
 /* mid_event: optional hipEvent_t recorded on `stream` once the gradients of group [0, split) are final (after the
  * decoder backward, before the encoder backward), so that their RCCL all-reduce can overlap the rest.           */
+
+/* (v7) One optimisation step in one call: `loss.backward(); optimizer.step()` of run_model.py:104-111 for a single device --
+ * fira_train_fwd_bwd followed by fira_adam_step_mb over [0, live) with the token normaliser of run_model.py:105, bit for bit
+ * (Adam is element-wise).  What the single call adds is the ORDER: the update of the head + decoder slice [0, split) is
+ * enqueued as soon as the caller's stream has finished the encoder's backward chain, beside the last weight gradients of the
+ * library's other streams; [split, live) follows their join.  params is updated in place, m / v are the Adam moments
+ * ([>= live] floats each), step counts from 1.  Data-parallel runs keep the two-call form (the all-reduce sits between). */
+typedef struct fira_adam_opts {
+    float   lr, beta1, beta2, eps;
+    int32_t step;
+    float*  m;
+    float*  v;
+} fira_adam_opts;
+int fira_train_step(void* stream, const fira_dims* d, const fira_batch* batch, float* params, float* grads,
+                    void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                    int32_t* n_tok, const fira_adam_opts* adam);
 
 /* TransModel.forward(..., 'dev') (Model.py:85-86): teacher-forced argmax ids [B, tar_len].         */
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,

@@ -49,6 +49,11 @@ for ST in "$@"; do
       for i in 1 2; do
         for V in "FIRA_HIP_LIB=$PREV" "FIRA_X=1"; do echo -n "${V##*/} decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done
       done 2>&1 | tee $OUT/abdec.txt ;;
+    abdecenv)   # environment switches of ONE build on the greedy search, alternating: ABENV_DEC="A=1|B=2"
+      IFS='|' read -ra VARS <<< "$ABENV_DEC"
+      for i in 1 2; do
+        for V in "${VARS[@]}"; do echo -n "$V decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done
+      done 2>&1 | tee $OUT/abdecenv.txt ;;
     bench)
       timeout 900 python bench.py --detail $OUT/bench_detail_f32.json > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "bench f32 rc=$? bytes=$(wc -c < $OUT/bench_f32.json)"; cat $OUT/bench_f32.json; tail -n 5 $OUT/bench_f32.err ;;
     bench16)

@@ -151,6 +151,8 @@ struct UnfoldEntry { const float *W2, *b1, *dc; float *dW2, *db1; };
 struct UnfoldTable { int n = 0; UnfoldEntry e[16]; };
 int gcn_bias_unfold_all(hipStream_t s, const UnfoldTable& tab);      // every GCN layer in one launch
 // dW2[l] += dW21[l] W1[l]^T and dW1[l] += W2[l]^T dW21[l] for every layer in ONE launch (gemm_small.hip; [256,256] matrices)
+int gcn_fold_weights(hipStream_t s, int n_layers, const float* const* W2, const float* const* W1, const float* const* b1,
+                     float* W21, float* W21t, float* c21);       // W21 = W2 W1, W21t = its transpose, c21 = W2 b1: one launch
 int gcn_unfold_products(hipStream_t s, int n_layers, const float* const* dW21, const float* const* W1, const float* const* W2,
                         float* const* dW1, float* const* dW2);
 int colsum(hipStream_t s, int M, int N, const float* X, int ldx, float* out, const float* row_weight = nullptr);

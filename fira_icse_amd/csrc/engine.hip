@@ -401,11 +401,61 @@ static int side_fork(hipStream_t main_s) {
         return set_err("side stream fork failed");
     return 0;
 }
+// FIRA_WAIT_PROBE=1 (measurement aid): every wait of the caller's stream for one of the library's streams is bracketed by two
+// timed events on the caller's stream; every 20th training call synchronises and prints, per source line of the wait, the
+// mean time the caller's stream stood there (stderr).  Off: no event is created.
+struct WaitProbe {
+    bool on = false, init = false;
+    struct Rec { int line; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    int calls = 0;
+    bool enabled() {
+        if (!init) { const char* e = getenv("FIRA_WAIT_PROBE"); on = e && e[0] == '1'; init = true; }
+        return on;
+    }
+    hipEvent_t ev() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void report() {
+        (void)hipDeviceSynchronize();
+        std::vector<std::pair<int, std::pair<double, int>>> acc;
+        for (auto& r : recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+            bool found = false;
+            for (auto& q : acc) if (q.first == r.line) { q.second.first += ms; q.second.second++; found = true; }
+            if (!found) acc.push_back({r.line, {ms, 1}});
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+        fprintf(stderr, "[fira wait probe] over %d calls, us per call the caller's stream spent at each wait (engine.hip line: us):", calls);
+        double tot = 0;
+        for (auto& q : acc) { fprintf(stderr, "  %d: %.1f", q.first, 1e3 * q.second.first / calls); tot += 1e3 * q.second.first / calls; }
+        fprintf(stderr, "  | total %.1f\n", tot);
+        calls = 0;
+    }
+};
+static WaitProbe& wait_probe() { static thread_local WaitProbe w; return w; }
+static int stream_wait_probed(hipStream_t main_s, hipEvent_t e, int line) {
+    WaitProbe& w = wait_probe();
+    if (!w.enabled()) return hipStreamWaitEvent(main_s, e, 0) == hipSuccess ? 0 : 1;
+    WaitProbe::Rec r{line, w.ev(), w.ev()};
+    (void)hipEventRecord(r.a, main_s);
+    const bool ok = hipStreamWaitEvent(main_s, e, 0) == hipSuccess;
+    (void)hipEventRecord(r.b, main_s);
+    w.recs.push_back(r);
+    return ok ? 0 : 1;
+}
+
 // join: `main` waits for everything enqueued on the side stream so far
-static int side_join(hipStream_t main_s) {
+static int side_join(hipStream_t main_s, int line = 0) {
     SideStream& sd = side();
     hipEvent_t e = sd.ev();
-    if (hipEventRecord(e, sd.stream) != hipSuccess || hipStreamWaitEvent(main_s, e, 0) != hipSuccess)
+    if (hipEventRecord(e, sd.stream) != hipSuccess || stream_wait_probed(main_s, e, line))
         return set_err("side stream join failed");
     return 0;
 }
@@ -427,8 +477,8 @@ static int side_mark(hipEvent_t* out) {
     *out = e;
     return 0;
 }
-static int main_wait(hipStream_t main_s, hipEvent_t e) {
-    if (hipStreamWaitEvent(main_s, e, 0) != hipSuccess) return set_err("stream wait failed");
+static int main_wait(hipStream_t main_s, hipEvent_t e, int line = 0) {
+    if (stream_wait_probed(main_s, e, line)) return set_err("stream wait failed");
     return 0;
 }
 
@@ -644,6 +694,12 @@ struct Ctx {
 // The encoder runs on the batch's COMPUTED node list only (fira_batch.node_rows): padded nodes carry nothing but a
 // self-loop, are masked as attention keys / copy slots and receive exactly zero gradient (SURVEY.md §8a note N1), so
 // leaving them out changes no consumed value.  Nc = n_nodes, Cc = n_code, Mc = n_mem below.
+// FIRA_FOLD_ONE=0: the folded GCN weights as two products + a transpose per layer (14 launches) instead of one launch (A/B switch)
+static inline bool fold_one_launch() {
+    static const bool off = [] { const char* e = getenv("FIRA_FOLD_ONE"); return e && e[0] == '0'; }();
+    return !off;
+}
+
 static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
@@ -677,6 +733,15 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             TRY(transpose256_table(fs, tt));
             if (ax) TRY(side_mark(&ev_comb));
         }
+        const bool fold_one = fold_one_launch() && p.nl <= 10;
+        if (fold_one) {
+            // (round 5) every layer's W21, its k-major copy and c21: ONE launch (gemm_small.hip: gcn_fold_weights).  The fused GCN
+            // kernels read the fp32 matrices in both modes, so the mark behind this launch is all the first layer waits for
+            const float *fW2[16], *fW1[16], *fb1[16];
+            for (int l = 0; l < p.nl; ++l) { fW2[l] = c.P + L.enc[l].fc2w; fW1[l] = c.P + L.enc[l].fc1w; fb1[l] = c.P + L.enc[l].fc1b; }
+            TRY(gcn_fold_weights(fs, p.nl, fW2, fW1, fb1, p.W21, gcn_fused_on() ? p.W21t : nullptr, p.c21));
+            if (ax && (!g_Wb || gcn_fused_on())) TRY(side_mark(&ev_fold0));
+        } else
         for (int l = 0; l < p.nl; ++l) {
             const EncLayer& w = L.enc[l];
             TRY(gemm_f32_ex(fs, 0, 0, D, D, D, c.P + w.fc2w, D, c.P + w.fc1w, D, p.W21 + (size_t)l * D * D, D, nullptr, 0, 0, nullptr));
@@ -694,7 +759,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             TRY(weight_shadows(fs, t21, p.W21, p.w21b, p.w21bt));
             g_W21 = p.W21; g_W21n = (int64_t)p.nl * D * D; g_W21b = p.w21b; g_W21bT = p.w21bt;
         }
-        if (gcn_fused_on() && p.nl > 1) TRY(transpose256(fs, p.nl - 1, p.W21 + (size_t)D * D, p.W21t + (size_t)D * D));
+        if (!fold_one && gcn_fused_on() && p.nl > 1) TRY(transpose256(fs, p.nl - 1, p.W21 + (size_t)D * D, p.W21t + (size_t)D * D));
         if (ax) TRY(side_mark(&ev_fold));
         if (!ev_fold0) ev_fold0 = ev_fold;           // bf16 mode / one layer: a single mark
     }
@@ -717,7 +782,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // Combination (gnn_transformer.py:192-205): code rows only; the result overwrites them in place.  e.Xc (the code
         // rows before the update: residual, and the q|k weight gradient's operand) was stored by the kernel that produced X
         if (comb_fused_on() && l < 8) {
-            if (l == 0 && ev_comb) TRY(main_wait(s, ev_comb));
+            if (l == 0 && ev_comb) TRY(main_wait(s, ev_comb, __LINE__));
             const float* wt = p.WcT + (size_t)l * 3 * D * D;
             TRY(comb_fused_fwd(s, Cc, e.Xc, wt, wt + (size_t)D * D, wt + (size_t)2 * D * D, c.P + w.bqk, c.P + w.bo,
                                p.vtab_all + l * D, p.nl * D, bt.code_mark, e.qk, e.c, c.P + w.ln1g, c.P + w.ln1b, e.s1, X,
@@ -731,8 +796,8 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // GCN in folded form: U = A_hat X -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
         const bool fused = gcn_fused_on();
         if (!fused) TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
-        if (l == 0 && ev_fold0) TRY(main_wait(s, ev_fold0));              // the product below is the first reader of W21 / c21
-        if (l == 1 && ev_fold && ev_fold != ev_fold0) TRY(main_wait(s, ev_fold));
+        if (l == 0 && ev_fold0) TRY(main_wait(s, ev_fold0, __LINE__));              // the product below is the first reader of W21 / c21
+        if (l == 1 && ev_fold && ev_fold != ev_fold0) TRY(main_wait(s, ev_fold, __LINE__));
         // second store of the output: the next layer's code rows (its Xc), or after the last layer the memory rows
         // (memory = [code ; sub-token] rows, Model.py:48: compact copy for the GEMMs.  The cross-attention K|V stay in that
         // compact row order -- the attention kernels take commit b's key range from mem_off; the dense [B,370,256] rows the
@@ -832,7 +897,7 @@ static int decoder_forward(Ctx& c) {
             int m = l;
             while (m < p.nl - 1 && c.ev_kv[m] == nullptr) ++m;     // the first mark at or behind this layer
             if (c.ev_kv[m] != nullptr && c.kv_waited < m + 1) {
-                TRY(main_wait(s, c.ev_kv[m]));
+                TRY(main_wait(s, c.ev_kv[m], __LINE__));
                 c.kv_waited = m + 1;                               // layers < kv_waited are covered
             }
         }
@@ -872,7 +937,7 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
     }
     TRY(linear(s, R, p.V, D, dec_rows, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
     TRY(gemm_any(s, 0, 1, c.Td, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
-    if (c.deferred) TRY(main_wait(s, c.ev_src));                   // LinearSource(memory) (side stream)
+    if (c.deferred) TRY(main_wait(s, c.ev_src, __LINE__));                   // LinearSource(memory) (side stream)
     // teacher-forced ids (dev) need every row's copy distribution; the training loss only the copy-labelled rows
     TRY(copy_score_fwd_ex(s, p.B, p.T, Sm, p.src, p.tgt, c.P + L.wres, c.P + L.bres, p.score, 1, p.mem_valid,
                           argmax_out ? nullptr : c.bt->tar_label, p.V, c.dec_off));
@@ -883,6 +948,11 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
 }
 
 // ------------------------------------------------------------------------------------------ backward
+static inline int enc_wgrad_every() {
+    static const int n = [] { const char* e = getenv("FIRA_ENC_WGRAD_EVERY"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
+    return n;
+}
+
 static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
@@ -904,7 +974,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     hipEvent_t ev_dfc = nullptr;
     // dvtab_all, dW21|dc21, dtgt, ddec_c: accumulated into below, one fill for all of them -- issued on the auxiliary stream
     // at the start of the step (under the encoder's forward pass) when there is one, otherwise here
-    if (c.ev_zero) TRY(main_wait(s, c.ev_zero));
+    if (c.ev_zero) TRY(main_wait(s, c.ev_zero, __LINE__));
     else TRY(zero(s, p.zero_beg, (size_t)((char*)p.zero_end - (char*)p.zero_beg)));
     if (R > 0) {
         if (so) TRY(aux_fork(s));
@@ -941,7 +1011,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(linear_dgrad(ss, Mc, D, D, p.dsrc_c, D, c.P + L.ws, p.dmem_c, D, false));
     TRY(linear_wgrad(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr));
     if (R > 0) {
-        if (ev_dfc) TRY(main_wait(s, ev_dfc));
+        if (ev_dfc) TRY(main_wait(s, ev_dfc, __LINE__));
         TRY(rows_scatter_add_idx(s, R, p.ddec_c, p.ddec, rows));
     }
 
@@ -1056,7 +1126,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     float *uf_dW1[16], *uf_dW2[16];
     int uf_n = 0;
     if (!c.ev_zero) TRY(zero(s, dXn, (size_t)Nc * D * sizeof(float)));   // AST/edit rows of the last layer feed nothing
-    if (ev_dmem) TRY(main_wait(s, ev_dmem));
+    if (ev_dmem) TRY(main_wait(s, ev_dmem, __LINE__));
     TRY(rows_move(s, 1, Mc, D, dXn, p.dmem_c, nullptr, bt.mem_rows));
     for (int l = p.nl - 1; l >= 0; --l) {
         const EncLayer& w = L.enc[l];
@@ -1149,7 +1219,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         }
         TRY(enc_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
         if (grouped) {                           // the layer's three weight gradients: one fork, one launch, then the unfold
-            TRY(flush_grouped_wgrads(s));
+            // (FIRA_ENC_WGRAD_EVERY=n: one launch for every n layers' gradients -- their operands are per-layer slots)
+            if ((p.nl - l) % enc_wgrad_every() == 0 || l == 0) TRY(flush_grouped_wgrads(s));
             TRY(unfold());
         }
         if (!comb_done)
@@ -1194,11 +1265,11 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         // and then run the whole update alone.  Nothing enqueued after the decoder's backward pass reads a parameter of
         // [0, split): the encoder's backward kernels read encoder weights, the weight-gradient stream reads activations.
         const fira_adam_opts& ad = *c.adam;
-        if (ev_groupA) TRY(main_wait(s, ev_groupA));
+        if (ev_groupA) TRY(main_wait(s, ev_groupA, __LINE__));
         TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
     }
-    if (ev_tail) TRY(main_wait(s, ev_tail));
-    if (side().stream && side().enabled) TRY(side_join(s));        // every weight gradient is complete past this point
+    if (ev_tail) TRY(main_wait(s, ev_tail, __LINE__));
+    if (side().stream && side().enabled) TRY(side_join(s, __LINE__));        // every weight gradient is complete past this point
     // dc of every GCN layer is final (deferred reduction above) and so are the side stream's additions to dW2: back to the
     // reference's fc2.weight / fc1.bias gradients, one launch for all layers
     TRY(gcn_bias_unfold_all(s, unfold_tab));
@@ -1334,6 +1405,7 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
     TRY(decoder_forward(c));
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
     TRY(backward(c, R, rows, (hipEvent_t)mid_event));
+    if (wait_probe().enabled() && ++wait_probe().calls == 20) wait_probe().report();
     return 0;
 }
 
@@ -1566,7 +1638,7 @@ int fira_debug_chain(void* stream, int n, int mode, float* scratch) {
             if (hipEventRecord(e, s) != hipSuccess) return set_err("event record failed");
         }
     }
-    if (mode == 1 || mode == 3 || mode == 5 || mode == 6) TRY(side_join(s));
+    if (mode == 1 || mode == 3 || mode == 5 || mode == 6) TRY(side_join(s, __LINE__));
     FIRA_CHECK_LAUNCH("debug_chain");
     return 0;
 }

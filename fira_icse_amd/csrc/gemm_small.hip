@@ -544,13 +544,29 @@ bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const flo
 // gradient: one 32x32 output tile per workgroup, the four waves split K = 256 (gemm_small_kernel's decomposition: every wave
 // fetches its fragments straight into registers, 2 x 16 MFMAs, partial tiles combined through LDS), operands addressed by
 // (row stride, k stride) so that both products read the matrices as stored.
-struct UnfoldGemm { const float *A, *B; float* C; int a_rs, a_ks, b_rs, b_ks; };      // C[i,j] += sum_k A[i*a_rs + k*a_ks] B[j*b_rs + k*b_ks]
+// mode 0: C[i,j] += sum_k A[i*a_rs + k*a_ks] B[j*b_rs + k*b_ks];  1: C[i,j] = the same sum;
+// mode 2: C[i] = sum_k A[i*a_rs + k] B[k]  (a 256-row matrix-vector product: the first 8 workgroups of the entry, 32 rows each)
+struct UnfoldGemm { const float *A, *B; float* C; int a_rs, a_ks, b_rs, b_ks, mode; };
 struct UnfoldGemmTable { int n = 0; UnfoldGemm e[32]; };
 __global__ __launch_bounds__(256) void unfold_gemm_kernel(const UnfoldGemmTable tab) {
     __shared__ float red[4][1024];
     const UnfoldGemm& q = tab.e[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
+    if (q.mode == 2) {                                  // (workgroup-uniform) matrix-vector product: a wave owns 8 rows, a lane 4 k
+        if (blockIdx.x >= 8) return;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(q.B + lane * 4);
+        f32x4 a[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            a[r] = *reinterpret_cast<const f32x4*>(q.A + (size_t)(blockIdx.x * 32 + wave * 8 + r) * q.a_rs + lane * 4);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float d = wave_sum((a[r].x * x.x + a[r].y * x.y) + (a[r].z * x.z + a[r].w * x.w));
+            if (lane == 0) q.C[blockIdx.x * 32 + wave * 8 + r] = d;
+        }
+        return;
+    }
     const int m0 = (blockIdx.x >> 3) * 32, n0 = (blockIdx.x & 7) * 32;
     const float* pa = q.A + (size_t)(m0 + l31) * q.a_rs;
     const float* pb = q.B + (size_t)(n0 + l31) * q.b_rs;
@@ -595,7 +611,9 @@ __global__ __launch_bounds__(256) void unfold_gemm_kernel(const UnfoldGemmTable 
         const int r = idx >> 6, ln = idx & 63;
         const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
         float* pc = q.C + (size_t)row * FIRA_D + col;
-        *pc += (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        const float v = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+        if (q.mode == 0) *pc += v;
+        else *pc = v;
     }
 }
 int gcn_unfold_products(hipStream_t s, int n_layers, const float* const* dW21, const float* const* W1, const float* const* W2,
@@ -604,13 +622,38 @@ int gcn_unfold_products(hipStream_t s, int n_layers, const float* const* dW21, c
     if (n_layers > 16) return set_err("gcn_unfold_products: %d layers", n_layers);
     UnfoldGemmTable tab;
     for (int l = 0; l < n_layers; ++l) {
-        tab.e[tab.n++] = UnfoldGemm{dW21[l], W1[l], dW2[l], FIRA_D, 1, FIRA_D, 1};        // dW2[i,j] += sum_k dW21[i,k] W1[j,k]
-        tab.e[tab.n++] = UnfoldGemm{W2[l], dW21[l], dW1[l], 1, FIRA_D, 1, FIRA_D};        // dW1[i,j] += sum_k W2[k,i] dW21[k,j]
+        tab.e[tab.n++] = UnfoldGemm{dW21[l], W1[l], dW2[l], FIRA_D, 1, FIRA_D, 1, 0};     // dW2[i,j] += sum_k dW21[i,k] W1[j,k]
+        tab.e[tab.n++] = UnfoldGemm{W2[l], dW21[l], dW1[l], 1, FIRA_D, 1, FIRA_D, 0};     // dW1[i,j] += sum_k W2[k,i] dW21[k,j]
     }
     ProfScope prof(s, PROF_GEMM, 2.0 * tab.n * FIRA_D * (double)FIRA_D * FIRA_D, 4.0 * tab.n * 3.0 * FIRA_D * FIRA_D);
     hipLaunchKernelGGL(unfold_gemm_kernel, dim3(64, tab.n), dim3(256), 0, s, tab);
     hipError_t e = hipGetLastError();
     return e != hipSuccess ? set_err("gcn_unfold_products: %s", hipGetErrorString(e)) : 0;
+}
+
+// Round 5: the FOLD itself (engine.hip: encoder_forward) through the same kernel.  Per layer
+//     W21 = W2 W1        W21t = W1^T W2^T (the k-major copy the fused GCN forward streams)        c21 = W2 b1
+// were two product launches + a transpose launch per layer at the head of the auxiliary stream: 14 launch-bound kernels
+// (~100 us of that stream) that the caller's stream waited for at the first / second GCN layer -- FIRA_WAIT_PROBE: ~28 us per
+// step at batch 32, ~48 at batch 64, ~75 in bf16 mode (one mark behind all of them).  One launch now.  W21t is computed as a
+// product of its own (the operands swap roles: same products, same k order, so W21t[j][i] == W21[i][j] bit for bit) rather
+// than stored transposed: all stores stay coalesced.
+int gcn_fold_weights(hipStream_t s, int n_layers, const float* const* W2, const float* const* W1, const float* const* b1,
+                     float* W21, float* W21t, float* c21) {
+    if (n_layers <= 0) return 0;
+    if (n_layers > 10) return set_err("gcn_fold_weights: %d layers", n_layers);
+    UnfoldGemmTable tab;
+    for (int l = 0; l < n_layers; ++l) {
+        float* w = W21 + (size_t)l * FIRA_D * FIRA_D;
+        tab.e[tab.n++] = UnfoldGemm{W2[l], W1[l], w, FIRA_D, 1, 1, FIRA_D, 1};            // W21[i,j] = sum_k W2[i,k] W1[k,j]
+        if (W21t)                                                                          // W21t[j,i] = sum_k W1[k,j] W2[i,k]
+            tab.e[tab.n++] = UnfoldGemm{W1[l], W2[l], W21t + (size_t)l * FIRA_D * FIRA_D, 1, FIRA_D, FIRA_D, 1, 1};
+        tab.e[tab.n++] = UnfoldGemm{W2[l], b1[l], c21 + (size_t)l * FIRA_D, FIRA_D, 1, 0, 0, 2};   // c21[i] = sum_k W2[i,k] b1[k]
+    }
+    ProfScope prof(s, PROF_GEMM, 2.0 * n_layers * (W21t ? 2 : 1) * FIRA_D * (double)FIRA_D * FIRA_D, 4.0 * tab.n * 3.0 * FIRA_D * FIRA_D);
+    hipLaunchKernelGGL(unfold_gemm_kernel, dim3(64, tab.n), dim3(256), 0, s, tab);
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? set_err("gcn_fold_weights: %s", hipGetErrorString(e)) : 0;
 }
 
 // true if this kernel took the call

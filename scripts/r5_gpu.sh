@@ -54,6 +54,11 @@ for ST in "$@"; do
       for i in 1 2; do
         for V in "${VARS[@]}"; do echo -n "$V decode: "; env $V timeout 200 python scripts/decode_only.py 2>/dev/null | tail -n 2 | tr "\n" ";"; echo; done
       done 2>&1 | tee $OUT/abdecenv.txt ;;
+    waitprobe)   # where the caller's stream stands waiting for the library's streams (FIRA_WAIT_PROBE=1: engine.hip lines)
+      for B in 32 64; do
+        echo "batch $B f32:"; FIRA_WAIT_PROBE=1 timeout 300 python bench.py --batch $B --steps 40 --no-decode --no-cpu-baseline --no-extras --detail $OUT/one_detail.json 2>&1 | grep "wait probe" | tail -n 2
+      done 2>&1 | tee $OUT/waitprobe.txt
+      echo "batch 64 bf16:"; FIRA_WAIT_PROBE=1 timeout 300 python bench.py --dtype bf16 --batch 64 --steps 40 --no-decode --no-cpu-baseline --no-extras --detail $OUT/one_detail.json 2>&1 | grep "wait probe" | tail -n 2 | tee -a $OUT/waitprobe.txt ;;
     bench)
       timeout 900 python bench.py --detail $OUT/bench_detail_f32.json > $OUT/bench_f32.json 2> $OUT/bench_f32.err; echo "bench f32 rc=$? bytes=$(wc -c < $OUT/bench_f32.json)"; cat $OUT/bench_f32.json; tail -n 5 $OUT/bench_f32.err ;;
     bench16)

@@ -688,6 +688,11 @@ struct Ctx {
     // writable (nothing reads [0, split) after the decoder's backward pass; see backward()).
     const fira_adam_opts* adam = nullptr;
     float* Pw = nullptr;
+    // bf16 mode (round 5): the refresh of the bf16 weight shadows (one 46 us launch) runs on the auxiliary stream behind the GCN
+    // fold instead of at the head of the caller's stream -- with the fused Combination / GCN kernels (which round the fp32
+    // weights themselves) the first reader of a shadow is the decoder (and the auxiliary stream's own K|V projections)
+    const ShadowTable* shadow_tab = nullptr;
+    hipEvent_t ev_shadow = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------ encoder forward
@@ -762,6 +767,10 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         if (!fold_one && gcn_fused_on() && p.nl > 1) TRY(transpose256(fs, p.nl - 1, p.W21 + (size_t)D * D, p.W21t + (size_t)D * D));
         if (ax) TRY(side_mark(&ev_fold));
         if (!ev_fold0) ev_fold0 = ev_fold;           // bf16 mode / one layer: a single mark
+        if (c.shadow_tab) {                          // (see Ctx::shadow_tab)
+            TRY(weight_shadows(fs, *c.shadow_tab, c.P, p.wb, p.wbt));
+            if (ax) TRY(side_mark(&c.ev_shadow));
+        }
     }
     // masks, position tables, inverse of the head-row list: one launch; node features straight into the compact layout
     const int32_t* head_list = c.dec_off ? c.rows_dense : c.rows;          // flat (b*T + t) head rows, as the caller lists them
@@ -948,9 +957,17 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
 }
 
 // ------------------------------------------------------------------------------------------ backward
-static inline int enc_wgrad_every() {
-    static const int n = [] { const char* e = getenv("FIRA_ENC_WGRAD_EVERY"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
-    return n;
+// How many encoder layers' weight gradients go into one grouped launch (their operands are per-layer slots).  Measured
+// (profiles/r5_probes.md): the encoder's backward chain and its weight gradients are BOTH bound by the fp32 MFMA pipe, so a
+// layer's grouped launch beside the next layer's chain only slowed that chain (fused GCN backward 21 -> 48 us in the step);
+// ALL layers' gradients as one launch behind the chain -- beside the embedding gradients and the HBM-bound Adam of [0, split)
+// -- is +2.0 % at batch 32, +0.5 % at batch 64, +0.8 % in bf16 at batch 64, and -0.4 % at batch 170, where that launch is
+// ~1.5 ms long and nothing is left to hide it.  Default: all layers up to 32 768 computed node rows, per layer beyond;
+// FIRA_ENC_WGRAD_EVERY=n overrides.
+static inline int enc_wgrad_every(int n_rows, int n_layers) {
+    static const int forced = [] { const char* e = getenv("FIRA_ENC_WGRAD_EVERY"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 0; }();
+    if (forced) return forced;
+    return n_rows <= 32768 ? std::max(1, n_layers) : 1;
 }
 
 static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
@@ -1219,8 +1236,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         }
         TRY(enc_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
         if (grouped) {                           // the layer's three weight gradients: one fork, one launch, then the unfold
-            // (FIRA_ENC_WGRAD_EVERY=n: one launch for every n layers' gradients -- their operands are per-layer slots)
-            if ((p.nl - l) % enc_wgrad_every() == 0 || l == 0) TRY(flush_grouped_wgrads(s));
+            // (one launch for every n layers' gradients: enc_wgrad_every)
+            if ((p.nl - l) % enc_wgrad_every(Nc, p.nl) == 0 || l == 0) TRY(flush_grouped_wgrads(s));
             TRY(unfold());
         }
         if (!comb_done)
@@ -1232,6 +1249,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // encoder LayerNorms, dvtab_all and the two products that read it: beside the embedding kernels below, on the auxiliary
     // stream (idle since the decoder's backward pass)
     hipEvent_t ev_tail = nullptr;
+    int64_t adam_b0 = L.split;               // fira_train_step: first parameter the closing Adam launch still has to update
     {
         const bool ax = side_on();
         hipStream_t rs = ax ? side().aux : s;
@@ -1267,6 +1285,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         const fira_adam_opts& ad = *c.adam;
         if (ev_groupA) TRY(main_wait(s, ev_groupA, __LINE__));
         TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+        // ... and the encoder's two embedding tables (the head of group B: layout.cpp), whose gradients the two launches above
+        // on this stream have just completed -- also ahead of the join
+        static const bool emb_early_off = [] { const char* e = getenv("FIRA_ADAM_EMB_EARLY"); return e && e[0] == '0'; }();   // A/B switch
+        if (!emb_early_off) adam_b0 = L.mark_emb;
+        if (adam_b0 > L.split)
+        TRY(adam_step_mb(s, adam_b0 - L.split, c.Pw + L.split, G + L.split, nullptr, ad.m + L.split, ad.v + L.split, ad.lr, ad.beta1,
+                         ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
     }
     if (ev_tail) TRY(main_wait(s, ev_tail, __LINE__));
     if (side().stream && side().enabled) TRY(side_join(s, __LINE__));        // every weight gradient is complete past this point
@@ -1275,7 +1300,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     TRY(gcn_bias_unfold_all(s, unfold_tab));
     if (c.adam) {
         const fira_adam_opts& ad = *c.adam;
-        TRY(adam_step_mb(s, L.live - L.split, c.Pw + L.split, G + L.split, nullptr, ad.m + L.split, ad.v + L.split, ad.lr, ad.beta1,
+        TRY(adam_step_mb(s, L.live - adam_b0, c.Pw + adam_b0, G + adam_b0, nullptr, ad.m + adam_b0, ad.v + adam_b0, ad.lr, ad.beta1,
                          ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
     }
     return 0;
@@ -1364,7 +1389,11 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
     const bool bf16 = opts && opts->dtype == 1;
     const ShadowTable* tab = bf16 ? shadow_table(*L) : nullptr;
     ShadowScope shadow_scope(params, L->total, bf16 ? p.wb : nullptr, bf16 ? p.wbt : nullptr, tab);
-    if (bf16) TRY(weight_shadows(c.s, *tab, params, p.wb, p.wbt));
+    // FIRA_SHADOWS_LATE=0: the shadow refresh at the head of the caller's stream, as before round 5 (A/B switch)
+    static const bool shadows_late_off = [] { const char* e = getenv("FIRA_SHADOWS_LATE"); return e && e[0] == '0'; }();
+    const bool defer_sh = bf16 && !shadows_late_off && side_on() && gcn_fused_on() && comb_fused_on() && L->d.n_layer <= 8;
+    if (bf16 && !defer_sh) TRY(weight_shadows(c.s, *tab, params, p.wb, p.wbt));
+    if (defer_sh) c.shadow_tab = tab;
     // computed target rows: the decoder / head run on the prefix rows the batch lists (fira_batch.dec_off)
     c.Td = p.TB;
     if (opts && opts->compact_dec && batch->dec_off) {
@@ -1402,6 +1431,7 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
         if (zero_g) TRY(zero(side().aux, grads, (size_t)L->live * sizeof(float)));
         TRY(side_mark(&c.ev_zero));
     }
+    if (c.ev_shadow) TRY(main_wait(c.s, c.ev_shadow, __LINE__));      // the decoder's products read the bf16 shadows
     TRY(decoder_forward(c));
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
     TRY(backward(c, R, rows, (hipEvent_t)mid_event));

@@ -89,12 +89,15 @@ def main():
         for k, v in sorted(aggq.items(), key=lambda kv: -kv[1][1])[:24]:
             print("| `%s` | %.1f | %.1f | %.1f |" % (k[:110], v[0] / steps, v[1] / steps, v[1] / v[0]))
     if qcol and len(sys.argv) > 3:
-        # timeline of ONE step (the last adam_mb_kernel-delimited one): every dispatch on every stream, ordered by start
+        # timeline of ONE step (the last but one adam_mb_kernel-delimited one): every dispatch on every stream, ordered by start
         allr = cur.execute("select s.kernel_name, d.start, d.end, d.%s, d.grid_size, d.workgroup_size from %s d join %s s on d.kernel_id = s.id "
                            "order by d.start" % (qcol, disp, sym)).fetchall() if "grid_size" in cols else \
             [r + (0, 0) for r in cur.execute("select s.kernel_name, d.start, d.end, d.%s from %s d join %s s on d.kernel_id = s.id "
                                              "order by d.start" % (qcol, disp, sym)).fetchall()]
         adam = [i for i, r in enumerate(allr) if "adam_mb" in r[0]]
+        # (round 5: fira_train_step updates in up to three launches per step -- a step ends with the LAST of a run of Adam
+        #  launches less than 300 us apart)
+        adam = [i for n, i in enumerate(adam) if n + 1 == len(adam) or allr[adam[n + 1]][1] - allr[i][2] > 300e3]
         if len(adam) >= 3:
             lo, hi = adam[-3] + 1, adam[-2] + 1
             t0 = allr[lo][1]

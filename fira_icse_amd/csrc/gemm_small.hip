@@ -212,15 +212,23 @@ struct LnB {
     uint32_t site = 0;
 };
 
-template <bool B_KCONTIG, int NCH, bool LN_A = false, bool LN_B = false>
-__global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const float* __restrict__ A, int lda,
+// NW (round 5): wavefronts per workgroup.  The K chunks go round-robin over the waves, so a long reduction on a SMALL grid
+// (the FFN's K = 1024 products at M = 64 .. 600 rows: 16 .. 136 workgroups on 256 CUs) can be cut into 2 chunks per wave by
+// 8 / 12 / 16 waves instead of 4 / 6 / 8 serial rounds of (stage, 16 MFMAs) on 4: the workgroup's dependent chain is what such
+// a launch costs.  The wave-private staging slots then take NW x 8 KB of DYNAMIC LDS (128 KB at 16 waves: one workgroup per CU,
+// so only grids of at most 256 workgroups take that shape; tile32_waves()).
+template <bool B_KCONTIG, int NCH, bool LN_A = false, bool LN_B = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_tile32_kernel(int M, int N, const float* __restrict__ A, int lda,
                                                           const float* __restrict__ B, int ldb, float* __restrict__ C,
                                                           int ldc, const float* __restrict__ bias, int flags,
                                                           const int32_t* __restrict__ c_rows,
                                                           const float* __restrict__ relu_mask,
                                                           const int32_t* __restrict__ a_rows, int tiles_n, const EpiRes er,
                                                           const LnA ln, const LnB lb) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
+    static_assert(NW == 4 || (!LN_A && !LN_B), "the LayerNorm prologues are written for four waves");
+    extern __shared__ __attribute__((aligned(16))) char tile32_dyn[];
+    __shared__ __attribute__((aligned(16))) char smem4[NW == 4 ? 4 * 8192 : 16];
+    char* const smem = NW == 4 ? smem4 : tile32_dyn;
     __shared__ float ln_red[2][4][32];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     ChunkRegs R0, R1;
     tile32_fetch<B_KCONTIG>(R0, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, wave << 5, ldb);
-    if (NCH > 1) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4) << 5, ldb);
+    if (NCH > 1) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + NW) << 5, ldb);
     if (LN_A) {
         static_assert(!LN_A || NCH == 2, "the LayerNorm prologue needs the whole row in the two chunks of the four waves");
         // this lane holds, of rows 8j + lr (j = 0..3), the four columns kc + ((ls ^ sw_j) << 2) .. + 3 of each chunk
@@ -425,10 +433,10 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     for (int ci = 0; ci < NCH; ++ci) {
         if ((ci & 1) == 0) {
             tile32_stage(R0, slot, wr_off);
-            if (ci + 2 < NCH) tile32_fetch<B_KCONTIG>(R0, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4 * (ci + 2)) << 5, ldb);
+            if (ci + 2 < NCH) tile32_fetch<B_KCONTIG>(R0, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + NW * (ci + 2)) << 5, ldb);
         } else {
             tile32_stage(R1, slot, wr_off);
-            if (ci + 2 < NCH) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + 4 * (ci + 2)) << 5, ldb);
+            if (ci + 2 < NCH) tile32_fetch<B_KCONTIG>(R1, pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3, (wave + NW * (ci + 2)) << 5, ldb);
         }
         acc = tile32_compute<B_KCONTIG>(slot, fa0, fa1, fa2, fa3, fb, acc);
     }
@@ -438,18 +446,31 @@ __global__ __launch_bounds__(256) void gemm_tile32_kernel(int M, int N, const fl
     for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
     __syncthreads();
     {
-        const int lnn = threadIdx.x & 63, rq = threadIdx.x >> 6;
-        float vals[4];
-        int rows[4];
+        // thread t combines elements idx = t + 64 NW i (< 1024) of the tile (accumulator register idx / 64 of lane idx % 64): one
+        // column, up to ceil(16 / NW) rows
+        constexpr int NV = (16 + NW - 1) / NW;
+        const int lnn = threadIdx.x & 63;
+        float vals[NV];
+        int rows[NV];
         const float* p0 = reinterpret_cast<const float*>(smem);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + 256 * i, r = rq + 4 * i;
-            vals[i] = (p0[idx] + p0[2048 + idx]) + (p0[4096 + idx] + p0[6144 + idx]);
-            rows[i] = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lnn >> 5);
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + NW * 64 * i, r = idx >> 6;
+            const bool in = (16 % NW == 0) || idx < 1024;        // (12 waves: the second round covers registers 12..15 only)
+            const int ix = in ? idx : threadIdx.x;
+            if constexpr (NW == 4) {
+                vals[i] = (p0[ix] + p0[2048 + ix]) + (p0[4096 + ix] + p0[6144 + ix]);
+            } else {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; w += 4)
+                    v += (p0[w * 2048 + ix] + p0[(w + 1) * 2048 + ix]) + (p0[(w + 2) * 2048 + ix] + p0[(w + 3) * 2048 + ix]);
+                vals[i] = v;
+            }
+            rows[i] = in ? m0 + (r & 3) + 8 * (r >> 2) + 4 * (lnn >> 5) : M;      // row M: outside, dropped by the descriptor
         }
-        epilogue_col<4>(vals, rows, n0 + (lnn & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
-                        c_rows, relu_mask, er);
+        epilogue_col<NV>(vals, rows, n0 + (lnn & 31), M, N, C, ldc, bias, flags & FIRA_GEMM_RELU, flags & FIRA_GEMM_ACCUM, false,
+                         c_rows, relu_mask, er);
     }
 }
 
@@ -459,6 +480,44 @@ static void tile32_launch(hipStream_t s, dim3 grid, int M, int N, const float* A
                           const int32_t* a_rows, int tiles_n, const EpiRes& er) {
     hipLaunchKernelGGL((gemm_tile32_kernel<B_KCONTIG, NCH, false, false>), grid, dim3(256), 0, s, M, N, A, lda, B, ldb, C, ldc, bias,
                        flags, c_rows, relu_mask, a_rows, tiles_n, er, LnA(), LnB());
+}
+
+// FIRA_TILE32_WAVES=0: always four waves (A/B switch).  8 waves (64 KB of slots: two workgroups per CU) up to 512 workgroups,
+// 12 / 16 waves (96 / 128 KB: one per CU) up to 256.
+static int tile32_waves(int K, int n_wg) {
+    static const bool off = [] { const char* e = getenv("FIRA_TILE32_WAVES"); return e && e[0] == '0'; }();
+    if (off) return 4;
+    const int chunks = K / 32;
+    if (chunks == 32 && n_wg <= 256) return 16;
+    if (chunks == 24 && n_wg <= 256) return 12;
+    if ((chunks == 16 || chunks == 32) && n_wg <= 512) return 8;
+    return 4;
+}
+template <bool B_KCONTIG, int NCH, int NW>
+static int tile32_launch_wide_t(hipStream_t s, dim3 grid, int M, int N, const float* A, int lda, const float* B, int ldb, float* C,
+                                int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask,
+                                const int32_t* a_rows, int tiles_n, const EpiRes& er) {
+    auto kern = gemm_tile32_kernel<B_KCONTIG, NCH, false, false, NW>;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NW * 8192);
+    if (attr != hipSuccess) return set_err("gemm_tile32: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), NW * 8192, s, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows,
+                       tiles_n, er, LnA(), LnB());
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? set_err("gemm_tile32 (%d waves): %s", NW, hipGetErrorString(e)) : 0;
+}
+static int tile32_launch_wide(hipStream_t s, int nw, int K, int tB, dim3 grid, int M, int N, const float* A, int lda, const float* B,
+                              int ldb, float* C, int ldc, const float* bias, int flags, const int32_t* c_rows,
+                              const float* relu_mask, const int32_t* a_rows, int tiles_n, const EpiRes& er) {
+#define FIRA_T32W(NCH, NW)                                                                                             \
+    return tB ? tile32_launch_wide_t<true, NCH, NW>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n, er) \
+              : tile32_launch_wide_t<false, NCH, NW>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n, er);
+    const int per_wave = K / 32 / nw;              // chunks per wave
+    if (nw == 16 && per_wave == 2) { FIRA_T32W(2, 16) }
+    if (nw == 12 && per_wave == 2) { FIRA_T32W(2, 12) }
+    if (nw == 8 && per_wave == 2) { FIRA_T32W(2, 8) }
+    if (nw == 8 && per_wave == 4) { FIRA_T32W(4, 8) }
+    return set_err("gemm_tile32: unsupported shape K = %d on %d waves", K, nw);
+#undef FIRA_T32W
 }
 
 // shapes the coalesced tile kernel takes (the engine asks before it plans a fused LayerNorm prologue / residual epilogue)
@@ -481,6 +540,13 @@ bool gemm_tile32_try(hipStream_t s, int tB, int M, int N, int K, const float* A,
     const int nch = K / 128;
     const int tiles_n = cdiv(N, 32);
     const dim3 grid(cdiv(M, 32) * tiles_n);
+    {   // long reduction on a small grid: more waves per workgroup, two chunks each (see the kernel's NW)
+        const int nw = tile32_waves(K, (int)grid.x);
+        if (nw > 4) {
+            *rc = tile32_launch_wide(s, nw, K, tB, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n, er);
+            return true;
+        }
+    }
 #define FIRA_T32(NCH)                                                                                                  \
     case NCH:                                                                                                          \
         if (tB) tile32_launch<true, NCH>(s, grid, M, N, A, lda, B, ldb, C, ldc, bias, flags, c_rows, relu_mask, a_rows, tiles_n, er); \

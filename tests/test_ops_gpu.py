@@ -52,6 +52,27 @@ def test_gemm_layouts(M, N, K, layout):
         assert rel_err(out, ref - bias.double() + C0.double()) < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 1024), (530, 256, 1024), (530, 256, 768), (1000, 256, 512), (2000, 256, 1024),
+                                   (33, 64, 1024), (45, 96, 768)])
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_gemm_long_reduction_on_a_small_grid(M, N, K, layout):
+    """The 32x32 tile kernel with 8 / 12 / 16 waves per workgroup (two K chunks per wave: gemm_small.hip, round 5) -- the
+    FFN-shaped products of the decoder chain and of the decode step; FIRA_TILE32_WAVES=0 restores four waves."""
+    from fira_icse_amd import ops
+    tB = layout == "nt"
+    A = randn(M, K, seed=11)
+    B = randn(*((N, K) if tB else (K, N)), seed=12)
+    bias = randn(N, seed=13)
+    ref = A.double() @ (B.t() if tB else B).double() + bias.double()
+    out = ops.gemm(A, B, transB=tB, bias=bias)
+    assert rel_err(out, ref) < 2e-6
+    out = ops.gemm(A, B, transB=tB, bias=bias, relu=True)
+    assert rel_err(out, ref.clamp_min(0)) < 2e-6
+    C0 = randn(M, N, seed=14)
+    out = ops.gemm(A, B, transB=tB, out=C0.clone(), accumulate=True)
+    assert rel_err(out, ref - bias.double() + C0.double()) < 2e-6
+
+
 def test_gemm_accumulate_and_splitk():
     from fira_icse_amd import ops
     M, N, K = 256, 256, 20800                      # the weight-gradient shape of a GCN layer at batch 32

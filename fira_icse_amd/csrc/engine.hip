@@ -499,14 +499,14 @@ static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* 
 // queued and launched as ONE grouped kernel after the decoder's backward loop (gemm_f32.hip), instead of ~40 launches
 // of ~15 us that are mostly fill and drain.  Operands must stay untouched until then (they are per-layer slots).
 static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X,
-                                       int ldx, float* dW, float* db) {
+                                       int ldx, float* dW, float* db, int max_split = 0) {
     SideStream& sd = side();
     if (!(sd.stream && sd.enabled)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
     if (g_dtype == 1) {
         if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);   // e.g. the 2-column gate
-        return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
+        return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, max_split);
     }
-    return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db);
+    return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, max_split);
 }
 // One encoder layer's three weight gradients (folded GCN weight, Combination output and q|k projections): queued while
 // the layer's data-gradient chain runs, then issued as ONE grouped launch behind ONE fork (enc_wgrads_flush) -- every fork
@@ -720,6 +720,8 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     // ~100 us into the call, 12 launches of the auxiliary stream would not be through by then); the rest is awaited at
     // layer 1.
     hipEvent_t ev_fold0 = nullptr, ev_fold = nullptr, ev_comb = nullptr;
+    static const bool one_wait = [] { const char* e = getenv("FIRA_FOLD_ONE_WAIT"); return !(e && e[0] == '0'); }();   // A/B switch
+    bool fold_waited = false;
     {
         const bool ax = side_on() && !c.serial;
         hipStream_t fs = ax ? side().aux : s;
@@ -736,7 +738,10 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
                 tt.src[tt.n] = c.P + w.wo; tt.dst[tt.n++] = dst + (size_t)2 * D * D;
             }
             TRY(transpose256_table(fs, tt));
-            if (ax) TRY(side_mark(&ev_comb));
+            // (with the one-launch fold right behind it, ONE mark serves the first Combination block and the first GCN layer: every
+            //  wait is a barrier packet in the caller's chain, and the fold is through ~25 us into the call, before the first
+            //  Combination block starts)
+            if (ax && !(one_wait && fold_one_launch() && p.nl <= 10 && (!g_Wb || gcn_fused_on()))) TRY(side_mark(&ev_comb));
         }
         const bool fold_one = fold_one_launch() && p.nl <= 10;
         if (fold_one) {
@@ -765,7 +770,9 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             g_W21 = p.W21; g_W21n = (int64_t)p.nl * D * D; g_W21b = p.w21b; g_W21bT = p.w21bt;
         }
         if (!fold_one && gcn_fused_on() && p.nl > 1) TRY(transpose256(fs, p.nl - 1, p.W21 + (size_t)D * D, p.W21t + (size_t)D * D));
-        if (ax) TRY(side_mark(&ev_fold));
+        // (the closing mark only where something follows the fold that the encoder's own launches read: the unfused GCN path's
+        //  bf16 shadows of the folded weights, or the layer-by-layer fold)
+        if (ax && !(one_wait && ev_fold0 && fold_one && gcn_fused_on())) TRY(side_mark(&ev_fold));
         if (!ev_fold0) ev_fold0 = ev_fold;           // bf16 mode / one layer: a single mark
         if (c.shadow_tab) {                          // (see Ctx::shadow_tab)
             TRY(weight_shadows(fs, *c.shadow_tab, c.P, p.wb, p.wbt));
@@ -792,6 +799,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // rows before the update: residual, and the q|k weight gradient's operand) was stored by the kernel that produced X
         if (comb_fused_on() && l < 8) {
             if (l == 0 && ev_comb) TRY(main_wait(s, ev_comb, __LINE__));
+            else if (l == 0 && ev_fold0) { TRY(main_wait(s, ev_fold0, __LINE__)); fold_waited = true; }
             const float* wt = p.WcT + (size_t)l * 3 * D * D;
             TRY(comb_fused_fwd(s, Cc, e.Xc, wt, wt + (size_t)D * D, wt + (size_t)2 * D * D, c.P + w.bqk, c.P + w.bo,
                                p.vtab_all + l * D, p.nl * D, bt.code_mark, e.qk, e.c, c.P + w.ln1g, c.P + w.ln1b, e.s1, X,
@@ -805,7 +813,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // GCN in folded form: U = A_hat X -> U W21^T + b2 -> (+ r c^T) dropout, +X, LN
         const bool fused = gcn_fused_on();
         if (!fused) TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, X, D, e.Z, D, 0, 1, 0, l == 0 ? p.rsum : nullptr));
-        if (l == 0 && ev_fold0) TRY(main_wait(s, ev_fold0, __LINE__));              // the product below is the first reader of W21 / c21
+        if (l == 0 && ev_fold0 && !fold_waited) TRY(main_wait(s, ev_fold0, __LINE__));   // the product below is the first reader of W21 / c21
         if (l == 1 && ev_fold && ev_fold != ev_fold0) TRY(main_wait(s, ev_fold, __LINE__));
         // second store of the output: the next layer's code rows (its Xc), or after the last layer the memory rows
         // (memory = [code ; sub-token] rows, Model.py:48: compact copy for the GEMMs.  The cross-attention K|V stay in that
@@ -970,6 +978,11 @@ static inline int enc_wgrad_every(int n_rows, int n_layers) {
     return n_rows <= 32768 ? std::max(1, n_layers) : 1;
 }
 
+static inline bool fewer_forks() {
+    static const bool off = [] { const char* e = getenv("FIRA_FEWER_FORKS"); return e && e[0] == '0'; }();
+    return !off;
+}
+
 static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
@@ -1026,7 +1039,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // products of the decoder loop below add to it)
     if (so) TRY(aux_fork(s));
     TRY(linear_dgrad(ss, Mc, D, D, p.dsrc_c, D, c.P + L.ws, p.dmem_c, D, false));
-    TRY(linear_wgrad(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr));
+    // (round 5: LinearSource's weight gradient rides in the decoder's grouped launch -- its own fork was an event record on the
+    //  caller's stream right behind the auxiliary stream's; FIRA_FEWER_FORKS=0: its own fork and launch)
+    if (fewer_forks()) TRY(linear_wgrad_grouped(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr, 8));
+    else TRY(linear_wgrad(s, Mc, D, D, p.dsrc_c, D, p.mem_c, D, G + L.ws, nullptr));
     if (R > 0) {
         if (ev_dfc) TRY(main_wait(s, ev_dfc, __LINE__));
         TRY(rows_scatter_add_idx(s, R, p.ddec_c, p.ddec, rows));
@@ -1101,6 +1117,11 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     } else {
         TRY(linear_dgrad(s, Mc, KV, D, p.dkv_all, p.kvp, c.P + L.wkv_all, p.dmem_c, D, true));
     }
+    // (round 5: no fork of its own -- the weight-gradient stream waited for the caller's stream at the grouped launch above, and
+    //  dkv_all was complete by then)
+    if (fewer_forks() && side().stream && side().enabled)
+        TRY(gemm_any(side().stream, 1, 0, KV, D, Mc, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, D, nullptr, FIRA_GEMM_ACCUM, 0, G + L.bkv_all));
+    else
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     // decoder LayerNorms, copy head: their partial rows were written before the fork of the weight gradient above, and only
     // the end of the step (or the mid-event below, which waits for this stream) reads the sums: off the dependent chain

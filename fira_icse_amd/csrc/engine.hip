@@ -1053,6 +1053,15 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // output rows, by / bz are free.  Every LayerNorm backward writes its residual-branch gradient to a buffer OTHER than the
     // one it reads (it runs in the prologue of the product that follows it: the product's other column tiles still read dy).
     float *bx = p.ddec, *by = p.dT_a, *bz = p.dT_c;
+    // The decoder's weight gradients (twelve small products per two layers + their row block of the stacked K|V weight) in launches
+    // of dec_every layers beside the DECODER's chain (latency-bound, the MFMA pipe idle) instead of one launch behind it, beside the
+    // first layers of the encoder's MFMA-bound chain.  Round 4 / early round 5 measured the early launches at -0.6 % (the
+    // weight-gradient stream was busy with the encoder's per-layer launches afterwards anyway); with those behind the chain:
+    // three layers per launch +0.9 % (fast class) / +-0 (slow class) at batch 32, +1.0 % at batch 64, two layers -1.3 %, bf16
+    // neutral (profiles/r5_probes.md).  fp32, single device (data-parallel runs hand the bucket over at the mid event);
+    // FIRA_DEC_WGRAD_EVERY=0: one launch behind the loop.
+    static const int dec_every_env = [] { const char* e = getenv("FIRA_DEC_WGRAD_EVERY"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 0; }();
+    const int dec_every = (mid_event || g_dtype != 0 || dec_every_env == 0 || p.nl % dec_every_env != 0) ? 0 : dec_every_env;
     for (int l = p.nl - 1; l >= 0; --l) {
         ProfDecoderTag prof_tag;               // data gradients of the M = B*30 products (the grouped wgrads flush later)
         const DecLayer& w = L.dec[l];
@@ -1096,6 +1105,14 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
                           e.ao, D, bx, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1, attn_bf16()));
         TRY(linear_wgrad_grouped(s, c.Td, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
         TRY(linear_dgrad(s, c.Td, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, by, D, true));       // by = d x_in
+        if (dec_every > 0 && l % dec_every == 0 && side().stream && side().enabled) {
+            // the weight gradients of the last dec_every layers: one grouped launch + their row block of the stacked K|V weight
+            const int nlay = std::min(dec_every, p.nl - l);
+            const size_t o = (size_t)l * 2 * D;
+            TRY(flush_grouped_wgrads(s));
+            TRY(gemm_any(side().stream, 1, 0, nlay * 2 * D, D, Mc, p.dkv_all + o, p.kvp, p.mem_c, D, G + L.wkv_all + o * D, D, nullptr,
+                         FIRA_GEMM_ACCUM, 0, G + L.bkv_all + o));
+        }
         float* t = bx; bx = by; by = t;         // the next layer's output gradient is in (the old) by; bz stays free
     }
     const float* dy = bx;
@@ -1119,7 +1136,9 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     }
     // (round 5: no fork of its own -- the weight-gradient stream waited for the caller's stream at the grouped launch above, and
     //  dkv_all was complete by then)
-    if (fewer_forks() && side().stream && side().enabled)
+    if (dec_every > 0 && side().stream && side().enabled) {
+        // (the K|V weight gradient went out in row blocks inside the loop)
+    } else if (fewer_forks() && side().stream && side().enabled)
         TRY(gemm_any(side().stream, 1, 0, KV, D, Mc, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, D, nullptr, FIRA_GEMM_ACCUM, 0, G + L.bkv_all));
     else
     TRY(linear_wgrad(s, Mc, KV, D, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));

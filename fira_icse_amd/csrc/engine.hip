@@ -1109,9 +1109,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
             // the weight gradients of the last dec_every layers: one grouped launch + their row block of the stacked K|V weight
             const int nlay = std::min(dec_every, p.nl - l);
             const size_t o = (size_t)l * 2 * D;
-            TRY(flush_grouped_wgrads(s));
-            TRY(gemm_any(side().stream, 1, 0, nlay * 2 * D, D, Mc, p.dkv_all + o, p.kvp, p.mem_c, D, G + L.wkv_all + o * D, D, nullptr,
-                         FIRA_GEMM_ACCUM, 0, G + L.bkv_all + o));
+            prof_decoder_tag(-1);               // weight gradients: not among the decoder's forward / data-gradient products
+            int rc_w = flush_grouped_wgrads(s);
+            if (!rc_w)
+                rc_w = gemm_any(side().stream, 1, 0, nlay * 2 * D, D, Mc, p.dkv_all + o, p.kvp, p.mem_c, D, G + L.wkv_all + o * D, D, nullptr,
+                                FIRA_GEMM_ACCUM, 0, G + L.bkv_all + o);
+            prof_decoder_tag(+1);
+            TRY(rc_w);
         }
         float* t = bx; bx = by; by = t;         // the next layer's output gradient is in (the old) by; bz stays free
     }

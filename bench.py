@@ -204,6 +204,54 @@ def spmm_standalone(cfg, store):
     cfg5["note"] = ("22 % dense adjacency: the CSR gathers are bound by the L2 / LDS gather rate, the block-dense kernels "
                     "by the MFMA pipe (fp32: 17.2 GFLOP = 110 us at peak) or HBM (bf16 operands, fp32 accumulate)")
     out["spmm_cfg5"] = cfg5
+    # SURVEY.md 8(d) row 5, second unit: one full GCN layer (folded form) forward + backward on the same graphs.
+    # fused = the launches the engine issues per layer: gcn_fused fwd | LayerNorm backward + gcn_fused bwd + the weight
+    # gradient dW21 = V^T X; unfused = aggregation kernel of the density crossover + product + row kernel (forward only).
+    n = B * N
+    W21 = torch.randn(256, 256, device="cuda") * 0.06
+    W21t = W21.t().contiguous()
+    b2, c21 = torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1
+    gamma, beta = torch.ones(256, device="cuda"), torch.zeros(256, device="cuda")
+    dW = torch.zeros(256, 256, device="cuda")
+    layer_bytes_fwd = 4 * (n + 1) + 8 * c.numel() + 3 * n * 1024          # (col, val) + rows in, pre-norm + normalised rows out
+    layer_bytes_bwd = 4 * (n + 1) + 8 * c.numel() + 4 * n * 1024 + 4 * n * 1024   # LN bwd: dy, sum in, ds, dx out; fused: dY in, V out, acc in + out
+    g5 = {"rows": n, "nnz": int(c.numel()), "flop_fwd": 2.0 * n * 256 * 256, "bytes_fwd": layer_bytes_fwd, "bytes_bwd": layer_bytes_bwd}
+    for dt, name in ((0, "f32"), (1, "bf16")):
+        k = [0]
+
+        def fwd():
+            i = k[0] % 3
+            k[0] += 1
+            return ops.gcn_layer_fwd(rp, c, v, Xs[i], W21t, b2, c21, gamma, beta, dropout=0.2, seed=1, site=3, dtype=dt,
+                                     want_rowsum=False)
+        summ, y, stats, _ = fwd()
+        t_f = time_gpu(fwd, iters=9, warmup=3)
+
+        def bwd():
+            i = k[0] % 3
+            k[0] += 1
+            ds, dxd, _, _ = ops.add_layernorm_bwd(Ys[i], summ, stats, gamma, dropout=0.2, seed=1, site=3, want_dx_drop=True)
+            V = ops.gcn_layer_bwd(rp, c, v, dxd, W21, ds, dtype=dt)
+            ops.gemm(V, Xs[i], transA=True, transB=False, out=dW, accumulate=True)
+        t_b = time_gpu(bwd, iters=9, warmup=3)
+
+        def unfused():
+            i = k[0] % 3
+            k[0] += 1
+            Z = ops.csr_spmm(rp, c, v, Xs[i], graph_rows=N, variant=0, out=Ys[i], dtype=dt, auto=True)
+            lin = ops.gemm(Z, W21, bias=b2)
+            ops.add_layernorm_fwd(lin, Xs[i], gamma, beta, dropout=0.2, seed=1, site=3)
+        try:
+            t_u = time_gpu(unfused, iters=9, warmup=3)
+        except Exception as ex:                       # noqa: BLE001 -- the comparison leg must not take the object down
+            t_u = float("nan")
+            g5["unfused_error_%s" % name] = str(ex)[:120]
+        g5[name] = {"fwd_us": t_f * 1e6, "bwd_us": t_b * 1e6, "unfused_fwd_us": t_u * 1e6,
+                    "frac_hbm_fwd": layer_bytes_fwd / t_f / 1e9 / HBM_PEAK_GBS, "frac_hbm_bwd": layer_bytes_bwd / t_b / 1e9 / HBM_PEAK_GBS,
+                    "frac_mfma_fwd": 2.0 * n * 256 * 256 / t_f / 1e12 / (FP32_MFMA_PEAK_TF if dt == 0 else BF16_MFMA_PEAK_TF)}
+    g5["note"] = ("one GCN layer on config 5 (116 entries per row: the fused kernel's gather is its tail path throughout); "
+                  "bwd = LayerNorm backward + fused V = A dY, dX += V W21 + the weight gradient V^T X")
+    out["gcn_cfg5"] = g5
     return out
 
 
@@ -555,6 +603,10 @@ def compact_line(line, detail_path):
     put("spmm_b64_compact_frac", line, "spmm_b64_compact", "frac")
     put("spmm_cfg5_frac_f32", line, "spmm_cfg5", "frac")
     put("spmm_cfg5_frac_bf16", line, "spmm_cfg5", "frac_bf16")
+    put("gcn_cfg5_f32_fwd_us", line, "gcn_cfg5", "f32", "fwd_us")
+    put("gcn_cfg5_f32_bwd_us", line, "gcn_cfg5", "f32", "bwd_us")
+    put("gcn_cfg5_bf16_fwd_us", line, "gcn_cfg5", "bf16", "fwd_us")
+    put("gcn_cfg5_bf16_bwd_us", line, "gcn_cfg5", "bf16", "bwd_us")
     put("host_inclusive_commits_per_s", line, "host_inclusive", "commits_per_s")
     for leg in ("b64", "b170"):
         for dt in ("f32", "bf16"):

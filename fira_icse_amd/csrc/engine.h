@@ -42,11 +42,13 @@ int gemm_bf16_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A
 int gemm_bf16_group_flush(hipStream_t s);
 bool gemm_bf16_takes(int M, int N, int K);     // false: the product is too small for the bf16 tiles (runs in fp32)
 void gemm_bf16_group_reset();
+bool gemm_bf16_group_full();     // the next add would launch the queue by itself: the caller forks + flushes first
 // grouped weight gradients (one launch for many small dW += dY^T X problems; see gemm_f32.hip)
 int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                          int ldc, float* colsum, int max_split = 0);
 int gemm_group_flush(hipStream_t s);
 void gemm_group_reset();
+bool gemm_group_full();
 // coalesced 32x32 tile kernel (gemm_small.hip): shape test, launch with an optional residual epilogue (epilogue.h: EpiRes),
 // the stream whose gemm_f32 launches pad their LDS request (gemm_f32.hip: side_lds_pad)
 void gemm_set_pad_stream(hipStream_t s);

@@ -151,7 +151,7 @@ struct Plan {
             dCB_a = a.f((size_t)CB * D);
             red_cap = (size_t)nl * ((size_t)cdiv(NB, 16) * 4 * D + (size_t)cdiv(CB, 16) * 2 * D)                 // encoder LNs (GCN: + 2 sums)
                     + (size_t)3 * nl * cdiv(TB, 16) * 2 * D                                                      // decoder LNs
-                    + (size_t)nl * std::max((size_t)cdiv(CB, 16) * 4 * D, (size_t)256 * 6 * D)                           // Combination (fused: 256 x 1536)
+                    + (size_t)nl * std::max((size_t)cdiv(CB, 16) * 4 * D, (size_t)comb_fused_bwd_parts() * 6 * D + 64)  // Combination (fused: one {LN | dvtab} row pair per workgroup)
                     + (size_t)cdiv(L + S, 16) * B * COPY_PART_STRIDE + 4096;                                     // copy head
             red_buf = a.f(red_cap);
             // buffers that must start a backward pass at zero, contiguous: ONE fill per step (zero_beg .. zero_end)
@@ -498,10 +498,18 @@ static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* 
 // The same for the small reductions over the B*30 target rows (decoder layers, gate / target projections of the head):
 // queued and launched as ONE grouped kernel after the decoder's backward loop (gemm_f32.hip), instead of ~40 launches
 // of ~15 us that are mostly fill and drain.  Operands must stay untouched until then (they are per-layer slots).
+static inline int flush_grouped_wgrads(hipStream_t s);
+// A full queue launches itself at the next add -- on the weight-gradient stream, WITHOUT a fork from the caller's stream, i.e.
+// possibly ahead of the kernels that write its operands (deeper models: > 40 queued problems).  Fork + flush first.
+static inline int group_make_room(hipStream_t s) {
+    if (g_dtype == 1 ? gemm_bf16_group_full() : gemm_group_full()) return flush_grouped_wgrads(s);
+    return 0;
+}
 static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X,
                                        int ldx, float* dW, float* db, int max_split = 0) {
     SideStream& sd = side();
     if (!(sd.stream && sd.enabled)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    TRY(group_make_room(s));
     if (g_dtype == 1) {
         if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);   // e.g. the 2-column gate
         return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, max_split);
@@ -521,6 +529,7 @@ static inline int enc_wgrad(hipStream_t s, int M, int N, int K, const float* dY,
                             float* db) {
     if (!enc_group_on()) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
     SideStream& sd = side();
+    TRY(group_make_room(s));
     if (g_dtype == 1) {
         if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
         return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, 32);
@@ -542,8 +551,9 @@ struct RedCollector {
     size_t cap = 0, used = 0;
     RedTable tab;
     void reset(float* b, size_t c) { buf = b; cap = c; used = 0; tab.n = 0; }
-    float* alloc(size_t n) {                      // nullptr: no room -> the kernel falls back to atomics
-        if (!buf || used + n > cap || tab.n + 4 > RED_MAX) return nullptr;
+    // nullptr: no room (floats, or the `entries` table rows the caller is going to add()) -> the kernel falls back to atomics
+    float* alloc(size_t n, int entries = 4) {
+        if (!buf || used + n > cap || tab.n + entries > RED_MAX) return nullptr;
         float* p = buf + used;
         used += (n + 63) / 64 * 64;
         return p;
@@ -1183,6 +1193,10 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // weight gradients (A/B switch); default: all layers in one launch behind the last group
     static const bool unfold_late_off = [] { const char* e = getenv("FIRA_UNFOLD_LATE"); return e && e[0] == '0'; }();
     const bool unfold_late = !unfold_late_off && enc_group_on() && p.nl <= 16;
+    // The per-layer unfold reads dW21 right behind the layer's grouped launch: without the late launch (the switch, or more
+    // than 16 layers) every layer flushes its own group -- a group spanning several layers would leave dW21 unwritten
+    // (still the zero fill) when the layer's unfold products run.
+    const int wgrad_every = unfold_late ? enc_wgrad_every(Nc, p.nl) : 1;
     const float *uf_dW21[16], *uf_W1[16], *uf_W2[16];
     float *uf_dW1[16], *uf_dW2[16];
     int uf_n = 0;
@@ -1207,10 +1221,13 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         float* dW21 = p.dW21 + (size_t)l * D * D;
         const bool grouped = enc_group_on();
         // back to the reference's parameters (reads dW21: after its weight gradient on the same stream)
+        bool flushed = false;                    // this layer's grouped launch went out (behind a fork from the caller's stream)
         auto unfold = [&]() -> int {
             hipStream_t ws = s;
             if (side().stream && side().enabled) {
-                if (!grouped) TRY(side_fork(s));
+                // (dY2 / dW21's operands are written on the caller's stream: whatever reads them over there needs a fork behind
+                //  them -- the grouped flush of this layer was one)
+                if (!grouped || (!flushed && (!sums || !unfold_late))) TRY(side_fork(s));
                 ws = side().stream;
             }
             if (!sums) TRY(colsum(ws, Nc, D, g.dY2, D, dc21, p.rsum));
@@ -1249,8 +1266,9 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         if (comb_fused_bwd_on()) {
             // one launch (comb_fused.hip): LayerNorm backward, dgrad through Wo, gate backward, dgrad through Wq | Wk
             const int nb = comb_fused_bwd_parts();
-            float* part_ln = red().alloc((size_t)nb * 2 * D);
-            float* part_v = part_ln ? red().alloc((size_t)nb * 4 * D) : nullptr;
+            // (both blocks or neither: six table rows and nb * 6 * D floats asked for at once)
+            float* part_ln = red().alloc((size_t)nb * 6 * D, 6);
+            float* part_v = part_ln ? part_ln + (size_t)nb * 2 * D : nullptr;
             if (part_v) {
                 TRY(comb_fused_bwd(s, Cc, other, bt.code_rows, e.s1, e.st1, c.P + w.ln1g, c.P + w.wo, c.P + w.wqk, e.qk,
                                    p.vtab_all + l * D, p.nl * D, bt.code_mark, g.dYc, g.dqk, part_ln, part_v, c.p_drop, c.seed,
@@ -1281,7 +1299,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         TRY(enc_wgrad(s, Cc, 2 * D, D, g.dqk, 2 * D, e.Xc, D, G + w.wqk, G + w.bqk));
         if (grouped) {                           // the layer's three weight gradients: one fork, one launch, then the unfold
             // (one launch for every n layers' gradients: enc_wgrad_every)
-            if ((p.nl - l) % enc_wgrad_every(Nc, p.nl) == 0 || l == 0) TRY(flush_grouped_wgrads(s));
+            if ((p.nl - l) % wgrad_every == 0 || l == 0) { TRY(flush_grouped_wgrads(s)); flushed = true; }
             TRY(unfold());
         }
         if (!comb_done)

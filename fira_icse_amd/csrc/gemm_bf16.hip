@@ -746,6 +746,7 @@ struct GroupBuilder16 {
 static GroupBuilder16& group16() { static thread_local GroupBuilder16 g; return g; }
 
 void gemm_bf16_group_reset() { group16().t.n = 0; }
+bool gemm_bf16_group_full() { return group16().t.n == GROUP16_MAX; }
 int gemm_bf16_group_flush(hipStream_t s) {
     GroupTable16& t = group16().t;
     if (t.n == 0) return 0;

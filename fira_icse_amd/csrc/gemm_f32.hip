@@ -461,6 +461,7 @@ struct GroupBuilder {
 static GroupBuilder& group() { static thread_local GroupBuilder g; return g; }
 
 void gemm_group_reset() { group().t.n = 0; }
+bool gemm_group_full() { return group().t.n == GROUP_MAX; }
 int gemm_group_flush(hipStream_t s) {
     GroupTable& t = group().t;
     if (t.n == 0) return 0;

@@ -59,6 +59,8 @@ def parse_args(argv):
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many optimisation steps (0 = no limit)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--loss-log", default=None, help="write one JSON line per optimisation step: the train-split positions "
+                    "of the global batch and its mean token loss (synchronises every step, like run_model.py:112 does)")
     ap.add_argument("--save-optimizer", action="store_true", help="also write fira_train_state.pt (Adam moments, step)")
     ap.add_argument("--resume", action="store_true", help="start from best_model.pt (+ fira_train_state.pt if present)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="arithmetic of the nn.Linear products: f32 = "
@@ -183,6 +185,10 @@ class Run:
                 trainer.step(db)                     # db None (empty shard of a short tail batch): still joins the collectives
                 total_data += len(gidx)
                 steps += 1
+                if a.loss_log and self.rank == 0:
+                    with open(a.loss_log, "a") as f:
+                        f.write(json.dumps({"epoch": epoch, "batch": idx_b, "index": [int(i) for i in gidx],
+                                            "loss": trainer.last_loss()}) + "\n")
                 if idx_b % 10 == 0 and self.rank == 0:
                     print("epoch: %d batch: %d/%d  data: %d/%d loss: %.4f  (%.1f commits/s)" % (
                         epoch, idx_b, n_batches, total_data, len(store), trainer.last_loss(),

@@ -24,6 +24,11 @@ GOLDEN_B = 4                  # batch the golden model run uses (first commits o
 LARGE_SEED = 11
 LARGE_SPLIT = (128, 4, 64)
 LARGE_N = sum(LARGE_SPLIT)
+# BASELINE configs[0] (tests/golden/make_golden_epoch.py): one epoch of the reference's train() at batch 4
+EPOCH_SEED = 21
+EPOCH_SPLIT = (96, 16, 16)
+EPOCH_N = sum(EPOCH_SPLIT)
+EPOCH_B = 4
 
 GRAD_SAMPLE_KEYS = [
     "encoder.embedding.weight", "encoder.mark_embedding.weight", "encoder.ast_change_embedding.weight",

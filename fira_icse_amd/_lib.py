@@ -31,7 +31,8 @@ class Batch(C.Structure):
                 ("n_mem", C.c_int32), ("mem_rows", C.c_void_p), ("mem_dst", C.c_void_p), ("head_rows", C.c_void_p),
                 ("n_head_rows", C.c_int32), ("n_emb_items", C.c_int32), ("emb_item_tok", C.c_void_p),
                 ("emb_item_ptr", C.c_void_p), ("emb_rows", C.c_void_p), ("n_ast_items", C.c_int32),
-                ("ast_rows", C.c_void_p), ("ast_ids", C.c_void_p), ("dec_off", C.c_void_p), ("n_dec_rows", C.c_int32)]
+                ("ast_rows", C.c_void_p), ("ast_ids", C.c_void_p), ("dec_off", C.c_void_p), ("n_dec_rows", C.c_int32),
+                ("dec_off_host", C.c_void_p)]
 
 
 class TrainOpts(C.Structure):
@@ -153,9 +154,9 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # FIRA_HIP_LIB (A/B timing of an older build through the model-level entry points, whose signatures did not change
-    # between v5 and v7; callers ask has_symbol() before using an entry a v5 / v6 build lacks) may load an older library; the
-    # tree's own library must be v7
-    ok = (7,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7)
+    # between v5 and v8 -- v8 appended a field to fira_batch, which older builds never read; callers ask has_symbol() before
+    # using an entry an older build lacks) may load an older library; the tree's own library must be v8
+    ok = (8,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7, 8)
     if lib.fira_abi_version() not in ok:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib

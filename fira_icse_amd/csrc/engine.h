@@ -65,7 +65,8 @@ bool gemm_tile32_ln_try(hipStream_t s, int M, int N, const float* S, int lds, co
 int gemm_tile32_lnb_blocks(int M);
 bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const float* W, int ldw, float* dX, int lddx,
                          const float* relu_mask, const float* sum, const float* stats, const float* gamma, float* ds,
-                         float* dx_drop, float* part, float dropout, uint64_t seed, uint32_t site, int* rc);
+                         float* dx_drop, float* part, float dropout, uint64_t seed, uint32_t site, int* rc,
+                         uint32_t idx0 = 0);      // idx0: dropout element index of row 0 (the rows are a slice of the site's rows)
 bool gemm_small_try(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, int flags, int* rc, const int32_t* c_rows = nullptr,
                     const float* relu_mask = nullptr);
@@ -133,7 +134,8 @@ int deferred_reduce(hipStream_t s, RedTable& tab);       // dst[c] += sum_p src[
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows, const float* r1_row = nullptr,
                       const float* r1_col = nullptr,    // x += r1_row[r] * r1_col[:] before the dropout
-                      const int32_t* slot2 = nullptr, float* y2 = nullptr);   // rows with slot2[r] >= 0 are also stored at y2[slot2[r]]
+                      const int32_t* slot2 = nullptr, float* y2 = nullptr,    // rows with slot2[r] >= 0 are also stored at y2[slot2[r]]
+                      uint32_t idx0 = 0);       // dropout element index of row 0, column 0 (a row slice of the site: decoder lanes)
 bool gemm_bf16_k256_try(hipStream_t s, int M, int N, int K, const float* A, int lda, const uint16_t* Bb, int ldb, float* C,
                         int ldc, const float* bias, int flags, const int32_t* c_rows, const float* relu_mask, int* rc);
 bool linear_ln_bf16_try(hipStream_t s, int M, int K, const float* X, int ldx, const uint16_t* Wb, int ldb, const float* bias,
@@ -146,7 +148,7 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
                       float* part = nullptr,    // part: [add_layernorm_bwd_blocks(M), 512] partial {dgamma | dbeta} rows instead of atomics
                       // row_w (with part): partial rows are 1024 wide, {dgamma | dbeta | sum_r dx[r,:] | sum_r row_w[r] dx[r,:]}
                       // with dx the un-dropped gradient rows (what dx_drop receives)
-                      const float* row_w = nullptr);
+                      const float* row_w = nullptr, uint32_t idx0 = 0);
 int add_layernorm_bwd_blocks(int M);
 int gcn_bias_unfold(hipStream_t s, const float* W2, const float* b1, const float* dc, float* dW2, float* db1);
 struct UnfoldEntry { const float *W2, *b1, *dc; float *dW2, *db1; };

@@ -196,6 +196,7 @@ static int zero(hipStream_t s, void* p, size_t bytes) {
 // configs[2]).  Only the nn.Linear products switch; LayerNorm, soft-max, the gate, the loss and Adam stay fp32, and
 // so do the products on parameters alone (the folded GCN weights) and the tiny ones gemm_bf16_ex forwards.
 static thread_local int g_dtype = 0;
+static thread_local int g_lanes = 1;            // commit-lanes of the running decoder pass (decoder_lanes)
 struct DtypeScope {
     int prev;
     explicit DtypeScope(int d) : prev(g_dtype) { g_dtype = d; }
@@ -315,10 +316,11 @@ static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx
                             const float* r1_row = nullptr, const float* r1_col = nullptr,
                             // second, compact copy of the listed output rows: y2[k] = y[rows2[k]] for k < n2, slot2 = the
                             // inverse list (row -> k or -1); written by the row kernel itself, or by a gather after a fused launch
-                            const int32_t* slot2 = nullptr, float* y2 = nullptr, int n2 = 0, const int32_t* rows2 = nullptr) {
+                            const int32_t* slot2 = nullptr, float* y2 = nullptr, int n2 = 0, const int32_t* rows2 = nullptr,
+                            uint32_t idx0 = 0) {     // dropout element index of row 0 (the rows are a slice of the site's rows)
     bool fused = false;
     int rc = 0;
-    if (g_dtype != 0) {                          // bf16: the panel kernel with a LayerNorm epilogue (gemm_bf16_panel.hip)
+    if (g_dtype != 0 && idx0 == 0 && g_lanes == 1) {   // bf16: the panel kernel with a LayerNorm epilogue (gemm_bf16_panel.hip)
         const uint16_t* wb;
         int ldw;
         fused = shadow_of(W, false, &wb, &ldw) && ldw == K &&
@@ -331,7 +333,7 @@ static inline int linear_ln(hipStream_t s, int M, int K, const float* X, int ldx
         return 0;
     }
     TRY(linear(s, M, FIRA_D, K, X, ldx, W, b, sum, FIRA_D));
-    return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col, slot2, y2);
+    return add_layernorm_fwd(s, M, sum, res, gamma, beta, y, stats, p_drop, seed, st, y_rows, r1_row, r1_col, slot2, y2, idx0);
 }
 // The same block with its LayerNorm moved into the CONSUMER (fp32, coalesced tile kernel): the closing product stores the
 // pre-norm sum  sum = dropout(X W^T + b) + res  (EpiRes epilogue) and the next product normalises its A rows itself
@@ -342,11 +344,12 @@ static bool presum_on() {
     return !off && g_dtype == 0;
 }
 static inline bool linear_presum(hipStream_t s, int M, int K, const float* X, int ldx, const float* W, const float* b,
-                                 const float* res, float* sum, float p_drop, uint64_t seed, uint32_t st, int* rc) {
+                                 const float* res, float* sum, float p_drop, uint64_t seed, uint32_t st, int* rc,
+                                 uint32_t idx0 = 0) {
     if (!presum_on() || !gemm_tile32_takes(1, M, FIRA_D, K, X, ldx, W, K)) return false;
     EpiRes er;
     er.res = res; er.ldr = FIRA_D; er.p = p_drop; er.inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    er.seed = seed; er.site = st;
+    er.seed = seed; er.site = st; er.idx0 = idx0;
     ProfScope prof(s, PROF_GEMM, 2.0 * M * FIRA_D * (double)K, 4.0 * ((double)M * K + (double)FIRA_D * K + 2.0 * M * FIRA_D));
     return gemm_tile32_try(s, 1, M, FIRA_D, K, X, ldx, W, K, sum, FIRA_D, b, 0, rc, nullptr, nullptr, nullptr, &er);
 }
@@ -362,6 +365,7 @@ static inline int linear_dgrad(hipStream_t s, int M, int N, int K, const float* 
 struct SideStream {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;   // high priority: the few off-chain products the main stream waits for later
+    hipStream_t lane = nullptr;  // second commit-lane of the decoder's chain (round 6; created on first use)
     std::vector<hipEvent_t> events;
     size_t next = 0;
     bool enabled = true;
@@ -570,7 +574,8 @@ static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const
                   const int32_t* rows = nullptr,
                   // optional (GCN blocks): the kernel also leaves sum_r dx[r,:] -> dsum and sum_r row_w[r] dx[r,:] -> dwsum
                   // (deferred like dgamma / dbeta); *extras tells whether it did (false: no room for the partial rows)
-                  const float* row_w = nullptr, float* dsum = nullptr, float* dwsum = nullptr, bool* extras = nullptr) {
+                  const float* row_w = nullptr, float* dsum = nullptr, float* dwsum = nullptr, bool* extras = nullptr,
+                  uint32_t idx0 = 0) {
     const int nb = add_layernorm_bwd_blocks(M);
     static const bool no_extra = [] { const char* e = getenv("FIRA_LN_BWD_EXTRA"); return e && e[0] == '0'; }();   // A/B switch
     const bool want = row_w && dsum && dwsum && !no_extra;
@@ -580,7 +585,7 @@ static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const
     if (extras) *extras = ex;
     const int w = ex ? 4 * FIRA_D : 2 * FIRA_D;
     TRY(add_layernorm_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st, rows, part,
-                          ex ? row_w : nullptr));
+                          ex ? row_w : nullptr, idx0));
     if (part) {
         red().add(dgamma, part, FIRA_D, nb, w);
         red().add(dbeta, part + FIRA_D, FIRA_D, nb, w);
@@ -597,7 +602,7 @@ static int ln_bwd(hipStream_t s, int M, const float* dy, const float* sum, const
 // the product.  dX[M,N] = dx_drop[M,256] . W[256,N] (W row-major [256,N]) (masked by relu_mask > 0); ds must not alias dy.
 static int ln_bwd_dgrad(hipStream_t s, int M, int N, const float* dy, const float* sum, const float* stats, const float* gamma,
                         float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed, uint32_t st,
-                        const float* W, int ldw, float* dX, int lddx, const float* relu_mask) {
+                        const float* W, int ldw, float* dX, int lddx, const float* relu_mask, uint32_t idx0 = 0) {
     // Up to ~1 500 rows (batch 64): beyond, the prologue repeated in each of the N / 32 column tiles of a row block is no longer
     // hidden by idle CUs (batch 170, 2 700 rows: 20 177 -> 20 567 commits/s without it; batch 64 neutral, batch 32 +0.5 % with it)
     static const int lnb_max_rows = [] { const char* e = getenv("FIRA_LN_BWD_MAX_ROWS"); return e ? atoi(e) : 1536; }();
@@ -606,14 +611,14 @@ static int ln_bwd_dgrad(hipStream_t s, int M, int N, const float* dy, const floa
         float* part = red().alloc((size_t)nb * 2 * FIRA_D);
         int rc = 0;
         if (part && gemm_tile32_lnb_try(s, M, N, dy, W, ldw, dX, lddx, relu_mask, sum, stats, gamma, ds, dx_drop, part, dropout, seed,
-                                        st, &rc)) {
+                                        st, &rc, idx0)) {
             TRY(rc);
             red().add(dgamma, part, FIRA_D, nb, 2 * FIRA_D);
             red().add(dbeta, part + FIRA_D, FIRA_D, nb, 2 * FIRA_D);
             return 0;
         }
     }
-    TRY(ln_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st));
+    TRY(ln_bwd(s, M, dy, sum, stats, gamma, ds, dx_drop, dgamma, dbeta, dropout, seed, st, nullptr, nullptr, nullptr, nullptr, nullptr, idx0));
     return gemm_any(s, 0, 0, M, N, FIRA_D, dx_drop, FIRA_D, W, ldw, dX, lddx, nullptr, 0, 0, nullptr, nullptr, relu_mask);
 }
 
@@ -703,7 +708,68 @@ struct Ctx {
     // weights themselves) the first reader of a shadow is the decoder (and the auxiliary stream's own K|V projections)
     const ShadowTable* shadow_tab = nullptr;
     hipEvent_t ev_shadow = nullptr;
+    // (round 6) commit-lanes of the decoder's chain: see decoder_lanes()
+    int n_lanes = 1;
+    struct Lane { hipStream_t s; int b0, nb, r0, nr; } lanes[2] = {};
 };
+typedef Ctx::Lane Lane;
+
+// ------------------------------------------------------------------------------------------ commit-lanes (round 6)
+// The decoder's layers -- forward and backward -- are a dependent chain of ~100 launches whose kernels each leave most of the
+// chip idle (17 .. 136 workgroups of a 32x32 tile kernel, one workgroup per (commit, head) in the attention kernels) and cost
+// their latency, not their work.  Commits are independent (every kernel of the chain is row-wise or per commit, and the
+// weight gradients are sums over commits): the batch's computed target rows are cut at a commit boundary into TWO contiguous
+// lanes, lane 0 on the caller's stream and lane 1 on a library-owned stream, each running the same launches on its rows of the
+// SAME activation buffers; the grouped weight-gradient launches and the d-memory products on the other streams read the
+// operands of both lanes and are forked from both.  Results are those of one lane (same dropout masks: the kernels take the
+// element index of a slice's first row) up to the row-block boundaries of the deferred column sums.
+// FIRA_DEC_LANES=1|2 (default: see decoder_lanes); needs the host copy of dec_off (fira_batch.dec_off_host).
+static int decoder_lanes(Ctx& c) {
+    static const int want = [] { const char* e = getenv("FIRA_DEC_LANES"); const int v = e ? atoi(e) : 1; return v >= 2 ? 2 : 1; }();
+    c.n_lanes = g_lanes = 1;
+    c.lanes[0] = Lane{c.s, 0, c.pl->B, 0, c.Td};
+    const fira_batch& bt = *c.bt;
+    if (want < 2 || !c.dec_off || !bt.dec_off_host || bt.B < 2 || !side_on() || c.serial || !c.kv_ragged) return 0;
+    SideStream& sd = side();
+    if (!sd.lane) {
+        // same (default) priority as a caller's stream: the two lanes are peers
+        if (hipStreamCreateWithFlags(&sd.lane, hipStreamNonBlocking) != hipSuccess) return set_err("lane stream: create failed");
+    }
+    int bm = 1, best = 1 << 30;
+    for (int b = 1; b < bt.B; ++b) {                        // the commit boundary closest to half of the rows
+        const int d = abs(2 * bt.dec_off_host[b] - c.Td);
+        if (d < best) { best = d; bm = b; }
+    }
+    const int rm = bt.dec_off_host[bm];
+    if (rm <= 0 || rm >= c.Td || bt.dec_off_host[bt.B] != c.Td) return 0;
+    c.n_lanes = g_lanes = 2;
+    c.lanes[0] = Lane{c.s, 0, bm, 0, rm};
+    c.lanes[1] = Lane{sd.lane, bm, bt.B - bm, rm, c.Td - rm};
+    return 0;
+}
+// lane 1 starts behind everything the caller's stream holds so far / the caller's stream continues behind lane 1
+static int lanes_fork(Ctx& c) {
+    for (int k = 1; k < c.n_lanes; ++k) {
+        hipEvent_t e = side().ev();
+        if (hipEventRecord(e, c.s) != hipSuccess || hipStreamWaitEvent(c.lanes[k].s, e, 0) != hipSuccess) return set_err("lane fork failed");
+    }
+    return 0;
+}
+static int lanes_join(Ctx& c) {
+    for (int k = 1; k < c.n_lanes; ++k) {
+        hipEvent_t e = side().ev();
+        if (hipEventRecord(e, c.lanes[k].s) != hipSuccess || hipStreamWaitEvent(c.s, e, 0) != hipSuccess) return set_err("lane join failed");
+    }
+    return 0;
+}
+// `target` (the weight-gradient or the auxiliary stream) waits for everything enqueued on EVERY lane so far
+static int lanes_fork_to(Ctx& c, hipStream_t target) {
+    for (int k = 0; k < c.n_lanes; ++k) {
+        hipEvent_t e = side().ev();
+        if (hipEventRecord(e, c.lanes[k].s) != hipSuccess || hipStreamWaitEvent(target, e, 0) != hipSuccess) return set_err("lane -> side stream fork failed");
+    }
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------ encoder forward
 // The encoder runs on the batch's COMPUTED node list only (fira_batch.node_rows): padded nodes carry nothing but a
@@ -873,77 +939,98 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
 static int decoder_forward(Ctx& c) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
-    hipStream_t s = c.s;
-    const int D = FIRA_D, H = L.d.n_head, KV = p.nl * 2 * D, Sm = p.L + p.S;
-    if (c.row_bt) TRY(embed_rows_fwd(s, c.Td, p.T, c.row_bt, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0));
-    else TRY(embed_gather_fwd(s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
+    const int D = FIRA_D, H = L.d.n_head, Sm = p.L + p.S;
+    if (c.row_bt) TRY(embed_rows_fwd(c.s, c.Td, p.T, c.row_bt, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0));
+    else TRY(embed_gather_fwd(c.s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
     ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
-    const float* x = p.x0;
-    // pend_*: a block whose pre-norm sums are stored but whose LayerNorm is still owed (it runs in the prologue of the next
-    // product: see linear_presum).  y = LN(pend_sum) goes to pend_y, the statistics to pend_st.
-    const float *pend_sum = nullptr, *pend_g = nullptr, *pend_b = nullptr;
-    float *pend_y = nullptr, *pend_st = nullptr;
-    // Y = x W^T + b where x is either materialised or owed (pend_*): the fused launch, or the row kernel + a plain product
-    auto consume = [&](int N, const float* W, const float* b, float* Y, int flags) -> int {
-        if (pend_sum) {
-            int rc = 0;
-            const bool fused = gemm_tile32_ln_try(s, c.Td, N, pend_sum, D, W, b, Y, N, flags, pend_g, pend_b, pend_y, pend_st, &rc);
-            if (!fused)
-                rc = add_layernorm_fwd(s, c.Td, const_cast<float*>(pend_sum), nullptr, pend_g, pend_b, pend_y, pend_st, 0.f, 0, 0,
-                                       nullptr);
-            pend_sum = nullptr;
-            if (rc || fused) return rc;
-        }
-        return linear(s, c.Td, N, D, x, D, W, b, Y, N, flags);
-    };
-    // closing product of a block: y = LN(dropout(X W^T + b) + res); its LayerNorm is deferred to the next product when the
-    // shapes allow it
-    auto close_block = [&](int K, const float* X, const float* W, const float* b, const float* res, const float* g, const float* be,
-                           float* sum, float* y, float* st, uint32_t stt, bool may_defer, const int32_t* slot2, float* y2, int n2,
-                           const int32_t* rows2) -> int {
-        int rc = 0;
-        if (may_defer && linear_presum(s, c.Td, K, X, K, W, b, res, sum, c.p_drop, c.seed, stt, &rc)) {
-            pend_sum = sum; pend_g = g; pend_b = be; pend_y = y; pend_st = st;
-            return rc;
-        }
-        return linear_ln(s, c.Td, K, X, K, W, b, res, g, be, sum, y, st, c.p_drop, c.seed, stt, nullptr, nullptr, nullptr, slot2, y2,
-                         n2, rows2);
-    };
+    TRY(decoder_lanes(c));
+    TRY(lanes_fork(c));
+    // Per lane (Ctx::lanes; one lane = the whole batch on the caller's stream): x = the current rows; pend_*: a block whose
+    // pre-norm sums are stored but whose LayerNorm is still owed (it runs in the prologue of the next product: see
+    // linear_presum).  y = LN(pend_sum) goes to pend_y, the statistics to pend_st.  All pointers are buffer BASES: a lane
+    // addresses its rows r0 .. r0 + nr of every buffer.
+    struct LaneState {
+        const float *x = nullptr, *pend_sum = nullptr, *pend_g = nullptr, *pend_b = nullptr;
+        float *pend_y = nullptr, *pend_st = nullptr;
+        int kv_waited = 0;
+    } state[2];
+    for (int k = 0; k < c.n_lanes; ++k) state[k].x = p.x0;
     for (int l = 0; l < p.nl; ++l) {
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
-        TRY(consume(3 * D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 0));
-        TRY(attention_fwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0, e.ao, D,
-                          c.dec_off, 1, attn_bf16()));
-        TRY(close_block(D, e.ao, c.P + w.wo_s, c.P + w.bo_s, x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
-                        site(l, SITE_SELF), true, nullptr, nullptr, 0, nullptr));
-        x = e.x_a;
-        TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
-        // this layer's K|V rows (auxiliary stream): the first mark at or behind the layer, waited for once
-        if (c.deferred) {
-            int m = l;
-            while (m < p.nl - 1 && c.ev_kv[m] == nullptr) ++m;     // the first mark at or behind this layer
-            if (c.ev_kv[m] != nullptr && c.kv_waited < m + 1) {
-                TRY(main_wait(s, c.ev_kv[m], __LINE__));
-                c.kv_waited = m + 1;                               // layers < kv_waited are covered
-            }
-        }
-        TRY(attention_fwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
-                          c.kv_ragged ? p.mem_valid_c : p.mem_valid, 0, 0, e.ao2, D, c.dec_off, 0, attn_bf16(),
-                          c.kv_ragged ? p.mem_off : nullptr));
-        TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
-                        site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
-        x = e.x_c;
-        TRY(consume(p.F, c.P + w.w1, c.P + w.b1, e.h, FIRA_GEMM_RELU));
-        // the last layer's output rows that need the vocabulary head (Ctx::rows) are also stored compactly (dec_c); its
-        // LayerNorm is not deferred (several consumers: vocabulary head, target projection, gate)
         const bool last = l + 1 == p.nl;
-        const bool head_copy = last && c.rows != nullptr && c.R > 0;
-        TRY(close_block(p.F, e.h, c.P + w.w2, c.P + w.b2, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.s_f, e.x_f, e.st_f,
-                        site(l, SITE_FFN), !last, head_copy ? p.compact_row : nullptr, head_copy ? p.dec_c : nullptr,
-                        head_copy ? c.R : 0, head_copy ? c.rows : nullptr));
-        x = e.x_f;
+        for (int k = 0; k < c.n_lanes; ++k) {
+            const Lane& ln = c.lanes[k];
+            LaneState& st = state[k];
+            hipStream_t s = ln.s;
+            const size_t r0 = (size_t)ln.r0;
+            const int nr = ln.nr;
+            const uint32_t idx0 = (uint32_t)(r0 * D);          // dropout element index of the lane's first row
+            // Y = x W^T + b where x is either materialised or owed (pend_*): the fused launch, or the row kernel + a plain product
+            auto consume = [&](int N, const float* W, const float* b, float* Y, int flags) -> int {
+                if (st.pend_sum) {
+                    int rc = 0;
+                    float* sum = const_cast<float*>(st.pend_sum) + r0 * D;
+                    const bool fused = gemm_tile32_ln_try(s, nr, N, sum, D, W, b, Y + r0 * N, N, flags, st.pend_g, st.pend_b,
+                                                          st.pend_y + r0 * D, st.pend_st + r0 * 2, &rc);
+                    if (!fused)
+                        rc = add_layernorm_fwd(s, nr, sum, nullptr, st.pend_g, st.pend_b, st.pend_y + r0 * D, st.pend_st + r0 * 2, 0.f, 0, 0,
+                                               nullptr);
+                    st.pend_sum = nullptr;
+                    if (rc || fused) return rc;
+                }
+                return linear(s, nr, N, D, st.x + r0 * D, D, W, b, Y + r0 * N, N, flags);
+            };
+            // closing product of a block: y = LN(dropout(X W^T + b) + res); its LayerNorm is deferred to the next product when
+            // the shapes allow it
+            auto close_block = [&](int K, const float* X, const float* W, const float* b, const float* res, const float* g,
+                                   const float* be, float* sum, float* y, float* stt, uint32_t site_id, bool may_defer,
+                                   const int32_t* slot2, float* y2, int n2, const int32_t* rows2) -> int {
+                int rc = 0;
+                if (may_defer && linear_presum(s, nr, K, X + r0 * K, K, W, b, res + r0 * D, sum + r0 * D, c.p_drop, c.seed, site_id,
+                                               &rc, idx0)) {
+                    st.pend_sum = sum; st.pend_g = g; st.pend_b = be; st.pend_y = y; st.pend_st = stt;
+                    return rc;
+                }
+                return linear_ln(s, nr, K, X + r0 * K, K, W, b, res + r0 * D, g, be, sum + r0 * D, y + r0 * D, stt + r0 * 2, c.p_drop,
+                                 c.seed, site_id, nullptr, nullptr, nullptr, slot2 ? slot2 + r0 : nullptr, y2, n2, rows2, idx0);
+            };
+            // (a lane's commits: ranges of the ragged row lists start at its first commit; the dense key mask of the self
+            //  attention is indexed by commit)
+            const int32_t* q_off = c.dec_off ? c.dec_off + ln.b0 : nullptr;
+            TRY(consume(3 * D, c.P + w.wqkv, c.P + w.bqkv, e.qkv, 0));
+            TRY(attention_fwd(s, ln.nb, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid + (size_t)ln.b0 * p.T,
+                              1, 0, e.ao, D, q_off, 1, attn_bf16()));
+            TRY(close_block(D, e.ao, c.P + w.wo_s, c.P + w.bo_s, st.x, c.P + w.lns_g, c.P + w.lns_b, e.s_a, e.x_a, e.st_a,
+                            site(l, SITE_SELF), true, nullptr, nullptr, 0, nullptr));
+            st.x = e.x_a;
+            TRY(consume(D, c.P + w.wq_c, c.P + w.bq_c, e.qc, 0));
+            // this layer's K|V rows (auxiliary stream): the first mark at or behind the layer, waited for once per lane
+            if (c.deferred) {
+                int m = l;
+                while (m < p.nl - 1 && c.ev_kv[m] == nullptr) ++m;     // the first mark at or behind this layer
+                if (c.ev_kv[m] != nullptr && st.kv_waited < m + 1) {
+                    TRY(main_wait(s, c.ev_kv[m], __LINE__));
+                    st.kv_waited = m + 1;                              // layers < kv_waited are covered
+                }
+            }
+            TRY(attention_fwd(s, ln.nb, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
+                              c.kv_ragged ? p.mem_valid_c : p.mem_valid, 0, 0, e.ao2, D, q_off, 0, attn_bf16(),
+                              c.kv_ragged ? p.mem_off + ln.b0 : nullptr));
+            TRY(close_block(D, e.ao2, c.P + w.wo_c, c.P + w.bo_c, e.x_a, c.P + w.lnc_g, c.P + w.lnc_b, e.s_c, e.x_c, e.st_c,
+                            site(l, SITE_CROSS), true, nullptr, nullptr, 0, nullptr));
+            st.x = e.x_c;
+            TRY(consume(p.F, c.P + w.w1, c.P + w.b1, e.h, FIRA_GEMM_RELU));
+            // the last layer's output rows that need the vocabulary head (Ctx::rows) are also stored compactly (dec_c); its
+            // LayerNorm is not deferred (several consumers: vocabulary head, target projection, gate)
+            const bool head_copy = last && c.rows != nullptr && c.R > 0;
+            TRY(close_block(p.F, e.h, c.P + w.w2, c.P + w.b2, e.x_c, c.P + w.lnf_g, c.P + w.lnf_b, e.s_f, e.x_f, e.st_f,
+                            site(l, SITE_FFN), !last, head_copy ? p.compact_row : nullptr, head_copy ? p.dec_c : nullptr,
+                            head_copy ? c.R : 0, head_copy ? c.rows : nullptr));
+            st.x = e.x_f;
+        }
     }
+    TRY(lanes_join(c));
     return 0;
 }
 
@@ -1072,55 +1159,81 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // FIRA_DEC_WGRAD_EVERY=0: one launch behind the loop.
     static const int dec_every_env = [] { const char* e = getenv("FIRA_DEC_WGRAD_EVERY"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 0; }();
     const int dec_every = (mid_event || g_dtype != 0 || dec_every_env == 0 || p.nl % dec_every_env != 0) ? 0 : dec_every_env;
+    TRY(lanes_fork(c));                        // (lane 1 starts behind the head's backward kernels)
+    // the other streams' launches inside the loop read rows of EVERY lane: they fork from all of them
+    auto aux_fork_all = [&]() -> int { return c.n_lanes > 1 ? lanes_fork_to(c, side().aux) : aux_fork(s); };
+    auto flush_wgrads_all = [&]() -> int {
+        if (c.n_lanes == 1) return flush_grouped_wgrads(s);
+        SideStream& sd = side();
+        if (!(sd.stream && sd.enabled)) return 0;
+        TRY(lanes_fork_to(c, sd.stream));
+        return g_dtype == 1 ? gemm_bf16_group_flush(sd.stream) : gemm_group_flush(sd.stream);
+    };
     for (int l = p.nl - 1; l >= 0; --l) {
         ProfDecoderTag prof_tag;               // data gradients of the M = B*30 products (the grouped wgrads flush later)
         const DecLayer& w = L.dec[l];
         DecSave& e = p.dec[l];
         DecGrad& g = p.decg[l];
         const float* x_in = l == 0 ? p.x0 : p.dec[l - 1].x_f;
-        // FeedForward (gnn_transformer.py:170-174): LayerNorm backward + d hidden = (dYf W2) masked by the saved activation > 0
-        // (ReLU backward in the GEMM epilogue)
-        TRY(ln_bwd_dgrad(s, c.Td, p.F, bx, e.s_f, e.st_f, c.P + w.lnf_g, by, g.dYf, G + w.lnf_g, G + w.lnf_b, c.p_drop, c.seed,
-                         site(l, SITE_FFN), c.P + w.w2, p.F, g.dh, p.F, e.h));
-        TRY(linear_wgrad_grouped(s, c.Td, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
-        TRY(linear_wgrad_grouped(s, c.Td, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
-        TRY(linear_dgrad(s, c.Td, p.F, D, g.dh, p.F, c.P + w.w1, by, D, true));               // by = d x_c
-        // cross attention: LayerNorm backward + d ao2 = dYc Wo_c
-        TRY(ln_bwd_dgrad(s, c.Td, D, by, e.s_c, e.st_c, c.P + w.lnc_g, bz, g.dYc, G + w.lnc_g, G + w.lnc_b, c.p_drop, c.seed,
-                         site(l, SITE_CROSS), c.P + w.wo_c, D, bx, D, nullptr));              // bx = d ao2
-        TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
-        // (ragged key rows: dkv_all holds the computed memory rows only, every one of them written by this launch)
-        TRY(attention_bwd(s, p.B, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
-                          p.mem_valid_c, 0, 0, e.ao2, D, bx, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
-                          p.dkv_all + l * 2 * D + D, p.kvp, c.dec_off, 0, attn_bf16(), p.mem_off));
-        if (so && (l % 2 == 0 || l == 0)) {
-            // dK|dV of this layer and of the one above it (adjacent column blocks of dkv_all / row blocks of the stacked K|V
-            // weight) -> d memory, beside the chain.  TWO layers per fork: a fork costs the dependent chain
-            // ~15 us (r3_event_cost.txt) and hides ~20 us of work per layer
+        // dK|dV of this layer and of the one above it (adjacent column blocks of dkv_all / row blocks of the stacked K|V
+        // weight) -> d memory, beside the chain.  TWO layers per fork: a fork costs the dependent chain ~15 us
+        // (r3_event_cost.txt) and hides ~20 us of work per layer
+        auto dmem_pair = [&]() -> int {
+            if (!(so && (l % 2 == 0 || l == 0))) return 0;
             const int nlay = std::min(2, p.nl - l);
             const size_t o = (size_t)l * 2 * D;
-            TRY(aux_fork(s));
+            TRY(aux_fork_all());
             prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
             const int rc_kv = linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_all + o, p.kvp, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
             prof_decoder_tag(+1);
-            TRY(rc_kv);
+            return rc_kv;
+        };
+        for (int k = 0; k < c.n_lanes; ++k) {
+            const Lane& ln = c.lanes[k];
+            hipStream_t ls = ln.s;
+            const size_t r0 = (size_t)ln.r0;
+            const int nr = ln.nr;
+            const uint32_t idx0 = (uint32_t)(r0 * D);
+            const int32_t* q_off = c.dec_off ? c.dec_off + ln.b0 : nullptr;
+            const bool q = k == 0;             // the weight gradients read the rows of all lanes: queued once
+            // FeedForward (gnn_transformer.py:170-174): LayerNorm backward + d hidden = (dYf W2) masked by the saved activation > 0
+            // (ReLU backward in the GEMM epilogue)
+            TRY(ln_bwd_dgrad(ls, nr, p.F, bx + r0 * D, e.s_f + r0 * D, e.st_f + r0 * 2, c.P + w.lnf_g, by + r0 * D, g.dYf + r0 * D,
+                             G + w.lnf_g, G + w.lnf_b, c.p_drop, c.seed, site(l, SITE_FFN), c.P + w.w2, p.F, g.dh + r0 * p.F, p.F,
+                             e.h + r0 * p.F, idx0));
+            if (q) TRY(linear_wgrad_grouped(s, c.Td, D, p.F, g.dYf, D, e.h, p.F, G + w.w2, G + w.b2));
+            if (q) TRY(linear_wgrad_grouped(s, c.Td, p.F, D, g.dh, p.F, e.x_c, D, G + w.w1, G + w.b1));
+            TRY(linear_dgrad(ls, nr, p.F, D, g.dh + r0 * p.F, p.F, c.P + w.w1, by + r0 * D, D, true));               // by = d x_c
+            // cross attention: LayerNorm backward + d ao2 = dYc Wo_c
+            TRY(ln_bwd_dgrad(ls, nr, D, by + r0 * D, e.s_c + r0 * D, e.st_c + r0 * 2, c.P + w.lnc_g, bz + r0 * D, g.dYc + r0 * D,
+                             G + w.lnc_g, G + w.lnc_b, c.p_drop, c.seed, site(l, SITE_CROSS), c.P + w.wo_c, D, bx + r0 * D, D, nullptr,
+                             idx0));                                                                              // bx = d ao2
+            if (q) TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYc, D, e.ao2, D, G + w.wo_c, G + w.bo_c));
+            // (ragged key rows: dkv_all holds the computed memory rows only, every one of them written by this launch)
+            TRY(attention_bwd(ls, ln.nb, H, p.T, Sm, e.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
+                              p.mem_valid_c, 0, 0, e.ao2, D, bx, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
+                              p.dkv_all + l * 2 * D + D, p.kvp, q_off, 0, attn_bf16(), p.mem_off + ln.b0));
+            if (c.n_lanes == 1) TRY(dmem_pair());
+            if (q) TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
+            TRY(linear_dgrad(ls, nr, D, D, g.dq + r0 * D, D, c.P + w.wq_c, bz + r0 * D, D, true));                 // bz = d x_a
+            // self attention: LayerNorm backward + d ao = dYs Wo_s
+            TRY(ln_bwd_dgrad(ls, nr, D, bz + r0 * D, e.s_a + r0 * D, e.st_a + r0 * 2, c.P + w.lns_g, by + r0 * D, g.dYs + r0 * D,
+                             G + w.lns_g, G + w.lns_b, c.p_drop, c.seed, site(l, SITE_SELF), c.P + w.wo_s, D, bx + r0 * D, D, nullptr,
+                             idx0));                                                                              // bx = d ao
+            if (q) TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
+            TRY(attention_bwd(ls, ln.nb, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D,
+                              p.tar_valid + (size_t)ln.b0 * p.T, 1, 0, e.ao, D, bx, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D,
+                              3 * D, q_off, 1, attn_bf16()));
+            if (q) TRY(linear_wgrad_grouped(s, c.Td, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
+            TRY(linear_dgrad(ls, nr, 3 * D, D, g.dqkv + r0 * 3 * D, 3 * D, c.P + w.wqkv, by + r0 * D, D, true));   // by = d x_in
         }
-        TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
-        TRY(linear_dgrad(s, c.Td, D, D, g.dq, D, c.P + w.wq_c, bz, D, true));                 // bz = d x_a
-        // self attention: LayerNorm backward + d ao = dYs Wo_s
-        TRY(ln_bwd_dgrad(s, c.Td, D, bz, e.s_a, e.st_a, c.P + w.lns_g, by, g.dYs, G + w.lns_g, G + w.lns_b, c.p_drop, c.seed,
-                         site(l, SITE_SELF), c.P + w.wo_s, D, bx, D, nullptr));               // bx = d ao
-        TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dYs, D, e.ao, D, G + w.wo_s, G + w.bo_s));
-        TRY(attention_bwd(s, p.B, H, p.T, p.T, e.qkv, 3 * D, e.qkv + D, 3 * D, e.qkv + 2 * D, 3 * D, p.tar_valid, 1, 0,
-                          e.ao, D, bx, D, g.dqkv, 3 * D, g.dqkv + D, 3 * D, g.dqkv + 2 * D, 3 * D, c.dec_off, 1, attn_bf16()));
-        TRY(linear_wgrad_grouped(s, c.Td, 3 * D, D, g.dqkv, 3 * D, x_in, D, G + w.wqkv, G + w.bqkv));
-        TRY(linear_dgrad(s, c.Td, 3 * D, D, g.dqkv, 3 * D, c.P + w.wqkv, by, D, true));       // by = d x_in
+        if (c.n_lanes > 1) TRY(dmem_pair());   // (behind the layer of every lane: dkv_all's column block is complete)
         if (dec_every > 0 && l % dec_every == 0 && side().stream && side().enabled) {
             // the weight gradients of the last dec_every layers: one grouped launch + their row block of the stacked K|V weight
             const int nlay = std::min(dec_every, p.nl - l);
             const size_t o = (size_t)l * 2 * D;
             prof_decoder_tag(-1);               // weight gradients: not among the decoder's forward / data-gradient products
-            int rc_w = flush_grouped_wgrads(s);
+            int rc_w = flush_wgrads_all();
             if (!rc_w)
                 rc_w = gemm_any(side().stream, 1, 0, nlay * 2 * D, D, Mc, p.dkv_all + o, p.kvp, p.mem_c, D, G + L.wkv_all + o * D, D, nullptr,
                                 FIRA_GEMM_ACCUM, 0, G + L.bkv_all + o);
@@ -1129,6 +1242,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         }
         float* t = bx; bx = by; by = t;         // the next layer's output gradient is in (the old) by; bz stays free
     }
+    TRY(lanes_join(c));
     const float* dy = bx;
     TRY(flush_grouped_wgrads(s));                                  // the decoder's and the head's small weight gradients
     // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions

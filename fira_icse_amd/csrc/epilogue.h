@@ -39,6 +39,7 @@ struct EpiRes {
     float p = 0.f, inv_keep = 1.f;
     uint64_t seed = 0;
     uint32_t site = 0;
+    uint32_t idx0 = 0;               // dropout element index of C[0,0]: the rows of a launch may be a slice of the site's rows
 };
 
 template <int NV>
@@ -91,7 +92,7 @@ __device__ __forceinline__ void epilogue_col(const float (&acc)[NV], const int (
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             float v = acc[i] + bv;
-            if (er.p > 0.f) v *= dropout_scale(er.seed, er.site, (uint32_t)row[i] * FIRA_D + (uint32_t)col, er.p, er.inv_keep);
+            if (er.p > 0.f) v *= dropout_scale(er.seed, er.site, er.idx0 + (uint32_t)row[i] * FIRA_D + (uint32_t)col, er.p, er.inv_keep);
             v += rv[i];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, off[i], 0, 0);
         }

@@ -210,6 +210,7 @@ struct LnB {
     float p = 0.f, inv_keep = 1.f;
     uint64_t seed = 0;
     uint32_t site = 0;
+    uint32_t idx0 = 0;               // dropout element index of row 0, column 0 (a row slice of the site: engine.hip lanes)
 };
 
 // NW (round 5): wavefronts per workgroup.  The K chunks go round-robin over the waves, so a long reduction on a SMALL grid
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tile32_kernel(int M, int N, cons
         const f32x4 e03 = (h03 - m1[3] - s03 * m2[3]) * rstd3, e13 = (h13 - m1[3] - s13 * m2[3]) * rstd3;
         auto drop = [&](const f32x4 v, int row, int col) {
             if (lb.p <= 0.f) return v;
-            const uint32_t e0 = (uint32_t)row * FIRA_D + (uint32_t)col;
+            const uint32_t e0 = lb.idx0 + (uint32_t)row * FIRA_D + (uint32_t)col;
             return f32x4{v.x * dropout_scale(lb.seed, lb.site, e0, lb.p, lb.inv_keep), v.y * dropout_scale(lb.seed, lb.site, e0 + 1, lb.p, lb.inv_keep),
                          v.z * dropout_scale(lb.seed, lb.site, e0 + 2, lb.p, lb.inv_keep), v.w * dropout_scale(lb.seed, lb.site, e0 + 3, lb.p, lb.inv_keep)};
         };
@@ -585,7 +586,7 @@ bool gemm_tile32_ln_try(hipStream_t s, int M, int N, const float* S, int lds, co
 int gemm_tile32_lnb_blocks(int M) { return cdiv(M, 32); }
 bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const float* W, int ldw, float* dX, int lddx,
                          const float* relu_mask, const float* sum, const float* stats, const float* gamma, float* ds,
-                         float* dx_drop, float* part, float dropout, uint64_t seed, uint32_t site, int* rc) {
+                         float* dx_drop, float* part, float dropout, uint64_t seed, uint32_t site, int* rc, uint32_t idx0) {
     static const bool off = [] { const char* e = getenv("FIRA_LN_BWD_PROLOGUE"); return e && e[0] == '0'; }();     // A/B switch
     if (off || !gemm_tile32_takes(0, M, N, FIRA_D, dy, FIRA_D, W, ldw)) return false;
     if (((uintptr_t)sum % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)ds % 16) || ((uintptr_t)dx_drop % 16) || ds == dy) return false;
@@ -593,7 +594,7 @@ bool gemm_tile32_lnb_try(hipStream_t s, int M, int N, const float* dy, const flo
     const int tiles_n = cdiv(N, 32);
     LnB lb;
     lb.sum = sum; lb.stats = stats; lb.gamma = gamma; lb.ds = ds; lb.dx = dx_drop; lb.part = part;
-    lb.p = dropout; lb.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; lb.seed = seed; lb.site = site;
+    lb.p = dropout; lb.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; lb.seed = seed; lb.site = site; lb.idx0 = idx0;
     hipLaunchKernelGGL((gemm_tile32_kernel<false, 2, false, true>), dim3(cdiv(M, 32) * tiles_n), dim3(256), 0, s, M, N, dy, FIRA_D, W, ldw,
                        dX, lddx, (const float*)nullptr, 0, (const int32_t*)nullptr, relu_mask, (const int32_t*)nullptr, tiles_n,
                        EpiRes(), LnA(), lb);

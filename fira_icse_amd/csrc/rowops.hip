@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
                                                                 const float* __restrict__ r1_row,
                                                                 const float* __restrict__ r1_col,
                                                                 const int32_t* __restrict__ slot2,
-                                                                float* __restrict__ y2) {
+                                                                float* __restrict__ y2, uint32_t idx0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(int M, float* __
         a.x = fmaf(w, c4.x, a.x); a.y = fmaf(w, c4.y, a.y); a.z = fmaf(w, c4.z, a.z); a.w = fmaf(w, c4.w, a.w);
     }
     if (p > 0.f) {
-        const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
+        const uint32_t e0 = idx0 + (uint32_t)r * FIRA_D + lane * 4;
         a.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
         a.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
         a.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
                                                                 float p, float inv_keep, uint64_t seed, uint32_t site,
                                                                 int steps, const int32_t* __restrict__ rows,
                                                                 float* __restrict__ part,
-                                                                const float* __restrict__ row_w) {
+                                                                const float* __restrict__ row_w, uint32_t idx0) {
     constexpr int NV = EXTRA ? 4 : 2;               // column-sum vectors per workgroup: dgamma | dbeta (| sum dx | sum w dx)
     __shared__ __attribute__((aligned(16))) float red[4][NV * FIRA_D];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(int M, const flo
             f32x4 o4 = (h[u] - m1[u] - xh[u] * m2[u]) * rstd[u];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32v4_t, o4), rDs, om[u], 0, 0);
             if (p > 0.f) {                                  // wave-uniform; no memory instruction inside
-                const uint32_t e0 = (uint32_t)r * FIRA_D + lane * 4;
+                const uint32_t e0 = idx0 + (uint32_t)r * FIRA_D + lane * 4;
                 o4.x *= dropout_scale(seed, site, e0 + 0, p, inv_keep);
                 o4.y *= dropout_scale(seed, site, e0 + 1, p, inv_keep);
                 o4.z *= dropout_scale(seed, site, e0 + 2, p, inv_keep);
@@ -833,12 +833,12 @@ int combination_bwd(hipStream_t s, int M, const float* qk, const float* vtab, in
 }
 int add_layernorm_fwd(hipStream_t s, int M, float* x, const float* res, const float* gamma, const float* beta,
                       float* y, float* stats, float dropout, uint64_t seed, uint32_t site, const int32_t* y_rows,
-                      const float* r1_row, const float* r1_col, const int32_t* slot2, float* y2) {
+                      const float* r1_row, const float* r1_col, const int32_t* slot2, float* y2, uint32_t idx0) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     const float inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, s, M, x, res, gamma, beta, y, stats,
-                       dropout, inv_keep, seed, site, y_rows, r1_row, r1_col, y2 ? slot2 : nullptr, y2);
+                       dropout, inv_keep, seed, site, y_rows, r1_row, r1_col, y2 ? slot2 : nullptr, y2, idx0);
     FIRA_CHECK_LAUNCH("add_layernorm_fwd");
     return 0;
 }
@@ -850,7 +850,7 @@ static int ln_bwd_steps(int M, bool deferred) { return deferred ? 1 : std::max(1
 int add_layernorm_bwd_blocks(int M) { return M > 0 ? cdiv(M, LNB_ROWS) : 0; }
 int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, const float* stats, const float* gamma,
                       float* ds, float* dx_drop, float* dgamma, float* dbeta, float dropout, uint64_t seed,
-                      uint32_t site, const int32_t* rows, float* part, const float* row_w) {
+                      uint32_t site, const int32_t* rows, float* part, const float* row_w, uint32_t idx0) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (M <= 0) return 0;
     FIRA_REQUIRE(M < (1 << 21), "add_layernorm_bwd: %d rows exceed the 2 GiB the kernel addresses", M);
@@ -859,10 +859,10 @@ int add_layernorm_bwd(hipStream_t s, int M, const float* dy, const float* sum, c
     const int steps = ln_bwd_steps(M, part != nullptr);
     if (row_w)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<true>, dim3(cdiv(M, LNB_ROWS * steps)), dim3(256), 0, s, M, dy, sum, stats,
-                           gamma, ds, dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part, row_w);
+                           gamma, ds, dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part, row_w, idx0);
     else
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<false>, dim3(cdiv(M, LNB_ROWS * steps)), dim3(256), 0, s, M, dy, sum, stats,
-                           gamma, ds, dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part, row_w);
+                           gamma, ds, dx_drop, dgamma, dbeta, dropout, inv_keep, seed, site, steps, rows, part, row_w, idx0);
     FIRA_CHECK_LAUNCH("add_layernorm_bwd");
     return 0;
 }

@@ -302,6 +302,8 @@ class DeviceBatch:
             self.n_dec_rows = int(dec_off[-1])
             b_of = np.repeat(np.arange(self.B, dtype=np.int64), length)
             self.dec_rows_host = (b_of * T + np.arange(self.n_dec_rows) - dec_off[b_of]).astype(np.int32)   # dense b*T + t
+        # host copy for the library's commit-lanes (fira_batch.dec_off_host; kept alive with the batch)
+        self.dec_off_host = None if dec_off is None else np.ascontiguousarray(dec_off, dtype=np.int32)
         fields = [("sou", hb.sou, np.int32), ("tar", hb.tar, np.int32), ("mark", hb.mark, np.int32),
                   ("ast_change", hb.ast_change, np.int32), ("tar_label", hb.tar_label, np.int32),
                   ("sub_token", hb.sub_token, np.int32), ("node_rows", node_rows, np.int32),
@@ -360,7 +362,8 @@ class DeviceBatch:
             p(self.sub_token), self.n_nodes, p(self.node_rows), p(self.rowptr), p(self.col), p(self.val), self.n_code,
             p(self.code_rows), p(self.code_mark), self.n_mem, p(self.mem_rows), p(self.mem_dst), p(self.head_rows),
             self.n_head_rows, self.n_emb_items, p(self.emb_item_tok), p(self.emb_item_ptr), p(self.emb_rows),
-            self.n_ast_items, p(self.ast_rows), p(self.ast_ids), p(self.dec_off), self.n_dec_rows)
+            self.n_ast_items, p(self.ast_rows), p(self.ast_ids), p(self.dec_off), self.n_dec_rows,
+            self.dec_off_host.ctypes.data if self.dec_off_host is not None else None)
 
     def wait_ready(self):
         """Order the CURRENT stream behind this batch's host->device copy.  The copy is enqueued on the stream that was

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 7
+#define FIRA_ABI_VERSION 8
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -89,6 +89,10 @@ typedef struct fira_batch {
      * NULL (or fira_train_opts.compact_dec == 0) = all B*tar_len rows. */
     const int32_t* dec_off;      /* [B + 1] ascending, dec_off[0] = 0, 1 <= dec_off[b+1] - dec_off[b] <= tar_len          */
     int32_t n_dec_rows;          /* dec_off[B]                                                                         */
+    /* ---- optional (v8): a HOST copy of dec_off ([B + 1], host memory, valid for the duration of the call).  With it the
+     * library may split the decoder's chain at a commit boundary into two commit-lanes on two streams (it needs the row
+     * offset of that boundary on the host to size the launches); NULL = one lane.  Results do not depend on it. */
+    const int32_t* dec_off_host;
 } fira_batch;
 
 typedef struct fira_train_opts {

@@ -22,9 +22,18 @@ def main(path, dtype):
     model.load_state_dict(sd)
     model.compute_dtype = dtype
     model.eval()
-    loss, ntok = model.train_fwd_bwd(DeviceBatch(hb, cfg))
+    db = DeviceBatch(hb, cfg)
+    loss, ntok = model.train_fwd_bwd(db)
     torch.cuda.synchronize()
-    np.savez(path, loss=float(loss), g=model.gbuf[:model.layout.live].cpu().numpy())
+    out = dict(loss=float(loss), g=model.gbuf[:model.layout.live].cpu().numpy())
+    # dropout on: the masks are a function of (seed, rank, step) -- the same in every process
+    model.train()
+    model.set_dropout_stream(5, 0)
+    model.dropout_step = 0
+    loss, ntok = model.train_fwd_bwd(db)
+    torch.cuda.synchronize()
+    out.update(loss_train=float(loss), g_train=model.gbuf[:model.layout.live].cpu().numpy())
+    np.savez(path, **out)
 
 
 if __name__ == "__main__":

@@ -97,16 +97,20 @@ def self_launch(a) -> int:
 
 def prof_report():
     from fira_icse_amd import _lib
-    n = 10
+    n = 11
     ms, work, byts, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
     _lib.lib().fira_prof_report(n, ms, work, byts, cnt)
     # gemm_dec: the decoder's M = B*30 row products (forward + data gradients), split out of the GEMM family by the library
     # gcn: the fused GCN-layer launches (gather + product + LayerNorm / accumulate in one kernel): work = FLOP, bytes = bytes
     # comb: the fused Combination-block launches (round 5: q|k products + gate + output product + LayerNorm in one kernel)
-    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec", "gcn", "comb"]
+    # dec_region (round 6): WALL time on the caller's stream of the decoder's layer loops (forward + backward; with two
+    # commit-lanes the lanes' launches overlap inside it) -- not a kernel class: taken out of the per-class sums below
+    names = ["gemm", "spmm", "attention", "rowops", "copy", "head", "adam", "gemm_dec", "gcn", "comb", "dec_region"]
     out = {k: dict(ms=ms[i], work=work[i], bytes=byts[i], count=int(cnt[i])) for i, k in enumerate(names)}
+    region = out.pop("dec_region")
     dec = out.pop("gemm_dec")
-    out["gemm"] = {k: out["gemm"][k] + dec[k] for k in dec}         # the family = every GEMM launch of the step
+    dec["region_ms"], dec["region_count"] = region["ms"], region["count"]
+    out["gemm"] = {k: out["gemm"][k] + dec[k] for k in ("ms", "work", "bytes", "count")}   # the family = every GEMM launch of the step
     out["gemm"]["decoder"] = dec
     return out
 
@@ -484,6 +488,14 @@ def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
                     "hbm_GBs": dec["bytes"] / d_s / 1e9,
                     "note": "the decoder's M = B*30 row products only (forward + data gradients), FLOP / summed launch "
                             "time: the quantity north_star's >= 40 % MFMA target is set on"}
+    if dec.get("region_ms", 0) > 0:
+        # FLOP of the decoder's products over the WALL time of the decoder's layer loops on the caller's stream (attention,
+        # LayerNorm prologues, waits and -- with two commit-lanes -- the overlap of the lanes included): occupancy of the
+        # region, not per-launch latency
+        r_s = dec["region_ms"] * 1e-3
+        decoder_gemm["region_ms_per_step"] = dec["region_ms"] / prof_steps
+        decoder_gemm["achieved_region"] = dec["work"] / r_s / 1e12
+        decoder_gemm["frac_region"] = dec["work"] / r_s / 1e12 / peak_tf
     if dec_rows and dec_rows[0] > 0:
         ratio = dec_rows[1] / dec_rows[0]
         decoder_gemm["rows_computed_over_dense"] = dec_rows[0] / dec_rows[1]
@@ -592,6 +604,7 @@ def compact_line(line, detail_path):
             pass
     put("decoder_gemm_frac", line, "decoder_gemm", "frac")
     put("decoder_gemm_frac_dense_equiv", line, "decoder_gemm", "frac_dense_equiv")
+    put("decoder_region_ms", line, "decoder_gemm", "region_ms_per_step")
     for k in ("avg_launch_us", "frac_mfma", "frac_hbm", "traffic"):
         put("gcn_" + k, line, "gcn", k)
         put("attention_" + k, line, "attention", k)

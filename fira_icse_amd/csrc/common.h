@@ -35,7 +35,7 @@ int set_err(const char* fmt, ...);
 // PROF_GCN: the fused GCN-layer launches (gcn_fused.hip): work = FLOP of the [rows,256]x[256,256] product, bytes = the
 // algorithmic bytes of the whole layer (gather in, rows out)
 // PROF_COMB: the fused Combination-block launches (comb_fused.hip): work = FLOP of its three [rows,256]x[256,256] products
-enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_GCN, PROF_COMB, PROF_NCLASS };
+enum ProfClass { PROF_GEMM = 0, PROF_SPMM, PROF_ATTN, PROF_ROWOPS, PROF_COPY, PROF_HEAD, PROF_ADAM, PROF_GEMM_DEC, PROF_GCN, PROF_COMB, PROF_DEC_REGION, PROF_NCLASS };
 bool prof_on();
 void prof_decoder_tag(int delta);      // +1 / -1 (nesting counter, thread-local)
 struct ProfDecoderTag {

@@ -725,7 +725,13 @@ typedef Ctx::Lane Lane;
 // element index of a slice's first row) up to the row-block boundaries of the deferred column sums.
 // FIRA_DEC_LANES=1|2 (default: see decoder_lanes); needs the host copy of dec_off (fira_batch.dec_off_host).
 static int decoder_lanes(Ctx& c) {
-    static const int want = [] { const char* e = getenv("FIRA_DEC_LANES"); const int v = e ? atoi(e) : 1; return v >= 2 ? 2 : 1; }();
+    // Measured (profiles/r6_probes.md, same-box triples): two lanes are -1.9 % at batch 32 (530 rows: every launch of the chain is
+    // a latency-bound workgroup chain whose duration does not shrink with half the rows -- the two lanes' launches take as long
+    // each as the one they replace, and the extra forks / joins are pure cost), +2.2 % at batch 64 (1 130 rows, fp32), +0.6 % in
+    // bf16 at batch 64.  Default: two lanes from FIRA_DEC_LANES_MIN_ROWS computed target rows; FIRA_DEC_LANES=1|2 forces.
+    static const int forced = [] { const char* e = getenv("FIRA_DEC_LANES"); return e ? (atoi(e) >= 2 ? 2 : 1) : 0; }();
+    static const int min_rows = [] { const char* e = getenv("FIRA_DEC_LANES_MIN_ROWS"); return e ? atoi(e) : 768; }();
+    const int want = forced ? forced : (c.Td >= min_rows ? 2 : 1);
     c.n_lanes = g_lanes = 1;
     c.lanes[0] = Lane{c.s, 0, c.pl->B, 0, c.Td};
     const fira_batch& bt = *c.bt;
@@ -944,6 +950,8 @@ static int decoder_forward(Ctx& c) {
     else TRY(embed_gather_fwd(c.s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
     ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
     TRY(decoder_lanes(c));
+    // wall time of the (possibly two-lane) layer loop on the caller's stream: what the decoder's products cost the step
+    ProfScope prof_region(c.s, PROF_DEC_REGION, 0.0);
     TRY(lanes_fork(c));
     // Per lane (Ctx::lanes; one lane = the whole batch on the caller's stream): x = the current rows; pend_*: a block whose
     // pre-norm sums are stored but whose LayerNorm is still owed (it runs in the prologue of the next product: see
@@ -1159,6 +1167,8 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // FIRA_DEC_WGRAD_EVERY=0: one launch behind the loop.
     static const int dec_every_env = [] { const char* e = getenv("FIRA_DEC_WGRAD_EVERY"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 0; }();
     const int dec_every = (mid_event || g_dtype != 0 || dec_every_env == 0 || p.nl % dec_every_env != 0) ? 0 : dec_every_env;
+    {
+    ProfScope prof_region(s, PROF_DEC_REGION, 0.0);      // wall time of the decoder's backward layers (see decoder_forward)
     TRY(lanes_fork(c));                        // (lane 1 starts behind the head's backward kernels)
     // the other streams' launches inside the loop read rows of EVERY lane: they fork from all of them
     auto aux_fork_all = [&]() -> int { return c.n_lanes > 1 ? lanes_fork_to(c, side().aux) : aux_fork(s); };
@@ -1243,6 +1253,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         float* t = bx; bx = by; by = t;         // the next layer's output gradient is in (the old) by; bz stays free
     }
     TRY(lanes_join(c));
+    }
     const float* dy = bx;
     TRY(flush_grouped_wgrads(s));                                  // the decoder's and the head's small weight gradients
     // decoder embedding.  The table has no padding_idx (gnn_transformer.py:92-93), but rows of padded target positions

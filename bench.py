@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--dp-same-device", action="store_true", help="all ranks on cuda:0 over gloo (one-GPU testing)")
     ap.add_argument("--detail", default="", help="where the full-precision record of every measured object goes "
                     "(default gpurun_out/bench_detail_<dtype>.json); stdout carries ONE short JSON line")
+    ap.add_argument("--grad-wire", choices=["auto", "f32", "bf16"], default="auto", help="N > 1, all-reduce path: wire format of "
+                    "the two gradient buckets; auto = bf16 with --dtype bf16 (BASELINE configs[2]: 55.6 MB per step), else f32")
     ap.add_argument("--zero1", action="store_true", help="N > 1: reduce-scatter + sharded Adam + all-gather instead of "
                     "all-reduce + replicated Adam")
     return ap.parse_args()
@@ -680,7 +682,8 @@ def main():
     model.compute_dtype = a.dtype
     model.set_dropout_stream(0, rank)
     model.train()                                      # dropout on, as the reference trains
-    trainer = Trainer(model, distributed=world > 1, zero1=a.zero1)
+    wire = a.grad_wire if a.grad_wire != "auto" else ("bf16" if a.dtype == "bf16" else "f32")
+    trainer = Trainer(model, distributed=world > 1, zero1=a.zero1, grad_wire=wire)
     lib = _lib.lib()
     try:        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
         with open(os.path.join(HERE, "profiles", "traffic.json")) as f:
@@ -905,7 +908,11 @@ def main():
         if world > 1:
             pg = {"rccl_world_size": torch.distributed.get_world_size(), "backend": torch.distributed.get_backend(),
                   "mode": "zero1 (reduce-scatter + sharded Adam + all-gather)" if a.zero1 else "all-reduce in 2 readiness buckets",
-                  "gradient_bytes_per_rank": 4 * int(model.layout.live)}
+                  "gradient_bytes_per_rank": 4 * int(model.layout.live),
+                  "fused_step": bool(getattr(trainer, "fused_dp", False)) and not a.zero1}
+            if trainer.reducer is not None and not a.zero1:
+                pg["wire"] = trainer.reducer.wire
+                pg["bytes_per_step"] = trainer.reducer.bytes_per_step()
             if comm:
                 pg.update(comm)
                 pg["note"] = ("allreduce_ms_early = head+decoder bucket on the side stream from the mid-backward event "

@@ -100,6 +100,10 @@ SIGNATURES = {
     "fira_debug_chain": (_I, [_P, _I, _I, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_train_step": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, C.POINTER(AdamOpts)]),
+    "fira_train_step_begin": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
+    "fira_train_step_end": (_I, [_P, _P, C.POINTER(AdamOpts), _P, _P]),
+    "fira_f32_to_bf16": (_I, [_P, _L, _P, _P]),
+    "fira_bf16_to_f32": (_I, [_P, _L, _P, _P]),
     "fira_prof_enable": (None, [_I]),
     "fira_prof_report": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
     "fira_param_groups": (_I, [_DP, C.POINTER(_L), C.POINTER(_L)]),

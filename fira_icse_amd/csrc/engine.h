@@ -222,6 +222,7 @@ int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, 
                           const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
                           const int32_t* k_off = nullptr);
 int rows_to_bf16(hipStream_t s, int64_t n, const float* in, uint16_t* out);      // out[i] = bf16(in[i]) (RNE), n % 4 == 0
+int rows_from_bf16(hipStream_t s, int64_t n, const uint16_t* in, float* out);    // out[i] = float(in[i]), n % 4 == 0
 int attention_bwd(hipStream_t s, int B, int H, int Tq, int Tk, const float* Q, int ldq, const float* K, int ldk,
                   const float* V, int ldv, const int32_t* key_valid, int causal, int q_pos0, const float* O, int ldo,
                   const float* dO, int lddo, float* dQ, int lddq, float* dK, int lddk, float* dV, int lddv,

@@ -703,6 +703,13 @@ struct Ctx {
     // writable (nothing reads [0, split) after the decoder's backward pass; see backward()).
     const fira_adam_opts* adam = nullptr;
     float* Pw = nullptr;
+    // data-parallel form of the same (fira_train_step_begin / _end, round 6): the gradients of [0, split) are all-reduced by the
+    // caller between the two calls -- Adam of [0, split) waits for ev_early (the caller's event behind that collective) instead of
+    // the local weight-gradient mark, scales by the all-reduced token count `count` (a device float), and [split, live) is the
+    // caller's (its bucket is reduced after the call)
+    bool adam_a_only = false;
+    hipEvent_t ev_early = nullptr;
+    const float* count = nullptr;
     // bf16 mode (round 5): the refresh of the bf16 weight shadows (one 46 us launch) runs on the auxiliary stream behind the GCN
     // fold instead of at the head of the caller's stream -- with the fused Combination / GCN kernels (which round the fp32
     // weights themselves) the first reader of a shadow is the decoder (and the auxiliary stream's own K|V projections)
@@ -1088,7 +1095,14 @@ static inline bool fewer_forks() {
     return !off;
 }
 
-static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
+// what the encoder half of the backward pass needs from the decoder half (the two halves are one call, or the two calls
+// fira_train_step_begin / fira_train_step_end with the caller's collective in between)
+struct BwdMid {
+    hipEvent_t ev_dmem = nullptr;      // d memory is complete (auxiliary stream)
+    hipEvent_t ev_groupA = nullptr;    // every gradient of [0, split) is final (weight-gradient stream)
+};
+
+static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event, BwdMid& mid) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
     hipStream_t s = c.s;
@@ -1267,7 +1281,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         else TRY(embed_gather_bwd(es, p.B, p.T, c.bt->tar, G + L.dec_emb, dy, p.T, 0, 0));
     }
     // cross-attention K|V projections of all layers (computed memory rows only)
-    hipEvent_t ev_dmem = nullptr;
+    hipEvent_t& ev_dmem = mid.ev_dmem;
     if (so) {
         TRY(side_mark(&ev_dmem));                // dmem_c is complete at this point of the auxiliary stream
     } else {
@@ -1287,7 +1301,7 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // every gradient of [0, split) is final once the weight-gradient stream has passed this point (its launches above: the
     // vocabulary / copy / decoder weight gradients, the decoder embedding, the stacked K|V weight, the deferred column sums;
     // the auxiliary stream writes data gradients only)
-    hipEvent_t ev_groupA = nullptr;
+    hipEvent_t& ev_groupA = mid.ev_groupA;
     if (c.adam && side().stream && side().enabled) {
         ev_groupA = side().ev();
         if (hipEventRecord(ev_groupA, side().stream) != hipSuccess) return set_err("group-A mark failed");
@@ -1309,7 +1323,18 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         hipError_t e = hipEventRecord(mid_event, es);
         if (e != hipSuccess) return set_err("hipEventRecord: %s", hipGetErrorString(e));
     }
+    return 0;
+}
 
+static int backward_encoder(Ctx& c, BwdMid& mid) {
+    Plan& p = *c.pl;
+    const Layout& L = *c.L;
+    hipStream_t s = c.s;
+    const int D = FIRA_D;
+    const fira_batch& bt = *c.bt;
+    const int Nc = bt.n_nodes, Cc = bt.n_code, Mc = bt.n_mem;
+    float* G = c.G;
+    hipEvent_t ev_dmem = mid.ev_dmem, ev_groupA = mid.ev_groupA;
     // ---- encoder layers, last to first (compact node rows) -------------------------------------------------
     float* dXn = p.dXa;
     float* other = p.dXb;
@@ -1470,12 +1495,20 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
         // and then run the whole update alone.  Nothing enqueued after the decoder's backward pass reads a parameter of
         // [0, split): the encoder's backward kernels read encoder weights, the weight-gradient stream reads activations.
         const fira_adam_opts& ad = *c.adam;
+        if (c.adam_a_only) {
+            // data parallel: the bucket's all-reduce (enqueued by the caller between the two calls) has passed ev_early; the
+            // normaliser is the all-reduced token count
+            if (c.ev_early) TRY(main_wait(s, c.ev_early, __LINE__));
+            if (c.count) TRY(adam_step(s, L.split, c.Pw, G, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.count, 1));
+            else TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+        } else {
         if (ev_groupA) TRY(main_wait(s, ev_groupA, __LINE__));
         TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+        }
         // ... and the encoder's two embedding tables (the head of group B: layout.cpp), whose gradients the two launches above
         // on this stream have just completed -- also ahead of the join
         static const bool emb_early_off = [] { const char* e = getenv("FIRA_ADAM_EMB_EARLY"); return e && e[0] == '0'; }();   // A/B switch
-        if (!emb_early_off) adam_b0 = L.mark_emb;
+        if (!emb_early_off && !c.adam_a_only) adam_b0 = L.mark_emb;
         if (adam_b0 > L.split)
         TRY(adam_step_mb(s, adam_b0 - L.split, c.Pw + L.split, G + L.split, nullptr, ad.m + L.split, ad.v + L.split, ad.lr, ad.beta1,
                          ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
@@ -1485,12 +1518,18 @@ static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
     // dc of every GCN layer is final (deferred reduction above) and so are the side stream's additions to dW2: back to the
     // reference's fc2.weight / fc1.bias gradients, one launch for all layers
     TRY(gcn_bias_unfold_all(s, unfold_tab));
-    if (c.adam) {
+    if (c.adam && !c.adam_a_only) {
         const fira_adam_opts& ad = *c.adam;
         TRY(adam_step_mb(s, L.live - adam_b0, c.Pw + adam_b0, G + adam_b0, nullptr, ad.m + adam_b0, ad.v + adam_b0, ad.lr, ad.beta1,
                          ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
     }
     return 0;
+}
+
+static int backward(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_event) {
+    BwdMid mid;
+    TRY(backward_decoder(c, R, rows, mid_event, mid));
+    return backward_encoder(c, mid);
 }
 
 static int check_batch(const fira_batch* b) {
@@ -1555,9 +1594,27 @@ size_t fira_decode_workspace_bytes_ex(const fira_dims* d, int B, int n_beam, int
     return dp.build(nullptr, *d, B, n_beam, flags);
 }
 
+// fira_train_step_begin leaves its step here (per thread) for fira_train_step_end: the plan of the workspace, the call's
+// context (a copy of the batch descriptor: its arrays must stay valid until the second call) and what the two halves of the
+// backward pass share.  The dtype / shadow scopes of the first call are re-entered by the second.
+struct PendingStep {
+    bool active = false;
+    Plan plan;
+    fira_batch batch;
+    Ctx ctx{};
+    BwdMid mid;
+    int dtype = 0;
+    const float* params = nullptr;
+    const ShadowTable* tab = nullptr;
+    const float* W21 = nullptr;
+    int64_t W21n = 0;
+    const uint16_t *W21b = nullptr, *W21bT = nullptr;
+};
+static thread_local PendingStep g_pending;
+
 static int train_call(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
                       void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
-                      int32_t* n_tok, void* mid_event, float* params_w, const fira_adam_opts* adam) {
+                      int32_t* n_tok, void* mid_event, float* params_w, const fira_adam_opts* adam, bool begin_only = false) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
     TRY(check_batch(batch));
@@ -1621,6 +1678,24 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
     if (c.ev_shadow) TRY(main_wait(c.s, c.ev_shadow, __LINE__));      // the decoder's products read the bf16 shadows
     TRY(decoder_forward(c));
     TRY(head_forward(c, R, rows, loss_sum, n_tok, nullptr, 1));
+    if (begin_only) {
+        // first half of a data-parallel step: up to the point where the gradients of [0, split) are final (mid_event)
+        PendingStep& ps = g_pending;
+        ps.active = false;
+        ps.mid = BwdMid();
+        TRY(backward_decoder(c, R, rows, (hipEvent_t)mid_event, ps.mid));
+        ps.plan = p;
+        ps.batch = *batch;
+        ps.ctx = c;
+        ps.ctx.pl = &ps.plan;
+        ps.ctx.bt = &ps.batch;
+        ps.dtype = opts ? opts->dtype : 0;
+        ps.params = params;
+        ps.tab = tab;
+        ps.W21 = g_W21; ps.W21n = g_W21n; ps.W21b = g_W21b; ps.W21bT = g_W21bT;
+        ps.active = true;
+        return 0;
+    }
     TRY(backward(c, R, rows, (hipEvent_t)mid_event));
     if (wait_probe().enabled() && ++wait_probe().calls == 20) wait_probe().report();
     return 0;
@@ -1631,6 +1706,36 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
                        int32_t* n_tok, void* mid_event) {
     return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, mid_event, nullptr,
                       nullptr);
+}
+
+int fira_train_step_begin(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                          void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                          int32_t* n_tok, void* mid_event) {
+    FIRA_REQUIRE(mid_event, "fira_train_step_begin: mid_event missing (the caller's collective waits for it)");
+    return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, mid_event, nullptr,
+                      nullptr, true);
+}
+
+int fira_train_step_end(void* stream, float* params, const fira_adam_opts* adam, void* early_event, const float* count) {
+    PendingStep& ps = g_pending;
+    FIRA_REQUIRE(ps.active, "fira_train_step_end: no step begun on this thread (fira_train_step_begin)");
+    ps.active = false;
+    FIRA_REQUIRE((hipStream_t)stream == ps.ctx.s, "fira_train_step_end: not the stream the step was begun on");
+    FIRA_REQUIRE(!adam || (adam->m && adam->v && adam->step >= 1 && params), "fira_train_step_end: bad Adam arguments");
+    FIRA_REQUIRE(!params || params == ps.params, "fira_train_step_end: not the parameter buffer the step was begun with");
+    DtypeScope dtype_scope(ps.dtype);
+    const bool bf16 = ps.dtype == 1;
+    ShadowScope shadow_scope(ps.params, ps.ctx.L->total, bf16 ? ps.plan.wb : nullptr, bf16 ? ps.plan.wbt : nullptr, ps.tab);
+    g_W21 = ps.W21; g_W21n = ps.W21n; g_W21b = ps.W21b; g_W21bT = ps.W21bT;
+    Ctx& c = ps.ctx;
+    c.adam = adam;
+    c.Pw = params;
+    c.adam_a_only = true;
+    c.ev_early = (hipEvent_t)early_event;
+    c.count = count;
+    TRY(backward_encoder(c, ps.mid));
+    if (wait_probe().enabled() && ++wait_probe().calls == 20) wait_probe().report();
+    return 0;
 }
 
 int fira_train_step(void* stream, const fira_dims* d, const fira_batch* batch, float* params, float* grads, void* workspace,

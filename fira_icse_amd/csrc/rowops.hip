@@ -981,6 +981,25 @@ int rows_to_bf16(hipStream_t s, int64_t n, const float* in, uint16_t* out) {
     FIRA_CHECK_LAUNCH("rows_to_bf16");
     return 0;
 }
+// out[i] = float(in[i]) (exact): the way back from the bf16 gradient wire format (parallel.GradReducer)
+__global__ __launch_bounds__(256) void rows_from_bf16_kernel(int64_t n4, const uint2* __restrict__ in, float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const uint2 q = in[i];
+        float4 o;
+        o.x = __builtin_bit_cast(float, q.x << 16); o.y = __builtin_bit_cast(float, q.x & 0xffff0000u);
+        o.z = __builtin_bit_cast(float, q.y << 16); o.w = __builtin_bit_cast(float, q.y & 0xffff0000u);
+        out[i] = o;
+    }
+}
+int rows_from_bf16(hipStream_t s, int64_t n, const uint16_t* in, float* out) {
+    if (n <= 0) return 0;
+    FIRA_REQUIRE(n % 4 == 0 && (uintptr_t)in % 8 == 0 && (uintptr_t)out % 16 == 0, "rows_from_bf16: bad size / alignment");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(rows_from_bf16_kernel, dim3((unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 32)), dim3(256), 0, s, n4,
+                       reinterpret_cast<const uint2*>(in), reinterpret_cast<float4*>(out));
+    FIRA_CHECK_LAUNCH("rows_from_bf16");
+    return 0;
+}
 int mark_history(hipStream_t s, int BR, int T, int step, const int32_t* tokens, int32_t* hist) {
     hipLaunchKernelGGL(mark_history_kernel, dim3(cdiv(BR, 256)), dim3(256), 0, s, BR, T, step, tokens, hist);
     FIRA_CHECK_LAUNCH("mark_history");
@@ -1034,6 +1053,14 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(int64_t n, float* __r
 }  // namespace fira
 
 extern "C" {
+int fira_f32_to_bf16(void* stream, int64_t n, const float* in, uint16_t* out) {
+    FIRA_REQUIRE(in && out && n >= 0, "fira_f32_to_bf16: bad argument");
+    return fira::rows_to_bf16((hipStream_t)stream, n, in, out);
+}
+int fira_bf16_to_f32(void* stream, int64_t n, const uint16_t* in, float* out) {
+    FIRA_REQUIRE(in && out && n >= 0, "fira_bf16_to_f32: bad argument");
+    return fira::rows_from_bf16((hipStream_t)stream, n, in, out);
+}
 int fira_dropout_mask(void* stream, uint64_t seed, uint32_t site, int64_t n, float p, float* out) {
     FIRA_REQUIRE(out && n >= 0 && p >= 0.f && p < 1.f, "fira_dropout_mask: bad argument");
     if (n == 0) return 0;

@@ -503,6 +503,36 @@ class TransModel(nn.Module):
                    "fira_train_step")
         return self.loss_sum, self.n_tok
 
+    def train_step_begin(self, db: DeviceBatch, mid_event, dropout: Optional[float] = None,
+                         gcn_dropout: Optional[float] = None):
+        """First half of a data-parallel step (fira_train_step_begin): forward + the backward pass of the head and the decoder;
+        ``mid_event`` fires when the gradients of ``[0, split)`` are final.  The step stays pending until
+        :meth:`train_step_end`; ``db`` must stay alive until then."""
+        lib = _lib.lib()
+        db.wait_ready()
+        p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
+        pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
+        self.dropout_step += 1
+        opts = _lib.TrainOpts(p, pg, self.dropout_seed, 1 if self.compact_head else 0, self._dtype_code(),
+                              1 if self.compact_dec else 0, 1)
+        ws = self.workspace(db.B, 1)
+        self._pending_db = db
+        _lib.check(lib.fira_train_step_begin(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
+                                             _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
+                                             C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok),
+                                             self._event_handle(mid_event)), "fira_train_step_begin")
+        return self.loss_sum, self.n_tok
+
+    def train_step_end(self, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, early_event=None, count=None,
+                       beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+        """Second half (fira_train_step_end): the encoder's backward pass; Adam of ``[0, split)`` once the current stream has
+        passed ``early_event`` (the caller's event behind the all-reduce of that slice), scaled by ``1 / count`` (a device
+        float, the all-reduced token count).  ``[split, live)`` is left to the caller (its bucket is reduced afterwards)."""
+        adam = _lib.AdamOpts(lr, beta1, beta2, eps, int(step), _lib.ptr(m), _lib.ptr(v))
+        _lib.check(_lib.lib().fira_train_step_end(_lib.cur_stream(), _lib.ptr(self.flat.data), C.byref(adam),
+                                                  self._event_handle(early_event), _lib.ptr(count)), "fira_train_step_end")
+        self._pending_db = None
+
     def _dtype_code(self) -> int:
         try:
             return {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[self.compute_dtype]

@@ -405,3 +405,18 @@ def adam_step_mb(p, g0, g1, m, v, lr, step, n_tok0, n_tok1=None, beta1=0.9, beta
 def inv_count(n_tok, out):
     check(_lib.lib().fira_inv_count(cur_stream(), ptr(_i32(n_tok)), ptr(_f32(out))), "fira_inv_count")
     return out
+
+
+def f32_to_bf16(src, dst):
+    """dst (torch.bfloat16, same numel) = bf16(src) on the current stream: the gradient wire format (fira_f32_to_bf16)."""
+    n = src.numel()
+    assert dst.numel() == n and dst.dtype == torch.bfloat16 and src.dtype == torch.float32 and n % 4 == 0
+    check(_lib.lib().fira_f32_to_bf16(cur_stream(), n, ptr(src), ptr(dst)), "fira_f32_to_bf16")
+    return dst
+
+
+def bf16_to_f32(src, dst):
+    n = src.numel()
+    assert dst.numel() == n and src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and n % 4 == 0
+    check(_lib.lib().fira_bf16_to_f32(cur_stream(), n, ptr(src), ptr(dst)), "fira_bf16_to_f32")
+    return dst

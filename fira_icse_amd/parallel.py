@@ -50,19 +50,39 @@ def shard_indices(idx: Sequence[int], rank: int, world: int) -> List[int]:
 
 
 class GradReducer:
-    """All-reduce of the flat gradient buffer in two readiness buckets + the (loss_sum, n_tok) pair."""
+    """All-reduce of the flat gradient buffer in two readiness buckets + the (loss_sum, n_tok) pair.
 
-    def __init__(self, split: int, live: int, group=None):
-        self.split, self.live, self.group = split, live, group
+    Order of the collectives of a step (identical on every rank, whatever path computed the gradients):
+      1. ``reduce_early``: on the communication stream, behind ``mid_event`` (the decoder's backward pass is through): the
+         2-float stats, then the head + decoder bucket ``[0, split)`` -- beside the encoder's backward pass; an event is recorded
+         behind them (``early_event``: what ``fira_train_step_end`` / ``wait_early`` wait for before Adam of that slice);
+      2. ``start_late`` / ``wait_late``: the encoder bucket ``[split, live)`` once the backward pass is complete.
+    ``wire="bf16"`` (BASELINE configs[2]; SURVEY.md 2.2: 55.6 MB instead of 111.2 MB per step on xGMI): each bucket is rounded
+    to bf16 into a staging buffer, all-reduced in bf16 and widened back into the fp32 gradient buffer -- Adam, the master
+    weights and the token normaliser stay fp32.  Error: one bf16 rounding (2^-9 relative) per rank's contribution and per
+    partial sum of the collective (tests/test_parallel.py: 2 ranks, gradient rel-L2 <= 4e-3 against the fp32 reduction).
+    """
+
+    def __init__(self, split: int, live: int, group=None, wire: str = "f32"):
+        assert wire in ("f32", "bf16"), wire
+        self.split, self.live, self.group, self.wire = split, live, group, wire
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._pending = None
         self._late = None
+        self._stage = None
         self._side = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.early_event = None
+        if torch.cuda.is_available():
+            self.early_event = torch.cuda.Event()
+            self.early_event.record()          # torch creates the hipEvent lazily: force it so its handle can be passed on
         # optional per-collective timing (bench.py's process_group object): HIP events around each bucket on the stream
         # that carries it, and around the points where the caller's stream waits for it (= the EXPOSED communication)
         self.timing = False
         self._ev = {}
         self._timings = []
+
+    def bytes_per_step(self) -> int:
+        """Bytes every rank contributes to the collectives of one step (both buckets + the stats pair)."""
+        return self.live * (2 if self.wire == "bf16" else 4) + 8
 
     def _mark(self, name, stream=None):
         if self.timing and torch.cuda.is_available():
@@ -87,61 +107,98 @@ class GradReducer:
         self._timings = []
         return res
 
-    def start_early_bucket(self, gbuf: torch.Tensor, mid_event=None):
-        """Launch the all-reduce of [0, split) as soon as ``mid_event`` fires (decoder backward done)."""
-        if self.world == 1:
-            return
-        self._ev = {}
-        if self._side is not None and mid_event is not None:
-            self._side.wait_event(mid_event)
-            with torch.cuda.stream(self._side):
-                self._mark("early0")
-                self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                if self.timing:               # stream-level wait on the side stream (the host does not block with RCCL)
-                    self._pending.wait()
-                    self._mark("early1")
-        else:
-            self._pending = dist.all_reduce(gbuf[:self.split], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    # ---- wire format ------------------------------------------------------------------------------------------------
+    def _down(self, gbuf, lo, hi):
+        """The tensor that goes on the wire for gbuf[lo:hi] (the slice itself, or its bf16 rounding in the staging buffer)."""
+        if self.wire != "bf16":
+            return gbuf[lo:hi]
+        if self._stage is None or self._stage.device != gbuf.device:
+            self._stage = torch.empty(self.live, dtype=torch.bfloat16, device=gbuf.device)
+        w = self._stage[lo:hi]
+        if gbuf.is_cuda:
+            from . import ops
+            ops.f32_to_bf16(gbuf[lo:hi], w)
+        else:                                   # CPU tensors: the gloo tests of the N > 1 logic
+            w.copy_(gbuf[lo:hi])
+        return w
 
-    def reduce_stats_and_start_late_bucket(self, gbuf: torch.Tensor, stats: torch.Tensor):
-        """After the backward pass: all-reduce the 2-element stats (needed first: the token normaliser of every Adam
-        call), then launch the encoder bucket asynchronously.  ``wait_early`` / ``wait_late`` then let the caller run
-        Adam on the head+decoder slice while the encoder slice is still on the wire."""
-        if self.world == 1:
+    def _up(self, gbuf, lo, hi):
+        if self.wire != "bf16":
             return
-        if self._pending is None:
-            self.start_early_bucket(gbuf, None)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
-        self._mark("late0")
-        self._late = dist.all_reduce(gbuf[self.split:self.live], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if gbuf.is_cuda:
+            from . import ops
+            ops.bf16_to_f32(self._stage[lo:hi], gbuf[lo:hi])
+        else:
+            gbuf[lo:hi].copy_(self._stage[lo:hi])
+
+    # ---- the step's collectives -------------------------------------------------------------------------------------
+    def reduce_early(self, gbuf: torch.Tensor, stats: torch.Tensor, mid_event=None, pack=None):
+        """Stats pair + bucket [0, split) on the communication stream, behind ``mid_event`` (None: behind everything the
+        current stream holds).  ``pack``: optional callable that fills ``stats`` from the step's device scalars; it runs on
+        the communication stream too (loss and token count are final before ``mid_event``).  Returns ``early_event``
+        (None without a GPU: the CPU collectives have completed when the call returns)."""
+        self._ev = {}
+        cuda = self._side is not None and gbuf.is_cuda
+        if not cuda:
+            if pack is not None:
+                pack()
+            if self.world > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+                w = self._down(gbuf, 0, self.split)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                self._up(gbuf, 0, self.split)
+            return None
+        side = self._side
+        if mid_event is not None:
+            side.wait_event(mid_event)
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            if pack is not None:
+                pack()
+            self._mark("early0")
+            if self.world > 1:
+                dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=self.group)
+                w = self._down(gbuf, 0, self.split)
+                dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                self._up(gbuf, 0, self.split)
+            self._mark("early1")
+            self.early_event.record(side)
+        return self.early_event
 
     def wait_early(self):
-        if self._pending is not None:
+        """The current stream continues behind the early bucket (callers that hand ``early_event`` to the library skip this)."""
+        if self.early_event is not None:
             self._mark("wait_e0")
-            self._pending.wait()
-            if self.timing and self._side is not None:
-                torch.cuda.current_stream().wait_stream(self._side)     # (the side stream already waited for the collective)
+            torch.cuda.current_stream().wait_event(self.early_event)
             self._mark("wait_e1")
-            self._pending = None
 
-    def wait_late(self):
-        if getattr(self, "_late", None) is not None:
+    def start_late(self, gbuf: torch.Tensor):
+        """Bucket [split, live), asynchronously, behind everything the current stream holds (the backward pass is complete)."""
+        if self.world == 1:
+            return
+        self._mark("late0")
+        w = self._down(gbuf, self.split, self.live)
+        self._late = dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait_late(self, gbuf: torch.Tensor):
+        if self._late is not None:
             self._mark("wait_l0")
             self._late.wait()
+            self._up(gbuf, self.split, self.live)
             self._mark("wait_l1")
             self._ev["late1"] = self._ev.get("wait_l1")
             self._late = None
-            if self.timing and self._ev:
-                self._timings.append({k: v for k, v in self._ev.items() if v is not None})
-                self._ev = {}
+        if self.timing and self._ev:
+            self._timings.append({k: v for k, v in self._ev.items() if v is not None})
+            self._ev = {}
 
     def finish(self, gbuf: torch.Tensor, stats: torch.Tensor):
-        """Reduce the encoder bucket and the 2-element stats (fp32: loss_sum, n_tok); wait for both buckets."""
-        if self.world == 1:
-            return
-        self.reduce_stats_and_start_late_bucket(gbuf, stats)
+        """Everything of a step, in order, completed on return (CPU tests; a caller without overlap)."""
+        self.reduce_early(gbuf, stats, None)
         self.wait_early()
-        self.wait_late()
+        self.start_late(gbuf)
+        self.wait_late(gbuf)
 
 
 class ShardedOptimizerComm:

@@ -19,9 +19,11 @@ from .parallel import GradReducer, ShardedOptimizerComm
 
 class Trainer:
     def __init__(self, model: TransModel, lr: Optional[float] = None, betas=(0.9, 0.999), eps: float = 1e-8,
-                 distributed: bool = False, zero1: bool = False):
+                 distributed: bool = False, zero1: bool = False, grad_wire: str = "f32"):
         """``zero1`` (with ``distributed``): reduce-scatter + Adam on the owned 1/world shard + all-gather instead of
-        all-reduce + replicated Adam; Adam moments exist only for the owned shard (parallel.ShardedOptimizerComm)."""
+        all-reduce + replicated Adam; Adam moments exist only for the owned shard (parallel.ShardedOptimizerComm).
+        ``grad_wire`` (with ``distributed``, all-reduce path): "f32", or "bf16" = the two gradient buckets travel as bf16
+        (half the bytes on xGMI; parallel.GradReducer)."""
         self.model = model
         self.lr = model.cfg.lr if lr is None else lr
         self.betas, self.eps = betas, eps
@@ -40,11 +42,15 @@ class Trainer:
             self.end_event = torch.cuda.Event()
         # one library call per step (fira_train_step: the head + decoder slice of the update beside the last weight gradients);
         # FIRA_FUSED_STEP=0 = fira_train_fwd_bwd + one Adam launch over [0, live) (A/B switch; identical results)
-        self.fused_step = (not distributed) and os.environ.get("FIRA_FUSED_STEP", "1") != "0" and _lib.has_symbol("fira_train_step")
+        fused_on = os.environ.get("FIRA_FUSED_STEP", "1") != "0"
+        self.fused_step = (not distributed) and fused_on and _lib.has_symbol("fira_train_step")
+        # data parallel (round 6): the same schedule as two calls with the collectives in between (fira_train_step_begin / _end:
+        # Adam of [0, split) inside the library, beside its last weight gradients, behind the early bucket's event)
+        self.fused_dp = distributed and not zero1 and fused_on and _lib.has_symbol("fira_train_step_begin")
         self.t = 0
         self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
-        self.reducer = GradReducer(model.layout.split, model.layout.live) if distributed else None
+        self.reducer = GradReducer(model.layout.split, model.layout.live, wire=grad_wire) if distributed else None
         self.mid_event = None
         if distributed:
             # fires inside the backward pass when the gradients of [0, split) (head + decoder) are final: their all-reduce
@@ -60,8 +66,10 @@ class Trainer:
         still joins every collective of the step with a zero gradient and zero (loss_sum, n_tok) and applies the same
         Adam update as the others, so the replicas stay identical and nobody waits for a peer that never arrives."""
         m = self.model
+        dp = self.reducer is not None and self.reducer.world > 1
+        fused_dp = False
         if db is None:
-            if self.reducer is None or self.reducer.world == 1:
+            if not dp and not (self.zero is not None and self.zero.world > 1):
                 return                                           # nothing to learn from, nobody to keep in step
             m.gbuf[:m.layout.live].zero_()
             m.loss_sum.zero_()
@@ -72,26 +80,33 @@ class Trainer:
             self.t += 1
             m.train_step(db, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps)
             return
+        elif dp and self.fused_dp and self.zero is None:
+            fused_dp = True
+            loss_sum, n_tok = m.train_step_begin(db, self.mid_event)
         else:
             loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
         b1, b2 = self.betas
         if self.zero is not None and self.zero.world > 1:
             self._step_zero1(loss_sum, n_tok)
             return
-        if self.reducer is not None and self.reducer.world > 1:
+        if dp:
             red, split, live = self.reducer, m.layout.split, m.layout.live
-            red.start_early_bucket(m.gbuf, self.mid_event)
-            # one launch packs {loss_sum, float(n_tok)} (exact below 2^24 tokens); the update kernels form 1 / max(count, 1)
-            # from the all-reduced pair themselves: no torch arithmetic between the collective and Adam
-            ops.pack_stats(loss_sum, n_tok, self.stats)
-            red.reduce_stats_and_start_late_bucket(m.gbuf, self.stats)
+            # stats pair + head/decoder bucket on the communication stream behind the mid-backward event (beside the encoder's
+            # backward pass).  One launch packs {loss_sum, float(n_tok)} (exact below 2^24 tokens); the update kernels form
+            # 1 / max(count, 1) from the all-reduced pair themselves: no torch arithmetic between the collective and Adam
+            ev = red.reduce_early(m.gbuf, self.stats, self.mid_event, pack=lambda: ops.pack_stats(loss_sum, n_tok, self.stats))
             self.t += 1
             count = self.stats[1:2]
-            # Adam on the head+decoder slice runs while the encoder slice is still being reduced
-            red.wait_early()
-            ops.adam_step_count(m.flat.data[:split], m.gbuf[:split], self.m[:split], self.v[:split], self.lr, self.t, count,
-                                b1, b2, self.eps)
-            red.wait_late()
+            if fused_dp:
+                # encoder backward; Adam of [0, split) inside the library as soon as the caller's stream has passed the
+                # encoder's chain and `ev`, beside the last weight gradients; the join
+                m.train_step_end(self.m, self.v, self.lr, self.t, early_event=ev, count=count, beta1=b1, beta2=b2, eps=self.eps)
+            else:
+                red.wait_early()
+                ops.adam_step_count(m.flat.data[:split], m.gbuf[:split], self.m[:split], self.v[:split], self.lr, self.t, count,
+                                    b1, b2, self.eps)
+            red.start_late(m.gbuf)
+            red.wait_late(m.gbuf)
             ops.adam_step_count(m.flat.data[split:live], m.gbuf[split:live], self.m[split:live], self.v[split:live], self.lr,
                                 self.t, count, b1, b2, self.eps)
             return

@@ -437,6 +437,30 @@ int fira_train_step(void* stream, const fira_dims* d, const fira_batch* batch, f
                     void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
                     int32_t* n_tok, const fira_adam_opts* adam);
 
+/* (v8) The same step for DATA-PARALLEL runs (replaces nn.DataParallel's scatter / replicate / gather of run_model.py:392-394
+ * around run_model.py:104-111), as two calls with the caller's collectives in between:
+ *   fira_train_step_begin  forward + backward of the output head and the decoder; records mid_event (as fira_train_fwd_bwd
+ *                          does) when every gradient of [0, split) is final.  The step stays pending on the calling thread;
+ *                          the batch's arrays, the parameter / gradient buffers and the workspace must stay untouched.
+ *   -- caller: all-reduce (loss_sum, n_tok) and grads[0, split) on its own stream behind mid_event, record early_event there --
+ *   fira_train_step_end    backward of the encoder; Adam of [0, split) on the caller's stream as soon as that stream has
+ *                          passed the encoder's chain AND early_event (beside the library's last weight gradients), scaled by
+ *                          1 / max(*count, 1) (count: device float = the all-reduced token count; NULL = this rank's n_tok);
+ *                          then the join: grads[split, live) are final on `stream` when the call returns.  adam NULL = no update.
+ *   -- caller: all-reduce grads[split, live), then fira_adam_step_count on that slice --
+ * One process per GPU, one thread per step: the pending step is thread-local.  Same arithmetic as fira_train_fwd_bwd +
+ * fira_adam_step_count (tests/test_dp_gpu.py: two ranks == one process). */
+int fira_train_step_begin(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                          void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                          int32_t* n_tok, void* mid_event /* hipEvent_t, required */);
+int fira_train_step_end(void* stream, float* params, const fira_adam_opts* adam, void* early_event /* hipEvent_t or NULL */,
+                        const float* count);
+
+/* (v8) bf16 wire format of a gradient bucket (BASELINE configs[2]: 55.6 MB instead of 111.2 MB per step on xGMI):
+ * out[i] = bf16(in[i]) (round to nearest even) / out[i] = float(in[i]).  n % 4 == 0, 16-byte aligned buffers. */
+int fira_f32_to_bf16(void* stream, int64_t n, const float* in, uint16_t* out);
+int fira_bf16_to_f32(void* stream, int64_t n, const uint16_t* in, float* out);
+
 /* TransModel.forward(..., 'dev') (Model.py:85-86): teacher-forced argmax ids [B, tar_len].         */
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params,
                      void* workspace, size_t workspace_bytes, int32_t* ids_out, float* loss_sum, int32_t* n_tok,

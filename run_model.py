@@ -67,6 +67,9 @@ def parse_args(argv):
                     "the reference's (fp32 MFMA, default); bf16 = BASELINE configs[2] (bf16 MFMA, fp32 accumulate; master "
                     "weights, LayerNorm, soft-max, loss and Adam stay fp32).  Applies to train and dev (teacher-forced BLEU); the test-time "
                     "SEARCH always runs the reference's fp32 arithmetic (decode.Searcher / fira_decode_step), whatever --dtype says")
+    ap.add_argument("--grad-wire", choices=["auto", "f32", "bf16"], default="auto", help="multi-GPU, all-reduce path: wire format "
+                    "of the gradient buckets; auto = bf16 with --dtype bf16 (half the bytes on xGMI; Adam, master weights and the "
+                    "token normaliser stay fp32), else f32")
     ap.add_argument("--zero1", action="store_true", help="multi-GPU: reduce-scatter + Adam on the owned shard + all-gather "
                     "(Adam moments sharded over the ranks) instead of all-reduce + replicated Adam")
     return ap.parse_args(argv)
@@ -150,7 +153,8 @@ class Run:
             self.model.load_state_dict(torch.load(os.path.join(self.root, "best_model.pt"), map_location="cpu"))
         self.model.compute_dtype = a.dtype
         self.model.set_dropout_stream(a.seed, self.rank)           # masks depend on (--seed, rank, step)
-        trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1, zero1=a.zero1)
+        wire = a.grad_wire if a.grad_wire != "auto" else ("bf16" if a.dtype == "bf16" else "f32")
+        trainer = Trainer(self.model, lr=cfg.lr, distributed=self.world > 1, zero1=a.zero1, grad_wire=wire)
         state_path = os.path.join(self.root, "fira_train_state.pt")
         if a.resume and os.path.exists(state_path):
             trainer.load_state_dict(torch.load(state_path, map_location=self.model.device_))

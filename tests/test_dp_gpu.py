@@ -16,7 +16,7 @@ from fira_icse_amd.config import FiraConfig
 pytestmark = pytest.mark.gpu
 
 
-def _run(rank, world, port, out, zero1=False, backend="gloo"):
+def _run(rank, world, port, out, zero1=False, backend="gloo", wire="f32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, util.REPO)
@@ -34,7 +34,9 @@ def _run(rank, world, port, out, zero1=False, backend="gloo"):
     model = TransModel(cfg, init=False)
     model.load_state_dict(util.perturb_state_dict(reference_init_state_dict(cfg), seed=1))
     model.eval()                                        # dropout off: the comparison must be deterministic
-    trainer = Trainer(model, distributed=world > 1, zero1=zero1)
+    trainer = Trainer(model, distributed=world > 1, zero1=zero1, grad_wire=wire)
+    if world > 1 and not zero1:
+        assert trainer.fused_dp                         # (round 6) fira_train_step_begin / _end with the collectives in between
     losses = []
     for step in range(3):
         # the last global batch holds ONE commit: with two ranks, rank 1's shard is empty (DataParallel.scatter chunking)
@@ -67,6 +69,25 @@ def test_two_rank_training_equals_single_process(tmp_path):
     diff = (a["flat"] - b["flat"]).abs()
     assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
     assert float(diff.mean()) < 1e-3 * cfg.lr
+
+
+def test_two_ranks_with_bf16_gradient_wire_track_single_process(tmp_path):
+    """Trainer(grad_wire="bf16"): the two buckets travel as bf16 (cast -> all-reduce -> widen; BASELINE configs[2]).  The update
+    is no longer bit-comparable -- every gradient carries a 2^-9 relative rounding -- but three steps must stay on the
+    single-process trajectory: global losses within 1e-3, parameters within a fraction of the Adam step."""
+    port = 29350 + (os.getpid() % 150)
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    mp.spawn(_run, args=(1, port, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, port + 1, two, False, "gloo", "bf16"), nprocs=2, join=True)
+    a, b = torch.load(one, weights_only=False), torch.load(two, weights_only=False)
+    assert abs(a["losses"][0] - b["losses"][0]) / a["losses"][0] < 1e-5        # (the first loss precedes any update)
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) / x < 1e-3, (a["losses"], b["losses"])
+    cfg = FiraConfig()
+    diff = (a["flat"] - b["flat"]).abs()
+    assert float(diff.mean()) < 0.05 * cfg.lr, float(diff.mean())
+    d = (a["m"] - b["m"]).norm() / a["m"].norm()
+    assert 1e-6 < float(d) < 1e-2, float(d)                                    # (the wire really was bf16; first moments agree)
 
 
 def test_two_rank_zero1_equals_single_process(tmp_path):

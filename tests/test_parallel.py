@@ -62,7 +62,6 @@ def _worker(rank, world, port, tmp):
     g, ls, nt = grads_of(mine)
     red = GradReducer(layout.split, layout.live)
     stats = torch.tensor([ls, float(nt)])
-    red.start_early_bucket(g, None)
     red.finish(g, stats)
     lines = gather_lines(["r%d-%d" % (rank, i) for i in mine])
     if rank == 0:
@@ -100,7 +99,6 @@ def _worker_empty(rank, world, port, tmp):
         g, stats = torch.zeros(layout.total), torch.zeros(2)
     ref = g.clone()
     red = GradReducer(layout.split, layout.live)
-    red.start_early_bucket(g, None)
     red.finish(g, stats)
     out = [None, None]
     dist.all_gather_object(out, (g[:layout.live].clone(), stats.clone()))
@@ -170,3 +168,42 @@ def _zero_worker(rank, world, port, tmp):
 def test_sharded_optimizer_comm_partitions_reduces_and_gathers(tmp_path, world):
     """ZeRO-1 comm (reduce-scatter / owned shard / all-gather) over ragged buckets, gloo, world_size 2 and 3."""
     mp.spawn(_zero_worker, args=(world, 29650 + (os.getpid() % 200) + world, str(tmp_path)), nprocs=world, join=True)
+
+
+def _wire_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    split, live, total = 1024, 4096, 4160                    # (bucket bounds are multiples of 64 elements: csrc/layout.cpp)
+    mk = lambda r: torch.randn(total, generator=torch.Generator().manual_seed(7 + r)) * torch.logspace(-3, 1, total)
+    res = {}
+    for wire in ("f32", "bf16"):
+        g = mk(rank)
+        stats = torch.tensor([3.5 + rank, 11.0 + rank])
+        red = GradReducer(split, live, wire=wire)
+        red.finish(g, stats)
+        res[wire] = (g.clone(), stats.clone(), red.bytes_per_step())
+    if rank == 0:
+        res["want"] = sum(mk(r) for r in range(world))
+        torch.save(res, tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_wire_format(tmp_path):
+    """GradReducer(wire="bf16") (BASELINE configs[2]; SURVEY.md 2.2: 55.6 MB instead of 111.2 MB per step): both buckets are
+    rounded to bf16, summed over the ranks in bf16 and widened back -- the stats pair and everything outside [0, live) stay
+    fp32.  Two ranks: rel-L2 of the reduced gradient against the fp32 reduction <= 4e-3 (one rounding per contribution and
+    one per partial sum, 2^-9 each)."""
+    out = str(tmp_path / "res.pt")
+    port = 29400 + (os.getpid() % 200)
+    mp.spawn(_wire_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    live = 4096
+    g32, s32, b32 = r["f32"]
+    g16, s16, b16 = r["bf16"]
+    assert torch.allclose(g32[:live], r["want"][:live], rtol=1e-6, atol=1e-7)
+    assert torch.equal(s32, s16) and torch.equal(s32, torch.tensor([8.0, 23.0]))         # the normaliser never goes bf16
+    err = float((g16[:live] - g32[:live]).double().norm() / g32[:live].double().norm())
+    assert 1e-5 < err < 4e-3, err
+    assert torch.equal(g16[live:], g32[live:])                                             # dead tensors: untouched
+    assert b32 == 4 * live + 8 and b16 == 2 * live + 8

@@ -197,6 +197,57 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(int B, int T, int V
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&n_alive[step], __popcll(m));
 }
 
+// Row-wise top-k of a logits matrix (k <= BEAM_MAX): one workgroup per row, k passes -- pass j takes the best entry that comes
+// after pass j - 1's pick in the total order (value descending, index ascending; NaN never wins).  The row (98 KB at the
+// reference's vocabulary) stays in L2 between the passes.
+__global__ __launch_bounds__(256) void row_topk_kernel(int V, int k, const float* __restrict__ logits, int ldl,
+                                                       int32_t* __restrict__ ids, float* __restrict__ vals) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float pv;
+    __shared__ int pi;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* row = logits + (size_t)blockIdx.x * ldl;
+    float prev_v = INFINITY;
+    int prev_i = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+        for (int i = t; i < V; i += 256) {
+            const float v = row[i];
+            const bool after = v < prev_v || (v == prev_v && i > prev_i);       // not picked by an earlier pass
+            if (after && better(v, i, bv, bi)) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        if (t == 0) {
+            float v = sv[0];
+            int i = si[0];
+            for (int w = 1; w < 4; ++w)
+                if (better(sv[w], si[w], v, i)) { v = sv[w]; i = si[w]; }
+            pv = v; pi = i;
+            ids[(size_t)blockIdx.x * k + j] = i == INT_MAX ? -1 : i;
+            vals[(size_t)blockIdx.x * k + j] = v;
+        }
+        __syncthreads();
+        prev_v = pv; prev_i = pi;
+        __syncthreads();
+    }
+}
+int row_topk(hipStream_t s, int R, int V, int k, const float* logits, int ldl, int32_t* ids, float* vals) {
+    if (R <= 0) return 0;
+    FIRA_REQUIRE(k >= 1 && k <= BEAM_MAX && V >= k, "row_topk: k=%d must be in [1, %d] and <= V", k, BEAM_MAX);
+    hipLaunchKernelGGL(row_topk_kernel, dim3(R), dim3(256), 0, s, V, k, logits, ldl, ids, vals);
+    FIRA_CHECK_LAUNCH("row_topk");
+    return 0;
+}
+
 }  // namespace fira
 
 extern "C" {

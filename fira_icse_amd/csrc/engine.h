@@ -245,6 +245,8 @@ int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl
                 const int32_t* mem_valid, int qpk, const float* gate_logits, float* dist, int32_t* best_id,
                 float* best_p, const float* x = nullptr, const float* wp = nullptr, const float* bp = nullptr);
 int inv_count(hipStream_t s, const int32_t* n_tok, float* out);
+// ids / vals [R, k]: the k largest entries of every logits row, value descending, ties by ascending index (beam.hip; k <= 8)
+int row_topk(hipStream_t s, int R, int V, int k, const float* logits, int ldl, int32_t* ids, float* vals);
 int copy_score_bwd(hipStream_t s, int B, int T, int S, const float* src, const float* tgt, const float* w,
                    const float* dscore, float* dsrc, float* dtgt, float* dw, float* dbias);
 int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact_row, float* logits, int ldl,

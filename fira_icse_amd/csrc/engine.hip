@@ -1708,6 +1708,52 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
                       nullptr);
 }
 
+// ---- op-level entries named by SURVEY.md 8(b) that the model-level calls compose from smaller launches ------------------
+// FeedForward block (gnn_transformer.py:163-174): h = relu(x W1^T + b1); sum = dropout(h W2^T + b2) + x; y = LayerNorm(sum).
+int fira_ffn_fwd(void* stream, int M, int F, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                 const float* gamma, const float* beta, float* h, float* sum, float* y, float* stats, float dropout,
+                 uint64_t seed, uint32_t site_id, int dtype) {
+    FIRA_REQUIRE(x && w1 && b1 && w2 && b2 && gamma && beta && h && sum && y && stats && M > 0 && F > 0, "fira_ffn_fwd: bad argument");
+    FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f && (dtype == 0 || dtype == 1), "fira_ffn_fwd: bad dropout / dtype");
+    DtypeScope dtype_scope(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = FIRA_D;
+    TRY(linear(s, M, F, D, x, D, w1, b1, h, F, FIRA_GEMM_RELU));
+    return linear_ln(s, M, F, h, F, w2, b2, x, gamma, beta, sum, y, stats, dropout, seed, site_id);
+}
+// Its backward: dy = gradient w.r.t. y.  dx [M,256] is WRITTEN (gradient w.r.t. x: residual branch + through the two
+// products); dw1 [F,256], db1 [F], dw2 [256,F], db2 [256], dgamma, dbeta [256] are ACCUMULATED into.  dyf_ws [M,256] and
+// dh_ws [M,F] are caller-provided scratch (they hold d(h W2^T + b2) and d(x W1^T + b1) on return).
+int fira_ffn_bwd(void* stream, int M, int F, const float* dy, const float* x, const float* h, const float* sum,
+                 const float* stats, const float* w1, const float* w2, const float* gamma, float* dx, float* dyf_ws,
+                 float* dh_ws, float* dw1, float* db1, float* dw2, float* db2, float* dgamma, float* dbeta, float dropout,
+                 uint64_t seed, uint32_t site_id, int dtype) {
+    FIRA_REQUIRE(dy && x && h && sum && stats && w1 && w2 && gamma && dx && dyf_ws && dh_ws && dw1 && db1 && dw2 && db2 && dgamma &&
+                 dbeta && M > 0 && F > 0, "fira_ffn_bwd: bad argument");
+    FIRA_REQUIRE(dx != dy, "fira_ffn_bwd: dx must not alias dy");
+    FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f && (dtype == 0 || dtype == 1), "fira_ffn_bwd: bad dropout / dtype");
+    DtypeScope dtype_scope(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = FIRA_D;
+    red().reset(nullptr, 0);                    // stand-alone: column sums by atomics, nothing deferred
+    // LayerNorm backward (residual-branch gradient -> dx, un-dropped branch gradient -> dyf_ws) + d hidden = (dyf W2) where h > 0
+    TRY(ln_bwd_dgrad(s, M, F, dy, sum, stats, gamma, dx, dyf_ws, dgamma, dbeta, dropout, seed, site_id, w2, F, dh_ws, F, h));
+    TRY(gemm_any(s, 1, 0, D, F, M, dyf_ws, D, h, F, dw2, F, nullptr, FIRA_GEMM_ACCUM, 0, db2));     // dW2 += dyf^T h, db2 += colsum
+    TRY(gemm_any(s, 1, 0, F, D, M, dh_ws, F, x, D, dw1, D, nullptr, FIRA_GEMM_ACCUM, 0, db1));      // dW1 += dh^T x, db1 += colsum
+    return linear_dgrad(s, M, F, D, dh_ws, F, w1, dx, D, true);                                      // dx += dh W1
+}
+// Output head for teacher-forced / search decoding (Model.py:54 + the arg-max of Model.py:85, run_model.py:305): logits =
+// x Wout^T + bout into logits_ws [R, ldl >= V] and, per row, the k largest logits (value descending, ties by ascending id).
+int fira_head_topk(void* stream, int R, int V, int k, const float* x, const float* wout, const float* bout, float* logits_ws,
+                   int ldl, int32_t* ids, float* vals, int dtype) {
+    FIRA_REQUIRE(x && wout && logits_ws && ids && vals && R > 0 && V > 0 && ldl >= V, "fira_head_topk: bad argument");
+    FIRA_REQUIRE(dtype == 0 || dtype == 1, "fira_head_topk: bad dtype");
+    DtypeScope dtype_scope(dtype);
+    hipStream_t s = (hipStream_t)stream;
+    TRY(linear(s, R, V, FIRA_D, x, FIRA_D, wout, bout, logits_ws, ldl));
+    return row_topk(s, R, V, k, logits_ws, ldl, ids, vals);
+}
+
 int fira_train_step_begin(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
                           void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
                           int32_t* n_tok, void* mid_event) {

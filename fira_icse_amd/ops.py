@@ -420,3 +420,40 @@ def bf16_to_f32(src, dst):
     assert dst.numel() == n and src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and n % 4 == 0
     check(_lib.lib().fira_bf16_to_f32(cur_stream(), n, ptr(src), ptr(dst)), "fira_bf16_to_f32")
     return dst
+
+
+def ffn_fwd(x, w1, b1, w2, b2, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0):
+    """fira_ffn_fwd: (h, sum, y, stats) of the FeedForward block LN(dropout(relu(x W1^T + b1) W2^T + b2) + x)."""
+    M, F = x.shape[0], w1.shape[0]
+    h = torch.empty((M, F), dtype=torch.float32, device=x.device)
+    summ, y = torch.empty_like(x), torch.empty_like(x)
+    stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_ffn_fwd(cur_stream(), M, F, ptr(_f32(x)), ptr(_f32(w1)), ptr(_f32(b1)), ptr(_f32(w2)), ptr(_f32(b2)),
+                                  ptr(_f32(gamma)), ptr(_f32(beta)), ptr(h), ptr(summ), ptr(y), ptr(stats), dropout, seed, site,
+                                  dtype), "fira_ffn_fwd")
+    return h, summ, y, stats
+
+
+def ffn_bwd(dy, x, h, summ, stats, w1, w2, gamma, dropout=0.0, seed=0, site=0, dtype=0):
+    """fira_ffn_bwd: (dx, dw1, db1, dw2, db2, dgamma, dbeta) -- the parameter gradients start from zero here."""
+    M, F = x.shape[0], w1.shape[0]
+    dev = x.device
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    dx, dyf, dh = torch.empty_like(x), torch.empty_like(x), torch.empty((M, F), dtype=torch.float32, device=dev)
+    dw1, db1, dw2, db2, dg, db = z(F, 256), z(F), z(256, F), z(256), z(256), z(256)
+    check(_lib.lib().fira_ffn_bwd(cur_stream(), M, F, ptr(_f32(dy)), ptr(_f32(x)), ptr(_f32(h)), ptr(_f32(summ)), ptr(_f32(stats)),
+                                  ptr(_f32(w1)), ptr(_f32(w2)), ptr(_f32(gamma)), ptr(dx), ptr(dyf), ptr(dh), ptr(dw1), ptr(db1),
+                                  ptr(dw2), ptr(db2), ptr(dg), ptr(db), dropout, seed, site, dtype), "fira_ffn_bwd")
+    return dx, dw1, db1, dw2, db2, dg, db
+
+
+def head_topk(x, wout, bout, k, dtype=0):
+    """fira_head_topk: (ids [R,k] int32, vals [R,k], logits [R,V]) of the generator head x Wout^T + bout."""
+    R, V = x.shape[0], wout.shape[0]
+    ldl = (V + 63) // 64 * 64
+    logits = torch.empty((R, ldl), dtype=torch.float32, device=x.device)
+    ids = torch.empty((R, k), dtype=torch.int32, device=x.device)
+    vals = torch.empty((R, k), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_head_topk(cur_stream(), R, V, k, ptr(_f32(x)), ptr(_f32(wout)), ptr(_f32(bout)), ptr(logits), ldl,
+                                    ptr(ids), ptr(vals), dtype), "fira_head_topk")
+    return ids, vals, logits[:, :V]

@@ -421,6 +421,25 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
 /* mid_event: optional hipEvent_t recorded on `stream` once the gradients of group [0, split) are final (after the
  * decoder backward, before the encoder backward), so that their RCCL all-reduce can overlap the rest.           */
 
+/* (v8) FeedForward block of a decoder layer (gnn_transformer.py:163-174) as one entry (two products + the row kernel, or the
+ * LayerNorm-prologue forms, chosen as in the model-level calls):
+ *     h = relu(x W1^T + b1) [M,F] ;  sum = dropout(h W2^T + b2) + x ;  y = LayerNorm(sum) ;  stats = {mean, 1/std}
+ * w1 [F,256], w2 [256,F] as nn.Linear stores them; dropout element index = row*256 + col of `site`.  Backward: dy = gradient
+ * w.r.t. y; dx [M,256] is written (must not alias dy); dw1 / db1 / dw2 / db2 / dgamma / dbeta are accumulated into; dyf_ws
+ * [M,256] and dh_ws [M,F] are scratch.  dtype FIRA_F32 | FIRA_BF16 (operands of the products rounded, fp32 accumulate). */
+int fira_ffn_fwd(void* stream, int M, int F, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                 const float* gamma, const float* beta, float* h, float* sum, float* y, float* stats, float dropout,
+                 uint64_t seed, uint32_t site, int dtype);
+int fira_ffn_bwd(void* stream, int M, int F, const float* dy, const float* x, const float* h, const float* sum,
+                 const float* stats, const float* w1, const float* w2, const float* gamma, float* dx, float* dyf_ws,
+                 float* dh_ws, float* dw1, float* db1, float* dw2, float* db2, float* dgamma, float* dbeta, float dropout,
+                 uint64_t seed, uint32_t site, int dtype);
+/* (v8) Output head + arg-top-k (Model.py:54,85; the candidate ranking of run_model.py:305 restricted to the generator):
+ * logits_ws [R, ldl >= V] = x [R,256] Wout^T + bout; ids / vals [R, k] = the k <= 8 largest logits of every row, value
+ * descending, ties by ascending id (the order fira_beam_select uses). */
+int fira_head_topk(void* stream, int R, int V, int k, const float* x, const float* wout, const float* bout, float* logits_ws,
+                   int ldl, int32_t* ids, float* vals, int dtype);
+
 /* (v7) One optimisation step in one call: `loss.backward(); optimizer.step()` of run_model.py:104-111 for a single device --
  * fira_train_fwd_bwd followed by fira_adam_step_mb over [0, live) with the token normaliser of run_model.py:105, bit for bit
  * (Adam is element-wise).  What the single call adds is the ORDER: the update of the head + decoder slice [0, split) is

@@ -925,3 +925,62 @@ def test_adam_count_form_and_pack_stats():
     p = p0.clone()                                               # an all-empty global batch: the normaliser is 1, not inf
     ops.adam_step_count(p, grads[0], torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), 1e-4, 1, torch.zeros(1, device=DEV))
     assert bool(torch.isfinite(p).all())
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(b) block entries
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("M,p", [(530, 0.0), (530, 0.1), (37, 0.1), (2000, 0.1)])
+def test_ffn_block_fwd_bwd(M, p, dtype):
+    """fira_ffn_fwd / fira_ffn_bwd: the FeedForward block of gnn_transformer.py:163-174 as one entry each, against the fp64
+    statement LN(dropout(relu(x W1^T + b1) W2^T + b2) + x) with the engine's own dropout mask and its autograd; dtype 1:
+    operands of the two products (and of their gradients) rounded to bf16 -- tolerance of the bf16 level."""
+    from fira_icse_amd import ops
+    F_ = 1024
+    x = randn(M, 256, seed=1)
+    w1, b1 = randn(F_, 256, seed=2, scale=0.06), randn(F_, seed=3, scale=0.1)
+    w2, b2 = randn(256, F_, seed=4, scale=0.03), randn(256, seed=5, scale=0.1)
+    gamma, beta = 1 + randn(256, seed=6, scale=0.1), randn(256, seed=7, scale=0.1)
+    seed, site = 99, 46
+    h, summ, y, stats = ops.ffn_fwd(x, w1, b1, w2, b2, gamma, beta, dropout=p, seed=seed, site=site, dtype=dtype)
+    mask = ops.dropout_mask(seed, site, M * 256, p).view(M, 256).double() if p > 0 else torch.ones(M, 256, device=DEV).double()
+    leaf = [t.double().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, gamma, beta)]
+    X, W1, B1, W2, B2, G, Bt = leaf
+    H = torch.relu(X @ W1.t() + B1)
+    S = (H @ W2.t() + B2) * mask + X
+    Y = F.layer_norm(S, (256,), G, Bt, 1e-5)
+    t1, t2 = (2e-6, 1e-5) if dtype == 0 else (6e-3, 2e-2)
+    assert rel_err(h, H.detach()) < t1 and rel_err(summ, S.detach()) < t1 and rel_err(y, Y.detach()) < 2 * t1
+    dy = randn(M, 256, seed=8)
+    Y.backward(dy.double())
+    dx, dw1, db1, dw2, db2, dg, db = ops.ffn_bwd(dy, x, h, summ, stats, w1, w2, gamma, dropout=p, seed=seed, site=site, dtype=dtype)
+    for got, want, name in ((dx, X.grad, "dx"), (dw1, W1.grad, "dw1"), (db1, B1.grad, "db1"), (dw2, W2.grad, "dw2"),
+                            (db2, B2.grad, "db2"), (dg, G.grad, "dgamma"), (db, Bt.grad, "dbeta")):
+        assert rel_err(got, want) < t2, (name, rel_err(got, want))
+
+
+@pytest.mark.parametrize("R,V,k", [(64, 24650, 1), (192, 24650, 3), (7, 1001, 8)])
+def test_head_topk(R, V, k):
+    """fira_head_topk: generator logits + the k best of every row, value descending, ties by ascending id -- against torch.topk
+    on the fp64 logits (values), with exact duplicates planted to pin the tie rule."""
+    from fira_icse_amd import ops
+    x = randn(R, 256, seed=1)
+    w, b = randn(V, 256, seed=2, scale=0.2), randn(V, seed=3)
+    w[5], b[5] = w[900].clone(), b[900].clone()            # ids 5 and 900 tie exactly in every row
+    ids, vals, logits = ops.head_topk(x, w, b, k)
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel_err(logits, ref) < 2e-6
+    tv, ti = torch.topk(logits, k, dim=1)                   # the kernel ranks ITS logits: compare on those
+    assert torch.equal(vals, tv)
+    # ids: identical wherever the value is unique in the row; on ties the lower id comes first
+    want = torch.empty_like(ids)
+    lg = logits.clone()
+    for j in range(k):
+        m = lg.max(dim=1, keepdim=True).values
+        first = (lg == m).float().argmax(dim=1)             # argmax of a 0/1 row = the FIRST maximal position
+        want[:, j] = first.to(torch.int32)
+        lg[torch.arange(R, device=DEV), first] = -float("inf")
+    assert torch.equal(ids, want)
+    boost = torch.zeros(V, device=DEV)
+    boost[5] = boost[900] = 100.0
+    ids2, vals2, _ = ops.head_topk(x, w, b + boost, min(k, 2) if k > 1 else 1)
+    assert bool((ids2[:, 0] == 5).all()) and (k == 1 or bool((ids2[:, 1] == 900).all()))

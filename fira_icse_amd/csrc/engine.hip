@@ -631,9 +631,19 @@ static inline int attn_bf16() {
 
 // GCN layer as one fused launch per direction (gcn_fused.hip) instead of SpMM + product + add-LayerNorm (forward) /
 // product + SpMM (backward); FIRA_GCN_FUSED=0 restores the separate kernels (A/B switch)
+// ... and by the batch's density (round 6): the fused kernels' gather is built for FIRA's graphs (3-4 entries per computed row,
+// the first 16 of a row in one batched round trip); rows beyond 16 entries take a 64-at-a-time tail loop per row, and on BASELINE
+// config 5's graphs (116 entries per row) the fused forward costs 518 us against 319 us for aggregation + product + row kernel
+// (bench.py: gcn_cfg5).  Batches averaging more than FIRA_GCN_FUSED_MAX_DEG entries per computed row (default 48) run the separate
+// kernels; set per call by check_batch.
+static thread_local bool g_dense_graphs = false;
 static inline bool gcn_fused_on() {
     static const bool off = [] { const char* e = getenv("FIRA_GCN_FUSED"); return e && e[0] == '0'; }();
-    return !off;
+    return !off && !g_dense_graphs;
+}
+static inline void note_graph_density(const fira_batch* b) {
+    static const double max_deg = [] { const char* e = getenv("FIRA_GCN_FUSED_MAX_DEG"); return e ? atof(e) : 48.0; }();
+    g_dense_graphs = b->n_nodes > 0 && (double)b->nnz > max_deg * (double)b->n_nodes;
 }
 
 // ... and of the backward pass only (FIRA_GCN_FUSED_BWD=0: V = A_hat dY by the CSR kernel, dX += V W21 by the product -- the same
@@ -1540,6 +1550,7 @@ static int check_batch(const fira_batch* b) {
                  "batch has null node lists (node_rows / code_rows / code_mark / mem_rows / mem_dst)");
     FIRA_REQUIRE(b->n_nodes > 0 && b->n_code > 0 && b->n_mem > 0 && b->n_code <= b->n_nodes && b->n_mem <= b->n_nodes,
                  "inconsistent node counts %d / %d / %d", b->n_nodes, b->n_code, b->n_mem);
+    note_graph_density(b);
     return 0;
 }
 static int check_counts(const fira_batch* b, const Plan& p) {

@@ -948,7 +948,9 @@ def test_ffn_block_fwd_bwd(M, p, dtype):
     H = torch.relu(X @ W1.t() + B1)
     S = (H @ W2.t() + B2) * mask + X
     Y = F.layer_norm(S, (256,), G, Bt, 1e-5)
-    t1, t2 = (2e-6, 1e-5) if dtype == 0 else (6e-3, 2e-2)
+    # (bf16: every product rounds both operands, 2^-9 each; the gradients pass two products and a ReLU mask taken from the
+    #  rounded forward pass -- a few per cent against the exact fp64 gradient, as in tests/test_bf16_gpu.py)
+    t1, t2 = (2e-6, 1e-5) if dtype == 0 else (6e-3, 5e-2)
     assert rel_err(h, H.detach()) < t1 and rel_err(summ, S.detach()) < t1 and rel_err(y, Y.detach()) < 2 * t1
     dy = randn(M, 256, seed=8)
     Y.backward(dy.double())

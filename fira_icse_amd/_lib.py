@@ -100,6 +100,7 @@ SIGNATURES = {
     "fira_debug_chain": (_I, [_P, _I, _I, _P]),
     "fira_train_fwd_bwd": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_train_step": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, C.POINTER(AdamOpts)]),
+    "fira_gemm_wgrad_panel": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _Z]),
     "fira_ffn_fwd": (_I, [_P, _I, _I] + [_P] * 11 + [_F, _U64, _U32, _I]),
     "fira_ffn_bwd": (_I, [_P, _I, _I] + [_P] * 17 + [_F, _U64, _U32, _I]),
     "fira_head_topk": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I]),

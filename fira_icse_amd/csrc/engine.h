@@ -43,6 +43,18 @@ int gemm_bf16_group_flush(hipStream_t s);
 bool gemm_bf16_takes(int M, int N, int K);     // false: the product is too small for the bf16 tiles (runs in fp32)
 void gemm_bf16_group_reset();
 bool gemm_bf16_group_full();     // the next add would launch the queue by itself: the caller forks + flushes first
+// weight gradients as 256 x 256 panel products on the bf16 matrix cores (gemm_wgrad_panel.hip): C[M,N] += A^T B with A [K, lda],
+// B [K, ldb]; np = 1 (operands rounded to bf16) or 3 (three-term split: fp32-accurate).  A queue like the grouped launches.
+bool gemm_wgrad_panel_on();
+bool gemm_wgrad_panel_takes(int M, int N, int K, const float* A, int lda, const float* B, int ldb, int ldc);
+void gemm_wgrad_panel_reset();
+bool gemm_wgrad_panel_full();
+int gemm_wgrad_panel_pending();
+int gemm_wgrad_panel_add(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum);
+int gemm_wgrad_panel_flush(hipStream_t s, int np);
+void gemm_wgrad_panel_scratch(float* buf, size_t n_floats);      // scratch for split problems (thread-local; nullptr: no splits)
+int gemm_wgrad_panel(hipStream_t s, int np, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                     int ldc, float* colsum);
 // grouped weight gradients (one launch for many small dW += dY^T X problems; see gemm_f32.hip)
 int gemm_group_add_wgrad(hipStream_t s, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                          int ldc, float* colsum, int max_split = 0);

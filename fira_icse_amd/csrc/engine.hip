@@ -84,6 +84,8 @@ struct Plan {
     uint16_t *w21b = nullptr, *w21bt = nullptr;  // the same for the folded GCN weights W21 (formed per step)
     float* red_buf = nullptr;                    // per-workgroup partial rows of the deferred column reductions
     size_t red_cap = 0;
+    float* panel_scratch = nullptr;              // partial tiles of split panel weight gradients (training)
+    size_t panel_floats = 0;
     float *dmem_c, *dsrc, *dsrc_c, *dtgt, *dkv_all, *ddec, *ddec_c, *dT_a, *dT_c;
 
     size_t build(void* ws, const fira_dims& d, int B_, bool training) {
@@ -154,6 +156,10 @@ struct Plan {
                     + (size_t)nl * std::max((size_t)cdiv(CB, 16) * 4 * D, (size_t)comb_fused_bwd_parts() * 6 * D + 64)  // Combination (fused: one {LN | dvtab} row pair per workgroup)
                     + (size_t)cdiv(L + S, 16) * B * COPY_PART_STRIDE + 4096;                                     // copy head
             red_buf = a.f(red_cap);
+            // partial tiles of the panel weight-gradient launches (gemm_wgrad_panel.hip): one 256 x 256 tile per workgroup of a
+            // split product, ~one workgroup per CU and launch; used by the launches of the weight-gradient stream, in order
+            panel_floats = (size_t)320 * 256 * 256;
+            panel_scratch = a.f(panel_floats);
             // buffers that must start a backward pass at zero, contiguous: ONE fill per step (zero_beg .. zero_end)
             zero_beg = (float*)a.get<char>(0);
             dvtab_all = a.f((size_t)4 * nl * D);
@@ -488,14 +494,33 @@ static int main_wait(hipStream_t main_s, hipEvent_t e, int line = 0) {
 
 // dW += dY^T X ; db += colsum(dY)      (reduce over the M rows: split-K over rows keeps the chip busy)
 // dY and X must stay untouched until the next side_join (per-layer slots of Plan::encg / decg, saved activations).
+// (round 6) Weight gradients as panel products on the bf16 matrix cores (gemm_wgrad_panel.hip: 256 x 256 output tiles, every
+// operand row read once, no atomics; fp32 mode = three-term bf16 split, fp32-accurate) where the shape allows: dW [N,K] with
+// K (the layer's input width) a multiple of 256 and N >= 32.  FIRA_WGRAD_PANEL=0 restores the tiled kernels everywhere;
+// FIRA_WGRAD_PANEL_MASK selects the classes (1 encoder groups, 2 decoder / head groups, 4 vocabulary, 8 stacked K|V).
+enum { PANEL_ENC = 1, PANEL_DEC = 2, PANEL_VOCAB = 4, PANEL_KV = 8 };
+// (measured, profiles/r6_probes.md: fp32 -- every class wins, mask 15; bf16 -- the decoder / head groups (K = the ~1 000 computed
+//  target rows) lose to the tiled grouped kernel, whose single-rounding MFMAs are already short: mask 13)
+static inline bool panel_class(int cls) {
+    static const int forced = [] { const char* e = getenv("FIRA_WGRAD_PANEL_MASK"); return e ? atoi(e) : -1; }();
+    const int mask = forced >= 0 ? forced : (g_dtype == 1 ? 13 : 15);
+    return gemm_wgrad_panel_on() && (mask & cls);
+}
+static inline bool panel_takes(int cls, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx) {
+    return panel_class(cls) && gemm_wgrad_panel_takes(N, K, M, dY, lddy, X, ldx, K);
+}
+static inline int panel_np() { return g_dtype == 1 ? 1 : 3; }
+
 static inline int linear_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx,
-                               float* dW, float* db) {
+                               float* dW, float* db, int panel_cls = 0) {
     SideStream& sd = side();
     hipStream_t ws = s;
     if (sd.stream && sd.enabled) {
         TRY(side_fork(s));
         ws = sd.stream;
     }
+    if (panel_cls && gemm_wgrad_panel_pending() == 0 && panel_takes(panel_cls, M, N, K, dY, lddy, X, ldx))
+        return gemm_wgrad_panel(ws, panel_np(), N, K, M, dY, lddy, X, ldx, dW, K, db);
     return gemm_any(ws, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
 }
 
@@ -506,7 +531,7 @@ static inline int flush_grouped_wgrads(hipStream_t s);
 // A full queue launches itself at the next add -- on the weight-gradient stream, WITHOUT a fork from the caller's stream, i.e.
 // possibly ahead of the kernels that write its operands (deeper models: > 40 queued problems).  Fork + flush first.
 static inline int group_make_room(hipStream_t s) {
-    if (g_dtype == 1 ? gemm_bf16_group_full() : gemm_group_full()) return flush_grouped_wgrads(s);
+    if ((g_dtype == 1 ? gemm_bf16_group_full() : gemm_group_full()) || gemm_wgrad_panel_full()) return flush_grouped_wgrads(s);
     return 0;
 }
 static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X,
@@ -514,6 +539,7 @@ static inline int linear_wgrad_grouped(hipStream_t s, int M, int N, int K, const
     SideStream& sd = side();
     if (!(sd.stream && sd.enabled)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
     TRY(group_make_room(s));
+    if (panel_takes(PANEL_DEC, M, N, K, dY, lddy, X, ldx)) return gemm_wgrad_panel_add(N, K, M, dY, lddy, X, ldx, dW, K, db);
     if (g_dtype == 1) {
         if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);   // e.g. the 2-column gate
         return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, max_split);
@@ -531,20 +557,32 @@ static inline bool enc_group_on() {
 }
 static inline int enc_wgrad(hipStream_t s, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx, float* dW,
                             float* db) {
-    if (!enc_group_on()) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
+    if (!enc_group_on()) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db, PANEL_ENC);
     SideStream& sd = side();
     TRY(group_make_room(s));
+    if (panel_takes(PANEL_ENC, M, N, K, dY, lddy, X, ldx)) return gemm_wgrad_panel_add(N, K, M, dY, lddy, X, ldx, dW, K, db);
     if (g_dtype == 1) {
         if (!gemm_bf16_takes(N, K, M)) return linear_wgrad(s, M, N, K, dY, lddy, X, ldx, dW, db);
         return gemm_bf16_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, 32);
     }
     return gemm_group_add_wgrad(sd.stream, N, K, M, dY, lddy, X, ldx, dW, K, db, 32);
 }
+// dW [N,K] += dY^T X on stream ws, which already waits for its operands: panel product where the shape allows, tiled otherwise
+static inline int wgrad_on(hipStream_t ws, int panel_cls, int M, int N, int K, const float* dY, int lddy, const float* X, int ldx,
+                           float* dW, float* db) {
+    if (gemm_wgrad_panel_pending() == 0 && panel_takes(panel_cls, M, N, K, dY, lddy, X, ldx))
+        return gemm_wgrad_panel(ws, panel_np(), N, K, M, dY, lddy, X, ldx, dW, K, db);
+    return gemm_any(ws, 1, 0, N, K, M, dY, lddy, X, ldx, dW, K, nullptr, FIRA_GEMM_ACCUM, 0, db);
+}
+static inline int flush_wgrad_queues(hipStream_t ws) {     // the queued launches on the weight-gradient stream: tiled group, then panels
+    TRY(g_dtype == 1 ? gemm_bf16_group_flush(ws) : gemm_group_flush(ws));
+    return gemm_wgrad_panel_flush(ws, panel_np());
+}
 static inline int flush_grouped_wgrads(hipStream_t s) {
     SideStream& sd = side();
     if (!(sd.stream && sd.enabled)) return 0;
     TRY(side_fork(s));
-    return g_dtype == 1 ? gemm_bf16_group_flush(sd.stream) : gemm_group_flush(sd.stream);
+    return flush_wgrad_queues(sd.stream);
 }
 
 // Deferred column reductions of the backward pass (rowops.hip: deferred_reduce): kernels park one partial row per
@@ -1124,6 +1162,8 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
 
     gemm_group_reset();
     gemm_bf16_group_reset();
+    gemm_wgrad_panel_reset();
+    gemm_wgrad_panel_scratch(p.panel_scratch, p.panel_floats);
     red().reset(p.red_buf, p.red_cap);
     // ---- head: p.logits / p.score / p.gate now hold dlogits / dscore / dgate_logits -------------------------
     // The vocabulary dgrad ([R, V] x [V, 256], the head's largest product) and the copy branch are independent until
@@ -1146,7 +1186,7 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
     // behind the join of the head it ran under the decoder layers' small launches instead and the step lost 0.6 %, same box)
     if (R > 0)
         TRY(linear_wgrad(s, R, p.V, D, p.logits, p.ldl, (c.rows != nullptr && rows == c.rows) ? p.dec_c : dec, D, G + L.wout,
-                         G + L.bout));
+                         G + L.bout, PANEL_VOCAB));
     if (g_dtype == 0) TRY(rank2_rows(s, c.Td, p.gate, c.P + L.wp, p.ddec));        // ddec = dgate Wp: a rank-2 row kernel
     else TRY(linear_dgrad(s, c.Td, 2, D, p.gate, 2, c.P + L.wp, p.ddec, D, false));
     TRY(linear_wgrad_grouped(s, c.Td, 2, D, p.gate, 2, dec, D, G + L.wp, G + L.bp));
@@ -1201,7 +1241,7 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
         SideStream& sd = side();
         if (!(sd.stream && sd.enabled)) return 0;
         TRY(lanes_fork_to(c, sd.stream));
-        return g_dtype == 1 ? gemm_bf16_group_flush(sd.stream) : gemm_group_flush(sd.stream);
+        return flush_wgrad_queues(sd.stream);
     };
     for (int l = p.nl - 1; l >= 0; --l) {
         ProfDecoderTag prof_tag;               // data gradients of the M = B*30 products (the grouped wgrads flush later)
@@ -1269,8 +1309,8 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
             prof_decoder_tag(-1);               // weight gradients: not among the decoder's forward / data-gradient products
             int rc_w = flush_wgrads_all();
             if (!rc_w)
-                rc_w = gemm_any(side().stream, 1, 0, nlay * 2 * D, D, Mc, p.dkv_all + o, p.kvp, p.mem_c, D, G + L.wkv_all + o * D, D, nullptr,
-                                FIRA_GEMM_ACCUM, 0, G + L.bkv_all + o);
+                rc_w = wgrad_on(side().stream, PANEL_KV, Mc, nlay * 2 * D, D, p.dkv_all + o, p.kvp, p.mem_c, D, G + L.wkv_all + o * D,
+                                G + L.bkv_all + o);
             prof_decoder_tag(+1);
             TRY(rc_w);
         }
@@ -1302,9 +1342,9 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
     if (dec_every > 0 && side().stream && side().enabled) {
         // (the K|V weight gradient went out in row blocks inside the loop)
     } else if (fewer_forks() && side().stream && side().enabled)
-        TRY(gemm_any(side().stream, 1, 0, KV, D, Mc, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, D, nullptr, FIRA_GEMM_ACCUM, 0, G + L.bkv_all));
+        TRY(wgrad_on(side().stream, PANEL_KV, Mc, KV, D, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
     else
-    TRY(linear_wgrad(s, Mc, KV, D, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, G + L.bkv_all));
+    TRY(linear_wgrad(s, Mc, KV, D, p.dkv_all, p.kvp, p.mem_c, D, G + L.wkv_all, G + L.bkv_all, PANEL_KV));
     // decoder LayerNorms, copy head: their partial rows were written before the fork of the weight gradient above, and only
     // the end of the step (or the mid-event below, which waits for this stream) reads the sums: off the dependent chain
     TRY(deferred_reduce(side().stream && side().enabled ? side().stream : s, red().tab));

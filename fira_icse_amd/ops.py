@@ -457,3 +457,23 @@ def head_topk(x, wout, bout, k, dtype=0):
     check(_lib.lib().fira_head_topk(cur_stream(), R, V, k, ptr(_f32(x)), ptr(_f32(wout)), ptr(_f32(bout)), ptr(logits), ldl,
                                     ptr(ids), ptr(vals), dtype), "fira_head_topk")
     return ids, vals, logits[:, :V]
+
+
+_panel_scratch = {}
+
+
+def gemm_wgrad_panel(A, B, out, colsum=None, dtype=0, split=True):
+    """fira_gemm_wgrad_panel: out[M,N] += A^T B (A [K, >=M], B [K, N] row-major, row pitches = their strides), optional
+    colsum[M] += column sums of A.  dtype 0: fp32-accurate three-term bf16 split, 1: bf16-rounded operands.  ``split``: hand
+    the library a 64 MB scratch buffer so that it may cut K into slabs over the chip."""
+    K, M, N = A.shape[0], out.shape[0], out.shape[1]
+    assert B.shape[0] == K and B.shape[1] == N and A.stride(1) == 1 and B.stride(1) == 1 and out.stride(1) == 1
+    scratch = None
+    if split:
+        scratch = _panel_scratch.get(A.device)
+        if scratch is None:
+            scratch = _panel_scratch[A.device] = torch.empty(256 * 65536, dtype=torch.float32, device=A.device)
+    check(_lib.lib().fira_gemm_wgrad_panel(cur_stream(), dtype, M, N, K, ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out),
+                                           out.stride(0), ptr(colsum), ptr(scratch), scratch.numel() if split else 0),
+          "fira_gemm_wgrad_panel")
+    return out

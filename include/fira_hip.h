@@ -421,6 +421,18 @@ int fira_train_fwd_bwd(void* stream, const fira_dims* d, const fira_batch* batch
 /* mid_event: optional hipEvent_t recorded on `stream` once the gradients of group [0, split) are final (after the
  * decoder backward, before the encoder backward), so that their RCCL all-reduce can overlap the rest.           */
 
+/* (v8) Weight gradient as a panel product on the bf16 matrix cores (csrc/gemm_wgrad_panel.hip):
+ *     C[M,N] += A^T B ;  colsum[m] += sum_k A[k][m]  (optional: the bias gradient)       A [K, lda], B [K, ldb] row-major
+ * i.e. dW += dY^T X, db += column sums of dY for an nn.Linear with dY = A, X = B.  One workgroup owns a 256 x 256 tile of C
+ * for a slab of K; every operand element is read once per tile.  dtype FIRA_BF16: operands rounded to bf16 (RNE), fp32
+ * accumulation; FIRA_F32: every operand split into three bf16 terms, six exact term products per fp32 product -- fp32-accurate
+ * (error of the order of 2^-24 of |a||b| per term, tests/test_ops_gpu.py) at 2.7x the fp32 MFMA rate.  Shapes: M >= 32,
+ * N a multiple of 256, lda / ldb even, A / B 8-byte aligned, K * ld * 4 < 2 GiB.  C is accumulated into (no atomics: a
+ * workgroup owns its tile).  scratch (optional, scratch_floats >= 65 536 per workgroup of a split product): lets K be split
+ * into slabs over the chip -- the slabs' partial tiles go there and a closing launch adds them to C; NULL = one slab. */
+int fira_gemm_wgrad_panel(void* stream, int dtype, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          float* C, int ldc, float* colsum, float* scratch, size_t scratch_floats);
+
 /* (v8) FeedForward block of a decoder layer (gnn_transformer.py:163-174) as one entry (two products + the row kernel, or the
  * LayerNorm-prologue forms, chosen as in the model-level calls):
  *     h = relu(x W1^T + b1) [M,F] ;  sum = dropout(h W2^T + b2) + x ;  y = LayerNorm(sum) ;  stats = {mean, 1/std}

@@ -986,3 +986,34 @@ def test_head_topk(R, V, k):
     boost[5] = boost[900] = 100.0
     ids2, vals2, _ = ops.head_topk(x, w, b + boost, min(k, 2) if k > 1 else 1)
     assert bool((ids2[:, 0] == 5).all()) and (k == 1 or bool((ids2[:, 1] == 900).all()))
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(256, 256, 10031, 256), (512, 256, 3531, 512), (256, 1024, 530, 256), (24650, 256, 411, 24704),
+                                       (768, 256, 530, 768), (96, 256, 17, 96), (3072, 256, 5000, 3136)])
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("split", [True, False])
+def test_wgrad_panel_product(M, N, K, lda, dtype, split):
+    """fira_gemm_wgrad_panel (gemm_wgrad_panel.hip): C += A^T B, colsum += column sums of A, on the shapes of the training step
+    (encoder / decoder / vocabulary / stacked K|V weight gradients; ragged last tile, K not a multiple of 16, padded pitches).
+    dtype 0: the three-term bf16 split must be fp32-ACCURATE -- against fp64 at the tolerance of the exact-fp32 kernels, and not
+    worse than the fp32 MFMA kernel on the same operands; dtype 1: exact on the bf16-rounded operands."""
+    from fira_icse_amd import ops
+    Afull = randn(K, lda, seed=1)
+    A = Afull[:, :M]
+    B = randn(K, N, seed=2)
+    C0 = randn(M, N, seed=3)
+    cs0 = randn(M, seed=4)
+    C, cs = C0.clone(), cs0.clone()
+    if not split and K > 6000:
+        pytest.skip("one slab: covered by the shorter reductions")
+    ops.gemm_wgrad_panel(A, B, C, cs, dtype=dtype, split=split)
+    r16 = (lambda t: t.float().bfloat16().double()) if dtype else (lambda t: t.double())
+    ref = C0.double() + r16(A).t() @ r16(B)
+    assert rel_err(cs, cs0.double() + A.double().sum(0)) < 2e-6          # (column sums are taken from the fp32 registers)
+    err = rel_err(C, ref)
+    assert err < (3e-6 if K <= 4096 else 6e-6), err
+    if dtype == 0:
+        C32 = C0.clone()
+        ops.gemm(A, B, transA=True, transB=False, out=C32, accumulate=True)
+        e32 = rel_err(C32, ref)
+        assert err < 2.0 * e32 + 2e-7, (err, e32)                        # as accurate as the k-ordered fp32 chains

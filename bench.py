@@ -374,7 +374,8 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
     logit_bytes = 2 * 4 * Bd * cfg.out_len
     step_bytes = w_bytes + kv_bytes + logit_bytes
     step_s = ddt / max(steps_run, 1)
-    decode = {"tokens_per_s": toks * world / ddt, "commits_per_s": a.decode_batch * world / ddt,
+    decode = {"dtype": "f32 (the search always runs the reference's fp32 arithmetic, whatever --dtype says: engine.hip fira_decode_*)",
+              "tokens_per_s": toks * world / ddt, "commits_per_s": a.decode_batch * world / ddt,
               "step_tokens_per_s": a.decode_batch * steps_run * world / ddt, "steps_run": steps_run,
               "mean_tokens_per_commit": toks / a.decode_batch, "batch": a.decode_batch, "beam": 1,
               "ms_per_batch": ddt * 1e3, "ms_per_step": step_s * 1e3, "tokens_per_batch": toks,
@@ -468,7 +469,7 @@ def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     peak_tf = BF16_MFMA_PEAK_TF if dtype == "bf16" else FP32_MFMA_PEAK_TF
     kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if dtype == "bf16" else \
-        "gemm_f32_kernel / gemm_small_kernel (v_mfma_f32_32x32x2_f32)"
+        "gemm_f32_kernel / gemm_tile32_kernel (v_mfma_f32_32x32x2_f32) + wgrad_panel_kernel (weight gradients: fp32-accurate three-term bf16 split on v_mfma_f32_32x32x16_bf16)"
     roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
                 "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
@@ -526,15 +527,53 @@ def attention_work(metas, n_layers, d=256):
 
 
 def rocprof_reference(dtype):
-    """Per-class kernel time of the SAME command from the committed rocprofv3 kernel trace (profiles/r5_kernel_classes.json,
+    """Per-class kernel time of the SAME command from the committed rocprofv3 kernel trace (profiles/r6_kernel_classes.json,
     written by scripts/rocpd_stats.py from `rocprofv3 --kernel-trace --stats -- python bench.py --dtype <dtype> ...`):
     kernel begin-to-end durations, i.e. without the launch gaps and the cross-stream event overlap that the in-process
     HIP-event sums include.  Counters and traces cannot be collected inside this process."""
+    for name in ("r6_kernel_classes.json", "r5_kernel_classes.json"):        # the newest committed trace
+        try:
+            with open(os.path.join(HERE, "profiles", name)) as f:
+                ref = json.load(f).get(dtype)
+            if ref:
+                return ref
+        except Exception:
+            pass
+    return None
+
+
+def lib_sha16():
+    """First 16 hex digits of the SHA-256 of the libfira_hip.so this process loaded (which build produced the line)."""
+    import hashlib
+    from fira_icse_amd import _lib
     try:
-        with open(os.path.join(HERE, "profiles", "r5_kernel_classes.json")) as f:
-            return json.load(f).get(dtype)
-    except Exception:
+        with open(_lib.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
         return None
+
+
+def box_fingerprint():
+    """The pool's boxes fall into a slow and a fast class ~5 % apart on the training line; a device-to-device copy of 1 GiB
+    (read + write, 20 repetitions) separates them the same way and costs 10 ms: GB/s of that copy, with the host name."""
+    try:
+        n = 1 << 28
+        src = torch.empty(n, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            dst.copy_(src)
+        b.record()
+        torch.cuda.synchronize()
+        gbs = 20 * 2.0 * n * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
+        del src, dst
+        return {"host": socket.gethostname(), "copy_GBs": round(gbs, 1)}
+    except Exception as e:      # noqa: BLE001
+        return {"host": socket.gethostname(), "error": repr(e)[:80]}
 
 
 def _sig(x, n=6):
@@ -929,7 +968,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
-                       "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss},
+                       "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss,
+                       "lib_sha16": lib_sha16(), "box": box_fingerprint()},
             "roofline": roofline, "decoder_gemm": decoder_gemm, "gcn": gcn_obj, "comb": comb_object(prof, prof_steps),
             "attention": attn_obj, "spmm": spmm_obj,
             "decode": decode, "cpu_baseline": cpu,

@@ -277,12 +277,7 @@ int fira_beam_select(void* stream, const fira_dims* d, int B, int n_beam, const 
     FIRA_REQUIRE(d && B > 0 && n_beam >= 1 && n_beam <= fira::BEAM_MAX, "fira_beam_select: beam %d outside 1..%d", n_beam,
                  fira::BEAM_MAX);
     const int S = d->sub_len, L = d->sou_len, W = d->vocab + L + S;
-    static const int wide = [] { const char* e = getenv("FIRA_BEAM_SELECT_WIDE"); return e ? atoi(e) : 1; }();   // A/B switch
-    if (!wide)
-        hipLaunchKernelGGL((fira::beam_select_kernel<fira::BEAM_MAX, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, n_beam,
-                           d->tar_len, W, d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in,
-                           gen_out, len_out, prob_out, parent);
-    else if (n_beam <= 4)
+    if (n_beam <= 4)
         hipLaunchKernelGGL((fira::beam_select_kernel<4, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, n_beam, d->tar_len, W,
                            d->vocab, L, S, dist, finished, active, done, sou, sub_token, gen_in, len_in, prob_in, gen_out,
                            len_out, prob_out, parent);

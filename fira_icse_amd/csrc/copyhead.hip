@@ -786,16 +786,14 @@ int decode_dist(hipStream_t s, int R, int V, int S, const float* logits, int ldl
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (R <= 0) return 0;
     FIRA_REQUIRE(gate_logits || (x && wp && bp), "decode_dist: needs the gate logits or the rows / weights to form them");
-    static const int wide_mode = [] { const char* e = getenv("FIRA_DECODE_DIST_WIDE"); return e ? atoi(e) : 1; }();   // A/B switch
-    if ((wide_mode || !gate_logits) && V <= DDW_NPT * DDW_NT && S <= DDW_NT) {
+    if (V <= DDW_NPT * DDW_NT && S <= DDW_NT) {      // the 1024-thread kernel wherever the row fits its registers
         hipLaunchKernelGGL(decode_dist_wide_kernel, dim3(R), dim3(DDW_NT), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
                            gate_logits, x, wp, bp, dist, best_id, best_p);
         FIRA_CHECK_LAUNCH("decode_dist");
         return 0;
     }
     FIRA_REQUIRE(gate_logits, "decode_dist: vocabulary %d / %d memory slots need precomputed gate logits", V, S);
-    static const int reg_mode = [] { const char* e = getenv("FIRA_DECODE_DIST_REG"); return e ? atoi(e) : 1; }();   // A/B switch
-    if (reg_mode && V <= DD_NPT * 256)
+    if (V <= DD_NPT * 256)
         hipLaunchKernelGGL(decode_dist_reg_kernel, dim3(R), dim3(256), 0, s, V, S, logits, ldl, score, mem_valid, qpk,
                            gate_logits, dist, best_id, best_p);
     else
@@ -844,8 +842,7 @@ int head_loss(hipStream_t s, int BT, int T, int V, int S, const int32_t* compact
     ProfScope prof(s, PROF_HEAD, 0.0);
     if (BT <= 0) return 0;
     const bool reg = (V % 2 == 0) && (V / 2 <= 256 * HL_PAIRS) && (ldl % 2 == 0) && ((uintptr_t)logits % 8 == 0);
-    static const bool fast = [] { const char* e = getenv("FIRA_HEAD_FAST"); return !(e && e[0] == '0'); }();   // A/B switch
-    if (reg && !argmax_out && fast)
+    if (reg && !argmax_out)
         hipLaunchKernelGGL(head_loss_train_kernel, dim3(BT), dim3(256), 0, s, T, V, S, compact_row, logits, ldl, score,
                            mem_valid, gate_logits, tar_label, loss_sum, n_tok, want_grad, row_bt);
     else if (reg)

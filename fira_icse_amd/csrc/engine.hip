@@ -981,9 +981,8 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
                          0, nullptr));
             // two marks (behind layers 1 and the last one) instead of one per layer: every wait is a barrier packet in the
             // decoder's dependent chain, and the projections (~10 us each) are far ahead of the layers that read them
-            // (layer 2's cross attention starts ~170 us after this fork).  FIRA_KV_MARKS=6: one per layer (A/B switch)
-            static const bool per_layer = [] { const char* e = getenv("FIRA_KV_MARKS"); return e && e[0] == '6'; }();
-            if (per_layer || l == std::min(1, p.nl - 1) || l == p.nl - 1) TRY(side_mark(&c.ev_kv[l]));
+            // (layer 2's cross attention starts ~170 us after this fork; one mark per layer measured -0.5 % in round 4)
+            if (l == std::min(1, p.nl - 1) || l == p.nl - 1) TRY(side_mark(&c.ev_kv[l]));
         }
         // (LinearSource: output rows straight to their dense [B,370] slots through the row map of the GEMM epilogue)
         TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
@@ -1521,7 +1520,10 @@ static int backward_encoder(Ctx& c, BwdMid& mid) {
         TRY(gemm_f32_ex(rs, 1, 0, p.nl * D, D, 4, p.dvtab_all, p.nl * D, c.P + L.mark_emb, D, G + L.w2_all, D, nullptr,
                         FIRA_GEMM_ACCUM, 1, G + L.b2_all));
         // rows 1..3 only: padding_idx row 0 never gets a gradient (its slot of the zeroed gradient buffer stays untouched)
-        TRY(linear_dgrad(rs, 3, p.nl * D, D, p.dvtab_all + (size_t)p.nl * D, p.nl * D, c.P + L.w2_all, G + L.mark_emb + D, D, true));
+        // (a 3-row product over K = nl * 256: split over K -- as one latency-kernel chain it was a 48 us launch, the longest of
+        //  the auxiliary stream's tail)
+        TRY(gemm_f32_ex(rs, 0, 0, 3, D, p.nl * D, p.dvtab_all + (size_t)p.nl * D, p.nl * D, c.P + L.w2_all, D, G + L.mark_emb + D, D,
+                        nullptr, FIRA_GEMM_ACCUM, std::max(2, p.nl), nullptr));
         if (ax) TRY(side_mark(&ev_tail));
     }
     // embeddings (padding_idx = 0 on all three encoder tables: gnn_transformer.py:32-39)
@@ -1926,8 +1928,6 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
     // key-valid history of this step + token embedding + position `step` (gnn_transformer.py:110-113): one launch
     TRY(decode_embed(s, BR, T, step, tokens, params + L.dec_emb, p.pos_tar + (size_t)step * D, dp.x, dp.hist[cur]));
     const size_t lay = (size_t)BR * T * D;
-    // FIRA_DECODE_ATTN=0: the round-2 path (three projections + the 32-query MFMA attention kernel): A/B switch
-    static const bool stream_attn = [] { const char* e = getenv("FIRA_DECODE_ATTN"); return !(e && e[0] == '0'); }();
     // LayerNorms deferred into the next product's prologue (see decoder_forward): pend_* = the block still owed
     const float *pend_g = nullptr, *pend_b = nullptr;
     float* pend_y = nullptr;
@@ -1956,33 +1956,20 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
         const DecLayer& w = L.dec[l];
         float* kc = dp.kc[cur] + l * lay;
         float* vc = dp.vc[cur] + l * lay;
-        if (stream_attn) {
-            // q|k|v as ONE product; the attention kernel reads the new key / value from its output row and appends them
-            // to the cache (decode_attention, attention.hip)
-            TRY(consume(3 * D, dp.x, params + w.wqkv, params + w.bqkv, dp.qkv, 0));
-            TRY(decode_attention(s, BR, H, step + 1, dp.qkv, 3 * D, kc, D, vc, D, dp.hist[cur], dp.ao, D, T, T, 1,
-                                 dp.qkv + D, dp.qkv + 2 * D, 3 * D, kc, vc));
-        } else {
-            if (pending) {                      // three separate products read x: materialise it first
-                TRY(add_layernorm_fwd(s, BR, dp.s, nullptr, pend_g, pend_b, pend_y, nullptr, 0.f, 0, 0, nullptr));
-                pending = false;
-            }
-            TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv, params + w.bqkv, dp.q, D));
-            TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)D * D, params + w.bqkv + D, kc + (size_t)step * D, T * D));
-            TRY(linear(s, BR, D, D, dp.x, D, params + w.wqkv + (size_t)2 * D * D, params + w.bqkv + 2 * D, vc + (size_t)step * D, T * D));
-            TRY(attention_fwd_ex(s, BR, H, 1, step + 1, dp.q, D, kc, D, vc, D, dp.hist[cur], 0, 0, dp.ao, D, T, T, 1));
-        }
+        // q|k|v as ONE product; the attention kernel reads the new key / value from its output row and appends them to the
+        // cache (decode_attention, attention.hip).  (The round-2 path -- three projections + the 32-query MFMA attention
+        // kernel, FIRA_DECODE_ATTN=0 -- lost by 0.2 ms per step in round 3 and is gone.)
+        TRY(consume(3 * D, dp.x, params + w.wqkv, params + w.bqkv, dp.qkv, 0));
+        TRY(decode_attention(s, BR, H, step + 1, dp.qkv, 3 * D, kc, D, vc, D, dp.hist[cur], dp.ao, D, T, T, 1,
+                             dp.qkv + D, dp.qkv + 2 * D, 3 * D, kc, vc));
         TRY(close_block(D, dp.ao, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, true));
         TRY(consume(D, dp.xa, params + w.wq_c, params + w.bq_c, dp.qc, 0));
-        if (stream_attn && (flags & FIRA_DECODE_KV_BF16))
+        if (flags & FIRA_DECODE_KV_BF16)
             TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, p.kvp, dp.kv16 + l * 2 * D + D, p.kvp, p.mem_valid_c,
                                       dp.ao, D, Sm, Sm, n_beam, p.mem_off));
-        else if (stream_attn)
+        else
             TRY(decode_attention(s, BR, H, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp, p.mem_valid_c,
                                  dp.ao, D, Sm, Sm, n_beam, nullptr, nullptr, 0, nullptr, nullptr, p.mem_off));
-        else
-            TRY(attention_fwd_ex(s, BR, H, 1, Sm, dp.qc, D, p.kv_all + l * 2 * D, p.kvp, p.kv_all + l * 2 * D + D, p.kvp,
-                                 p.mem_valid_c, 0, 0, dp.ao, D, Sm, Sm, n_beam, nullptr, 0, 0, p.mem_off));
         TRY(close_block(D, dp.ao, params + w.wo_c, params + w.bo_c, dp.xa, params + w.lnc_g, params + w.lnc_b, dp.xc, true));
         TRY(consume(p.F, dp.xc, params + w.w1, params + w.b1, dp.h, FIRA_GEMM_RELU));
         // (the last block's LayerNorm is owed too: the target projection of the copy head consumes it and leaves x behind)

@@ -368,10 +368,6 @@ static unsigned side_lds_pad(hipStream_t s) {
     static const int pad = [] { const char* e = getenv("FIRA_SIDE_LDS_PAD"); return e ? atoi(e) : 7168; }();
     return (pad > 0 && s && s == g_pad_stream) ? (unsigned)pad : 0u;
 }
-static int wgrad_wg_cap() {
-    static const int cap = [] { const char* e = getenv("FIRA_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? (v + 7) / 8 * 8 : 0; }();
-    return cap;
-}
 
 template <int BM, int BN>
 static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -381,7 +377,6 @@ static int launch(hipStream_t s, int tA, int tB, int M, int N, int K, const floa
     const int spread_n = (long)N > (long)M ? 1 : 0;
     const int chunk = cdiv(tiles_m * tiles_n * splitk, 8);
     dim3 grid(8 * chunk);
-    if (tA && wgrad_wg_cap() > 0) grid.x = std::min<unsigned>(grid.x, (unsigned)wgrad_wg_cap());
     int k_chunk = cdiv(cdiv(K, splitk), BK) * BK;
     const int vecA = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
     const int vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
@@ -472,8 +467,7 @@ int gemm_group_flush(hipStream_t s) {
         bytes += 4.0 * (M * K + N * K + M * N);
     }
     ProfScope prof(s, PROF_GEMM, flop, bytes);
-    const int cap = wgrad_wg_cap();
-    hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(cap > 0 ? std::min(cap, t.wg_start[t.n]) : t.wg_start[t.n]), dim3(256), side_lds_pad(s), s, t);
+    hipLaunchKernelGGL(gemm_grouped_wgrad_kernel, dim3(t.wg_start[t.n]), dim3(256), side_lds_pad(s), s, t);
     t.n = 0;
     FIRA_CHECK_LAUNCH("gemm_grouped_wgrad");
     return 0;

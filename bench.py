@@ -969,7 +969,7 @@ def main():
             "host_enqueue_ms_per_step": t_enq / a.steps * 1e3,
             "config": {"workload": (wl % B) + ", 650-node graphs (mean nnz %.0f/graph), vocab 24650" % (nnz_mean / B),
                        "global_batch": B * world, "parallelism": "dp%d%s" % (world, "+zero1" if (a.zero1 and world > 1) else ""), "loss": loss,
-                       "lib_sha16": lib_sha16(), "box": box_fingerprint()},
+                       "lib_sha16": lib_sha16(), "box": box_fingerprint() if not a.no_extras else {"host": socket.gethostname()}},
             "roofline": roofline, "decoder_gemm": decoder_gemm, "gcn": gcn_obj, "comb": comb_object(prof, prof_steps),
             "attention": attn_obj, "spmm": spmm_obj,
             "decode": decode, "cpu_baseline": cpu,

@@ -1542,6 +1542,13 @@ static int backward_encoder(Ctx& c, BwdMid& mid) {
             TRY(embed_gather_bwd(s, p.B, p.A, bt.ast_change, G + L.ast_emb, p.H, p.N, p.L + p.S, 0));
     }
     if (c.adam) {
+        // INVARIANT this early update rests on (tests/test_model_gpu.py::test_one_call_step_equals_backward_then_adam
+        // compares with the two-call path in fp32 and bf16): behind the decoder's backward pass NOTHING, on any stream, reads a
+        // parameter of [0, mark_emb) -- the encoder's backward kernels read encoder weights of [mark_emb, live) and workspace
+        // copies (W21, WcT, the bf16 shadows), the weight-gradient stream reads activations only, the auxiliary stream's reads of
+        // wkv_all / ws precede ev_dmem, which the caller's stream has waited for -- and the gradients of [0, split) are final at
+        // ev_groupA, those of the two embedding tables when the two launches above have run.  A new kernel that breaks either
+        // half must move this update behind the final join.
         // Adam on [0, split) (69 % of the live parameters) HERE: the caller's stream would otherwise stand waiting for the last
         // grouped weight gradient / the unfold products / the deferred reductions of the other two streams (timeline: 30-60 us)
         // and then run the whole update alone.  Nothing enqueued after the decoder's backward pass reads a parameter of

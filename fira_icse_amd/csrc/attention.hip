@@ -606,6 +606,127 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(int H, int Tk, co
     }
 }
 
+// ---- (round 6) the decode step's whole self-attention block of one row as ONE launch -------------------------------------
+// run_model.py:250-267 runs, per decoder layer and step, gnn_transformer.py:137-161 on the newest position: the one-query self
+// attention over <= 30 cached keys, the output projection fc_o, the residual, the post-LayerNorm -- and then the cross
+// attention's query projection fc_q (gnn_transformer.py:142) reads the result.  At M = B * beam <= 192 rows these were three
+// dependent launches of the step's 53 (attention 4.8 us + two 32x32-tile products 5.8 us each, each ~1 us of work behind
+// a launch and a memory round trip).  Here one workgroup owns one ROW: scores of the 8 heads x <= 32 keys (a thread per
+// (head, key), a 128-byte key slice each), soft-max over the 32 lanes of a head, o = P V (a thread per output element,
+// coalesced 1 KiB value rows), then the two 256 x 256 products as MATRIX-VECTOR products on the VALU against k-major copies
+// of the weights (coalesced 1 KiB rows, L2-resident: 256 KB per product and workgroup -- at <= 192 rows the re-reads are
+// cheaper than a launch boundary), the LayerNorm in between.  The newest key / value come from the merged q|k|v projection's
+// output row and are appended to the cache, as decode_attention does.
+__global__ __launch_bounds__(256) void decode_self_block_kernel(int Tk, int T, const float* __restrict__ qkv,
+                                                                float* __restrict__ Kc, float* __restrict__ Vc,
+                                                                const int32_t* __restrict__ hist,
+                                                                const float* __restrict__ WoT, const float* __restrict__ bo,
+                                                                const float* __restrict__ xres,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ WqT, const float* __restrict__ bq,
+                                                                float* __restrict__ xa, float* __restrict__ qc) {
+    __shared__ __attribute__((aligned(16))) float s_q[FIRA_D], s_o[FIRA_D], s_x[FIRA_D];
+    __shared__ float s_p[8][32];
+    __shared__ float s_red[2][4];
+    __shared__ __attribute__((aligned(16))) float s_part[4][FIRA_D];
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* my = qkv + (size_t)row * 3 * FIRA_D;
+    const float knew = my[FIRA_D + t], vnew = my[2 * FIRA_D + t];
+    s_q[t] = my[t];
+    float* kc_row = Kc + (size_t)row * T * FIRA_D;
+    float* vc_row = Vc + (size_t)row * T * FIRA_D;
+    kc_row[(size_t)(Tk - 1) * FIRA_D + t] = knew;                 // append this step's key / value to the cache
+    vc_row[(size_t)(Tk - 1) * FIRA_D + t] = vnew;
+    __syncthreads();
+    // ---- scores: thread = (head h, key j); the newest key is read from the projection's row (the cache store above is not
+    // ordered against this workgroup's own loads)
+    {
+        const int h = t >> 5, j = t & 31;
+        const bool valid = j < Tk && hist[(size_t)row * T + j] != 0;
+        const float* kp = (j == Tk - 1) ? my + FIRA_D + h * FIRA_DH : kc_row + (size_t)min(j, Tk - 1) * FIRA_D + h * FIRA_DH;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < FIRA_DH / 4; ++c) {
+            const f32x4v k4 = *reinterpret_cast<const f32x4v*>(kp + c * 4);
+            const f32x4v q4 = *reinterpret_cast<const f32x4v*>(&s_q[h * FIRA_DH + c * 4]);
+            d = fmaf(q4.x, k4.x, d); d = fmaf(q4.y, k4.y, d); d = fmaf(q4.z, k4.z, d); d = fmaf(q4.w, k4.w, d);
+        }
+        const float sc = valid ? d * INV_SQRT_DH : -INFINITY;
+        float mx = sc;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));   // (xor < 32 stays inside the head's half-wave)
+        const float pr = valid ? __expf(sc - mx) : 0.f;
+        float sum = pr;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        s_p[h][j] = sum > 0.f ? pr / sum : 0.f;                    // (no valid key: zeros, as decode_attention writes)
+    }
+    __syncthreads();
+    // ---- o = P V: thread = output element (head t >> 5)
+    {
+        const int h = t >> 5;
+        float o = 0.f;
+        int j = 0;
+        for (; j + 4 <= Tk - 1; j += 4) {                          // cached values, four rows in flight
+            const float v0 = vc_row[(size_t)j * FIRA_D + t], v1 = vc_row[(size_t)(j + 1) * FIRA_D + t];
+            const float v2 = vc_row[(size_t)(j + 2) * FIRA_D + t], v3 = vc_row[(size_t)(j + 3) * FIRA_D + t];
+            o = fmaf(s_p[h][j], v0, o); o = fmaf(s_p[h][j + 1], v1, o); o = fmaf(s_p[h][j + 2], v2, o); o = fmaf(s_p[h][j + 3], v3, o);
+        }
+        for (; j < Tk - 1; ++j) o = fmaf(s_p[h][j], vc_row[(size_t)j * FIRA_D + t], o);
+        o = fmaf(s_p[h][Tk - 1], vnew, o);
+        s_o[t] = o;
+    }
+    __syncthreads();
+    // ---- s = o Wo^T + bo + x ;  xa = LayerNorm(s)       (thread = output column; WoT[k][n] coalesced over n)
+    // y[n] = bias[n] + sum_k v[k] WT[k][n]: wave w takes k in [64 w, 64 w + 64), a lane four columns (16-byte loads, one
+    // whole 1 KiB weight row per wave and instruction, 16 rows in flight); the four partial vectors meet in LDS.  (A thread
+    // per column walking all 256 k with 8 loads in flight -- the first version -- was a chain of 32 dependent round trips per
+    // product: the kernel was slower than the three launches it replaces.)
+    auto matvec = [&](const float* __restrict__ WT, const float* v, float bias_n) -> float {
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        const float* wp = WT + (size_t)(wave * 64) * FIRA_D + lane * 4;
+#pragma unroll
+        for (int k0 = 0; k0 < 64; k0 += 16) {
+            f32x4v w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4v*>(wp + (size_t)(k0 + u) * FIRA_D);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += w[u] * v[wave * 64 + k0 + u];
+        }
+        __syncthreads();                                   // (s_part may still be read from the previous product)
+        *reinterpret_cast<f32x4v*>(&s_part[wave][lane * 4]) = acc;
+        __syncthreads();
+        return bias_n + ((s_part[0][t] + s_part[1][t]) + (s_part[2][t] + s_part[3][t]));
+    };
+    const float sres = matvec(WoT, s_o, bo[t]) + xres[(size_t)row * FIRA_D + t];
+    float part = wave_sum(sres);
+    if (lane == 0) s_red[0][wave] = part;
+    __syncthreads();
+    const float mean = ((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3])) * (1.0f / FIRA_D);
+    const float dv = sres - mean;
+    part = wave_sum(dv * dv);
+    if (lane == 0) s_red[1][wave] = part;
+    __syncthreads();
+    const float var = ((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3])) * (1.0f / FIRA_D);
+    const float y = dv * (1.0f / sqrtf(var + 1e-5f)) * gamma[t] + beta[t];
+    xa[(size_t)row * FIRA_D + t] = y;
+    s_x[t] = y;
+    __syncthreads();
+    // ---- the cross attention's query: qc = xa Wq^T + bq
+    qc[(size_t)row * FIRA_D + t] = matvec(WqT, s_x, bq[t]);
+}
+int decode_self_block(hipStream_t s, int BR, int Tk, int T, const float* qkv, float* Kc, float* Vc, const int32_t* hist,
+                      const float* WoT, const float* bo, const float* xres, const float* gamma, const float* beta,
+                      const float* WqT, const float* bq, float* xa, float* qc) {
+    ProfScope prof(s, PROF_ATTN, 0.0);
+    if (BR <= 0) return 0;
+    FIRA_REQUIRE(Tk >= 1 && Tk <= 32 && Tk <= T, "decode_self_block: %d keys (at most 32)", Tk);
+    hipLaunchKernelGGL(decode_self_block_kernel, dim3(BR), dim3(256), 0, s, Tk, T, qkv, Kc, Vc, hist, WoT, bo, xres, gamma, beta,
+                       WqT, bq, xa, qc);
+    FIRA_CHECK_LAUNCH("decode_self_block");
+    return 0;
+}
+
 // bf16 K / V rows (raw bf16, ldk / ldv in elements, rows 8-byte aligned): the decode loop's optional bf16 cross-K|V cache
 int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const uint16_t* K, int ldk,
                           const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,

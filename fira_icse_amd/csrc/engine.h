@@ -230,6 +230,11 @@ int decode_attention(hipStream_t s, int BR, int H, int Tk, const float* Q, int l
                      const float* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
                      const float* Knew = nullptr, const float* Vnew = nullptr, int ldn = 0, float* Kc_out = nullptr,
                      float* Vc_out = nullptr, const int32_t* k_off = nullptr);
+// the decode step's self-attention block of every row as one launch (attention.hip): one-query attention over the <= 32 cached
+// keys (+ this step's, appended), xa = LN(o Wo^T + bo + xres), qc = xa Wq^T + bq; WoT / WqT are the k-major copies
+int decode_self_block(hipStream_t s, int BR, int Tk, int T, const float* qkv, float* Kc, float* Vc, const int32_t* hist,
+                      const float* WoT, const float* bo, const float* xres, const float* gamma, const float* beta,
+                      const float* WqT, const float* bq, float* xa, float* qc);
 int decode_attention_kv16(hipStream_t s, int BR, int H, int Tk, const float* Q, int ldq, const uint16_t* K, int ldk,
                           const uint16_t* V, int ldv, const int32_t* key_valid, float* O, int ldo, int kb, int kvb, int qpk,
                           const int32_t* k_off = nullptr);

@@ -1614,6 +1614,7 @@ struct DecodePlan {
     float *kc[2], *vc[2];
     int32_t* hist[2];
     float *x, *q, *qkv, *ao, *s, *xa, *qc, *xc, *h, *tgt, *score, *gate, *logits;
+    float* wsT;                      // (round 6) k-major copies of every layer's self-attention fc_o and cross-attention fc_q weights
     uint16_t* kv16;                  // optional bf16 copy of the cross K|V rows of all layers (FIRA_DECODE_KV_BF16)
     // flags: FIRA_DECODE_KV_BF16 reserves the bf16 copy of the cross K|V (148 MB at batch 64); without it nothing is reserved
     size_t build(void* ws, const fira_dims& d, int B, int n_beam, int flags = 0) {
@@ -1629,6 +1630,7 @@ struct DecodePlan {
         xc = a.f(BR * D); h = a.f((size_t)BR * d.d_ff); tgt = a.f(BR * D);
         score = a.f((size_t)BR * (d.sou_len + d.sub_len)); gate = a.f((size_t)BR * 2);
         logits = a.f((size_t)BR * enc.ldl);
+        wsT = a.f((size_t)d.n_layer * 2 * D * D);
         kv16 = (flags & FIRA_DECODE_KV_BF16) ? a.get<uint16_t>((size_t)enc.MB * enc.kvp) : nullptr;      // (last: the other offsets do not move)
         return used + a.used;
     }
@@ -1900,6 +1902,14 @@ int fira_decode_begin_ex(void* stream, const fira_dims* d, const fira_batch* bat
     TRY(check_counts(batch, p));
     TRY(encoder_forward(c, false));     // also leaves kv_all (cross K|V of all layers) and src = LinearSource(memory)
     TRY(rows_move(c.s, 1, b2.n_mem, FIRA_D, p.mem, p.mem_c, nullptr, b2.mem_dst));   // dense memory view for callers
+    {   // k-major copies of fc_o (self attention) and fc_q (cross attention) of every layer: decode_self_block streams them
+        TransposeTable tt;
+        for (int l = 0; l < p.nl && tt.n + 2 <= 24; ++l) {
+            tt.src[tt.n] = params + L->dec[l].wo_s; tt.dst[tt.n++] = dp.wsT + (size_t)(2 * l) * FIRA_D * FIRA_D;
+            tt.src[tt.n] = params + L->dec[l].wq_c; tt.dst[tt.n++] = dp.wsT + (size_t)(2 * l + 1) * FIRA_D * FIRA_D;
+        }
+        TRY(transpose256_table(c.s, tt));
+    }
     // optional: the cross K|V rows the step loop streams 30 times, once more in bf16 (half the bytes per step; rows of
     // masked slots are converted too -- they are never read)
     if (flags & FIRA_DECODE_KV_BF16) TRY(rows_to_bf16(c.s, (int64_t)b2.n_mem * p.kvp, p.kv_all, dp.kv16));
@@ -1940,6 +1950,9 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
     float* pend_y = nullptr;
     bool pending = false;
     DtypeScope dtype_scope(0);                  // the search runs the reference's fp32 arithmetic
+    // FIRA_DECODE_SELF_BLOCK=0: the three launches (A/B switch); the fused kernel needs the model's 8 x 32 heads and <= 32 keys
+    static const bool self_block_off = [] { const char* e = getenv("FIRA_DECODE_SELF_BLOCK"); return e && e[0] == '0'; }();
+    const bool self_block = !self_block_off && H * FIRA_DH == FIRA_D && H == 8 && T <= 32 && p.nl <= 12;
     auto consume = [&](int N, const float* xin, const float* W, const float* b, float* Y, int flags) -> int {
         if (pending) {
             int rc = 0;
@@ -1967,10 +1980,18 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
         // cache (decode_attention, attention.hip).  (The round-2 path -- three projections + the 32-query MFMA attention
         // kernel, FIRA_DECODE_ATTN=0 -- lost by 0.2 ms per step in round 3 and is gone.)
         TRY(consume(3 * D, dp.x, params + w.wqkv, params + w.bqkv, dp.qkv, 0));
+        if (self_block) {
+            // (round 6) attention over the cached keys + fc_o + residual + LayerNorm + the cross attention's fc_q: ONE launch per
+            // layer instead of three of the dependent chain (attention.hip: decode_self_block)
+            TRY(decode_self_block(s, BR, step + 1, T, dp.qkv, kc, vc, dp.hist[cur], dp.wsT + (size_t)(2 * l) * D * D, params + w.bo_s,
+                                  dp.x, params + w.lns_g, params + w.lns_b, dp.wsT + (size_t)(2 * l + 1) * D * D, params + w.bq_c, dp.xa,
+                                  dp.qc));
+        } else {
         TRY(decode_attention(s, BR, H, step + 1, dp.qkv, 3 * D, kc, D, vc, D, dp.hist[cur], dp.ao, D, T, T, 1,
                              dp.qkv + D, dp.qkv + 2 * D, 3 * D, kc, vc));
         TRY(close_block(D, dp.ao, params + w.wo_s, params + w.bo_s, dp.x, params + w.lns_g, params + w.lns_b, dp.xa, true));
         TRY(consume(D, dp.xa, params + w.wq_c, params + w.bq_c, dp.qc, 0));
+        }
         if (flags & FIRA_DECODE_KV_BF16)
             TRY(decode_attention_kv16(s, BR, H, Sm, dp.qc, D, dp.kv16 + l * 2 * D, p.kvp, dp.kv16 + l * 2 * D + D, p.kvp, p.mem_valid_c,
                                       dp.ao, D, Sm, Sm, n_beam, p.mem_off));

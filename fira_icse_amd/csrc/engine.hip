@@ -2002,6 +2002,9 @@ int fira_decode_step_ex(void* stream, const fira_dims* d, const float* params, v
         TRY(consume(p.F, dp.xc, params + w.w1, params + w.b1, dp.h, FIRA_GEMM_RELU));
         // (the last block's LayerNorm is owed too: the target projection of the copy head consumes it and leaves x behind)
         TRY(close_block(p.F, dp.h, params + w.w2, params + w.b2, dp.xc, params + w.lnf_g, params + w.lnf_b, dp.x, true));
+        // (round 6, measured and removed: fc_o + LayerNorm + FeedForward as two ROW kernels -- dot products on the k-contiguous
+        // weights, grid rows x 4 -- 0.351 against 0.333 ms per step: every row's workgroup pulls 512 KB of weights through its own
+        // CU's L2 port, 128 MB per launch at 64 rows, where the 32-row tiles amortise them; profiles/r6_probes.md)
     }
     TRY(consume(D, dp.x, params + L.wt, nullptr, dp.tgt, 0));      // LinearTarget(LN(..)) [+ x materialised]
     TRY(linear(s, BR, p.V, D, dp.x, D, params + L.wout, params + L.bout, dp.logits, p.ldl));

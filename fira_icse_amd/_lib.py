@@ -67,6 +67,7 @@ SIGNATURES = {
     "fira_csr_spmm": (_I, [_P, _I, _L, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I]),
     "fira_gcn_layer_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32, _I]),
     "fira_gcn_layer_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "fira_gcn_weight_planes": (_I, [_P, _I, _P, _P]),
     "fira_combination_block_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32, _U32, _I]),
     "fira_combination_block_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _F, _U64, _U32, _U32, _I]),
     "fira_combination_block_bwd_part_floats": (_I, []),
@@ -164,7 +165,7 @@ def load():
     # FIRA_HIP_LIB (A/B timing of an older build through the model-level entry points, whose signatures did not change
     # between v5 and v8 -- v8 appended a field to fira_batch, which older builds never read; callers ask has_symbol() before
     # using an entry an older build lacks) may load an older library; the tree's own library must be v8
-    ok = (8,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7, 8)
+    ok = (9,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7, 8, 9)
     if lib.fira_abi_version() not in ok:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib

@@ -93,9 +93,13 @@ int csr_spmm_ex(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t*
 int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                   const float* Wk, const float* bias, const float* r1_col, const float* gamma, const float* beta, float* sum,
                   float* y, float* stats, float* rowsum_out, const int32_t* slot2, float* y2, float dropout, uint64_t seed,
-                  uint32_t site, int bf16);
+                  uint32_t site, int bf16, const uint16_t* Wx = nullptr);
 int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* dY,
-                  const float* Wk, float* u_out, float* acc_out, int bf16);
+                  const float* Wk, float* u_out, float* acc_out, int bf16, const uint16_t* Wx = nullptr);
+// (round 6) Wx: the weight as three bf16 planes in fragment order (gcn_split_planes of the [256 n][256 k] matrix B with
+// out = U B^T: W21 for the forward product, W21^T for the backward one) -- fp32 mode then runs the product as six bf16 MFMA
+// terms per k step at fp32 accuracy (gcn_fused.hip: X3)
+int gcn_split_planes(hipStream_t s, int n, const float* const* src, uint16_t* const* dst);
 int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[l] = W[l]^T, nl stacked [256,256] matrices
 // One Combination block per launch (comb_fused.hip): q|k projections, the two-way gate, the output projection, dropout,
 // residual and LayerNorm of gnn_transformer.py:176-205 on the code rows.  WqT / WkT / WoT: the three weights K-MAJOR

@@ -74,6 +74,7 @@ struct Plan {
     float *vtab_all, *H, *mem, *mem_c, *src_c, *x0, *kv_all, *src, *tgt, *score, *gate, *dec_c, *logits;
     float *W21, *c21, *rsum;        // GCN: per layer fc2.weight . fc1.weight [256,256] and fc2.weight . fc1.bias [256]; A_hat 1
     float *W21t;                    // the folded weights transposed = k-major for U W21^T: what the fused GCN forward streams
+    uint16_t *W21x = nullptr, *W21tx = nullptr;   // (round 6) three bf16 planes of W21 / W21^T per layer, fragment order (gcn_fused.hip: X3)
     float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
@@ -128,6 +129,8 @@ struct Plan {
         vtab_all = a.f((size_t)4 * nl * D);
         W21 = a.f((size_t)nl * D * D); c21 = a.f((size_t)nl * D); rsum = a.f((size_t)NB);
         W21t = a.f((size_t)nl * D * D);
+        W21x = a.get<uint16_t>((size_t)nl * 3 * D * D);
+        W21tx = a.get<uint16_t>((size_t)nl * 3 * D * D);
         WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
@@ -837,6 +840,12 @@ static int lanes_fork_to(Ctx& c, hipStream_t target) {
 // self-loop, are masked as attention keys / copy slots and receive exactly zero gradient (SURVEY.md §8a note N1), so
 // leaving them out changes no consumed value.  Nc = n_nodes, Cc = n_code, Mc = n_mem below.
 // FIRA_FOLD_ONE=0: the folded GCN weights as two products + a transpose per layer (14 launches) instead of one launch (A/B switch)
+// FIRA_GCN_X3=0: the fused GCN product of fp32 mode as fp32 MFMAs instead of three bf16 terms (A/B switch; gcn_fused.hip)
+static inline bool fold_one_launch();
+static inline bool gcn_x3_on(int nl) {
+    static const bool off = [] { const char* e = getenv("FIRA_GCN_X3"); return e && e[0] == '0'; }();
+    return !off && g_dtype == 0 && gcn_fused_on() && fold_one_launch() && nl <= 10;
+}
 static inline bool fold_one_launch() {
     static const bool off = [] { const char* e = getenv("FIRA_FOLD_ONE"); return e && e[0] == '0'; }();
     return !off;
@@ -887,6 +896,16 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const float *fW2[16], *fW1[16], *fb1[16];
             for (int l = 0; l < p.nl; ++l) { fW2[l] = c.P + L.enc[l].fc2w; fW1[l] = c.P + L.enc[l].fc1w; fb1[l] = c.P + L.enc[l].fc1b; }
             TRY(gcn_fold_weights(fs, p.nl, fW2, fW1, fb1, p.W21, gcn_fused_on() ? p.W21t : nullptr, p.c21));
+            if (gcn_x3_on(p.nl)) {       // the planes of W21 (forward: out = U W21^T) and of W21^T (backward: out = V W21)
+                const float* src[24];
+                uint16_t* dst[24];
+                int n = 0;
+                for (int l = 0; l < p.nl; ++l) {
+                    src[n] = p.W21 + (size_t)l * D * D; dst[n++] = p.W21x + (size_t)l * 3 * D * D;
+                    if (c.G) { src[n] = p.W21t + (size_t)l * D * D; dst[n++] = p.W21tx + (size_t)l * 3 * D * D; }
+                }
+                TRY(gcn_split_planes(fs, n, src, dst));
+            }
             if (ax && (!g_Wb || gcn_fused_on())) TRY(side_mark(&ev_fold0));
         } else
         for (int l = 0; l < p.nl; ++l) {
@@ -961,7 +980,7 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             TRY(gcn_fused_fwd(s, Nc, bt.rowptr, bt.col, bt.val, X, p.W21t + (size_t)l * D * D, c.P + w.fc2b, p.c21 + (size_t)l * D,
                               c.P + w.ln2g, c.P + w.ln2b, e.s2, p.X[l + 1], e.st2, l == 0 ? p.rsum : nullptr,
                               last ? p.mem_slot : p.code_slot, last ? p.mem_c : p.enc[l + 1].Xc, c.p_gcn, c.seed,
-                              site(l, SITE_GCN), g_dtype == 1));
+                              site(l, SITE_GCN), g_dtype == 1, gcn_x3_on(p.nl) ? p.W21x + (size_t)l * 3 * D * D : nullptr));
         else
         TRY(linear_ln(s, Nc, D, e.Z, D, p.W21 + (size_t)l * D * D, c.P + w.fc2b, X, c.P + w.ln2g, c.P + w.ln2b, e.s2,
                       p.X[l + 1], e.st2, c.p_gcn, c.seed, site(l, SITE_GCN), nullptr, p.rsum, p.c21 + (size_t)l * D,
@@ -1445,7 +1464,8 @@ static int backward_encoder(Ctx& c, BwdMid& mid) {
             // one launch: V = A_hat dY (stored in e.Z, which the fused forward pass does not use), other = ds + V W21.
             // The weight gradient follows from the same V: dW21 = dY^T (A_hat X) = (A_hat dY)^T X = V^T X
             if (gcn_fused_bwd_on()) {
-                TRY(gcn_fused_bwd(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, p.W21 + (size_t)l * D * D, e.Z, other, g_dtype == 1));
+                TRY(gcn_fused_bwd(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, p.W21 + (size_t)l * D * D, e.Z, other, g_dtype == 1,
+                                  gcn_x3_on(p.nl) ? p.W21tx + (size_t)l * 3 * D * D : nullptr));
             } else {
                 TRY(csr_spmm_ex(s, Nc, bt.rowptr, bt.col, bt.val, g.dY2, D, e.Z, D, 0, 1, 0, nullptr));            // V
                 TRY(linear_dgrad(s, Nc, D, D, e.Z, D, p.W21 + (size_t)l * D * D, other, D, true));                 // other += V W21

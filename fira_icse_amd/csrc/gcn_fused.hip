@@ -45,6 +45,26 @@ constexpr int GF_GRID = 256;              // one workgroup per CU
 // dynamic LDS: the panel + the row sums; asking for more than half of a CU's 160 KB keeps the dispatcher from placing two
 // of these workgroups on one CU while another CU stays empty
 constexpr size_t GF_LDS = 84 * 1024;
+// X3 (round 6): the product on the bf16 matrix cores at fp32 accuracy.  The gathered rows are split once, by the wave that
+// gathered them, into three bf16 terms  u = hi + mid + lo  (each the RNE rounding of what the previous ones left) and stored as
+// three bf16 PLANES of the panel ([64 rows][256 k] x 2 B each: 96 KB); the weight arrives pre-split in fragment order
+// (gcn_split_planes: once per step and layer, beside the fold).  A k step of 32 is then six v_mfma_f32_16x16x32_bf16 per tile
+// -- lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, smallest first, fp32 accumulation; the three dropped terms are below 2^-24
+// of the product -- instead of eight v_mfma_f32_16x16x4_f32: 96 against 256 matrix-core cycles.  Per pass of three tiles the
+// product phase is 3.8 us of matrix-core time against 10.2 us, 1.15 MB of fragment reads from LDS (256 B / clk: 1.9 us) and
+// 384 KB of weight planes from L2 (2.6 us at 64 B / clk and CU).  Plane rows are 512 B with the 16-byte columns XOR-swizzled by
+// (row & 15): the 16 lanes of a ds_read_b128 group read 16 distinct bank quads.
+constexpr size_t GX_PLANE = (size_t)GF_ROWS * 512;                 // bytes of one bf16 plane of the panel
+constexpr size_t GF_LDS_X3 = 3 * GX_PLANE + 1024;                  // 97 KB: the planes + the row sums (one workgroup per CU)
+constexpr size_t GX_WPLANE = (size_t)FIRA_D * FIRA_D * 2;          // bytes of one bf16 plane of a weight
+__device__ __forceinline__ int gx_off(int row, int c16) { return row * 512 + ((c16 ^ (row & 15)) << 4); }
+__device__ __forceinline__ uint32_t gx_pack(float a, float b) {
+    const af32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));      // v_cvt_pk_bf16_f32 (RNE)
+}
+// what is left of (a, b) after their bf16 roundings `pk` (exact in fp32)
+__device__ __forceinline__ float gx_rest_lo(float a, uint32_t pk) { return a - __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float gx_rest_hi(float b, uint32_t pk) { return b - __builtin_bit_cast(float, pk & 0xffff0000u); }
 
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
@@ -70,11 +90,12 @@ struct GcnFusedArgs {
 // float offset of 16-byte column `quad` (0..63) of panel row `row`
 __device__ __forceinline__ int gf_off(int row, int quad) { return row * FIRA_D + ((quad ^ (row & 11)) << 2); }
 
-template <bool BF, bool BWD>
+template <bool BF, bool BWD, bool X3 = false>
 __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float gf_lds[];
-    float* const sm_u = gf_lds;                          // [64][256] swizzled
-    float* const sm_rs = gf_lds + GF_ROWS * FIRA_D;      // [64] row sums of A_hat
+    float* const sm_u = gf_lds;                          // [64][256] swizzled (X3: the RESULT rows only, over the dead planes)
+    char* const sm_p = reinterpret_cast<char*>(gf_lds);  // X3: three bf16 planes [64][256]
+    float* const sm_rs = X3 ? gf_lds + 3 * GX_PLANE / 4 : gf_lds + GF_ROWS * FIRA_D;      // [64] row sums of A_hat
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     // workgroup b runs on XCD b % 8: logical id (b % 8) * 32 + b / 8 gives every XCD a contiguous eighth of the tiles (whole
@@ -193,6 +214,16 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
 #pragma unroll
             for (int i = 0; i < GF_RPW; ++i) {
                 const int lr = wave * GF_RPW + i;
+                if constexpr (X3) {
+                    f32x4v u = acc[i];
+                    const int o = gx_off(lr, lane >> 1) + (lane & 1) * 8;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const uint32_t p0 = gx_pack(u.x, u.y), p1 = gx_pack(u.z, u.w);
+                        *reinterpret_cast<uint2*>(sm_p + pl * GX_PLANE + o) = uint2{p0, p1};
+                        if (pl < 2) { u.x = gx_rest_lo(u.x, p0); u.y = gx_rest_hi(u.y, p0); u.z = gx_rest_lo(u.z, p1); u.w = gx_rest_hi(u.w, p1); }
+                    }
+                } else
                 *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = acc[i];                  // (rows past the end: zeros)
                 if (lane == 0) sm_rs[lr] = vsum[i];
                 if (BWD && rbase + i < row_end && a.u_out)
@@ -203,12 +234,22 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
         // (round 5) the first 64-wide k chunk of this wave's B fragments is requested BEFORE the barrier that closes the gather: a wave
         // that is done early has its weights on the way while the slowest wave still collects neighbours (with the gather's 64
         // row registers live the request cannot move further up: 128 VGPRs per lane at 1024 threads)
-        const rsrc_t rW = buf_rsrc(a.W, FIRA_D * FIRA_D * 4u);
+        const rsrc_t rW = buf_rsrc(a.W, X3 ? 3u * (unsigned)GX_WPLANE : FIRA_D * FIRA_D * 4u);
         const unsigned wlane = (unsigned)((kq * 16) * FIRA_D + wave * 16 + l15) * 4u;
         float b[2][16];
+        // X3: the weight planes are stored in fragment order -- unit ((16-column block w) * 8 + k step s) * 64 + lane, 16 bytes
+        // each: one contiguous 1 KiB per wave, plane and k step
+        const unsigned xlane = (unsigned)(wave * 8 * 64 + lane) * 16u;
+        uint4 bx[2][3];
+        if constexpr (X3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bx[0][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, xlane, pl * (int)GX_WPLANE, 0));
+        } else {
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2)
             b[0][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
+        }
         asm volatile("" ::: "memory");
         __syncthreads();
 
@@ -216,7 +257,38 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
         f32x4acc acc[GF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < GF_TMAX; ++tt) acc[tt] = f32x4acc{0.f, 0.f, 0.f, 0.f};
-        {
+        if constexpr (X3) {
+            // fragment of tile tt, k step s: row 16 tt + l15, 16-byte column 4 s + kq  ->  byte (a_q ^ (s << 6)) + tt * 8192 of a plane
+            const int a_q = l15 * 512 + (((kq ^ (l15 & 3)) << 4) | ((l15 >> 2) << 6));
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bx[(ks + 1) & 1][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                              rW, xlane, pl * (int)GX_WPLANE + (ks + 1) * 1024, 0));
+                }
+                asm volatile("" ::: "memory");
+                const abf16x8 bh = __builtin_bit_cast(abf16x8, bx[ks & 1][0]), bm = __builtin_bit_cast(abf16x8, bx[ks & 1][1]),
+                              bl = __builtin_bit_cast(abf16x8, bx[ks & 1][2]);
+#pragma unroll
+                for (int tt = 0; tt < GF_TMAX; ++tt) {
+                    if (tt < nt) {                           // block-uniform
+                        const char* pa = sm_p + ((a_q ^ (ks << 6)) + tt * (GF_TILE * 512));
+                        const abf16x8 ah = *reinterpret_cast<const abf16x8*>(pa);
+                        const abf16x8 am = *reinterpret_cast<const abf16x8*>(pa + GX_PLANE);
+                        const abf16x8 al = *reinterpret_cast<const abf16x8*>(pa + 2 * GX_PLANE);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[tt], 0, 0, 0);
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[tt], 0, 0, 0);
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+        } else {
             constexpr int NC = FIRA_D / 64;              // k chunks: lane (row l15, quarter kq) holds k = 64 c + 16 kq + s
             // (buffer loads: ONE per-lane byte offset in a VGPR, the k row as the scalar offset -- with flat pointers the
             //  compiler kept a 64-bit address pair per 4 KB window of the weight, hoisted all 64 of them and spilled)
@@ -344,15 +416,15 @@ static double gcn_fused_bytes(int n_rows, bool bwd) {
     return 4.0 * (n_rows + 1) + (bwd ? 4.0 : 3.0) * n_rows * FIRA_D * 4.0;
 }
 template <typename K>
-static int gcn_fused_lds(K kernel) {            // once per kernel: allow the > 64 KB dynamic LDS request
-    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GF_LDS);
+static int gcn_fused_lds(K kernel, size_t bytes = GF_LDS) {            // once per kernel: allow the > 64 KB dynamic LDS request
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     return e == hipSuccess ? 0 : set_err("gcn_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
 }
 
 int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                   const float* Wk, const float* bias, const float* r1_col, const float* gamma, const float* beta, float* sum,
                   float* y, float* stats, float* rowsum_out, const int32_t* slot2, float* y2, float dropout, uint64_t seed,
-                  uint32_t site, int bf16) {
+                  uint32_t site, int bf16, const uint16_t* Wx) {
     if (n_rows <= 0) return 0;
     FIRA_REQUIRE(rowptr && col && val && X && Wk && bias && r1_col && gamma && beta && sum && y && stats,
                  "gcn_fused_fwd: null pointer argument");
@@ -364,8 +436,13 @@ int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     a.bias = bias; a.r1_col = r1_col; a.res = X; a.gamma = gamma; a.beta = beta;
     a.sum = sum; a.y = y; a.stats = stats; a.rowsum_out = rowsum_out; a.slot2 = y2 ? slot2 : nullptr; a.y2 = y2;
     a.p = dropout; a.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; a.seed = seed; a.site = site;
-    static const int attr = gcn_fused_lds(gcn_fused_kernel<true, false>) | gcn_fused_lds(gcn_fused_kernel<false, false>);
+    static const int attr = gcn_fused_lds(gcn_fused_kernel<true, false>) | gcn_fused_lds(gcn_fused_kernel<false, false>) |
+                            gcn_fused_lds(gcn_fused_kernel<false, false, true>, GF_LDS_X3);
     if (attr) return attr;
+    if (Wx && !bf16) {                   // fp32 mode, the product as three bf16 terms (Wx: the weight's planes, gcn_split_planes)
+        a.W = reinterpret_cast<const float*>(Wx);
+        hipLaunchKernelGGL((gcn_fused_kernel<false, false, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
+    } else
     if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, false>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     else hipLaunchKernelGGL((gcn_fused_kernel<false, false>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     FIRA_CHECK_LAUNCH("gcn_fused_fwd");
@@ -373,7 +450,7 @@ int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
 }
 
 int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* dY,
-                  const float* Wk, float* u_out, float* acc_out, int bf16) {
+                  const float* Wk, float* u_out, float* acc_out, int bf16, const uint16_t* Wx) {
     if (n_rows <= 0) return 0;
     FIRA_REQUIRE(rowptr && col && val && dY && Wk && acc_out, "gcn_fused_bwd: null pointer argument");
     FIRA_REQUIRE((uintptr_t)dY % 16 == 0 && (uintptr_t)Wk % 16 == 0 && (uintptr_t)acc_out % 16 == 0 && (uintptr_t)u_out % 16 == 0,
@@ -382,11 +459,50 @@ int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     GcnFusedArgs a{};
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.X = dY; a.W = Wk;
     a.u_out = u_out; a.acc_out = acc_out;
-    static const int attr = gcn_fused_lds(gcn_fused_kernel<true, true>) | gcn_fused_lds(gcn_fused_kernel<false, true>);
+    static const int attr = gcn_fused_lds(gcn_fused_kernel<true, true>) | gcn_fused_lds(gcn_fused_kernel<false, true>) |
+                            gcn_fused_lds(gcn_fused_kernel<false, true, true>, GF_LDS_X3);
     if (attr) return attr;
+    if (Wx && !bf16) {
+        a.W = reinterpret_cast<const float*>(Wx);
+        hipLaunchKernelGGL((gcn_fused_kernel<false, true, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
+    } else
     if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     else hipLaunchKernelGGL((gcn_fused_kernel<false, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     FIRA_CHECK_LAUNCH("gcn_fused_bwd");
+    return 0;
+}
+
+// The three bf16 planes of n [256 n][256 k] fp32 matrices in the fragment order the X3 product streams (see gcn_fused_kernel):
+// plane pl of matrix m at dst[m] + pl * 65536 elements; unit ((n / 16) * 8 + k / 32) * 64 + ((k / 8) % 4) * 16 + n % 16 holds the
+// eight values k .. k + 7 (k a multiple of 8) of row n.  A thread owns one unit: two float4 reads (a row's units are consecutive
+// threads), three 16-byte stores.
+struct SplitTable { int n = 0; const float* src[24]; uint16_t* dst[24]; };
+__global__ __launch_bounds__(256) void gcn_split_planes_kernel(const SplitTable tab) {
+    const int m = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;        // j < 8192: row n = j / 32, unit c = j % 32 of the row
+    const int n = j >> 5, c = j & 31;
+    const float* src = tab.src[m] + (size_t)n * FIRA_D + c * 8;
+    f32x4v u0 = *reinterpret_cast<const f32x4v*>(src), u1 = *reinterpret_cast<const f32x4v*>(src + 4);
+    const int unit = ((n >> 4) * 8 + (c >> 2)) * 64 + (c & 3) * 16 + (n & 15);
+    uint16_t* dst = tab.dst[m] + (size_t)unit * 8;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const uint32_t p0 = gx_pack(u0.x, u0.y), p1 = gx_pack(u0.z, u0.w), p2 = gx_pack(u1.x, u1.y), p3 = gx_pack(u1.z, u1.w);
+        *reinterpret_cast<uint4*>(dst + (size_t)pl * FIRA_D * FIRA_D) = uint4{p0, p1, p2, p3};
+        if (pl < 2) {
+            u0.x = gx_rest_lo(u0.x, p0); u0.y = gx_rest_hi(u0.y, p0); u0.z = gx_rest_lo(u0.z, p1); u0.w = gx_rest_hi(u0.w, p1);
+            u1.x = gx_rest_lo(u1.x, p2); u1.y = gx_rest_hi(u1.y, p2); u1.z = gx_rest_lo(u1.z, p3); u1.w = gx_rest_hi(u1.w, p3);
+        }
+    }
+}
+// n matrices [256 n][256 k] (fp32, row-major) -> their planes (3 * 65536 bf16 each)
+int gcn_split_planes(hipStream_t s, int n, const float* const* src, uint16_t* const* dst) {
+    if (n <= 0) return 0;
+    FIRA_REQUIRE(n <= 24, "gcn_split_planes: %d matrices", n);
+    SplitTable tab;
+    tab.n = n;
+    for (int i = 0; i < n; ++i) { tab.src[i] = src[i]; tab.dst[i] = dst[i]; }
+    hipLaunchKernelGGL(gcn_split_planes_kernel, dim3(FIRA_D * FIRA_D / 8 / 256, n), dim3(256), 0, s, tab);
+    FIRA_CHECK_LAUNCH("gcn_split_planes");
     return 0;
 }
 
@@ -416,14 +532,24 @@ int fira_gcn_layer_fwd(void* stream, int n_rows, const int32_t* rowptr, const in
                        const float* W21t, const float* bias, const float* c21, const float* gamma, const float* beta,
                        float* sum, float* y, float* stats, float* rowsum_out, float dropout, uint64_t seed, uint32_t site,
                        int dtype) {
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_gcn_layer_fwd: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_gcn_layer_fwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
     return fira::gcn_fused_fwd((hipStream_t)stream, n_rows, rowptr, col, val, X, W21t, bias, c21, gamma, beta, sum, y, stats,
-                               rowsum_out, nullptr, nullptr, dropout, seed, site, dtype == FIRA_BF16);
+                               rowsum_out, nullptr, nullptr, dropout, seed, site, dtype == FIRA_BF16,
+                               dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(W21t) : nullptr);
 }
 int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* dY,
                        const float* W21, float* V, float* dX, int dtype) {
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_gcn_layer_bwd: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_gcn_layer_bwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
     FIRA_REQUIRE(V != nullptr, "fira_gcn_layer_bwd: V (the weight gradient's operand) must be given");
-    return fira::gcn_fused_bwd((hipStream_t)stream, n_rows, rowptr, col, val, dY, W21, V, dX, dtype == FIRA_BF16);
+    return fira::gcn_fused_bwd((hipStream_t)stream, n_rows, rowptr, col, val, dY, W21, V, dX, dtype == FIRA_BF16,
+                               dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(W21) : nullptr);
+}
+int fira_gcn_weight_planes(void* stream, int n_mats, const float* B, uint16_t* planes) {
+    FIRA_REQUIRE(B && planes && n_mats > 0 && n_mats <= 24, "fira_gcn_weight_planes: bad argument");
+    FIRA_REQUIRE((uintptr_t)B % 16 == 0 && (uintptr_t)planes % 16 == 0, "fira_gcn_weight_planes: 16-byte aligned pointers");
+    const float* src[24];
+    uint16_t* dst[24];
+    for (int i = 0; i < n_mats; ++i) { src[i] = B + (size_t)i * FIRA_D * FIRA_D; dst[i] = planes + (size_t)i * 3 * FIRA_D * FIRA_D; }
+    return fira::gcn_split_planes((hipStream_t)stream, n_mats, src, dst);
 }
 }

@@ -203,15 +203,29 @@ def colsum(X):
     return out
 
 
+def gcn_weight_planes(B):
+    """fira_gcn_weight_planes: the three bf16 planes (fragment order) of n stacked [256, 256] fp32 matrices B[n][k] for the
+    FIRA_F32X3 form of fira_gcn_layer_{fwd,bwd} (out = U B^T)."""
+    B = _f32(B).contiguous()
+    n = B.numel() // (256 * 256)
+    planes = torch.empty(n * 3 * 256 * 256, dtype=torch.int16, device=B.device)
+    check(_lib.lib().fira_gcn_weight_planes(cur_stream(), n, ptr(B), ptr(planes)), "fira_gcn_weight_planes")
+    return planes
+
+
 def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0, want_rowsum=True):
     """fira_gcn_layer_fwd: (sum, y, stats, rowsum) of one folded GCN layer on the CSR adjacency (global column ids);
-    W21t = W21^T contiguous."""
+    W21t = W21^T contiguous.  dtype 2 (FIRA_F32X3): the planes of W21 are formed here."""
     n = X.shape[0]
+    if dtype == 2:
+        W21t = gcn_weight_planes(_f32(W21t).t().contiguous())
+    else:
+        W21t = _f32(W21t)
     summ, y = torch.empty_like(X), torch.empty_like(X)
     stats = torch.empty((n, 2), dtype=torch.float32, device=X.device)
     rs = torch.empty(n, dtype=torch.float32, device=X.device) if want_rowsum else None
     check(_lib.lib().fira_gcn_layer_fwd(cur_stream(), n, ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)), ptr(_f32(X)),
-                                        ptr(_f32(W21t)), ptr(_f32(bias)), ptr(_f32(c21)), ptr(_f32(gamma)), ptr(_f32(beta)),
+                                        ptr(W21t), ptr(_f32(bias)), ptr(_f32(c21)), ptr(_f32(gamma)), ptr(_f32(beta)),
                                         ptr(summ), ptr(y), ptr(stats), ptr(rs), dropout, seed, site, dtype),
           "fira_gcn_layer_fwd")
     return summ, y, stats, rs
@@ -261,8 +275,9 @@ def combination_block_bwd(dG, rows, summ, stats, gamma, Wo, Wqk, qk, vtab, mark,
 def gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=0):
     """fira_gcn_layer_bwd: V = A_hat dY (returned), dX += V W21 in place."""
     V = torch.empty_like(dY)
+    W = gcn_weight_planes(_f32(W21).t().contiguous()) if dtype == 2 else _f32(W21)     # (FIRA_F32X3: out = V B^T with B = W21^T)
     check(_lib.lib().fira_gcn_layer_bwd(cur_stream(), dY.shape[0], ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)),
-                                        ptr(_f32(dY)), ptr(_f32(W21)), ptr(V), ptr(_f32(dX)), dtype), "fira_gcn_layer_bwd")
+                                        ptr(_f32(dY)), ptr(W), ptr(V), ptr(_f32(dX)), dtype), "fira_gcn_layer_bwd")
     return V
 
 

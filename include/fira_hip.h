@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 8
+#define FIRA_ABI_VERSION 9
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -111,6 +111,8 @@ typedef struct fira_train_opts {
 } fira_train_opts;
 #define FIRA_F32 0
 #define FIRA_BF16 1
+#define FIRA_F32X3 2      /* (v9, fira_gcn_layer_* only) fp32 data and accuracy, the product on the bf16 matrix cores: every operand as
+                           * three bf16 terms hi + mid + lo, six of the nine term products, fp32 accumulation (see below)           */
 
 const char* fira_last_error(void);
 int         fira_abi_version(void);
@@ -213,6 +215,13 @@ int fira_gcn_layer_fwd(void* stream, int n_rows, const int32_t* rowptr, const in
                        uint64_t seed, uint32_t site, int dtype);
 int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val,
                        const float* dY, const float* W21, float* V, float* dX, int dtype);
+/* (v9) dtype FIRA_F32X3 -- what the engine's fp32 mode runs: the gathered rows are split into three bf16 terms by the wave
+ * that gathered them, the weight arrives pre-split: the weight argument (W21t / W21 above) is then the output of
+ * fira_gcn_weight_planes for the matrix B [256 n][256 k] with  out = U B^T , i.e. B = W21 for fira_gcn_layer_fwd and
+ * B = W21^T for fira_gcn_layer_bwd.  planes: n_mats x 3 x 65536 bf16 (hi | mid | lo plane, each in MFMA fragment order).
+ * The result differs from the FIRA_F32 launch by fp32 rounding noise only (the dropped lo.lo, lo.mid, mid.lo terms are
+ * below 2^-24 of a product).                                                                                           */
+int fira_gcn_weight_planes(void* stream, int n_mats, const float* B, uint16_t* planes);
 
 /* One Combination block (gnn_transformer.py:176-205 with combination_layer.py:7-17) on n_rows code rows as ONE launch
  * (round 5, csrc/comb_fused.hip; dtype FIRA_F32, or FIRA_BF16 = the operands of the three products rounded to bf16, fp32

@@ -20,6 +20,7 @@
 #include "engine.h"
 #include "mfma_frag.h"
 #include "epilogue.h"
+#include "x3.h"
 
 namespace fira {
 
@@ -125,11 +126,63 @@ __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const
     for (int s2 = 0; s2 < 16; ++s2) bx[s2] = b[0][s2];
 }
 
-template <bool BF>
+// X3 (round 6, fp32 mode; x3.h): the same chain on the bf16 matrix cores at fp32 accuracy.  The panel holds the A operand as
+// three bf16 planes, the weights arrive as pre-split planes in fragment order (gcn_split_planes of B[n][k] with out = U B^T:
+// Wq / Wk / Wo as stored for the forward block, their transposes for the backward one); a k step of 32 is six
+// v_mfma_f32_16x16x32_bf16 per tile.  bx = the three planes' units of k step 0, handed from product to product as above.
+__device__ __forceinline__ void cx_first(const uint16_t* __restrict__ Wx, unsigned xlane, uint4 (&b0)[3]) {
+    const rsrc_t rW = buf_rsrc(Wx, 3u * (unsigned)GX_WPLANE);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        b0[pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, xlane, pl * (int)GX_WPLANE, 0));
+}
+template <int TM>
+__device__ __forceinline__ void cx_product(const char* __restrict__ sm_p, size_t plane_bytes, int a_q, const uint16_t* __restrict__ Wx,
+                                           unsigned xlane, int nt, uint4 (&bx)[3], cf_acc (&acc)[TM],
+                                           const uint16_t* __restrict__ Wnext = nullptr) {
+    const rsrc_t rW = buf_rsrc(Wx, 3u * (unsigned)GX_WPLANE);
+    const rsrc_t rN = buf_rsrc(Wnext ? Wnext : Wx, 3u * (unsigned)GX_WPLANE);
+    uint4 b[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b[0][pl] = bx[pl];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks + 1 < 8) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[(ks + 1) & 1][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                    rW, xlane, pl * (int)GX_WPLANE + (ks + 1) * 1024, 0));
+        } else if (Wnext) {                              // (block-uniform; k step 7 reads b[1]: b[0] is free)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[0][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rN, xlane, pl * (int)GX_WPLANE, 0));
+        }
+        asm volatile("" ::: "memory");
+        const abf16x8 bh = __builtin_bit_cast(abf16x8, b[ks & 1][0]), bm = __builtin_bit_cast(abf16x8, b[ks & 1][1]),
+                      bl = __builtin_bit_cast(abf16x8, b[ks & 1][2]);
+#pragma unroll
+        for (int tt = 0; tt < TM; ++tt) {
+            if (tt < nt) {                               // block-uniform
+                const char* pa = sm_p + ((a_q ^ (ks << 6)) + tt * (CF_TILE * 512));
+                const abf16x8 ah = *reinterpret_cast<const abf16x8*>(pa);
+                const abf16x8 am = *reinterpret_cast<const abf16x8*>(pa + plane_bytes);
+                const abf16x8 al = *reinterpret_cast<const abf16x8*>(pa + 2 * plane_bytes);
+                FIRA_X3_MFMA(acc[tt], ah, am, al, bh, bm, bl)
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bx[pl] = b[0][pl];
+}
+constexpr size_t CX_PLANE = (size_t)CF_ROWS * 512;        // forward: bytes of one bf16 plane of the 32-row panel
+
+template <bool BF, bool X3 = false>
 __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const CombFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cf_lds[];
-    float* const sm_u = cf_lds;                                            // [32][256] swizzled
-    int* const sm_mark = reinterpret_cast<int*>(cf_lds + CF_ROWS * FIRA_D);   // [32]
+    float* const sm_u = cf_lds;                                            // [32][256] swizzled (X3: the closing rows only)
+    char* const sm_p = reinterpret_cast<char*>(cf_lds);                    // X3: three bf16 planes [32][256] (48 KB)
+    int* const sm_mark = reinterpret_cast<int*>(cf_lds + (X3 ? 3 * CX_PLANE / 4 : (size_t)CF_ROWS * FIRA_D));   // [32]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int wg = (blockIdx.x & 7) * (CF_GRID / 8) + (blockIdx.x >> 3);      // XCD b % 8 owns a contiguous eighth of the tiles
@@ -152,6 +205,10 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                 vt3 = a.vtab[(size_t)3 * a.ldv + col];
     const rsrc_t rQK = buf_rsrc(a.qk, (unsigned)((size_t)a.n_rows * 2 * FIRA_D * 4));
     const rsrc_t rC = buf_rsrc(a.c, (unsigned)((size_t)a.n_rows * FIRA_D * 4));
+    const unsigned xlane = gx_wlane(wave, lane);
+    const int a_q = gx_frag_base(l15, kq);
+    const uint16_t* const Wx = reinterpret_cast<const uint16_t*>(a.WqT);      // X3: planes of Wq | Wk | Wo (three matrices)
+    constexpr size_t WX = 3 * (size_t)FIRA_D * FIRA_D;                        // bf16 elements of one matrix's planes
 
     for (int pass = 0; pass < t_cnt; pass += CF_TMAX) {
         const int nt = min(CF_TMAX, t_cnt - pass);
@@ -159,7 +216,9 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
         // ------------------------------------------------------------ 1. the tile's code rows -> panel
         float bx[16];
-        cf_first_chunk(a.WqT, wlane, bx);
+        uint4 bx3[3];
+        if constexpr (X3) cx_first(Wx, xlane, bx3);
+        else cf_first_chunk(a.WqT, wlane, bx);
         asm volatile("" ::: "memory");
         {
             f32x4v x[CF_RPW];
@@ -172,7 +231,9 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
 #pragma unroll
             for (int i = 0; i < CF_RPW; ++i) {
                 const int row = row0 + wave * CF_RPW + i;
-                *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f};
+                const f32x4v xv = row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f};
+                if constexpr (X3) gx_store_row4(sm_p, CX_PLANE, wave * CF_RPW + i, lane, xv);
+                else *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = xv;
             }
         }
         __syncthreads();
@@ -180,8 +241,13 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc aq[CF_TMAX], ak[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) { aq[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; ak[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (X3) {
+            cx_product<CF_TMAX>(sm_p, CX_PLANE, a_q, Wx, xlane, nt, bx3, aq, Wx + WX);
+            cx_product<CF_TMAX>(sm_p, CX_PLANE, a_q, Wx + WX, xlane, nt, bx3, ak, Wx + 2 * WX);
+        } else {
         cf_product<BF, CF_TMAX>(sm_u, a_off, a.WqT, wlane, nt, bx, aq, a.WkT);
         cf_product<BF, CF_TMAX>(sm_u, a_off, a.WkT, wlane, nt, bx, ak, a.WoT);       // (Wo's first chunk: in flight under the gate)
+        }
         __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
         // ------------------------------------------------------------ 3. the gate, element by element in the accumulator layout
 #pragma unroll
@@ -203,7 +269,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q), rQK, o2, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, k), rQK, o2, FIRA_D * 4, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), rC, o, 0, 0);
-                    sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = live ? c : 0.f;
+                    if constexpr (X3) gx_store_elem(sm_p, CX_PLANE, rl, col, live ? c : 0.f);
+                    else sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = live ? c : 0.f;
                 }
             }
         }
@@ -212,7 +279,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc ao[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) ao[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
-        cf_product<BF, CF_TMAX>(sm_u, a_off, a.WoT, wlane, nt, bx, ao);
+        if constexpr (X3) cx_product<CF_TMAX>(sm_p, CX_PLANE, a_q, Wx + 2 * WX, xlane, nt, bx3, ao);
+        else cf_product<BF, CF_TMAX>(sm_u, a_off, a.WoT, wlane, nt, bx, ao);
         // what the closing rows need from memory, requested before the accumulators go back through the panel
         const int rbase = row0 + wave * CF_RPW;
         const f32x4v bias4 = *reinterpret_cast<const f32x4v*>(a.bo + lane * 4);
@@ -273,7 +341,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
-                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int bf16) {
+                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int bf16, const uint16_t* Wx) {
     if (n_rows <= 0) return 0;
     FIRA_REQUIRE(Xc && WqT && WkT && WoT && bqk && bo && vtab && mark && qk && c && gamma && beta && sum && y && stats,
                  "comb_fused_fwd: null pointer argument");
@@ -291,9 +359,15 @@ int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT,
         hipError_t e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }();
     if (attr) return attr;
+    if (Wx && !bf16) {                   // fp32 mode, three bf16 terms per operand (Wx: planes of Wq | Wk | Wo as stored)
+        a.WqT = reinterpret_cast<const float*>(Wx);
+        hipLaunchKernelGGL((comb_fused_fwd_kernel<false, true>), dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+    } else
     if (bf16) hipLaunchKernelGGL(comb_fused_fwd_kernel<true>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     else hipLaunchKernelGGL(comb_fused_fwd_kernel<false>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     FIRA_CHECK_LAUNCH("comb_fused_fwd");
@@ -336,15 +410,20 @@ struct CombFusedBwdArgs {
     uint32_t site_gate, site_out;
 };
 
-template <bool BF>
+constexpr size_t CBX_PLANE = (size_t)CB_ROWS * 512;       // backward: bytes of one bf16 plane of a 16-row panel
+constexpr size_t CB_LDS_X3 = 100 * 1024;                  // two panels of three planes (48 KB) + marks + the column sums (48 KB)
+template <bool BF, bool X3 = false>
 __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const CombFusedBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float cf_lds[];
-    float* const sm_u = cf_lds;                                            // panel 1 [32][256]: dYc, then dq, then dX
-    float* const sm_w = cf_lds + CB_ROWS * FIRA_D;                         // panel 2 [32][256]: dk
-    int* const sm_mark = reinterpret_cast<int*>(cf_lds + 2 * CB_ROWS * FIRA_D);
+    constexpr size_t PANEL = X3 ? 3 * CBX_PLANE / 4 : (size_t)CB_ROWS * FIRA_D;      // floats of one panel
+    float* const sm_u = cf_lds;                                            // panel 1 [16][256]: dYc, then dq, then dX (X3: fp32 only for dX)
+    float* const sm_w = cf_lds + PANEL;                                    // panel 2 [16][256]: dk
+    char* const sm_p1 = reinterpret_cast<char*>(sm_u);                     // X3: the panels as three bf16 planes each
+    char* const sm_p2 = reinterpret_cast<char*>(sm_w);
+    int* const sm_mark = reinterpret_cast<int*>(cf_lds + 2 * PANEL);
     // column sums of the whole workgroup, kept in LDS between the passes (in registers they cost 12 per lane next to the
     // product's fragments): every lane owns its slots -- plain read-modify-write, no atomics
-    float* const red = cf_lds + 2 * CB_ROWS * FIRA_D + 64;              // [16 waves][dgamma 256 | dbeta 256]
+    float* const red = cf_lds + 2 * PANEL + 64;                         // [16 waves][dgamma 256 | dbeta 256]
     float* const redv = red + CF_WAVES * 2 * FIRA_D;                    // [4 kq][4 marks][256 columns]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -364,6 +443,10 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
     const rsrc_t rQK = buf_rsrc(a.qk, (unsigned)((size_t)a.n_rows * 2 * FIRA_D * 4));
     const rsrc_t rDQK = buf_rsrc(a.dqk, (unsigned)((size_t)a.n_rows * 2 * FIRA_D * 4));
     const float is = 1.0f / 5.656854249492381f;
+    const unsigned xlane = gx_wlane(wave, lane);
+    const int a_q = gx_frag_base(l15, kq);
+    const uint16_t* const WTx = reinterpret_cast<const uint16_t*>(a.Wo);      // X3: planes of Wq^T | Wk^T | Wo^T (three matrices)
+    constexpr size_t WX = 3 * (size_t)FIRA_D * FIRA_D;
     *reinterpret_cast<f32x4v*>(&red[wave * 2 * FIRA_D + lane * 4]) = f32x4v{0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<f32x4v*>(&red[wave * 2 * FIRA_D + FIRA_D + lane * 4]) = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -374,7 +457,9 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         const int row0 = (t_beg + pass) * CF_TILE;
         const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
         float bx[16];
-        cf_first_chunk(a.Wo, wlane, bx);
+        uint4 bx3[3];
+        if constexpr (X3) cx_first(WTx + 2 * WX, xlane, bx3);
+        else cf_first_chunk(a.Wo, wlane, bx);
         asm volatile("" ::: "memory");
         // ------------------------------------------------------------ 1. LayerNorm backward of this wave's rows -> dYc
         const int rbase = row0 + wave * CB_RPW;
@@ -415,7 +500,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                     o4.z *= dropout_scale(a.seed, a.site_out, e0 + 2, a.p, a.inv_keep);
                     o4.w *= dropout_scale(a.seed, a.site_out, e0 + 3, a.p, a.inv_keep);
                 }
-                *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = o4;                 // (rows past the end: zeros)
+                if constexpr (X3) gx_store_row4(sm_p1, CBX_PLANE, wave * CB_RPW + i, lane, o4);
+                else *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = o4;                 // (rows past the end: zeros)
                 if (live) *reinterpret_cast<f32x4v*>(a.dYc + (size_t)(rbase + i) * FIRA_D + lane * 4) = o4;
             }
         }
@@ -440,6 +526,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         cf_acc ac[CB_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) ac[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+        if constexpr (X3) cx_product<CB_TMAX>(sm_p1, CBX_PLANE, a_q, WTx + 2 * WX, xlane, nt, bx3, ac, WTx);
+        else
         cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wo, wlane, nt, bx, ac, a.Wqk);    // (Wq's first chunk: in flight under the gate's arithmetic)
         if constexpr (BF) load_qk();
         __syncthreads();                                                // the panel's A fragments are consumed
@@ -468,8 +556,13 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dq), rDQK, o2, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dk), rDQK, o2, FIRA_D * 4, 0);
                     redv[(kq * 4 + m) * FIRA_D + col] += dv;             // (dv = 0 past the end; this lane's own slot)
+                    if constexpr (X3) {
+                        gx_store_elem(sm_p1, CBX_PLANE, rl, col, dq);
+                        gx_store_elem(sm_p2, CBX_PLANE, rl, col, dk);
+                    } else {
                     sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = dq;
                     sm_w[d_off[r] + tt * (CF_TILE * FIRA_D)] = dk;
+                    }
                 }
             }
         }
@@ -478,8 +571,13 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         cf_acc ax[CB_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) ax[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+        if constexpr (X3) {
+            cx_product<CB_TMAX>(sm_p1, CBX_PLANE, a_q, WTx, xlane, nt, bx3, ax, WTx + WX);
+            cx_product<CB_TMAX>(sm_p2, CBX_PLANE, a_q, WTx + WX, xlane, nt, bx3, ax);
+        } else {
         cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wqk, wlane, nt, bx, ax, a.Wqk + (size_t)FIRA_D * FIRA_D);
         cf_product<BF, CB_TMAX>(sm_w, a_off, a.Wqk + (size_t)FIRA_D * FIRA_D, wlane, nt, bx, ax);
+        }
         __syncthreads();
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) {
@@ -518,7 +616,7 @@ int comb_fused_bwd_parts() { return CF_GRID; }
 int comb_fused_bwd(hipStream_t s, int n_rows, float* dG, const int32_t* rows, const float* sum, const float* stats,
                    const float* gamma, const float* Wo, const float* Wqk, const float* qk, const float* vtab, int ldv,
                    const int32_t* mark, float* dYc, float* dqk, float* part_ln, float* part_v, float dropout, uint64_t seed,
-                   uint32_t site_gate, uint32_t site_out, int bf16) {
+                   uint32_t site_gate, uint32_t site_out, int bf16, const uint16_t* WTx) {
     if (n_rows <= 0) return 0;
     FIRA_REQUIRE(dG && rows && sum && stats && gamma && Wo && Wqk && qk && vtab && mark && dYc && dqk && part_ln && part_v,
                  "comb_fused_bwd: null pointer argument");
@@ -536,9 +634,15 @@ int comb_fused_bwd(hipStream_t s, int n_rows, float* dG, const int32_t* rows, co
         hipError_t e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3);
         return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }();
     if (attr) return attr;
+    if (WTx && !bf16) {                  // fp32 mode, three bf16 terms per operand (WTx: planes of Wq^T | Wk^T | Wo^T)
+        a.Wo = reinterpret_cast<const float*>(WTx);
+        hipLaunchKernelGGL((comb_fused_bwd_kernel<false, true>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3, s, a);
+    } else
     if (bf16) hipLaunchKernelGGL(comb_fused_bwd_kernel<true>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     else hipLaunchKernelGGL(comb_fused_bwd_kernel<false>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     FIRA_CHECK_LAUNCH("comb_fused_bwd");
@@ -571,13 +675,14 @@ int fira_combination_block_bwd(void* stream, int n_rows, float* dG, const int32_
                                const int32_t* mark, float* dYc, float* dqk, float* dgamma, float* dbeta, float* dvtab, int lddv,
                                float* part, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int dtype) {
     FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_bwd: dropout must be in [0,1)");
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_combination_block_bwd: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_combination_block_bwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
     FIRA_REQUIRE(dgamma && dbeta && dvtab && part, "fira_combination_block_bwd: null pointer argument");
     const int nb = fira::comb_fused_bwd_parts();
     float* part_ln = part;
     float* part_v = part + (size_t)nb * 2 * FIRA_D;
     if (int rc = fira::comb_fused_bwd((hipStream_t)stream, n_rows, dG, rows, sum, stats, gamma, Wo, Wqk, qk, vtab, ldv, mark, dYc, dqk,
-                                      part_ln, part_v, dropout, seed, site_gate, site_out, dtype == FIRA_BF16))
+                                      part_ln, part_v, dropout, seed, site_gate, site_out, dtype == FIRA_BF16,
+                                      dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(Wo) : nullptr))
         return rc;
     if (n_rows <= 0) return 0;
     fira::RedTable tab;
@@ -593,8 +698,9 @@ int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const 
                                float* c, const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows,
                                float* stats, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int dtype) {
     FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_fwd: dropout must be in [0,1)");
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16, "fira_combination_block_fwd: dtype must be FIRA_F32 or FIRA_BF16");
+    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_combination_block_fwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
     return fira::comb_fused_fwd((hipStream_t)stream, n_rows, Xc, WqT, WkT, WoT, bqk, bo, vtab, ldv, mark, qk, c, gamma, beta, sum,
-                                y, y_rows, stats, dropout, seed, site_gate, site_out, dtype == FIRA_BF16);
+                                y, y_rows, stats, dropout, seed, site_gate, site_out, dtype == FIRA_BF16,
+                                dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(WqT) : nullptr);
 }
 }

@@ -108,7 +108,9 @@ int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
-                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int bf16);
+                   float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int bf16, const uint16_t* Wx = nullptr);
+// (round 6) Wx / WTx: gcn_split_planes of Wq | Wk | Wo as stored (forward) / of their transposes (backward), three matrices of
+// 3 x 65536 bf16 each -- fp32 mode then runs the three products as six bf16 MFMA terms per k step (comb_fused.hip: X3)
 // Backward of the block in one launch: LayerNorm backward of the rows dG[rows[r]], data gradient through Wo, gate backward,
 // data gradient through Wq | Wk; dG[rows[r]] = ds + dX.  Leaves dYc [n,256] and dq|dk [n,512] for the weight gradients and
 // comb_fused_bwd_parts() partial rows: part_ln [.][512] = {dgamma | dbeta}, part_v [.][1024] = dvtab [4][256].
@@ -116,7 +118,7 @@ int comb_fused_bwd_parts();
 int comb_fused_bwd(hipStream_t s, int n_rows, float* dG, const int32_t* rows, const float* sum, const float* stats,
                    const float* gamma, const float* Wo, const float* Wqk, const float* qk, const float* vtab, int ldv,
                    const int32_t* mark, float* dYc, float* dqk, float* part_ln, float* part_v, float dropout, uint64_t seed,
-                   uint32_t site_gate, uint32_t site_out, int bf16);
+                   uint32_t site_gate, uint32_t site_out, int bf16, const uint16_t* WTx = nullptr);
 struct TransposeTable { int n = 0; const float* src[24]; float* dst[24]; };
 int transpose256_table(hipStream_t s, const TransposeTable& tab);         // dst[i] = src[i]^T, [256,256] each
 int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const float* table, const float* pos, float* out,

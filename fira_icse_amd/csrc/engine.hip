@@ -75,6 +75,7 @@ struct Plan {
     float *W21, *c21, *rsum;        // GCN: per layer fc2.weight . fc1.weight [256,256] and fc2.weight . fc1.bias [256]; A_hat 1
     float *W21t;                    // the folded weights transposed = k-major for U W21^T: what the fused GCN forward streams
     uint16_t *W21x = nullptr, *W21tx = nullptr;   // (round 6) three bf16 planes of W21 / W21^T per layer, fragment order (gcn_fused.hip: X3)
+    uint16_t *WcX = nullptr, *WcTX = nullptr;     // the same of the Combination weights Wq | Wk | Wo per layer, as stored / transposed
     float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
@@ -131,6 +132,8 @@ struct Plan {
         W21t = a.f((size_t)nl * D * D);
         W21x = a.get<uint16_t>((size_t)nl * 3 * D * D);
         W21tx = a.get<uint16_t>((size_t)nl * 3 * D * D);
+        WcX = a.get<uint16_t>((size_t)nl * 9 * D * D);
+        WcTX = a.get<uint16_t>((size_t)nl * 9 * D * D);
         WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
@@ -842,6 +845,11 @@ static int lanes_fork_to(Ctx& c, hipStream_t target) {
 // FIRA_FOLD_ONE=0: the folded GCN weights as two products + a transpose per layer (14 launches) instead of one launch (A/B switch)
 // FIRA_GCN_X3=0: the fused GCN product of fp32 mode as fp32 MFMAs instead of three bf16 terms (A/B switch; gcn_fused.hip)
 static inline bool fold_one_launch();
+// FIRA_COMB_X3=0: the same switch for the fused Combination block's three products per direction (comb_fused.hip)
+static inline bool comb_x3_on(int nl) {
+    static const bool off = [] { const char* e = getenv("FIRA_COMB_X3"); return e && e[0] == '0'; }();
+    return !off && g_dtype == 0 && comb_fused_on() && nl <= 8;
+}
 static inline bool gcn_x3_on(int nl) {
     static const bool off = [] { const char* e = getenv("FIRA_GCN_X3"); return e && e[0] == '0'; }();
     return !off && g_dtype == 0 && gcn_fused_on() && fold_one_launch() && nl <= 10;
@@ -884,6 +892,20 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
                 tt.src[tt.n] = c.P + w.wo; tt.dst[tt.n++] = dst + (size_t)2 * D * D;
             }
             TRY(transpose256_table(fs, tt));
+            if (comb_x3_on(p.nl)) {      // planes of Wq | Wk | Wo as stored (forward) and of the k-major copies (backward)
+                const float* src[48];
+                uint16_t* dst[48];
+                int n = 0;
+                for (int l = 0; l < p.nl; ++l) {
+                    const EncLayer& w = L.enc[l];
+                    const float* st[3] = {c.P + w.wqk, c.P + w.wqk + (size_t)D * D, c.P + w.wo};
+                    for (int j = 0; j < 3; ++j) {
+                        src[n] = st[j]; dst[n++] = p.WcX + ((size_t)l * 3 + j) * 3 * D * D;
+                        if (c.G) { src[n] = p.WcT + ((size_t)l * 3 + j) * D * D; dst[n++] = p.WcTX + ((size_t)l * 3 + j) * 3 * D * D; }
+                    }
+                }
+                TRY(gcn_split_planes(fs, n, src, dst));
+            }
             // (with the one-launch fold right behind it, ONE mark serves the first Combination block and the first GCN layer: every
             //  wait is a barrier packet in the caller's chain, and the fold is through ~25 us into the call, before the first
             //  Combination block starts)
@@ -959,7 +981,8 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             const float* wt = p.WcT + (size_t)l * 3 * D * D;
             TRY(comb_fused_fwd(s, Cc, e.Xc, wt, wt + (size_t)D * D, wt + (size_t)2 * D * D, c.P + w.bqk, c.P + w.bo,
                                p.vtab_all + l * D, p.nl * D, bt.code_mark, e.qk, e.c, c.P + w.ln1g, c.P + w.ln1b, e.s1, X,
-                               bt.code_rows, e.st1, c.p_drop, c.seed, site(l, SITE_GATE), site(l, SITE_COMB_OUT), g_dtype == 1));
+                               bt.code_rows, e.st1, c.p_drop, c.seed, site(l, SITE_GATE), site(l, SITE_COMB_OUT), g_dtype == 1,
+                               comb_x3_on(p.nl) ? p.WcX + (size_t)l * 9 * D * D : nullptr));
         } else {
         TRY(linear(s, Cc, 2 * D, D, e.Xc, D, c.P + w.wqk, c.P + w.bqk, e.qk, 2 * D));
         TRY(combination_fwd(s, Cc, e.qk, p.vtab_all + l * D, p.nl * D, bt.code_mark, e.c, c.p_drop, c.seed, site(l, SITE_GATE)));
@@ -1491,7 +1514,8 @@ static int backward_encoder(Ctx& c, BwdMid& mid) {
             if (part_v) {
                 TRY(comb_fused_bwd(s, Cc, other, bt.code_rows, e.s1, e.st1, c.P + w.ln1g, c.P + w.wo, c.P + w.wqk, e.qk,
                                    p.vtab_all + l * D, p.nl * D, bt.code_mark, g.dYc, g.dqk, part_ln, part_v, c.p_drop, c.seed,
-                                   site(l, SITE_GATE), site(l, SITE_COMB_OUT), g_dtype == 1));
+                                   site(l, SITE_GATE), site(l, SITE_COMB_OUT), g_dtype == 1,
+                                   comb_x3_on(p.nl) ? p.WcTX + (size_t)l * 9 * D * D : nullptr));
                 red().add(G + w.ln1g, part_ln, D, nb, 2 * D);
                 red().add(G + w.ln1b, part_ln + D, D, nb, 2 * D);
                 for (int k = 0; k < 4; ++k)

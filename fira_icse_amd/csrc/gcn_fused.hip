@@ -33,6 +33,7 @@
 #include "engine.h"
 #include "mfma_frag.h"
 #include "epilogue.h"
+#include "x3.h"
 
 namespace fira {
 
@@ -56,15 +57,6 @@ constexpr size_t GF_LDS = 84 * 1024;
 // (row & 15): the 16 lanes of a ds_read_b128 group read 16 distinct bank quads.
 constexpr size_t GX_PLANE = (size_t)GF_ROWS * 512;                 // bytes of one bf16 plane of the panel
 constexpr size_t GF_LDS_X3 = 3 * GX_PLANE + 1024;                  // 97 KB: the planes + the row sums (one workgroup per CU)
-constexpr size_t GX_WPLANE = (size_t)FIRA_D * FIRA_D * 2;          // bytes of one bf16 plane of a weight
-__device__ __forceinline__ int gx_off(int row, int c16) { return row * 512 + ((c16 ^ (row & 15)) << 4); }
-__device__ __forceinline__ uint32_t gx_pack(float a, float b) {
-    const af32x2 v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, abf16x2));      // v_cvt_pk_bf16_f32 (RNE)
-}
-// what is left of (a, b) after their bf16 roundings `pk` (exact in fp32)
-__device__ __forceinline__ float gx_rest_lo(float a, uint32_t pk) { return a - __builtin_bit_cast(float, pk << 16); }
-__device__ __forceinline__ float gx_rest_hi(float b, uint32_t pk) { return b - __builtin_bit_cast(float, pk & 0xffff0000u); }
 
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
 
@@ -215,14 +207,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             for (int i = 0; i < GF_RPW; ++i) {
                 const int lr = wave * GF_RPW + i;
                 if constexpr (X3) {
-                    f32x4v u = acc[i];
-                    const int o = gx_off(lr, lane >> 1) + (lane & 1) * 8;
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const uint32_t p0 = gx_pack(u.x, u.y), p1 = gx_pack(u.z, u.w);
-                        *reinterpret_cast<uint2*>(sm_p + pl * GX_PLANE + o) = uint2{p0, p1};
-                        if (pl < 2) { u.x = gx_rest_lo(u.x, p0); u.y = gx_rest_hi(u.y, p0); u.z = gx_rest_lo(u.z, p1); u.w = gx_rest_hi(u.w, p1); }
-                    }
+                    gx_store_row4(sm_p, GX_PLANE, lr, lane, acc[i]);
                 } else
                 *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = acc[i];                  // (rows past the end: zeros)
                 if (lane == 0) sm_rs[lr] = vsum[i];
@@ -239,7 +224,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
         float b[2][16];
         // X3: the weight planes are stored in fragment order -- unit ((16-column block w) * 8 + k step s) * 64 + lane, 16 bytes
         // each: one contiguous 1 KiB per wave, plane and k step
-        const unsigned xlane = (unsigned)(wave * 8 * 64 + lane) * 16u;
+        const unsigned xlane = gx_wlane(wave, lane);
         uint4 bx[2][3];
         if constexpr (X3) {
 #pragma unroll
@@ -259,7 +244,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
         for (int tt = 0; tt < GF_TMAX; ++tt) acc[tt] = f32x4acc{0.f, 0.f, 0.f, 0.f};
         if constexpr (X3) {
             // fragment of tile tt, k step s: row 16 tt + l15, 16-byte column 4 s + kq  ->  byte (a_q ^ (s << 6)) + tt * 8192 of a plane
-            const int a_q = l15 * 512 + (((kq ^ (l15 & 3)) << 4) | ((l15 >> 2) << 6));
+            const int a_q = gx_frag_base(l15, kq);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 1 < 8) {
@@ -278,12 +263,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                         const abf16x8 ah = *reinterpret_cast<const abf16x8*>(pa);
                         const abf16x8 am = *reinterpret_cast<const abf16x8*>(pa + GX_PLANE);
                         const abf16x8 al = *reinterpret_cast<const abf16x8*>(pa + 2 * GX_PLANE);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc[tt], 0, 0, 0);
-                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[tt], 0, 0, 0);
+                        FIRA_X3_MFMA(acc[tt], ah, am, al, bh, bm, bl)
                     }
                 }
                 asm volatile("" ::: "memory");
@@ -476,7 +456,7 @@ int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
 // plane pl of matrix m at dst[m] + pl * 65536 elements; unit ((n / 16) * 8 + k / 32) * 64 + ((k / 8) % 4) * 16 + n % 16 holds the
 // eight values k .. k + 7 (k a multiple of 8) of row n.  A thread owns one unit: two float4 reads (a row's units are consecutive
 // threads), three 16-byte stores.
-struct SplitTable { int n = 0; const float* src[24]; uint16_t* dst[24]; };
+struct SplitTable { int n = 0; const float* src[48]; uint16_t* dst[48]; };
 __global__ __launch_bounds__(256) void gcn_split_planes_kernel(const SplitTable tab) {
     const int m = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;        // j < 8192: row n = j / 32, unit c = j % 32 of the row
     const int n = j >> 5, c = j & 31;
@@ -497,7 +477,7 @@ __global__ __launch_bounds__(256) void gcn_split_planes_kernel(const SplitTable 
 // n matrices [256 n][256 k] (fp32, row-major) -> their planes (3 * 65536 bf16 each)
 int gcn_split_planes(hipStream_t s, int n, const float* const* src, uint16_t* const* dst) {
     if (n <= 0) return 0;
-    FIRA_REQUIRE(n <= 24, "gcn_split_planes: %d matrices", n);
+    FIRA_REQUIRE(n <= 48, "gcn_split_planes: %d matrices", n);
     SplitTable tab;
     tab.n = n;
     for (int i = 0; i < n; ++i) { tab.src[i] = src[i]; tab.dst[i] = dst[i]; }

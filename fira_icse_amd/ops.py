@@ -239,7 +239,10 @@ def combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout
     n = Xc.shape[0]
     dev = Xc.device
     assert vtab.is_cuda and vtab.dtype == torch.float32 and vtab.stride(1) == 1 and vtab.shape[0] == 4, "vtab: fp32 rows"
-    WqT, WkT, WoT = (_f32(Wqk[:256]).t().contiguous(), _f32(Wqk[256:]).t().contiguous(), _f32(Wo).t().contiguous())
+    if dtype == 2:          # FIRA_F32X3: planes of Wq | Wk | Wo as stored
+        WqT = WkT = WoT = gcn_weight_planes(torch.cat([_f32(Wqk), _f32(Wo)], 0))
+    else:
+        WqT, WkT, WoT = (_f32(Wqk[:256]).t().contiguous(), _f32(Wqk[256:]).t().contiguous(), _f32(Wo).t().contiguous())
     qk = torch.empty((n, 512), dtype=torch.float32, device=dev)
     c, summ = torch.empty_like(Xc), torch.empty_like(Xc)
     if y is None:
@@ -264,8 +267,12 @@ def combination_block_bwd(dG, rows, summ, stats, gamma, Wo, Wqk, qk, vtab, mark,
     dgamma, dbeta = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
     dvtab = torch.zeros((4, 256), device=dev)
     part = torch.empty(_lib.lib().fira_combination_block_bwd_part_floats(), dtype=torch.float32, device=dev)
+    if dtype == 2:          # FIRA_F32X3: planes of Wq^T | Wk^T | Wo^T
+        Wo = gcn_weight_planes(torch.stack([_f32(Wqk[:256]).t(), _f32(Wqk[256:]).t(), _f32(Wo).t()]).contiguous())
+    else:
+        Wo = _f32(Wo)
     check(_lib.lib().fira_combination_block_bwd(cur_stream(), n, ptr(_f32(dG)), ptr(_i32(rows)), ptr(_f32(summ)), ptr(_f32(stats)),
-                                                ptr(_f32(gamma)), ptr(_f32(Wo)), ptr(_f32(Wqk)), ptr(_f32(qk)), ptr(vtab),
+                                                ptr(_f32(gamma)), ptr(Wo), ptr(_f32(Wqk)), ptr(_f32(qk)), ptr(vtab),
                                                 vtab.stride(0), ptr(_i32(mark)), ptr(dYc), ptr(dqk), ptr(dgamma), ptr(dbeta),
                                                 ptr(dvtab), 256, ptr(part), dropout, seed, site_gate, site_out, dtype),
           "fira_combination_block_bwd")

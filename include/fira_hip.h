@@ -111,7 +111,7 @@ typedef struct fira_train_opts {
 } fira_train_opts;
 #define FIRA_F32 0
 #define FIRA_BF16 1
-#define FIRA_F32X3 2      /* (v9, fira_gcn_layer_* only) fp32 data and accuracy, the product on the bf16 matrix cores: every operand as
+#define FIRA_F32X3 2      /* (v9, fira_gcn_layer_* and fira_combination_block_* only) fp32 data and accuracy, the product on the bf16 matrix cores: every operand as
                            * three bf16 terms hi + mid + lo, six of the nine term products, fp32 accumulation (see below)           */
 
 const char* fira_last_error(void);
@@ -222,6 +222,9 @@ int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const in
  * The result differs from the FIRA_F32 launch by fp32 rounding noise only (the dropped lo.lo, lo.mid, mid.lo terms are
  * below 2^-24 of a product).                                                                                           */
 int fira_gcn_weight_planes(void* stream, int n_mats, const float* B, uint16_t* planes);
+/* The same for fira_combination_block_{fwd,bwd} with dtype FIRA_F32X3: the forward launch takes, in its WqT argument, the planes
+ * of the THREE stacked matrices Wq | Wk | Wo as nn.Linear stores them ([out][in]; WkT / WoT are then ignored, pass WqT again);
+ * the backward launch takes, in its Wo argument, the planes of Wq^T | Wk^T | Wo^T (Wqk is then ignored).                      */
 
 /* One Combination block (gnn_transformer.py:176-205 with combination_layer.py:7-17) on n_rows code rows as ONE launch
  * (round 5, csrc/comb_fused.hip; dtype FIRA_F32, or FIRA_BF16 = the operands of the three products rounded to bf16, fp32

@@ -13,8 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfira_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "gemm_wgrad_panel.hip", "gemm_bf16_panel.hip", "gemm_small.hip", "spmm.hip", "spmm_dense.hip", "gcn_fused.hip", "comb_fused.hip", "rowops.hip", "attention.hip", "copyhead.hip", "beam.hip", "engine.hip", "layout.cpp", "hostlists.cpp"]
-HEADERS = ["common.h", "engine.h", "epilogue.h", "mfma_frag.h", os.path.join("..", "..", "include", "fira_hip.h")]
+SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "gemm_wgrad_panel.hip", "gemm_bf16_panel.hip", "gemm_small.hip", "spmm.hip", "spmm_dense.hip", "gcn_fused.hip", "comb_fused.hip", "head_x3.hip", "rowops.hip", "attention.hip", "copyhead.hip", "beam.hip", "engine.hip", "layout.cpp", "hostlists.cpp"]
+HEADERS = ["common.h", "engine.h", "epilogue.h", "mfma_frag.h", "x3.h", os.path.join("..", "..", "include", "fira_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

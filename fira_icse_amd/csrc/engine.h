@@ -100,6 +100,11 @@ int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
 // out = U B^T: W21 for the forward product, W21^T for the backward one) -- fp32 mode then runs the product as six bf16 MFMA
 // terms per k step at fp32 accuracy (gcn_fused.hip: X3)
 int gcn_split_planes(hipStream_t s, int n, const float* const* src, uint16_t* const* dst);
+// (round 6, head_x3.hip) logits[R, V] = x[R, 256] W[V, 256]^T + bias on the bf16 matrix cores at fp32 accuracy (three bf16 terms
+// per operand); xplanes: head_logits_x3_scratch_elems(R) bf16 of scratch (the planes of x)
+size_t head_logits_x3_scratch_elems(int R);
+int head_logits_x3(hipStream_t s, int R, int V, const float* x, int ldx, const float* W, const float* bias, float* out, int ldo,
+                   uint16_t* xplanes);
 int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[l] = W[l]^T, nl stacked [256,256] matrices
 // One Combination block per launch (comb_fused.hip): q|k projections, the two-way gate, the output projection, dropout,
 // residual and LayerNorm of gnn_transformer.py:176-205 on the code rows.  WqT / WkT / WoT: the three weights K-MAJOR

@@ -76,6 +76,7 @@ struct Plan {
     float *W21t;                    // the folded weights transposed = k-major for U W21^T: what the fused GCN forward streams
     uint16_t *W21x = nullptr, *W21tx = nullptr;   // (round 6) three bf16 planes of W21 / W21^T per layer, fragment order (gcn_fused.hip: X3)
     uint16_t *WcX = nullptr, *WcTX = nullptr;     // the same of the Combination weights Wq | Wk | Wo per layer, as stored / transposed
+    uint16_t *xh_planes = nullptr;                // planes of the head's input rows (head_x3.hip)
     float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
     float *inv_ntok;
@@ -134,6 +135,7 @@ struct Plan {
         W21tx = a.get<uint16_t>((size_t)nl * 3 * D * D);
         WcX = a.get<uint16_t>((size_t)nl * 9 * D * D);
         WcTX = a.get<uint16_t>((size_t)nl * 9 * D * D);
+        xh_planes = a.get<uint16_t>(head_logits_x3_scratch_elems(TB));
         WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
         mem = a.f((size_t)MB * D);
@@ -1153,6 +1155,11 @@ static int head_forward(Ctx& c, int R, const int32_t* rows, float* loss_sum, int
         TRY(rows_gather_idx(s, R, p.dec_c, dec, rows));
         dec_rows = p.dec_c;
     }
+    // fp32 mode: the generator projection as three bf16 terms per operand (head_x3.hip; FIRA_HEAD_X3=0 = the fp32 tiled kernel)
+    static const bool head_x3_off = [] { const char* e = getenv("FIRA_HEAD_X3"); return e && e[0] == '0'; }();
+    if (g_dtype == 0 && !head_x3_off && R >= 64 && R <= p.TB)
+        TRY(head_logits_x3(s, R, p.V, dec_rows, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl, p.xh_planes));
+    else
     TRY(linear(s, R, p.V, D, dec_rows, D, c.P + L.wout, c.P + L.bout, p.logits, p.ldl));
     TRY(gemm_any(s, 0, 1, c.Td, D, D, dec, D, c.P + L.wt, D, p.tgt, D, nullptr, 0, 0, nullptr));
     if (c.deferred) TRY(main_wait(s, c.ev_src, __LINE__));                   // LinearSource(memory) (side stream)

@@ -481,6 +481,18 @@ def head_topk(x, wout, bout, k, dtype=0):
     return ids, vals, logits[:, :V]
 
 
+def head_logits_x3(x, wout, bout):
+    """fira_head_logits_x3: logits [R, V] = x Wout^T + bout on the bf16 matrix cores at fp32 accuracy (three bf16 terms)."""
+    R, V = x.shape[0], wout.shape[0]
+    ldl = (V + 63) // 64 * 64
+    logits = torch.empty((R, ldl), dtype=torch.float32, device=x.device)
+    scratch = torch.empty(_lib.lib().fira_head_logits_x3_scratch_bytes(R), dtype=torch.uint8, device=x.device)
+    x = _f32(x)
+    check(_lib.lib().fira_head_logits_x3(cur_stream(), R, V, ptr(x), x.stride(0), ptr(_f32(wout)), ptr(_f32(bout)), ptr(logits), ldl,
+                                         ptr(scratch)), "fira_head_logits_x3")
+    return logits[:, :V]
+
+
 _panel_scratch = {}
 
 

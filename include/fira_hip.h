@@ -464,6 +464,15 @@ int fira_ffn_bwd(void* stream, int M, int F, const float* dy, const float* x, co
 int fira_head_topk(void* stream, int R, int V, int k, const float* x, const float* wout, const float* bout, float* logits_ws,
                    int ldl, int32_t* ids, float* vals, int dtype);
 
+/* (v9) The generator projection alone, logits[R, V] = x[R, 256] W[V, 256]^T + bias (Model.py:54 / :85, out_fc), on the bf16
+ * matrix cores at fp32 accuracy: both operands as three bf16 terms, six of the nine term products, fp32 accumulation
+ * (csrc/head_x3.hip) -- what the model-level calls run in fp32 mode.  x rows at stride ldx, logits rows at stride ldl (both
+ * multiples of 4 floats, 16-byte aligned); scratch: fira_head_logits_x3_scratch_bytes(R) bytes (the planes of x).            */
+size_t fira_head_logits_x3_scratch_bytes(int R);
+int fira_head_logits_x3(void* stream, int R, int V, const float* x, int ldx, const float* W, const float* bias, float* logits,
+                        int ldl, void* scratch);
+
+
 /* (v7) One optimisation step in one call: `loss.backward(); optimizer.step()` of run_model.py:104-111 for a single device --
  * fira_train_fwd_bwd followed by fira_adam_step_mb over [0, live) with the token normaliser of run_model.py:105, bit for bit
  * (Adam is element-wise).  What the single call adds is the ORDER: the update of the head + decoder slice [0, split) is

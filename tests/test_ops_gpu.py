@@ -1019,3 +1019,21 @@ def test_wgrad_panel_product(M, N, K, lda, dtype, split):
         ops.gemm(A, B, transA=True, transB=False, out=C32, accumulate=True)
         e32 = rel_err(C32, ref)
         assert err < 2.0 * e32 + 2e-7, (err, e32)                        # as accurate as the k-ordered fp32 chains
+
+
+@pytest.mark.parametrize("R,V", [(530, 24650), (37, 24650), (1021, 4099), (64, 250), (2049, 1000)])
+def test_head_logits_three_term_product(R, V):
+    """fira_head_logits_x3 (head_x3.hip): out_fc (Model.py:54) as three bf16 terms per operand on the bf16 matrix cores --
+    against the fp64 product, at the tolerance of the fp32 product (the engine's fp32 mode runs this kernel); ragged row blocks
+    (R not a multiple of 16), ragged vocabulary tiles (V not a multiple of 16 or 4), fewer tiles than workgroups, more than one
+    chunk of row blocks (R > 512); the fp32 product of the tiled kernel beside it for comparison."""
+    from fira_icse_amd import ops
+    x = randn(R, 256, seed=1)
+    W, b = randn(V, 256, seed=2, scale=0.06), randn(V, seed=3, scale=0.1)
+    ref = x.double() @ W.double().t() + b.double()
+    got = ops.head_logits_x3(x, W, b)
+    f32 = ops.gemm(x, W, bias=b)
+    e3, e32 = rel_err(got, ref), rel_err(f32, ref)
+    assert e3 < 1e-6, (e3, e32)
+    assert e3 < 3 * e32 + 1e-7, (e3, e32)                      # no worse than the fp32 chain
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6

@@ -130,13 +130,15 @@ __device__ __forceinline__ void cf_product(const float* __restrict__ sm_u, const
 // three bf16 planes, the weights arrive as pre-split planes in fragment order (gcn_split_planes of B[n][k] with out = U B^T:
 // Wq / Wk / Wo as stored for the forward block, their transposes for the backward one); a k step of 32 is six
 // v_mfma_f32_16x16x32_bf16 per tile.  bx = the three planes' units of k step 0, handed from product to product as above.
+// NP = 3: fp32 mode (three terms); NP = 1: the engine's bf16 mode on the same machinery (one plane: operands rounded once)
+template <int NP>
 __device__ __forceinline__ void cx_first(const uint16_t* __restrict__ Wx, unsigned xlane, uint4 (&b0)[3]) {
     const rsrc_t rW = buf_rsrc(Wx, 3u * (unsigned)GX_WPLANE);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
         b0[pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, xlane, pl * (int)GX_WPLANE, 0));
 }
-template <int TM>
+template <int TM, int NP>
 __device__ __forceinline__ void cx_product(const char* __restrict__ sm_p, size_t plane_bytes, int a_q, const uint16_t* __restrict__ Wx,
                                            unsigned xlane, int nt, uint4 (&bx)[3], cf_acc (&acc)[TM],
                                            const uint16_t* __restrict__ Wnext = nullptr) {
@@ -144,41 +146,36 @@ __device__ __forceinline__ void cx_product(const char* __restrict__ sm_p, size_t
     const rsrc_t rN = buf_rsrc(Wnext ? Wnext : Wx, 3u * (unsigned)GX_WPLANE);
     uint4 b[2][3];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b[0][pl] = bx[pl];
+    for (int pl = 0; pl < NP; ++pl) b[0][pl] = bx[pl];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
         if (ks + 1 < 8) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 b[(ks + 1) & 1][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                     rW, xlane, pl * (int)GX_WPLANE + (ks + 1) * 1024, 0));
         } else if (Wnext) {                              // (block-uniform; k step 7 reads b[1]: b[0] is free)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 b[0][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rN, xlane, pl * (int)GX_WPLANE, 0));
         }
         asm volatile("" ::: "memory");
-        const abf16x8 bh = __builtin_bit_cast(abf16x8, b[ks & 1][0]), bm = __builtin_bit_cast(abf16x8, b[ks & 1][1]),
-                      bl = __builtin_bit_cast(abf16x8, b[ks & 1][2]);
 #pragma unroll
         for (int tt = 0; tt < TM; ++tt) {
-            if (tt < nt) {                               // block-uniform
-                const char* pa = sm_p + ((a_q ^ (ks << 6)) + tt * (CF_TILE * 512));
-                const abf16x8 ah = *reinterpret_cast<const abf16x8*>(pa);
-                const abf16x8 am = *reinterpret_cast<const abf16x8*>(pa + plane_bytes);
-                const abf16x8 al = *reinterpret_cast<const abf16x8*>(pa + 2 * plane_bytes);
-                FIRA_X3_MFMA(acc[tt], ah, am, al, bh, bm, bl)
-            }
+            if (tt < nt)                                 // block-uniform
+                gx_terms<NP>(acc[tt], sm_p + ((a_q ^ (ks << 6)) + tt * (CF_TILE * 512)), plane_bytes, b[ks & 1]);
         }
         asm volatile("" ::: "memory");
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bx[pl] = b[0][pl];
+    for (int pl = 0; pl < NP; ++pl) bx[pl] = b[0][pl];
 }
 constexpr size_t CX_PLANE = (size_t)CF_ROWS * 512;        // forward: bytes of one bf16 plane of the 32-row panel
 
-template <bool BF, bool X3 = false>
+template <bool BF, int NP = 0>
 __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const CombFusedArgs a) {
+    constexpr bool X3 = NP > 0;
+    constexpr int NPX = X3 ? NP : 3;
     extern __shared__ __attribute__((aligned(16))) float cf_lds[];
     float* const sm_u = cf_lds;                                            // [32][256] swizzled (X3: the closing rows only)
     char* const sm_p = reinterpret_cast<char*>(cf_lds);                    // X3: three bf16 planes [32][256] (48 KB)
@@ -217,7 +214,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         // ------------------------------------------------------------ 1. the tile's code rows -> panel
         float bx[16];
         uint4 bx3[3];
-        if constexpr (X3) cx_first(Wx, xlane, bx3);
+        if constexpr (X3) cx_first<NPX>(Wx, xlane, bx3);
         else cf_first_chunk(a.WqT, wlane, bx);
         asm volatile("" ::: "memory");
         {
@@ -232,7 +229,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
             for (int i = 0; i < CF_RPW; ++i) {
                 const int row = row0 + wave * CF_RPW + i;
                 const f32x4v xv = row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f};
-                if constexpr (X3) gx_store_row4(sm_p, CX_PLANE, wave * CF_RPW + i, lane, xv);
+                if constexpr (X3) gx_store_row4<NPX>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, xv);
                 else *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = xv;
             }
         }
@@ -242,8 +239,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) { aq[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; ak[tt] = cf_acc{0.f, 0.f, 0.f, 0.f}; }
         if constexpr (X3) {
-            cx_product<CF_TMAX>(sm_p, CX_PLANE, a_q, Wx, xlane, nt, bx3, aq, Wx + WX);
-            cx_product<CF_TMAX>(sm_p, CX_PLANE, a_q, Wx + WX, xlane, nt, bx3, ak, Wx + 2 * WX);
+            cx_product<CF_TMAX, NPX>(sm_p, CX_PLANE, a_q, Wx, xlane, nt, bx3, aq, Wx + WX);
+            cx_product<CF_TMAX, NPX>(sm_p, CX_PLANE, a_q, Wx + WX, xlane, nt, bx3, ak, Wx + 2 * WX);
         } else {
         cf_product<BF, CF_TMAX>(sm_u, a_off, a.WqT, wlane, nt, bx, aq, a.WkT);
         cf_product<BF, CF_TMAX>(sm_u, a_off, a.WkT, wlane, nt, bx, ak, a.WoT);       // (Wo's first chunk: in flight under the gate)
@@ -269,7 +266,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q), rQK, o2, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, k), rQK, o2, FIRA_D * 4, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), rC, o, 0, 0);
-                    if constexpr (X3) gx_store_elem(sm_p, CX_PLANE, rl, col, live ? c : 0.f);
+                    if constexpr (X3) gx_store_elem<NPX>(sm_p, CX_PLANE, rl, col, live ? c : 0.f);
                     else sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = live ? c : 0.f;
                 }
             }
@@ -279,7 +276,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_acc ao[CF_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) ao[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
-        if constexpr (X3) cx_product<CF_TMAX>(sm_p, CX_PLANE, a_q, Wx + 2 * WX, xlane, nt, bx3, ao);
+        if constexpr (X3) cx_product<CF_TMAX, NPX>(sm_p, CX_PLANE, a_q, Wx + 2 * WX, xlane, nt, bx3, ao);
         else cf_product<BF, CF_TMAX>(sm_u, a_off, a.WoT, wlane, nt, bx, ao);
         // what the closing rows need from memory, requested before the accumulators go back through the panel
         const int rbase = row0 + wave * CF_RPW;
@@ -360,13 +357,16 @@ int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT,
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+            e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_fwd_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }();
     if (attr) return attr;
-    if (Wx && !bf16) {                   // fp32 mode, three bf16 terms per operand (Wx: planes of Wq | Wk | Wo as stored)
+    if (Wx) {                            // bf16 planes (Wx: planes of Wq | Wk | Wo as stored): three terms in fp32 mode, one in bf16 mode
         a.WqT = reinterpret_cast<const float*>(Wx);
-        hipLaunchKernelGGL((comb_fused_fwd_kernel<false, true>), dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+        if (bf16) hipLaunchKernelGGL((comb_fused_fwd_kernel<false, 1>), dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
+        else hipLaunchKernelGGL((comb_fused_fwd_kernel<false, 3>), dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     } else
     if (bf16) hipLaunchKernelGGL(comb_fused_fwd_kernel<true>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     else hipLaunchKernelGGL(comb_fused_fwd_kernel<false>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
@@ -412,8 +412,10 @@ struct CombFusedBwdArgs {
 
 constexpr size_t CBX_PLANE = (size_t)CB_ROWS * 512;       // backward: bytes of one bf16 plane of a 16-row panel
 constexpr size_t CB_LDS_X3 = 100 * 1024;                  // two panels of three planes (48 KB) + marks + the column sums (48 KB)
-template <bool BF, bool X3 = false>
+template <bool BF, int NP = 0>
 __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const CombFusedBwdArgs a) {
+    constexpr bool X3 = NP > 0;
+    constexpr int NPX = X3 ? NP : 3;
     extern __shared__ __attribute__((aligned(16))) float cf_lds[];
     constexpr size_t PANEL = X3 ? 3 * CBX_PLANE / 4 : (size_t)CB_ROWS * FIRA_D;      // floats of one panel
     float* const sm_u = cf_lds;                                            // panel 1 [16][256]: dYc, then dq, then dX (X3: fp32 only for dX)
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
         float bx[16];
         uint4 bx3[3];
-        if constexpr (X3) cx_first(WTx + 2 * WX, xlane, bx3);
+        if constexpr (X3) cx_first<NPX>(WTx + 2 * WX, xlane, bx3);
         else cf_first_chunk(a.Wo, wlane, bx);
         asm volatile("" ::: "memory");
         // ------------------------------------------------------------ 1. LayerNorm backward of this wave's rows -> dYc
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                     o4.z *= dropout_scale(a.seed, a.site_out, e0 + 2, a.p, a.inv_keep);
                     o4.w *= dropout_scale(a.seed, a.site_out, e0 + 3, a.p, a.inv_keep);
                 }
-                if constexpr (X3) gx_store_row4(sm_p1, CBX_PLANE, wave * CB_RPW + i, lane, o4);
+                if constexpr (X3) gx_store_row4<NPX>(sm_p1, CBX_PLANE, wave * CB_RPW + i, lane, o4);
                 else *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = o4;                 // (rows past the end: zeros)
                 if (live) *reinterpret_cast<f32x4v*>(a.dYc + (size_t)(rbase + i) * FIRA_D + lane * 4) = o4;
             }
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         cf_acc ac[CB_TMAX];
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) ac[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
-        if constexpr (X3) cx_product<CB_TMAX>(sm_p1, CBX_PLANE, a_q, WTx + 2 * WX, xlane, nt, bx3, ac, WTx);
+        if constexpr (X3) cx_product<CB_TMAX, NPX>(sm_p1, CBX_PLANE, a_q, WTx + 2 * WX, xlane, nt, bx3, ac, WTx);
         else
         cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wo, wlane, nt, bx, ac, a.Wqk);    // (Wq's first chunk: in flight under the gate's arithmetic)
         if constexpr (BF) load_qk();
@@ -557,8 +559,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dk), rDQK, o2, FIRA_D * 4, 0);
                     redv[(kq * 4 + m) * FIRA_D + col] += dv;             // (dv = 0 past the end; this lane's own slot)
                     if constexpr (X3) {
-                        gx_store_elem(sm_p1, CBX_PLANE, rl, col, dq);
-                        gx_store_elem(sm_p2, CBX_PLANE, rl, col, dk);
+                        gx_store_elem<NPX>(sm_p1, CBX_PLANE, rl, col, dq);
+                        gx_store_elem<NPX>(sm_p2, CBX_PLANE, rl, col, dk);
                     } else {
                     sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = dq;
                     sm_w[d_off[r] + tt * (CF_TILE * FIRA_D)] = dk;
@@ -572,8 +574,8 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) ax[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
         if constexpr (X3) {
-            cx_product<CB_TMAX>(sm_p1, CBX_PLANE, a_q, WTx, xlane, nt, bx3, ax, WTx + WX);
-            cx_product<CB_TMAX>(sm_p2, CBX_PLANE, a_q, WTx + WX, xlane, nt, bx3, ax);
+            cx_product<CB_TMAX, NPX>(sm_p1, CBX_PLANE, a_q, WTx, xlane, nt, bx3, ax, WTx + WX);
+            cx_product<CB_TMAX, NPX>(sm_p2, CBX_PLANE, a_q, WTx + WX, xlane, nt, bx3, ax);
         } else {
         cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wqk, wlane, nt, bx, ax, a.Wqk + (size_t)FIRA_D * FIRA_D);
         cf_product<BF, CB_TMAX>(sm_w, a_off, a.Wqk + (size_t)FIRA_D * FIRA_D, wlane, nt, bx, ax);
@@ -635,13 +637,16 @@ int comb_fused_bwd(hipStream_t s, int n_rows, float* dG, const int32_t* rows, co
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_LDS);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3);
+            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3);
         return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }();
     if (attr) return attr;
-    if (WTx && !bf16) {                  // fp32 mode, three bf16 terms per operand (WTx: planes of Wq^T | Wk^T | Wo^T)
+    if (WTx) {                           // bf16 planes (WTx: planes of Wq^T | Wk^T | Wo^T): three terms in fp32 mode, one in bf16 mode
         a.Wo = reinterpret_cast<const float*>(WTx);
-        hipLaunchKernelGGL((comb_fused_bwd_kernel<false, true>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3, s, a);
+        if (bf16) hipLaunchKernelGGL((comb_fused_bwd_kernel<false, 1>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3, s, a);
+        else hipLaunchKernelGGL((comb_fused_bwd_kernel<false, 3>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3, s, a);
     } else
     if (bf16) hipLaunchKernelGGL(comb_fused_bwd_kernel<true>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);
     else hipLaunchKernelGGL(comb_fused_bwd_kernel<false>, dim3(CF_GRID), dim3(CF_WAVES * 64), CF_LDS, s, a);

@@ -850,11 +850,14 @@ static inline bool fold_one_launch();
 // FIRA_COMB_X3=0: the same switch for the fused Combination block's three products per direction (comb_fused.hip)
 static inline bool comb_x3_on(int nl) {
     static const bool off = [] { const char* e = getenv("FIRA_COMB_X3"); return e && e[0] == '0'; }();
-    return !off && g_dtype == 0 && comb_fused_on() && nl <= 8;
+    static const bool off16 = [] { const char* e = getenv("FIRA_X1_BF16"); return e && e[0] == '0'; }();
+    return !off && (g_dtype == 0 || !off16) && comb_fused_on() && nl <= 8;
 }
 static inline bool gcn_x3_on(int nl) {
     static const bool off = [] { const char* e = getenv("FIRA_GCN_X3"); return e && e[0] == '0'; }();
-    return !off && g_dtype == 0 && gcn_fused_on() && fold_one_launch() && nl <= 10;
+    // (bf16 mode runs the one-plane form of the same kernels; FIRA_X1_BF16=0 = its round-5 kernels, A/B switch)
+    static const bool off16 = [] { const char* e = getenv("FIRA_X1_BF16"); return e && e[0] == '0'; }();
+    return !off && (g_dtype == 0 || !off16) && gcn_fused_on() && fold_one_launch() && nl <= 10;
 }
 static inline bool fold_one_launch() {
     static const bool off = [] { const char* e = getenv("FIRA_FOLD_ONE"); return e && e[0] == '0'; }();

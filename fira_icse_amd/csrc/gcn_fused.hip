@@ -82,8 +82,12 @@ struct GcnFusedArgs {
 // float offset of 16-byte column `quad` (0..63) of panel row `row`
 __device__ __forceinline__ int gf_off(int row, int quad) { return row * FIRA_D + ((quad ^ (row & 11)) << 2); }
 
-template <bool BF, bool BWD, bool X3 = false>
+// NP = 0: the fp32 panel (fp32 MFMA chains, or BF = its fragments rounded to bf16 by every wave); NP = 3: the X3 form above;
+// NP = 1: the bf16 mode of the engine on the same machinery -- one plane, both operands rounded to bf16 once (RNE), one MFMA per
+// k step and tile (the values the BF form multiplies, a third of the X3 form's LDS and L2 traffic)
+template <bool BF, bool BWD, int NP = 0>
 __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFusedArgs a) {
+    constexpr bool X3 = NP > 0;
     extern __shared__ __attribute__((aligned(16))) float gf_lds[];
     float* const sm_u = gf_lds;                          // [64][256] swizzled (X3: the RESULT rows only, over the dead planes)
     char* const sm_p = reinterpret_cast<char*>(gf_lds);  // X3: three bf16 planes [64][256]
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             for (int i = 0; i < GF_RPW; ++i) {
                 const int lr = wave * GF_RPW + i;
                 if constexpr (X3) {
-                    gx_store_row4(sm_p, GX_PLANE, lr, lane, acc[i]);
+                    gx_store_row4<X3 ? NP : 3>(sm_p, GX_PLANE, lr, lane, acc[i]);
                 } else
                 *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = acc[i];                  // (rows past the end: zeros)
                 if (lane == 0) sm_rs[lr] = vsum[i];
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
         uint4 bx[2][3];
         if constexpr (X3) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 bx[0][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rW, xlane, pl * (int)GX_WPLANE, 0));
         } else {
 #pragma unroll
@@ -249,22 +253,15 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             for (int ks = 0; ks < 8; ++ks) {
                 if (ks + 1 < 8) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         bx[(ks + 1) & 1][pl] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                               rW, xlane, pl * (int)GX_WPLANE + (ks + 1) * 1024, 0));
                 }
                 asm volatile("" ::: "memory");
-                const abf16x8 bh = __builtin_bit_cast(abf16x8, bx[ks & 1][0]), bm = __builtin_bit_cast(abf16x8, bx[ks & 1][1]),
-                              bl = __builtin_bit_cast(abf16x8, bx[ks & 1][2]);
 #pragma unroll
                 for (int tt = 0; tt < GF_TMAX; ++tt) {
-                    if (tt < nt) {                           // block-uniform
-                        const char* pa = sm_p + ((a_q ^ (ks << 6)) + tt * (GF_TILE * 512));
-                        const abf16x8 ah = *reinterpret_cast<const abf16x8*>(pa);
-                        const abf16x8 am = *reinterpret_cast<const abf16x8*>(pa + GX_PLANE);
-                        const abf16x8 al = *reinterpret_cast<const abf16x8*>(pa + 2 * GX_PLANE);
-                        FIRA_X3_MFMA(acc[tt], ah, am, al, bh, bm, bl)
-                    }
+                    if (tt < nt)                             // block-uniform
+                        gx_terms<X3 ? NP : 3>(acc[tt], sm_p + ((a_q ^ (ks << 6)) + tt * (GF_TILE * 512)), GX_PLANE, bx[ks & 1]);
                 }
                 asm volatile("" ::: "memory");
             }
@@ -417,11 +414,13 @@ int gcn_fused_fwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     a.sum = sum; a.y = y; a.stats = stats; a.rowsum_out = rowsum_out; a.slot2 = y2 ? slot2 : nullptr; a.y2 = y2;
     a.p = dropout; a.inv_keep = dropout > 0.f ? 1.0f / (1.0f - dropout) : 1.0f; a.seed = seed; a.site = site;
     static const int attr = gcn_fused_lds(gcn_fused_kernel<true, false>) | gcn_fused_lds(gcn_fused_kernel<false, false>) |
-                            gcn_fused_lds(gcn_fused_kernel<false, false, true>, GF_LDS_X3);
+                            gcn_fused_lds(gcn_fused_kernel<false, false, 3>, GF_LDS_X3) |
+                            gcn_fused_lds(gcn_fused_kernel<false, false, 1>, GF_LDS_X3);
     if (attr) return attr;
-    if (Wx && !bf16) {                   // fp32 mode, the product as three bf16 terms (Wx: the weight's planes, gcn_split_planes)
-        a.W = reinterpret_cast<const float*>(Wx);
-        hipLaunchKernelGGL((gcn_fused_kernel<false, false, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
+    if (Wx) {                            // the product on bf16 planes (Wx: the weight's planes, gcn_split_planes): three terms in
+        a.W = reinterpret_cast<const float*>(Wx);                                    // fp32 mode, one in bf16 mode
+        if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<false, false, 1>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
+        else hipLaunchKernelGGL((gcn_fused_kernel<false, false, 3>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
     } else
     if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, false>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     else hipLaunchKernelGGL((gcn_fused_kernel<false, false>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
@@ -440,11 +439,13 @@ int gcn_fused_bwd(hipStream_t s, int n_rows, const int32_t* rowptr, const int32_
     a.n_rows = n_rows; a.rowptr = rowptr; a.col = col; a.val = val; a.X = dY; a.W = Wk;
     a.u_out = u_out; a.acc_out = acc_out;
     static const int attr = gcn_fused_lds(gcn_fused_kernel<true, true>) | gcn_fused_lds(gcn_fused_kernel<false, true>) |
-                            gcn_fused_lds(gcn_fused_kernel<false, true, true>, GF_LDS_X3);
+                            gcn_fused_lds(gcn_fused_kernel<false, true, 3>, GF_LDS_X3) |
+                            gcn_fused_lds(gcn_fused_kernel<false, true, 1>, GF_LDS_X3);
     if (attr) return attr;
-    if (Wx && !bf16) {
+    if (Wx) {
         a.W = reinterpret_cast<const float*>(Wx);
-        hipLaunchKernelGGL((gcn_fused_kernel<false, true, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
+        if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<false, true, 1>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
+        else hipLaunchKernelGGL((gcn_fused_kernel<false, true, 3>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS_X3, s, a);
     } else
     if (bf16) hipLaunchKernelGGL((gcn_fused_kernel<true, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);
     else hipLaunchKernelGGL((gcn_fused_kernel<false, true>), dim3(GF_GRID), dim3(GF_WAVES * 64), GF_LDS, s, a);

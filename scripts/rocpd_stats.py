@@ -44,7 +44,7 @@ def main():
     import json, os
     out = os.environ.get("ROCPD_CLASSES_JSON")
     if out:
-        cls = [("gemm", ("gemm_", "wgrad_panel")), ("gcn", ("gcn_fused",)), ("comb", ("comb_fused",)), ("attention", ("attention_",)), ("spmm", ("spmm_",)),
+        cls = [("gemm", ("gemm_", "wgrad_panel", "head_logits_x3")), ("gcn", ("gcn_fused",)), ("comb", ("comb_fused",)), ("attention", ("attention_",)), ("spmm", ("spmm_",)),
                ("copy", ("copy_score",)), ("head", ("head_loss",)), ("adam", ("adam_",))]
         acc = {c: [0, 0.0] for c, _ in cls}
         acc["rowops"] = [0, 0.0]

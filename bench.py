@@ -469,7 +469,7 @@ def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     peak_tf = BF16_MFMA_PEAK_TF if dtype == "bf16" else FP32_MFMA_PEAK_TF
     kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if dtype == "bf16" else \
-        "gemm_f32_kernel / gemm_tile32_kernel (v_mfma_f32_32x32x2_f32) + wgrad_panel_kernel (weight gradients: fp32-accurate three-term bf16 split on v_mfma_f32_32x32x16_bf16)"
+        "gemm_f32_kernel / gemm_tile32_kernel (v_mfma_f32_32x32x2_f32) + wgrad_panel_kernel (weight gradients) and head_logits_x3_kernel (generator projection): fp32-accurate three-term bf16 split on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16; algorithmic fp32 FLOP priced against the fp32 MFMA peak"
     roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
                 "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),
@@ -811,14 +811,17 @@ def main():
             return None
         t_s = g["ms"] * 1e-3
         peak_tf = BF16_MFMA_PEAK_TF if dtype == "bf16" else FP32_MFMA_PEAK_TF
-        return {"kernel": "gcn_fused_kernel (gather A_hat X -> LDS panel -> v_mfma 16x16 -> LayerNorm / accumulate rows)",
-                "bound": "mfma" if dtype == "f32" else "hbm", "launches_per_step": g["count"] // n_steps,
+        return {"kernel": "gcn_fused_kernel (gather A_hat X -> bf16 planes in LDS -> v_mfma_f32_16x16x32_bf16: six terms per k step "
+                          "in fp32 mode = fp32-accurate, one in bf16 mode -> LayerNorm / accumulate rows)",
+                "bound": "hbm", "launches_per_step": g["count"] // n_steps,
                 "avg_launch_us": 1e3 * g["ms"] / g["count"], "flop_per_launch": g["work"] / g["count"],
                 "bytes_per_launch": g["bytes"] / g["count"], "achieved_TFLOPs": g["work"] / t_s / 1e12,
                 "frac_mfma": g["work"] / t_s / 1e12 / peak_tf, "achieved_GBs": g["bytes"] / t_s / 1e9,
                 "frac_hbm": g["bytes"] / t_s / 1e9 / HBM_PEAK_GBS,
                 "note": "bytes = rowptr + gathered rows in + rows out (3 row streams forward, 4 backward); bench adds no "
-                        "(col, val) bytes here; FLOP = the [rows,256]x[256,256] product"}
+                        "(col, val) bytes here; FLOP = the algorithmic [rows,256]x[256,256] product (frac_mfma prices it against "
+                        "the mode's MFMA peak: fp32 157.3 TF although round 6 runs it as bf16 terms; the launch is bound by the "
+                        "gather's dependent round trips and the row phase, not by either roof)"}
 
     def comb_object(prof, n_steps):
         """The fused Combination-block launches (comb_fused.hip): three [n_code,256]x[256,256] products per launch, fp32 MFMA."""
@@ -826,7 +829,8 @@ def main():
         if not g or g["count"] == 0:
             return None
         t_s = g["ms"] * 1e-3
-        return {"kernel": "comb_fused_fwd_kernel (q|k products -> gate in registers -> output product -> LayerNorm rows)",
+        return {"kernel": "comb_fused_fwd_kernel / comb_fused_bwd_kernel (q|k products -> gate in registers -> output product -> LayerNorm "
+                          "rows; round 6: the products on bf16 planes, six terms per k step in fp32 mode)",
                 "bound": "mfma", "launches_per_step": g["count"] // n_steps, "avg_launch_us": 1e3 * g["ms"] / g["count"],
                 "flop_per_launch": g["work"] / g["count"], "bytes_per_launch": g["bytes"] / g["count"],
                 "achieved_TFLOPs": g["work"] / t_s / 1e12, "frac_mfma": g["work"] / t_s / 1e12 / FP32_MFMA_PEAK_TF,

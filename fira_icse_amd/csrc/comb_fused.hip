@@ -680,14 +680,14 @@ int fira_combination_block_bwd(void* stream, int n_rows, float* dG, const int32_
                                const int32_t* mark, float* dYc, float* dqk, float* dgamma, float* dbeta, float* dvtab, int lddv,
                                float* part, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int dtype) {
     FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_bwd: dropout must be in [0,1)");
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_combination_block_bwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
+    FIRA_REQUIRE(dtype >= FIRA_F32 && dtype <= FIRA_BF16X1, "fira_combination_block_bwd: dtype must be FIRA_F32, FIRA_BF16, FIRA_F32X3 or FIRA_BF16X1");
     FIRA_REQUIRE(dgamma && dbeta && dvtab && part, "fira_combination_block_bwd: null pointer argument");
     const int nb = fira::comb_fused_bwd_parts();
     float* part_ln = part;
     float* part_v = part + (size_t)nb * 2 * FIRA_D;
     if (int rc = fira::comb_fused_bwd((hipStream_t)stream, n_rows, dG, rows, sum, stats, gamma, Wo, Wqk, qk, vtab, ldv, mark, dYc, dqk,
-                                      part_ln, part_v, dropout, seed, site_gate, site_out, dtype == FIRA_BF16,
-                                      dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(Wo) : nullptr))
+                                      part_ln, part_v, dropout, seed, site_gate, site_out, dtype == FIRA_BF16 || dtype == FIRA_BF16X1,
+                                      dtype >= FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(Wo) : nullptr))
         return rc;
     if (n_rows <= 0) return 0;
     fira::RedTable tab;
@@ -703,9 +703,9 @@ int fira_combination_block_fwd(void* stream, int n_rows, const float* Xc, const 
                                float* c, const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows,
                                float* stats, float dropout, uint64_t seed, uint32_t site_gate, uint32_t site_out, int dtype) {
     FIRA_REQUIRE(dropout >= 0.f && dropout < 1.f, "fira_combination_block_fwd: dropout must be in [0,1)");
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_combination_block_fwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
+    FIRA_REQUIRE(dtype >= FIRA_F32 && dtype <= FIRA_BF16X1, "fira_combination_block_fwd: dtype must be FIRA_F32, FIRA_BF16, FIRA_F32X3 or FIRA_BF16X1");
     return fira::comb_fused_fwd((hipStream_t)stream, n_rows, Xc, WqT, WkT, WoT, bqk, bo, vtab, ldv, mark, qk, c, gamma, beta, sum,
-                                y, y_rows, stats, dropout, seed, site_gate, site_out, dtype == FIRA_BF16,
-                                dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(WqT) : nullptr);
+                                y, y_rows, stats, dropout, seed, site_gate, site_out, dtype == FIRA_BF16 || dtype == FIRA_BF16X1,
+                                dtype >= FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(WqT) : nullptr);
 }
 }

@@ -513,17 +513,17 @@ int fira_gcn_layer_fwd(void* stream, int n_rows, const int32_t* rowptr, const in
                        const float* W21t, const float* bias, const float* c21, const float* gamma, const float* beta,
                        float* sum, float* y, float* stats, float* rowsum_out, float dropout, uint64_t seed, uint32_t site,
                        int dtype) {
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_gcn_layer_fwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
+    FIRA_REQUIRE(dtype >= FIRA_F32 && dtype <= FIRA_BF16X1, "fira_gcn_layer_fwd: dtype must be FIRA_F32, FIRA_BF16, FIRA_F32X3 or FIRA_BF16X1");
     return fira::gcn_fused_fwd((hipStream_t)stream, n_rows, rowptr, col, val, X, W21t, bias, c21, gamma, beta, sum, y, stats,
-                               rowsum_out, nullptr, nullptr, dropout, seed, site, dtype == FIRA_BF16,
-                               dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(W21t) : nullptr);
+                               rowsum_out, nullptr, nullptr, dropout, seed, site, dtype == FIRA_BF16 || dtype == FIRA_BF16X1,
+                               dtype >= FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(W21t) : nullptr);
 }
 int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const int32_t* col, const float* val, const float* dY,
                        const float* W21, float* V, float* dX, int dtype) {
-    FIRA_REQUIRE(dtype == FIRA_F32 || dtype == FIRA_BF16 || dtype == FIRA_F32X3, "fira_gcn_layer_bwd: dtype must be FIRA_F32, FIRA_BF16 or FIRA_F32X3");
+    FIRA_REQUIRE(dtype >= FIRA_F32 && dtype <= FIRA_BF16X1, "fira_gcn_layer_bwd: dtype must be FIRA_F32, FIRA_BF16, FIRA_F32X3 or FIRA_BF16X1");
     FIRA_REQUIRE(V != nullptr, "fira_gcn_layer_bwd: V (the weight gradient's operand) must be given");
-    return fira::gcn_fused_bwd((hipStream_t)stream, n_rows, rowptr, col, val, dY, W21, V, dX, dtype == FIRA_BF16,
-                               dtype == FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(W21) : nullptr);
+    return fira::gcn_fused_bwd((hipStream_t)stream, n_rows, rowptr, col, val, dY, W21, V, dX, dtype == FIRA_BF16 || dtype == FIRA_BF16X1,
+                               dtype >= FIRA_F32X3 ? reinterpret_cast<const uint16_t*>(W21) : nullptr);
 }
 int fira_gcn_weight_planes(void* stream, int n_mats, const float* B, uint16_t* planes) {
     FIRA_REQUIRE(B && planes && n_mats > 0 && n_mats <= 24, "fira_gcn_weight_planes: bad argument");

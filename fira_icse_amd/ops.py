@@ -215,9 +215,9 @@ def gcn_weight_planes(B):
 
 def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0, want_rowsum=True):
     """fira_gcn_layer_fwd: (sum, y, stats, rowsum) of one folded GCN layer on the CSR adjacency (global column ids);
-    W21t = W21^T contiguous.  dtype 2 (FIRA_F32X3): the planes of W21 are formed here."""
+    W21t = W21^T contiguous.  dtype 2 / 3 (FIRA_F32X3 / FIRA_BF16X1): the planes of W21 are formed here."""
     n = X.shape[0]
-    if dtype == 2:
+    if dtype >= 2:
         W21t = gcn_weight_planes(_f32(W21t).t().contiguous())
     else:
         W21t = _f32(W21t)
@@ -239,7 +239,7 @@ def combination_block_fwd(Xc, Wqk, bqk, Wo, bo, vtab, mark, gamma, beta, dropout
     n = Xc.shape[0]
     dev = Xc.device
     assert vtab.is_cuda and vtab.dtype == torch.float32 and vtab.stride(1) == 1 and vtab.shape[0] == 4, "vtab: fp32 rows"
-    if dtype == 2:          # FIRA_F32X3: planes of Wq | Wk | Wo as stored
+    if dtype >= 2:          # FIRA_F32X3 / FIRA_BF16X1: planes of Wq | Wk | Wo as stored
         WqT = WkT = WoT = gcn_weight_planes(torch.cat([_f32(Wqk), _f32(Wo)], 0))
     else:
         WqT, WkT, WoT = (_f32(Wqk[:256]).t().contiguous(), _f32(Wqk[256:]).t().contiguous(), _f32(Wo).t().contiguous())
@@ -267,7 +267,7 @@ def combination_block_bwd(dG, rows, summ, stats, gamma, Wo, Wqk, qk, vtab, mark,
     dgamma, dbeta = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
     dvtab = torch.zeros((4, 256), device=dev)
     part = torch.empty(_lib.lib().fira_combination_block_bwd_part_floats(), dtype=torch.float32, device=dev)
-    if dtype == 2:          # FIRA_F32X3: planes of Wq^T | Wk^T | Wo^T
+    if dtype >= 2:          # FIRA_F32X3 / FIRA_BF16X1: planes of Wq^T | Wk^T | Wo^T
         Wo = gcn_weight_planes(torch.stack([_f32(Wqk[:256]).t(), _f32(Wqk[256:]).t(), _f32(Wo).t()]).contiguous())
     else:
         Wo = _f32(Wo)
@@ -282,7 +282,7 @@ def combination_block_bwd(dG, rows, summ, stats, gamma, Wo, Wqk, qk, vtab, mark,
 def gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=0):
     """fira_gcn_layer_bwd: V = A_hat dY (returned), dX += V W21 in place."""
     V = torch.empty_like(dY)
-    W = gcn_weight_planes(_f32(W21).t().contiguous()) if dtype == 2 else _f32(W21)     # (FIRA_F32X3: out = V B^T with B = W21^T)
+    W = gcn_weight_planes(_f32(W21).t().contiguous()) if dtype >= 2 else _f32(W21)     # (FIRA_F32X3: out = V B^T with B = W21^T)
     check(_lib.lib().fira_gcn_layer_bwd(cur_stream(), dY.shape[0], ptr(_i32(rowptr)), ptr(_i32(col)), ptr(_f32(val)),
                                         ptr(_f32(dY)), ptr(W), ptr(V), ptr(_f32(dX)), dtype), "fira_gcn_layer_bwd")
     return V

@@ -113,6 +113,8 @@ typedef struct fira_train_opts {
 #define FIRA_BF16 1
 #define FIRA_F32X3 2      /* (v9, fira_gcn_layer_* and fira_combination_block_* only) fp32 data and accuracy, the product on the bf16 matrix cores: every operand as
                            * three bf16 terms hi + mid + lo, six of the nine term products, fp32 accumulation (see below)           */
+#define FIRA_BF16X1 3     /* (v9, same entries) the engine's bf16 mode on the same machinery: ONE bf16 plane -- both operands rounded to
+                           * bf16 once (RNE), fp32 accumulation; weight argument = the planes as for FIRA_F32X3                       */
 
 const char* fira_last_error(void);
 int         fira_abi_version(void);

@@ -133,7 +133,7 @@ def test_csr_spmm_vs_dense_bmm(variant, N, nnz):
     assert rel_err(Y, ref) < 1e-6
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,nnz,p", [(650, 2500, 0.0), (97, 4000, 0.2), (33, 200, 0.2)])
 def test_gcn_layer_fused_fwd_bwd(N, nnz, p, dtype):
     """fira_gcn_layer_{fwd,bwd} (gcn_fused.hip): one launch per direction for the folded GCN layer
@@ -142,7 +142,8 @@ def test_gcn_layer_fused_fwd_bwd(N, nnz, p, dtype):
     -> the tail path of the gather), ragged last row block (B*N not a multiple of 32).  Backward: V = A_hat dY and
     dX += V W21 against autograd of the aggregation + product.  dtype 1: bf16 operands of the product (fp32 gather,
     accumulation, LayerNorm) vs the fp64 product of the ROUNDED operands.  dtype 2 (FIRA_F32X3, what the engine's fp32 mode
-    runs): three bf16 terms per operand on the bf16 matrix cores -- held to the fp32 launch's tolerance."""
+    runs): three bf16 terms per operand on the bf16 matrix cores -- held to the fp32 launch's tolerance.  dtype 3
+    (FIRA_BF16X1, what the engine's bf16 mode runs): one bf16 plane of the same kernels, held to dtype 1's tolerance."""
     from fira_icse_amd import ops
     B = 3
     rowptr, col, val, dense = random_graph_batch(B, N, nnz, seed=N + 1)
@@ -155,14 +156,14 @@ def test_gcn_layer_fused_fwd_bwd(N, nnz, p, dtype):
                                            dtype=dtype)
     A = torch.block_diag(*[dense[b] for b in range(B)]).double()
     U = A @ X.double()
-    r16 = (lambda t: t.float().bfloat16().double()) if dtype == 1 else (lambda t: t.double())
+    r16 = (lambda t: t.float().bfloat16().double()) if dtype in (1, 3) else (lambda t: t.double())
     pre = r16(U) @ r16(W21).t() + b2.double() + A.sum(1, keepdim=True) * c21.double()
     mask = ops.dropout_mask(seed, site, n * 256, p).view(n, 256).double() if p > 0 else 1.0
     ref_sum = pre * mask + X.double()
     ref_y = F.layer_norm(ref_sum, (256,), gamma.double(), beta.double(), 1e-5)
     # bf16: exact products of the rounded operands, fp32 accumulation; the kernel rounds the fp32 aggregate, the reference
     # the fp64 one -- a handful of elements land on the other side of a bf16 rounding boundary
-    tol = 3e-5 if dtype == 1 else 2e-6
+    tol = 3e-5 if dtype in (1, 3) else 2e-6
     assert rel_err(rs, A.sum(1)) < 1e-6
     assert rel_err(summ, ref_sum) < tol and rel_err(y, ref_y) < 5 * tol
     mean, rstd = ref_sum.mean(1), 1.0 / torch.sqrt(ref_sum.var(1, unbiased=False) + 1e-5)
@@ -177,7 +178,7 @@ def test_gcn_layer_fused_fwd_bwd(N, nnz, p, dtype):
     assert rel_err(dX, dX0.double() + r16(refV) @ r16(W21)) < tol
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("n,p", [(3667, 0.0), (3667, 0.1), (530, 0.1), (37, 0.1), (6861, 0.1)])
 def test_combination_block_fused_fwd(n, p, dtype):
     """fira_combination_block_fwd (comb_fused.hip): the Combination block of gnn_transformer.py:176-205 as one launch -- q|k
@@ -200,7 +201,7 @@ def test_combination_block_fused_fwd(n, p, dtype):
                                                       site_gate=sg, site_out=so, y=ybuf, y_rows=rows, dtype=dtype)
     # (b) fp64 reference with the engine's masks
     # (dtype 2 = FIRA_F32X3, three bf16 terms per operand, what the engine's fp32 mode runs: the fp32 tolerances)
-    r16 = (lambda t: t.float().bfloat16().double()) if dtype == 1 else (lambda t: t.double())
+    r16 = (lambda t: t.float().bfloat16().double()) if dtype in (1, 3) else (lambda t: t.double())
     q64 = r16(Xc) @ r16(Wqk[:256]).t() + bqk[:256].double()
     k64 = r16(Xc) @ r16(Wqk[256:]).t() + bqk[256:].double()
     v64 = vtab.double()[mark.long()]
@@ -212,7 +213,7 @@ def test_combination_block_fused_fwd(n, p, dtype):
     # (bf16: the kernel rounds ITS fp32 c, the reference the fp64 one -- a few elements fall on the other side of a boundary)
     s64 = (r16(c64) @ r16(Wo).t() + bo.double()) * mo + Xc.double()
     y64 = F.layer_norm(s64, (256,), gamma.double(), beta.double(), 1e-5)
-    t1, t2 = (2e-6, 5e-5) if dtype == 1 else (2e-6, 5e-6)
+    t1, t2 = (2e-6, 5e-5) if dtype in (1, 3) else (2e-6, 5e-6)
     assert rel_err(qk[:, :256], q64) < t1 and rel_err(qk[:, 256:], k64) < t1
     assert rel_err(c, c64) < 5e-6 and rel_err(summ, s64) < t2
     assert rel_err(y[rows.long()], y64) < 2 * t2
@@ -220,7 +221,7 @@ def test_combination_block_fused_fwd(n, p, dtype):
     untouched[rows.long()] = False
     assert bool(torch.isnan(y[untouched]).all())                     # only the listed rows are written
     assert rel_err(stats[:, 0], s64.mean(1)) < 1e-4 and rel_err(stats[:, 1], 1.0 / torch.sqrt(s64.var(1, unbiased=False) + 1e-5)) < 1e-5
-    if dtype == 1:
+    if dtype in (1, 3):
         return
     # (a) the separate launches, same masks
     qk2 = ops.gemm(Xc, Wqk, bias=bqk)
@@ -232,7 +233,7 @@ def test_combination_block_fused_fwd(n, p, dtype):
         assert bool(((c == 0) == (c2 == 0)).all())
 
 
-@pytest.mark.parametrize("dtype", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [0, 1, 2, 3])
 @pytest.mark.parametrize("n,p", [(3667, 0.0), (3667, 0.1), (37, 0.1), (6861, 0.1)])
 def test_combination_block_fused_bwd(n, p, dtype):
     """fira_combination_block_bwd (comb_fused.hip): LayerNorm backward, data gradient through the output projection, gate
@@ -266,7 +267,7 @@ def test_combination_block_fused_bwd(n, p, dtype):
         @staticmethod
         def backward(ctx, g):
             return g
-    r16 = R16.apply if dtype == 1 else (lambda t: t)
+    r16 = R16.apply if dtype in (1, 3) else (lambda t: t)
     dy = dG0[rows.long()].double()
     s_ = summ.double().requires_grad_(True)
     g_, b_ = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
@@ -282,7 +283,7 @@ def test_combination_block_fused_bwd(n, p, dtype):
     cc = (gg[..., 0] * k_ + gg[..., 1] * v_) * mg
     dq_ref, dk_ref, dvt_ref = torch.autograd.grad(cc, (q_, k_, vt_), dc)
     dX_ref = r16(dq_ref) @ r16(Wqk[:256].double()) + r16(dk_ref) @ r16(Wqk[256:].double())
-    t1 = 2e-4 if dtype == 1 else 5e-6
+    t1 = 2e-4 if dtype in (1, 3) else 5e-6
     assert rel_err(dYc, dYc_ref) < 5e-6
     assert rel_err(dqk[:, :256], dq_ref) < t1 and rel_err(dqk[:, 256:], dk_ref) < t1
     assert rel_err(dG[rows.long()], ds + dX_ref) < t1
@@ -290,7 +291,7 @@ def test_combination_block_fused_bwd(n, p, dtype):
     untouched[rows.long()] = False
     assert torch.equal(dG[untouched], dG0[untouched])
     assert rel_err(dgamma, dgam_ref) < 1e-5 and rel_err(dbeta, dbet_ref) < 1e-5
-    assert rel_err(dvtab, dvt_ref) < (2e-4 if dtype == 1 else 1e-5)
+    assert rel_err(dvtab, dvt_ref) < (2e-4 if dtype in (1, 3) else 1e-5)
 
 
 def dense_graph_batch(B, N, density, seed):
@@ -1037,3 +1038,54 @@ def test_head_logits_three_term_product(R, V):
     assert e3 < 1e-6, (e3, e32)
     assert e3 < 3 * e32 + 1e-7, (e3, e32)                      # no worse than the fp32 chain
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [2, 3])
+def test_gcn_layer_batch64_sized(dtype):
+    """The fused GCN launch at batch 64's size (19 500 rows = 4.8 tiles per workgroup: two passes, the second for one tile; hub rows of
+    13 and 40 entries: the gather's tail path) -- forward and backward, every graph against the fp64 statement; dtype 2 = three bf16
+    terms (fp32 tolerance), 3 = one plane (bf16 tolerance: 5e-5 at this size)."""
+    from fira_icse_amd import ops
+    B, N, nnz, p = 30, 650, 2600, 0.2
+    rng = np.random.default_rng(77)
+    dense_np = np.zeros((B, N, N), dtype=np.float32)
+    for b in range(B):                                       # symmetric pattern + diagonal + two hub rows (13 .. 40 entries: the tail path)
+        i, j = rng.integers(0, N, (2, nnz // 2))
+        dense_np[b, i, j] = rng.uniform(0.05, 1.0, i.shape).astype(np.float32)
+        dense_np[b, j, i] = dense_np[b, i, j]
+        for hub, deg in ((5, 40), (311, 13)):
+            cols = rng.choice(N, deg, replace=False)
+            dense_np[b, hub, cols] = rng.uniform(0.05, 1.0, deg).astype(np.float32)
+            dense_np[b, cols, hub] = dense_np[b, hub, cols]
+        dense_np[b, np.arange(N), np.arange(N)] = rng.uniform(0.05, 1.0, N).astype(np.float32)
+    bb, rr, cc = np.nonzero(dense_np)                        # row-major: sorted by (graph, row, column)
+    rowptr_np = np.zeros(B * N + 1, dtype=np.int64)
+    np.add.at(rowptr_np, bb * N + rr + 1, 1)
+    rowptr = torch.tensor(np.cumsum(rowptr_np).astype(np.int32), device=DEV)
+    col = torch.tensor((bb * N + cc).astype(np.int32), device=DEV)
+    val = torch.tensor(dense_np[bb, rr, cc], device=DEV)
+    dense = torch.tensor(dense_np, device=DEV)
+    n = B * N
+    X = randn(n, 256, seed=1)
+    W21, b2, c21 = randn(256, 256, seed=2, scale=0.06), randn(256, seed=3, scale=0.1), randn(256, seed=4, scale=0.1)
+    gamma, beta = 1 + randn(256, seed=5, scale=0.1), randn(256, seed=6, scale=0.1)
+    seed, site = 99, 23
+    summ, y, stats, rs = ops.gcn_layer_fwd(rowptr, col, val, X, W21.t().contiguous(), b2, c21, gamma, beta, dropout=p, seed=seed, site=site,
+                                           dtype=dtype)
+    r16 = (lambda t: t.float().bfloat16().double()) if dtype == 3 else (lambda t: t.double())
+    U = torch.bmm(dense.double(), X.view(B, N, 256).double()).view(n, 256)
+    rowsum = dense.double().sum(2).view(n, 1)
+    pre = r16(U) @ r16(W21).t() + b2.double() + rowsum * c21.double()
+    mask = ops.dropout_mask(seed, site, n * 256, p).view(n, 256).double()
+    ref_sum = pre * mask + X.double()
+    ref_y = F.layer_norm(ref_sum, (256,), gamma.double(), beta.double(), 1e-5)
+    per_graph = lambda a, b: float(((a.double() - b).view(B, -1).norm(dim=1) / b.view(B, -1).norm(dim=1)).max())
+    tol = 5e-5 if dtype == 3 else 2e-6
+    assert per_graph(rs.view(n, 1), rowsum) < 1e-6
+    assert per_graph(summ, ref_sum) < tol and per_graph(y, ref_y) < 5 * tol
+    dY, dX0 = randn(n, 256, seed=7), randn(n, 256, seed=8)
+    dX = dX0.clone()
+    V = ops.gcn_layer_bwd(rowptr, col, val, dY, W21, dX, dtype=dtype)
+    refV = torch.bmm(dense.double(), dY.view(B, N, 256).double()).view(n, 256)
+    assert per_graph(V, refV) < 1e-6
+    assert per_graph(dX, dX0.double() + r16(refV) @ r16(W21)) < tol

@@ -1303,10 +1303,20 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
         // dK|dV of this layer and of the one above it (adjacent column blocks of dkv_all / row blocks of the stacked K|V
         // weight) -> d memory, beside the chain.  TWO layers per fork: a fork costs the dependent chain ~15 us
         // (r3_event_cost.txt) and hides ~20 us of work per layer
+        // (two lanes, round 6: the product forks from the point where each lane's cross-attention backward has written its rows of
+        //  dkv_all -- ev_kv_done, recorded there -- not from the lanes' tails behind the whole layer: the last pair, which the
+        //  encoder's backward pass waits for, then runs beside layer 0's self-attention backward instead of behind it.
+        //  FIRA_DMEM_FORK_EARLY=0: from the tails, A/B switch)
+        static const bool dmem_early_off = [] { const char* e = getenv("FIRA_DMEM_FORK_EARLY"); return e && e[0] == '0'; }();
+        hipEvent_t ev_kv_done[2] = {nullptr, nullptr};
         auto dmem_pair = [&]() -> int {
             if (!(so && (l % 2 == 0 || l == 0))) return 0;
             const int nlay = std::min(2, p.nl - l);
             const size_t o = (size_t)l * 2 * D;
+            if (c.n_lanes > 1 && ev_kv_done[0] && ev_kv_done[1]) {
+                for (int k = 0; k < c.n_lanes; ++k)
+                    if (hipStreamWaitEvent(ss, ev_kv_done[k], 0) != hipSuccess) return set_err("lane -> auxiliary stream fork failed");
+            } else
             TRY(aux_fork_all());
             prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
             const int rc_kv = linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_all + o, p.kvp, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
@@ -1339,6 +1349,10 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
                               p.mem_valid_c, 0, 0, e.ao2, D, bx, D, g.dq, D, p.dkv_all + l * 2 * D, p.kvp,
                               p.dkv_all + l * 2 * D + D, p.kvp, q_off, 0, attn_bf16(), p.mem_off + ln.b0));
             if (c.n_lanes == 1) TRY(dmem_pair());
+            else if (!dmem_early_off && so && l % 2 == 0 && k < 2) {
+                ev_kv_done[k] = side().ev();
+                if (hipEventRecord(ev_kv_done[k], ls) != hipSuccess) return set_err("lane event record failed");
+            }
             if (q) TRY(linear_wgrad_grouped(s, c.Td, D, D, g.dq, D, e.x_a, D, G + w.wq_c, G + w.bq_c));
             TRY(linear_dgrad(ls, nr, D, D, g.dq + r0 * D, D, c.P + w.wq_c, bz + r0 * D, D, true));                 // bz = d x_a
             // self attention: LayerNorm backward + d ao = dYs Wo_s

@@ -107,6 +107,10 @@ SIGNATURES = {
     "fira_ffn_fwd": (_I, [_P, _I, _I] + [_P] * 11 + [_F, _U64, _U32, _I]),
     "fira_ffn_bwd": (_I, [_P, _I, _I] + [_P] * 17 + [_F, _U64, _U32, _I]),
     "fira_head_topk": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I]),
+    "fira_train_step_rows": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, C.POINTER(AdamOpts), _P]),
+    "fira_adam_rows_sync": (_I, [_P, _DP, _P, C.POINTER(AdamOpts), _P]),
+    "fira_adam_rows_catchup": (_I, [_P, _DP, _P, C.POINTER(AdamOpts), _P, _I, _P, _I]),
+    "fira_adam_rows_step": (_I, [_P, _DP, _P, _P, C.POINTER(AdamOpts), _P, _P]),
     "fira_train_step_begin": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_train_step_end": (_I, [_P, _P, C.POINTER(AdamOpts), _P, _P]),
     "fira_f32_to_bf16": (_I, [_P, _L, _P, _P]),
@@ -167,7 +171,7 @@ def load():
     # FIRA_HIP_LIB (A/B timing of an older build through the model-level entry points, whose signatures did not change
     # between v5 and v8 -- v8 appended a field to fira_batch, which older builds never read; callers ask has_symbol() before
     # using an entry an older build lacks) may load an older library; the tree's own library must be v8
-    ok = (9,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7, 8, 9)
+    ok = (10,) if not os.environ.get("FIRA_HIP_LIB") else (5, 6, 7, 8, 9, 10)
     if lib.fira_abi_version() not in ok:
         raise ImportError("libfira_hip.so ABI version mismatch")
     return lib

@@ -8,6 +8,7 @@
 // in registers (forward and re-computed in backward) and the loss kernel turns the logits into their
 // gradient in place, one pass after the soft-max statistics.
 #include "engine.h"
+#include "adam_rows.h"
 #include <stdlib.h>
 #include "epilogue.h"
 
@@ -527,15 +528,8 @@ __global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict_
     const float scale = scale_is_count ? 1.0f / fmaxf(sv, 1.0f) : sv;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const float step_size = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float gi = g[i] * scale;
-        const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);            // exp_avg.lerp_(grad, 1-beta1)
-        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;        // mul_(beta2).addcmul_(g, g, 1-beta2)
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= step_size * (mi / denom);
-    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        adam_elem(p[i], m[i], v[i], g[i] * scale, beta1, beta2, eps, step_size, bc2_sqrt);
 }
 
 // The same step for micro-batched training: the gradient is g0 (+ g1), each the loss_SUM gradient of one micro-batch
@@ -550,14 +544,102 @@ __global__ __launch_bounds__(256) void adam_mb_kernel(int64_t n, float* __restri
     const float scale = 1.0f / (float)(nt > 0 ? nt : 1);
     const int64_t stride = (int64_t)gridDim.x * 256;
     const float step_size = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float gi = (g1 ? g0[i] + g1[i] : g0[i]) * scale;
-        const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);
-        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= step_size * (mi / denom);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        adam_elem(p[i], m[i], v[i], (g1 ? g0[i] + g1[i] : g0[i]) * scale, beta1, beta2, eps, step_size, bc2_sqrt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-sparse form of the same update for the two vocabulary-sized embedding tables (round 6).  A row of an embedding table
+// whose gradient row is all zero still moves under Adam (its moments decay, the parameter follows the decayed first moment),
+// but that update is a function of (p, m, v, step) alone: it can be applied LATER, in registers, bit for bit, when the row is
+// next needed -- by a forward pass that gathers it (adam_rows_catchup_kernel, over the batch's token ids) or by a step whose
+// gradient row is not zero (adam_rows_kernel).  last[r] = the step up to which row r's (p, m, v) in memory are current.  A
+// training step then moves 28 bytes per parameter only for the rows its batch touched (12 % / 1.5 % of the two tables at
+// batch 32) instead of for all 2 x 6.3 M of them: -330 MB of the 780 MB the dense update moves.  Every ADAM_ROWS_K-th step
+// updates every row (force), so a catch-up never spans more than ADAM_ROWS_K - 1 steps and the bias corrections of the
+// skipped steps fit the kernel's argument block (AdamRowsHist: host-computed exactly as adam_step_mb computes its own).
+// lr / beta / eps must not change inside a window without a sync (fira_adam_rows_sync).  One wave per 256-float row.
+// gz: a zero the compiler cannot see through (the skipped updates must run the instruction sequence of the dense kernel)
+__global__ __launch_bounds__(256) void adam_rows_kernel(AdamRowsTables tb, const float* __restrict__ gbase, float lr,
+                                                        float beta1, float beta2, float eps, int step, AdamRowsHist h,
+                                                        const int32_t* __restrict__ n0, const float* __restrict__ count,
+                                                        int force, float gz) {
+    float scale;
+    if (count) scale = 1.0f / fmaxf(*count, 1.0f);
+    else { const int nt = *n0; scale = 1.0f / (float)(nt > 0 ? nt : 1); }
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    const int total = tb.rows[0] + tb.rows[1];
+    const float ss = lr / h.bc1[step % ADAM_ROWS_K], b2s = h.bc2s[step % ADAM_ROWS_K];
+    // four gradient rows requested per trip (the launch is a stream of 1 KB reads with a wave-uniform skip: one row per trip
+    // left it latency-bound at 2.5 TB/s)
+    for (int it0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; it0 < total; it0 += nw * 4) {
+        float4 gq[4];
+        size_t oq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = min(it0 + u, total - 1);
+            const int t = it >= tb.rows[0] ? 1 : 0;
+            oq[u] = (size_t)tb.off[t] + (size_t)(it - (t ? tb.rows[0] : 0)) * 256 + lane * 4;
+            gq[u] = *reinterpret_cast<const float4*>(gbase + oq[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + u;
+            if (it >= total) break;
+            const float4 gv = gq[u];
+            const size_t o = oq[u];
+            const bool nz = gv.x != 0.f || gv.y != 0.f || gv.z != 0.f || gv.w != 0.f;
+            if (!force && !__any(nz)) continue;           // wave-uniform: the row waits for its next reader
+            const int l = max(tb.last[it], step - ADAM_ROWS_K);
+            float4 pv = *reinterpret_cast<float4*>(tb.p + o), mv = *reinterpret_cast<float4*>(tb.m + o),
+                   vv = *reinterpret_cast<float4*>(tb.v + o);
+            adam_row_zero_steps(pv, mv, vv, l + 1, step - 1, gz, lr, beta1, beta2, eps, h);
+            adam_elem(pv.x, mv.x, vv.x, gv.x * scale, beta1, beta2, eps, ss, b2s);
+            adam_elem(pv.y, mv.y, vv.y, gv.y * scale, beta1, beta2, eps, ss, b2s);
+            adam_elem(pv.z, mv.z, vv.z, gv.z * scale, beta1, beta2, eps, ss, b2s);
+            adam_elem(pv.w, mv.w, vv.w, gv.w * scale, beta1, beta2, eps, ss, b2s);
+            *reinterpret_cast<float4*>(tb.p + o) = pv;
+            *reinterpret_cast<float4*>(tb.m + o) = mv;
+            *reinterpret_cast<float4*>(tb.v + o) = vv;
+            if (lane == 0) tb.last[it] = step;
+        }
+    }
+}
+// Rows brought up to step `to` (zero-gradient updates only): the rows listed in the id arrays of `ls` (duplicates and
+// out-of-range ids allowed: a row is claimed through atomicMax on last[]), or, with no list, every row of both tables.
+__global__ __launch_bounds__(256) void adam_rows_catchup_kernel(AdamRowsTables tb, AdamRowsLists ls, float lr, float beta1,
+                                                                float beta2, float eps, int to, AdamRowsHist h, float gz) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    const int total = ls.n_lists ? ls.end[ls.n_lists - 1] : tb.rows[0] + tb.rows[1];
+    for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < total; it += nw) {
+        int t, r, l;
+        if (ls.n_lists) {
+            int k = 0;
+            while (it >= ls.end[k]) ++k;
+            t = ls.table[k];
+            r = ls.ids[k][it - (k ? ls.end[k - 1] : 0)];
+            if (r < 0 || r >= tb.rows[t]) continue;
+            int32_t* last = tb.last + (t ? tb.rows[0] : 0);
+            l = 0;
+            if (lane == 0) l = atomicMax(&last[r], to);
+            l = __builtin_amdgcn_readfirstlane(l);
+        } else {
+            t = it >= tb.rows[0] ? 1 : 0;
+            r = it - (t ? tb.rows[0] : 0);
+            l = tb.last[it];
+        }
+        if (l >= to) continue;
+        l = max(l, to - (ADAM_ROWS_K - 1));
+        const size_t o = (size_t)tb.off[t] + (size_t)r * 256 + lane * 4;
+        float4 pv = *reinterpret_cast<float4*>(tb.p + o), mv = *reinterpret_cast<float4*>(tb.m + o),
+               vv = *reinterpret_cast<float4*>(tb.v + o);
+        adam_row_zero_steps(pv, mv, vv, l + 1, to, gz, lr, beta1, beta2, eps, h);
+        *reinterpret_cast<float4*>(tb.p + o) = pv;
+        *reinterpret_cast<float4*>(tb.m + o) = mv;
+        *reinterpret_cast<float4*>(tb.v + o) = vv;
+        if (!ls.n_lists && lane == 0) tb.last[it] = to;
     }
 }
 
@@ -877,6 +959,51 @@ int adam_step_mb(hipStream_t s, int64_t n, float* p, const float* g0, const floa
     hipLaunchKernelGGL(adam_mb_kernel, dim3(grid), dim3(256), 0, s, n, p, g0, g1, m, v, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2), n0, n1);
     FIRA_CHECK_LAUNCH("adam_step_mb");
+    return 0;
+}
+static AdamRowsHist adam_rows_hist(float beta1, float beta2, int end) {
+    AdamRowsHist h;
+    for (int k = 0; k < ADAM_ROWS_K; ++k) h.bc1[k] = h.bc2s[k] = 1.f;
+    for (int j = std::max(1, end - ADAM_ROWS_K + 1); j <= end; ++j) {       // as adam_step_mb forms them for step j
+        h.bc1[j % ADAM_ROWS_K] = (float)(1.0 - pow((double)beta1, j));
+        h.bc2s[j % ADAM_ROWS_K] = (float)sqrt(1.0 - pow((double)beta2, j));
+    }
+    return h;
+}
+AdamRowsView adam_rows_view(const AdamRowsTables& tb, int table, float lr, float beta1, float beta2, float eps, int to) {
+    AdamRowsView vw;
+    if (to < 1) return vw;                                   // nothing owed ahead of step 1
+    vw.m = tb.m + tb.off[table]; vw.v = tb.v + tb.off[table];
+    vw.last = tb.last + (table ? tb.rows[0] : 0);
+    vw.to = to; vw.lr = lr; vw.beta1 = beta1; vw.beta2 = beta2; vw.eps = eps; vw.gz = 0.f;
+    vw.h = adam_rows_hist(beta1, beta2, to);
+    return vw;
+}
+int adam_rows_step(hipStream_t s, const AdamRowsTables& tb, const float* g, float lr, float beta1, float beta2, float eps,
+                   int step, const int32_t* n0, const float* count) {
+    ProfScope prof(s, PROF_ADAM, 0.0);
+    FIRA_REQUIRE(step >= 1 && tb.last && (n0 || count), "adam_rows_step: bad argument");
+    const int total = tb.rows[0] + tb.rows[1];
+    if (total <= 0) return 0;
+    const int grid = std::min(cdiv(total, 16), 256 * 8);
+    hipLaunchKernelGGL(adam_rows_kernel, dim3(grid), dim3(256), 0, s, tb, g, lr, beta1, beta2, eps, step,
+                       adam_rows_hist(beta1, beta2, step), n0, count, step % ADAM_ROWS_K == 0 ? 1 : 0, 0.0f);
+    FIRA_CHECK_LAUNCH("adam_rows_step");
+    return 0;
+}
+int adam_rows_catchup(hipStream_t s, const AdamRowsTables& tb, const AdamRowsLists* ls, float lr, float beta1, float beta2,
+                      float eps, int to) {
+    ProfScope prof(s, PROF_ADAM, 0.0);
+    FIRA_REQUIRE(tb.last, "adam_rows_catchup: bad argument");
+    if (to < 1) return 0;
+    AdamRowsLists none{};
+    const AdamRowsLists& l = ls ? *ls : none;
+    const int total = l.n_lists ? l.end[l.n_lists - 1] : tb.rows[0] + tb.rows[1];
+    if (total <= 0) return 0;
+    const int grid = std::min(cdiv(total, 4), 256 * 8);
+    hipLaunchKernelGGL(adam_rows_catchup_kernel, dim3(grid), dim3(256), 0, s, tb, l, lr, beta1, beta2, eps, to,
+                       adam_rows_hist(beta1, beta2, to), 0.0f);
+    FIRA_CHECK_LAUNCH("adam_rows_catchup");
     return 0;
 }
 int inv_count(hipStream_t s, const int32_t* n_tok, float* out) {

@@ -199,13 +199,15 @@ int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const in
          // -> mem_off [B+1] (commit b's range of the list) and mem_valid_c [Mc] (key mask per listed row)
          const int32_t* mem_dst = nullptr, int32_t* mem_off = nullptr, int32_t* mem_valid_c = nullptr);
 // the decoder's token embedding on a list of target rows (row_bt[r] = flat b*T + t) and its backward
+struct AdamRowsView;
 int embed_rows_fwd(hipStream_t s, int R, int T, const int32_t* row_bt, const int32_t* idx, const float* table,
-                   const float* pos, float* out);
+                   const float* pos, float* out, const AdamRowsView* vw = nullptr);   // vw: the table under a row-sparse Adam
 int embed_rows_bwd(hipStream_t s, int R, const int32_t* row_bt, const int32_t* idx, float* dtable, const float* dout,
                    int padding_idx);
 int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
                   const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
-                  float* X, const int32_t* slot2 = nullptr, float* X2 = nullptr);   // rows with a slot also go to X2[slot]
+                  float* X, const int32_t* slot2 = nullptr, float* X2 = nullptr,     // rows with a slot also go to X2[slot]
+                  const AdamRowsView* vw = nullptr);                                 // vw: `emb` under a row-sparse Adam
 int rows_move(hipStream_t s, int mode, int R, int W, float* out, const float* in, const int32_t* src, const int32_t* dst);
 int rows_move_ld(hipStream_t s, int mode, int R, int W, float* out, int ld_out, const float* in, int ld_in,
                  const int32_t* src, const int32_t* dst);
@@ -285,6 +287,30 @@ int adam_step(hipStream_t s, int64_t n, float* p, const float* g, float* m, floa
               float beta2, float eps, int step, const float* scale_ptr, int scale_is_count = 0);
 int adam_step_mb(hipStream_t s, int64_t n, float* p, const float* g0, const float* g1, float* m, float* v, float lr,
                  float beta1, float beta2, float eps, int step, const int32_t* n0, const int32_t* n1);
+// Row-sparse Adam of the two vocabulary-sized embedding tables (copyhead.hip: adam_rows_kernel).  p / m / v: the flat buffers;
+// off[t] / rows[t]: first float and row count of table t (0 = decoder.embedding, 1 = encoder.embedding; 256 floats per row);
+// last [rows[0] + rows[1]]: the step up to which each row is current.
+constexpr int ADAM_ROWS_K = 32;            // every K-th step updates every row: a catch-up spans at most K - 1 steps
+struct AdamRowsHist { float bc1[ADAM_ROWS_K], bc2s[ADAM_ROWS_K]; };          // bias corrections of step j at [j % K]
+struct AdamRowsTables { float *p, *m, *v; int64_t off[2]; int rows[2]; int32_t* last; };
+// a lazily updated table seen by a forward gather (adam_rows.h: adam_rows_load): m / v / last of THAT table, rows current at
+// step `to` once their owed zero-gradient updates are applied; last == nullptr: a plain table
+struct AdamRowsView {
+    const float *m = nullptr, *v = nullptr;
+    const int32_t* last = nullptr;
+    int to = 0;
+    float lr = 0.f, beta1 = 0.f, beta2 = 0.f, eps = 0.f, gz = 0.f;
+    AdamRowsHist h;
+};
+AdamRowsView adam_rows_view(const AdamRowsTables& tb, int table, float lr, float beta1, float beta2, float eps, int to);
+struct AdamRowsLists { int n_lists; int end[4]; int table[4]; const int32_t* ids[4]; };   // end[k]: items of lists 0..k
+// the step `step` on every row whose gradient row is not zero (every row when step % K == 0); g: the flat gradient buffer;
+// normaliser 1 / max(*count, 1) if count else 1 / max(*n0, 1)
+int adam_rows_step(hipStream_t s, const AdamRowsTables& tb, const float* g, float lr, float beta1, float beta2, float eps,
+                   int step, const int32_t* n0, const float* count);
+// rows brought up to step `to` by zero-gradient updates: the listed ids (ls) or, ls == nullptr, every row
+int adam_rows_catchup(hipStream_t s, const AdamRowsTables& tb, const AdamRowsLists* ls, float lr, float beta1, float beta2,
+                      float eps, int to);
 
 // ---- parameter layout ---------------------------------------------------------------------------------
 struct ParamInfo {

@@ -759,6 +759,11 @@ struct Ctx {
     // writable (nothing reads [0, split) after the decoder's backward pass; see backward()).
     const fira_adam_opts* adam = nullptr;
     float* Pw = nullptr;
+    // (round 6) row-sparse Adam of the two vocabulary-sized embedding tables (fira_train_step_rows; copyhead.hip:
+    // adam_rows_kernel): row_step [2 * vocab] = the step up to which each row of decoder.embedding / encoder.embedding is
+    // current.  The rows this batch gathers are brought up to step - 1 ahead of the forward pass; the update itself runs on
+    // the rows whose gradient row is not zero.
+    int32_t* row_step = nullptr;
     // data-parallel form of the same (fira_train_step_begin / _end, round 6): the gradients of [0, split) are all-reduced by the
     // caller between the two calls -- Adam of [0, split) waits for ev_early (the caller's event behind that collective) instead of
     // the local weight-gradient mark, scales by the all-reduced token count `count` (a device float), and [split, live) is the
@@ -776,6 +781,15 @@ struct Ctx {
     struct Lane { hipStream_t s; int b0, nb, r0, nr; } lanes[2] = {};
 };
 typedef Ctx::Lane Lane;
+
+static AdamRowsTables adam_rows_tables(const Layout& L, float* params, const fira_adam_opts& ad, int32_t* row_step) {
+    AdamRowsTables tb;
+    tb.p = params; tb.m = ad.m; tb.v = ad.v;
+    tb.off[0] = L.dec_emb; tb.off[1] = L.emb;
+    tb.rows[0] = tb.rows[1] = L.d.vocab;
+    tb.last = row_step;
+    return tb;
+}
 
 // ------------------------------------------------------------------------------------------ commit-lanes (round 6)
 // The decoder's layers -- forward and backward -- are a dependent chain of ~100 launches whose kernels each leave most of the
@@ -862,6 +876,24 @@ static inline bool gcn_x3_on(int nl) {
 static inline bool fold_one_launch() {
     static const bool off = [] { const char* e = getenv("FIRA_FOLD_ONE"); return e && e[0] == '0'; }();
     return !off;
+}
+
+// the target-word rows this batch's decoder gathers, brought up to step - 1 in memory (the dense-target-row path only: the
+// compact paths read lazily, adam_rows_load)
+static int adam_rows_prefetch(Ctx& c, hipStream_t st) {
+    const fira_batch& bt = *c.bt;
+    const Plan& p = *c.pl;
+    const fira_adam_opts& ad = *c.adam;
+    AdamRowsLists ls{};
+    auto add = [&](const int32_t* ids, int n, int table) {
+        if (!ids || n <= 0) return;
+        const int k = ls.n_lists++;
+        ls.ids[k] = ids; ls.table[k] = table;
+        ls.end[k] = (k ? ls.end[k - 1] : 0) + n;
+    };
+    add(bt.tar, p.B * p.T, 0);
+    return adam_rows_catchup(st, adam_rows_tables(*c.L, c.Pw, ad, c.row_step), &ls, ad.lr, ad.beta1, ad.beta2, ad.eps,
+                             ad.step - 1);
 }
 
 static int encoder_forward(Ctx& c, bool defer_memory_proj) {
@@ -970,8 +1002,14 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
              p.mem_off, p.mem_valid_c));
     c.kv_ragged = true;
     // layer 0's code rows are also stored compactly (Xc of the first Combination): no gather launch on the chain
+    // (row-sparse Adam: a word row the last steps did not touch is read with the zero-gradient updates it still owes applied in
+    //  registers -- adam_rows.h; the view is empty otherwise)
+    AdamRowsView vw_emb;
+    if (c.row_step && c.adam)
+        vw_emb = adam_rows_view(adam_rows_tables(L, c.Pw, *c.adam, c.row_step), 1, c.adam->lr, c.adam->beta1, c.adam->beta2,
+                                c.adam->eps, c.adam->step - 1);
     TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
-                      p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc));
+                      p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc, &vw_emb));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
     TRY(linear(s, 4, p.nl * D, D, c.P + L.mark_emb, D, c.P + L.w2_all, c.P + L.b2_all, p.vtab_all, p.nl * D));
     for (int l = 0; l < p.nl; ++l) {
@@ -1047,8 +1085,16 @@ static int decoder_forward(Ctx& c) {
     Plan& p = *c.pl;
     const Layout& L = *c.L;
     const int D = FIRA_D, H = L.d.n_head, Sm = p.L + p.S;
-    if (c.row_bt) TRY(embed_rows_fwd(c.s, c.Td, p.T, c.row_bt, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0));
-    else TRY(embed_gather_fwd(c.s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
+    if (c.row_bt) {
+        AdamRowsView vw;                          // (see encoder_forward: the target-word table under a row-sparse Adam)
+        if (c.row_step && c.adam)
+            vw = adam_rows_view(adam_rows_tables(L, c.Pw, *c.adam, c.row_step), 0, c.adam->lr, c.adam->beta1, c.adam->beta2,
+                                c.adam->eps, c.adam->step - 1);
+        TRY(embed_rows_fwd(c.s, c.Td, p.T, c.row_bt, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, &vw));
+    } else {
+        if (c.row_step && c.adam) TRY(adam_rows_prefetch(c, c.s));      // dense target rows: the batch's rows brought up to date first
+        TRY(embed_gather_fwd(c.s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
+    }
     ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
     TRY(decoder_lanes(c));
     // wall time of the (possibly two-lane) layer loop on the caller's stream: what the decoder's products cost the step
@@ -1630,12 +1676,22 @@ static int backward_encoder(Ctx& c, BwdMid& mid) {
             else TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
         } else {
         if (ev_groupA) TRY(main_wait(s, ev_groupA, __LINE__));
-        TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+        // (row-sparse tables: decoder.embedding is the head of [0, split) -- layout.cpp -- and is left to the rows launch below)
+        const int64_t a0 = c.row_step ? L.dec_emb + (int64_t)L.d.vocab * D : 0;
+        TRY(adam_step_mb(s, L.split - a0, c.Pw + a0, G + a0, nullptr, ad.m + a0, ad.v + a0, ad.lr, ad.beta1, ad.beta2, ad.eps,
+                         ad.step, c.n_tok, nullptr));
         }
         // ... and the encoder's two embedding tables (the head of group B: layout.cpp), whose gradients the two launches above
         // on this stream have just completed -- also ahead of the join
         static const bool emb_early_off = [] { const char* e = getenv("FIRA_ADAM_EMB_EARLY"); return e && e[0] == '0'; }();   // A/B switch
         if (!emb_early_off && !c.adam_a_only) adam_b0 = L.mark_emb;
+        if (c.row_step && !c.adam_a_only) {
+            // both vocabulary-sized tables as ONE launch over the rows whose gradient row is not zero (the gradient rows are
+            // inspected: 2 x 25 MB read instead of 2 x 177 MB moved); the 71-row table joins the closing launch
+            TRY(adam_rows_step(s, adam_rows_tables(L, c.Pw, ad, c.row_step), G, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step,
+                               c.n_tok, nullptr));
+            adam_b0 = L.ast_emb;
+        } else
         if (adam_b0 > L.split)
         TRY(adam_step_mb(s, adam_b0 - L.split, c.Pw + L.split, G + L.split, nullptr, ad.m + L.split, ad.v + L.split, ad.lr, ad.beta1,
                          ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
@@ -1744,7 +1800,8 @@ static thread_local PendingStep g_pending;
 
 static int train_call(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
                       void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
-                      int32_t* n_tok, void* mid_event, float* params_w, const fira_adam_opts* adam, bool begin_only = false) {
+                      int32_t* n_tok, void* mid_event, float* params_w, const fira_adam_opts* adam, bool begin_only = false,
+                      int32_t* row_step = nullptr) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
     TRY(check_batch(batch));
@@ -1792,6 +1849,7 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
     c.Pw = params_w;
     const bool zero_g = opts && opts->zero_grads;
     if (!side_on() && zero_g) TRY(zero(c.s, grads, (size_t)L->live * sizeof(float)));
+    if (adam && row_step && L->d.d_model == FIRA_D) c.row_step = row_step;      // (encoder_forward brings the batch's rows up to date)
     TRY(encoder_forward(c, true));
     if (side_on()) {
         // the buffers the backward pass accumulates into are cleared on the auxiliary stream beside the forward pass (they
@@ -1920,6 +1978,47 @@ int fira_train_step(void* stream, const fira_dims* d, const fira_batch* batch, f
     FIRA_REQUIRE(adam && adam->m && adam->v, "fira_train_step: Adam moments missing");
     FIRA_REQUIRE(adam->step >= 1, "fira_train_step: the Adam step counter starts at 1");
     return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, nullptr, params, adam);
+}
+
+int fira_train_step_rows(void* stream, const fira_dims* d, const fira_batch* batch, float* params, float* grads, void* workspace,
+                         size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum, int32_t* n_tok,
+                         const fira_adam_opts* adam, int32_t* row_step) {
+    FIRA_REQUIRE(adam && adam->m && adam->v, "fira_train_step_rows: Adam moments missing");
+    FIRA_REQUIRE(adam->step >= 1, "fira_train_step_rows: the Adam step counter starts at 1");
+    FIRA_REQUIRE(row_step, "fira_train_step_rows: row_step missing");
+    FIRA_REQUIRE(opts && opts->zero_grads, "fira_train_step_rows: needs opts.zero_grads (an all-zero gradient row = an untouched row)");
+    return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, nullptr, params, adam,
+                      false, row_step);
+}
+// op-level pieces of the same (tests/test_adam_rows_gpu.py compares them with fira_adam_step_mb bit for bit)
+int fira_adam_rows_step(void* stream, const fira_dims* d, float* params, const float* grads, const fira_adam_opts* adam,
+                        int32_t* row_step, const int32_t* n_tok) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    FIRA_REQUIRE(params && grads && adam && adam->m && adam->v && row_step && n_tok && adam->step >= 1, "fira_adam_rows_step: bad argument");
+    FIRA_REQUIRE(L->d.d_model == FIRA_D, "fira_adam_rows_step: model width must be %d", FIRA_D);
+    return adam_rows_step((hipStream_t)stream, adam_rows_tables(*L, params, *adam, row_step), grads, adam->lr, adam->beta1,
+                          adam->beta2, adam->eps, adam->step, n_tok, nullptr);
+}
+int fira_adam_rows_catchup(void* stream, const fira_dims* d, float* params, const fira_adam_opts* adam, int32_t* row_step,
+                           int table, const int32_t* ids, int n_ids) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    FIRA_REQUIRE(params && adam && adam->m && adam->v && row_step && ids && n_ids >= 0 && (table == 0 || table == 1),
+                 "fira_adam_rows_catchup: bad argument");
+    FIRA_REQUIRE(L->d.d_model == FIRA_D, "fira_adam_rows_catchup: model width must be %d", FIRA_D);
+    AdamRowsLists ls{};
+    ls.n_lists = 1; ls.ids[0] = ids; ls.table[0] = table; ls.end[0] = n_ids;
+    return adam_rows_catchup((hipStream_t)stream, adam_rows_tables(*L, params, *adam, row_step), &ls, adam->lr, adam->beta1,
+                             adam->beta2, adam->eps, adam->step);
+}
+int fira_adam_rows_sync(void* stream, const fira_dims* d, float* params, const fira_adam_opts* adam, int32_t* row_step) {
+    const Layout* L = get_layout(d);
+    if (!L) return 1;
+    FIRA_REQUIRE(params && adam && adam->m && adam->v && row_step && adam->step >= 0, "fira_adam_rows_sync: bad argument");
+    FIRA_REQUIRE(L->d.d_model == FIRA_D, "fira_adam_rows_sync: model width must be %d", FIRA_D);
+    return adam_rows_catchup((hipStream_t)stream, adam_rows_tables(*L, params, *adam, row_step), nullptr, adam->lr, adam->beta1,
+                             adam->beta2, adam->eps, adam->step);
 }
 
 int fira_forward_dev(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, void* workspace,

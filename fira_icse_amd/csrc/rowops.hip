@@ -3,6 +3,7 @@
 // One wavefront owns one 256-float row as float4 per lane (a 1 KiB coalesced access);
 // row statistics are wave reductions (no LDS, no atomics on the forward path).
 #include "engine.h"
+#include "adam_rows.h"
 #include "epilogue.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -56,12 +57,13 @@ __global__ __launch_bounds__(256) void embed_gather_bwd_kernel(int rows, int L, 
 __global__ __launch_bounds__(256) void embed_rows_fwd_kernel(int R, int T, const int32_t* __restrict__ row_bt,
                                                              const int32_t* __restrict__ idx,
                                                              const float* __restrict__ table,
-                                                             const float* __restrict__ pos, float* __restrict__ out) {
+                                                             const float* __restrict__ pos, float* __restrict__ out,
+                                                             AdamRowsView vw) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int d = row_bt[r], t = d % T;
-    float4 v = *reinterpret_cast<const float4*>(table + (size_t)idx[d] * FIRA_D + lane * 4);
+    float4 v = adam_rows_load(table, idx[d], lane, vw);
     const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)t * FIRA_D + lane * 4);
     v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     *reinterpret_cast<float4*>(out + (size_t)r * FIRA_D + lane * 4) = v;
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256) void node_features_kernel(int Nc, const int32_
                                                             const float* __restrict__ ast_emb,
                                                             const float* __restrict__ pos_code,
                                                             float* __restrict__ X, const int32_t* __restrict__ slot2,
-                                                            float* __restrict__ X2) {
+                                                            float* __restrict__ X2, AdamRowsView vw) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= Nc) return;
@@ -659,11 +661,11 @@ __global__ __launch_bounds__(256) void node_features_kernel(int Nc, const int32_
     const int s2 = slot2 ? slot2[r] : -1;              // second, compact copy of the listed rows (the first layer's code rows)
     float4 v;
     if (loc < L) {
-        v = *reinterpret_cast<const float4*>(emb + (size_t)sou[b * L + loc] * FIRA_D + lane * 4);
+        v = adam_rows_load(emb, sou[b * L + loc], lane, vw);         // (vw: the word table under a row-sparse Adam)
         const float4 p = *reinterpret_cast<const float4*>(pos_code + (size_t)loc * FIRA_D + lane * 4);
         v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     } else if (loc < L + S) {
-        v = *reinterpret_cast<const float4*>(emb + (size_t)sub[b * S + loc - L] * FIRA_D + lane * 4);
+        v = adam_rows_load(emb, sub[b * S + loc - L], lane, vw);
     } else {
         v = *reinterpret_cast<const float4*>(ast_emb + (size_t)ast[b * A + loc - L - S] * FIRA_D + lane * 4);
     }
@@ -719,11 +721,11 @@ int prep(hipStream_t s, int B, int L, int S, int T, const int32_t* sou, const in
 }
 int node_features(hipStream_t s, int Nc, const int32_t* node_rows, int N, int L, int S, const int32_t* sou,
                   const int32_t* sub, const int32_t* ast, const float* emb, const float* ast_emb, const float* pos_code,
-                  float* X, const int32_t* slot2, float* X2) {
+                  float* X, const int32_t* slot2, float* X2, const AdamRowsView* vw) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (Nc <= 0) return 0;
     hipLaunchKernelGGL(node_features_kernel, dim3(cdiv(Nc, 4)), dim3(256), 0, s, Nc, node_rows, N, L, S, sou, sub, ast, emb,
-                       ast_emb, pos_code, X, slot2, X2);
+                       ast_emb, pos_code, X, slot2, X2, vw ? *vw : AdamRowsView());
     FIRA_CHECK_LAUNCH("node_features");
     return 0;
 }
@@ -744,10 +746,11 @@ int embed_gather_fwd(hipStream_t s, int B, int L, const int32_t* idx, const floa
     return 0;
 }
 int embed_rows_fwd(hipStream_t s, int R, int T, const int32_t* row_bt, const int32_t* idx, const float* table,
-                   const float* pos, float* out) {
+                   const float* pos, float* out, const AdamRowsView* vw) {
     ProfScope prof(s, PROF_ROWOPS, 0.0);
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(embed_rows_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, R, T, row_bt, idx, table, pos, out);
+    hipLaunchKernelGGL(embed_rows_fwd_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, R, T, row_bt, idx, table, pos, out,
+                       vw ? *vw : AdamRowsView());
     FIRA_CHECK_LAUNCH("embed_rows_fwd");
     return 0;
 }

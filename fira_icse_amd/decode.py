@@ -76,6 +76,7 @@ class Searcher:
 
     def _begin(self, db, beam):
         ws = self._workspace(db.B, beam)
+        self.model.sync_params()
         db.wait_ready()
         _lib.check(_lib.lib().fira_decode_begin_ex(_lib.cur_stream(), C.byref(self.model.dims), C.byref(db.struct),
                                                    _lib.ptr(self.model.flat.data), _lib.ptr(ws), ws.numel(), beam,

@@ -424,14 +424,24 @@ class TransModel(nn.Module):
         # training: decoder / head on the computed target rows only (fira_batch.dec_off); FIRA_COMPACT_DEC=0: A/B switch
         self.compact_dec = os.environ.get("FIRA_COMPACT_DEC", "1") != "0"
         self.compute_dtype = "f32"             # "f32" (the reference's arithmetic) | "bf16" (BASELINE configs[2])
+        self._rows_sync = None                 # see sync_params
         if init:
             self.load_state_dict(reference_init_state_dict(self.cfg))
 
     # ------------------------------------------------------------------ checkpoint surface
+    def sync_params(self):
+        """Bring every parameter in ``self.flat`` up to date.  A :class:`train.Trainer` on the row-sparse Adam path
+        (fira_train_step_rows) leaves embedding rows its batches did not touch a few zero-gradient updates behind; it registers
+        ``self._rows_sync`` and every reader of the parameters other than its own step calls this first."""
+        if self._rows_sync is not None:
+            self._rows_sync()
+
     def state_dict(self, *a, **k):
+        self.sync_params()
         return OrderedDict((n, v.detach().clone()) for n, v in self._views.items())
 
     def load_state_dict(self, sd, strict: bool = True):
+        self.sync_params()
         missing = [k for k in self._views if k not in sd]
         unexpected = [k for k in sd if k not in self._views]
         if strict and (missing or unexpected):
@@ -445,6 +455,7 @@ class TransModel(nn.Module):
         return self
 
     def named_views(self):
+        self.sync_params()
         return self._views
 
     def grad_views(self):
@@ -466,6 +477,7 @@ class TransModel(nn.Module):
         """loss_sum, n_tok (device scalars) and d(loss_sum)/d(params) into ``self.gbuf`` (reference
         run_model.py:104-108 minus the optimizer).  Dropout follows ``self.training`` unless given."""
         lib = _lib.lib()
+        self.sync_params()
         db.wait_ready()
         # zero_grad: the library clears gbuf[0, live) itself (opts.zero_grads), beside the encoder's forward pass; tensors
         # past `live` never receive a gradient (SURVEY.md F6)
@@ -484,11 +496,15 @@ class TransModel(nn.Module):
 
     def train_step(self, db: DeviceBatch, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, beta1: float = 0.9,
                    beta2: float = 0.999, eps: float = 1e-8, dropout: Optional[float] = None,
-                   gcn_dropout: Optional[float] = None):
+                   gcn_dropout: Optional[float] = None, row_step: Optional[torch.Tensor] = None):
         """``loss.backward(); optimizer.step()`` of run_model.py:104-111 as ONE library call (fira_train_step): the same
         arithmetic as :meth:`train_fwd_bwd` + ``ops.adam_step_mb`` over ``[0, live)``; the head + decoder slice of the update
-        runs beside the last weight gradients.  ``m`` / ``v``: the Adam moments (flat, like ``self.flat``)."""
+        runs beside the last weight gradients.  ``m`` / ``v``: the Adam moments (flat, like ``self.flat``).
+        ``row_step`` (int32 ``[2 * vocab]``): fira_train_step_rows -- the two vocabulary-sized embedding tables are updated on
+        the rows the step touched only; the caller owns the sync (:meth:`sync_params`, ``Trainer.sync``)."""
         lib = _lib.lib()
+        if row_step is None:
+            self.sync_params()
         db.wait_ready()
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
         pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
@@ -497,6 +513,12 @@ class TransModel(nn.Module):
                               1 if self.compact_dec else 0, 1)
         adam = _lib.AdamOpts(lr, beta1, beta2, eps, int(step), _lib.ptr(m), _lib.ptr(v))
         ws = self.workspace(db.B, 1)
+        if row_step is not None:
+            _lib.check(lib.fira_train_step_rows(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
+                                                _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
+                                                C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok), C.byref(adam),
+                                                _lib.ptr(row_step)), "fira_train_step_rows")
+            return self.loss_sum, self.n_tok
         _lib.check(lib.fira_train_step(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct), _lib.ptr(self.flat.data),
                                        _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(), C.byref(opts),
                                        _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok), C.byref(adam)),
@@ -509,6 +531,7 @@ class TransModel(nn.Module):
         ``mid_event`` fires when the gradients of ``[0, split)`` are final.  The step stays pending until
         :meth:`train_step_end`; ``db`` must stay alive until then."""
         lib = _lib.lib()
+        self.sync_params()
         db.wait_ready()
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
         pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
@@ -563,6 +586,7 @@ class TransModel(nn.Module):
     def forward_dev(self, db: DeviceBatch) -> torch.Tensor:
         """Teacher-forced argmax ids [B, tar_len] (reference Model.py:85-86)."""
         lib = _lib.lib()
+        self.sync_params()
         db.wait_ready()
         ids = torch.empty((db.B, self.cfg.tar_len), dtype=torch.int32, device=self.device_)
         ws = self._ws.get((db.B, 1))          # share the training arena when it exists
@@ -583,6 +607,7 @@ class TransModel(nn.Module):
         db = edge if isinstance(edge, DeviceBatch) else self.make_batch(
             input_token, None, mark, ast_change, edge, None, sub_token)
         lib = _lib.lib()
+        self.sync_params()
         db.wait_ready()
         n = lib.fira_decode_workspace_bytes(C.byref(self.dims), db.B, 1)
         if ("enc", db.B) not in self._ws:
@@ -603,6 +628,7 @@ class TransModel(nn.Module):
         """Full-recompute Decoder.forward (gnn_transformer.py:108-122): ids [B,30], memory [B,370,256], mask [B,370]."""
         B = output_token.shape[0]
         lib = _lib.lib()
+        self.sync_params()
         ws = self.workspace(B, 0)
         out = torch.empty((B, self.cfg.tar_len, 256), dtype=torch.float32, device=self.device_)
         tar = output_token.to(self.device_, torch.int32).contiguous()

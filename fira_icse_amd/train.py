@@ -48,6 +48,17 @@ class Trainer:
         # Adam of [0, split) inside the library, beside its last weight gradients, behind the early bucket's event)
         self.fused_dp = distributed and not zero1 and fused_on and _lib.has_symbol("fira_train_step_begin")
         self.t = 0
+        # row-sparse Adam of the two vocabulary-sized embedding tables (fira_train_step_rows, round 6): the rows a batch did
+        # not touch are updated lazily, bit for bit (include/fira_hip.h); FIRA_ADAM_ROWS=0 = every row every step (A/B switch).
+        # The model calls self.sync before anything but this trainer's step reads the parameters.
+        self.row_step = None
+        self._rows_dirty = False
+        self._rows_hyper = None
+        if self.fused_step and os.environ.get("FIRA_ADAM_ROWS", "1") != "0" and _lib.has_symbol("fira_train_step_rows") \
+                and model.cfg.embedding_dim == 256:
+            model.sync_params()                                  # (an earlier trainer of this model may still owe rows)
+            self.row_step = torch.zeros(2 * model.cfg.vocab_size, dtype=torch.int32, device=model.gbuf.device)
+            model._rows_sync = self.sync
         self.inv = torch.zeros(1, dtype=torch.float32, device=model.gbuf.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=model.gbuf.device)
         self.reducer = GradReducer(model.layout.split, model.layout.live, wire=grad_wire) if distributed else None
@@ -77,8 +88,13 @@ class Trainer:
             self.mid_event.record()
             loss_sum, n_tok = m.loss_sum, m.n_tok
         elif self.fused_step and self.reducer is None and self.zero is None:
+            hyper = (self.lr, self.betas[0], self.betas[1], self.eps)
+            if self._rows_hyper != hyper:                        # lazily applied updates use the step's own lr / beta / eps
+                self.sync()
+                self._rows_hyper = hyper
             self.t += 1
-            m.train_step(db, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps)
+            m.train_step(db, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps, row_step=self.row_step)
+            self._rows_dirty = self.row_step is not None
             return
         elif dp and self.fused_dp and self.zero is None:
             fused_dp = True
@@ -147,6 +163,20 @@ class Trainer:
                 z.all_gather(b, m.flat.data)
         main.wait_stream(zs)                                   # the next forward pass reads every parameter
 
+    def sync(self):
+        """Apply the embedding-row updates the row-sparse path still owes (fira_adam_rows_sync): afterwards ``model.flat``,
+        ``self.m`` and ``self.v`` are what the dense update leaves after ``self.t`` steps, bit for bit.  Cheap when nothing
+        is owed.  Synchronises the stream (a phase change -- checkpoint, dev pass, search -- not a per-step call)."""
+        if self.row_step is None or not self._rows_dirty:
+            return
+        self._rows_dirty = False
+        lr, b1, b2, eps = self._rows_hyper
+        import ctypes as C
+        adam = _lib.AdamOpts(lr, b1, b2, eps, int(self.t), _lib.ptr(self.m), _lib.ptr(self.v))
+        _lib.check(_lib.lib().fira_adam_rows_sync(_lib.cur_stream(), C.byref(self.model.dims), _lib.ptr(self.model.flat.data),
+                                                  C.byref(adam), _lib.ptr(self.row_step)), "fira_adam_rows_sync")
+        torch.cuda.current_stream().synchronize()
+
     def last_loss(self) -> float:
         """Mean token loss of the last (global) batch; synchronises."""
         if self.reducer is not None and self.reducer.world > 1:
@@ -162,6 +192,7 @@ class Trainer:
             total = self.model.layout.total
             return {"m": self.zero.gather_full(self.m_sh, total), "v": self.zero.gather_full(self.v_sh, total),
                     "t": self.t, "dropout_step": self.model.dropout_step}
+        self.sync()
         return {"m": self.m, "v": self.v, "t": self.t, "dropout_step": self.model.dropout_step}
 
     def load_state_dict(self, sd):
@@ -170,6 +201,9 @@ class Trainer:
                 lo, hi = self.zero.owned(b)
                 self.m_sh[b][:hi - lo].copy_(sd["m"][lo:hi]); self.v_sh[b][:hi - lo].copy_(sd["v"][lo:hi])
         else:
+            self.sync()
             self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.t = int(sd["t"])
+        if self.row_step is not None:
+            self.row_step.fill_(self.t)                          # a checkpoint holds synced tables
         self.model.dropout_step = int(sd.get("dropout_step", self.t))

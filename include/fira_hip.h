@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FIRA_ABI_VERSION 9
+#define FIRA_ABI_VERSION 10
 
 /* ---- model geometry: reference run_model.py:30-46 (args) ---------------------------------- */
 typedef struct fira_dims {
@@ -509,6 +509,31 @@ int fira_train_step_begin(void* stream, const fira_dims* d, const fira_batch* ba
                           int32_t* n_tok, void* mid_event /* hipEvent_t, required */);
 int fira_train_step_end(void* stream, float* params, const fira_adam_opts* adam, void* early_event /* hipEvent_t or NULL */,
                         const float* count);
+
+/* (v10) fira_train_step with a ROW-SPARSE Adam of the two vocabulary-sized embedding tables (decoder.embedding.weight,
+ * encoder.embedding.weight: 2 x 6.3 M of the 27.8 M parameters; run_model.py:396's torch.optim.Adam updates every row of both
+ * every step).  An embedding row whose gradient row is all zero still moves under Adam -- its moments decay and the parameter
+ * follows -- but that update is a function of the row's (p, m, v) and the step number alone, so it is applied LATER, in
+ * registers, bit for bit: ahead of a forward pass for the rows that pass gathers (the batch's token ids), or together with the
+ * next step whose gradient row is not zero.  row_step [2 * vocab] int32 (zero-initialised with the moments; decoder table
+ * first) holds the step up to which each row of params / m / v is current.  Every 32nd step updates every row, so a row lags
+ * at most 31 steps.  Results are those of fira_train_step bit for bit ONCE fira_adam_rows_sync has run: call it (same adam
+ * values, step = the last completed step) before anything else reads the tables or the moments -- checkpoint, dev pass,
+ * search, another optimizer -- and before changing lr / beta / eps.  adam->step must advance by one per call.  Needs
+ * opts->zero_grads = 1.  Single-device training only (a data-parallel step keeps fira_train_step_begin / _end).             */
+int fira_train_step_rows(void* stream, const fira_dims* d, const fira_batch* batch, float* params, float* grads,
+                         void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                         int32_t* n_tok, const fira_adam_opts* adam, int32_t* row_step);
+int fira_adam_rows_sync(void* stream, const fira_dims* d, float* params, const fira_adam_opts* adam, int32_t* row_step);
+/* The two pieces fira_train_step_rows is made of, as op-level entries (params / grads / m / v: the flat buffers of geometry d):
+ * fira_adam_rows_catchup  rows ids[0 .. n_ids) of table `table` (0 decoder.embedding, 1 encoder.embedding; duplicates and
+ *                         out-of-range ids allowed) brought up to step adam->step by zero-gradient updates;
+ * fira_adam_rows_step     step adam->step on every row of the two tables whose gradient row is not all zero (every row when
+ *                         step % 32 == 0), normaliser 1 / max(*n_tok, 1) as fira_adam_step_mb.                              */
+int fira_adam_rows_catchup(void* stream, const fira_dims* d, float* params, const fira_adam_opts* adam, int32_t* row_step,
+                           int table, const int32_t* ids, int n_ids);
+int fira_adam_rows_step(void* stream, const fira_dims* d, float* params, const float* grads, const fira_adam_opts* adam,
+                        int32_t* row_step, const int32_t* n_tok);
 
 /* (v8) bf16 wire format of a gradient bucket (BASELINE configs[2]: 55.6 MB instead of 111.2 MB per step on xGMI):
  * out[i] = bf16(in[i]) (round to nearest even) / out[i] = float(in[i]).  n % 4 == 0, 16-byte aligned buffers. */

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_abi_version_and_error_string(lib):
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fira_hip.h")).read()
-    assert lib.fira_abi_version() == int(re.search(r"#define FIRA_ABI_VERSION (\d+)", header).group(1)) == 9
+    assert lib.fira_abi_version() == int(re.search(r"#define FIRA_ABI_VERSION (\d+)", header).group(1)) == 10
     bad = _lib.make_dims(FiraConfig(embedding_dim=128))
     assert lib.fira_param_count(C.byref(bad)) == -1
     assert b"d_model=256" in lib.fira_last_error()

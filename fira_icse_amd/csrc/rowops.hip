@@ -109,7 +109,18 @@ __global__ __launch_bounds__(256) void embed_grouped_bwd_kernel(int n_items, con
         for (int u = 0; u < 4; ++u)
             if (k + u < cnt) { acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w; }
     }
-    float* p = dtable + (size_t)item_tok[item] * FIRA_D + lane * 4;
+    // items are grouped by word id (model.embedding_items / fira_host_node_lists: a word with more than 32 rows is cut into
+    // ADJACENT items): a word with a single item is the only writer of its gradient row in this launch -- one 16-byte
+    // read-modify-write instead of four float atomics per lane (768 k atomics per launch at batch 32 otherwise)
+    const int tok = item_tok[item];
+    const bool shared = (item > 0 && item_tok[item - 1] == tok) || (item + 1 < n_items && item_tok[item + 1] == tok);
+    float* p = dtable + (size_t)tok * FIRA_D + lane * 4;
+    if (!shared) {
+        float4 cur = *reinterpret_cast<float4*>(p);
+        cur.x += acc.x; cur.y += acc.y; cur.z += acc.z; cur.w += acc.w;
+        *reinterpret_cast<float4*>(p) = cur;
+        return;
+    }
     unsafeAtomicAdd(p + 0, acc.x);
     unsafeAtomicAdd(p + 1, acc.y);
     unsafeAtomicAdd(p + 2, acc.z);

@@ -71,7 +71,8 @@ typedef struct fira_batch {
      * grouped by word id for the embedding gradient (gnn_transformer.py:46-52 backward).  Frequent tokens ('(' ';' ...)
      * occur hundreds of times per batch; one wave sums up to 32 positions of one id before touching the table row. */
     int32_t n_emb_items;
-    const int32_t* emb_item_tok; /* [n_emb_items] word id of the item (never 0 = padding_idx)                      */
+    const int32_t* emb_item_tok; /* [n_emb_items] word id of the item (never 0 = padding_idx); the items of one word
+                                  * are ADJACENT (a word with a single item is written without atomics)           */
     const int32_t* emb_item_ptr; /* [n_emb_items + 1] offsets into emb_rows; at most 32 rows per item              */
     const int32_t* emb_rows;     /* COMPACT node ids (position in node_rows) of code / sub-token nodes, grouped by word id */
     /* ---- optional, together with emb_*: the computed AST / edit-operation nodes with a non-zero id, so that the whole

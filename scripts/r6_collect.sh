@@ -5,7 +5,7 @@
 TAG=${1:-r6final}; COMMIT=${2:-$(git rev-parse --short HEAD)}
 S=gpurun_out/$TAG
 VAL=$(python -c "import json;print(round(json.loads(open('$S/bench_f32.json').read().strip().splitlines()[-1])['value']))")
-STAMP="<!-- round 6, session $TAG, built from commit $COMMIT; this box: $VAL commits/s on the default bench line (pool classes this round: ~12 500 slow, ~13 400 fast at this commit) -->"
+STAMP="<!-- round 6, session $TAG, built from commit $COMMIT; this box: $VAL commits/s on the default bench line (pool classes this round: ~12 600 slow, ~13 600 fast at this commit) -->"
 stamp() { { echo "$STAMP"; echo; cat "$1"; } > "$2"; }
 for DT in f32 bf16; do
   [ -f $S/kernel_stats_$DT.md ] && stamp $S/kernel_stats_$DT.md profiles/r6_kernel_stats_$DT.md

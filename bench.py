@@ -47,6 +47,12 @@ import subprocess
 import sys
 import time
 
+# The search keeps several batches in flight, each on its own HIP stream (decode.Searcher.greedy_many); HIP multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two lanes that land on one queue run one after the other: four lanes
+# took 0.38 ms per batch-step on 4 queues and 0.14 on 8 (profiles/r6_probes.md).  Read by the HIP runtime when it initialises,
+# so it is set before torch is imported; training is unaffected (same-box triple).  An exported value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -393,7 +399,7 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
     # with the test set's consecutive batches); the batch size per search call stays BASELINE configs[3]'s 64
     try:
         n_store = len(store)
-        n_fl = 3
+        n_fl = int(os.environ.get("FIRA_DECODE_IN_FLIGHT", "4"))
         group = [dbd] + [DeviceBatch(store.batch([(j * a.decode_batch + k) % n_store for k in range(a.decode_batch)]), cfg,
                                      model.device_) for j in range(1, n_fl)]
         for _ in range(2):
@@ -413,8 +419,8 @@ def decode_leg(cfg, store, model, trainer, batches, a, world, barrier):
                                "speedup_over_one_at_a_time": (a.decode_batch * steps2 / d2) / (a.decode_batch * steps_run / ddt),
                                "batch": a.decode_batch, "batches_in_flight": n_fl, "ids_equal_to_single": same,
                                "note": "%d independent batches of %d, each on its own stream / workspace / captured graphs "
-                                       "(one decode step is ~58 dependent launches of 16-48 workgroups: one chain leaves most "
-                                       "of the chip idle); per-batch arithmetic and ids unchanged" % (n_fl, a.decode_batch)}
+                                       "(one decode step is 41 dependent launches of 16-64 workgroups: one chain leaves most "
+                                       "of the chip idle; GPU_MAX_HW_QUEUES=%s); per-batch arithmetic and ids unchanged" % (n_fl, a.decode_batch, os.environ.get("GPU_MAX_HW_QUEUES", "default"))}
     except Exception as e:
         decode["in_flight"] = {"error": repr(e)}
     # the same greedy search streaming a bf16 copy of the cross K|V (FIRA_DECODE_KV_BF16; not the default: the ids are no

@@ -181,15 +181,17 @@ class Searcher:
         return st["out"].long(), st["length"].long(), st["prob"].clone()
 
     @torch.no_grad()
-    def greedy_many(self, dbs, in_flight: int = 3, chunk: int = 5):
+    def greedy_many(self, dbs, in_flight: int = 4, chunk: int = 5):
         """Greedy search over a sequence of batches with ``in_flight`` of them on the GPU at once, each on its own stream
         (its own workspace, hypothesis state and captured graphs); results are returned in the order of ``dbs``.
 
         One decode step is ~58 dependent launches of 16-48 workgroups each: a single batch of 64 keeps a fraction of the 256
         CUs busy and the loop is bound by the launch chain, not by the chip.  The reference walks the test set batch after
-        batch (run_model.py:225); nothing couples two batches, so independent chains share the chip.  Three lanes: x1.7
-        step-tokens/s in every process tried; four lanes reach x2.5 in a fresh process but fall BELOW one lane (x0.8) once
-        the process has created more streams (a trainer's): HIP oversubscribes its hardware queues -- DESIGN.md section 6.
+        batch (run_model.py:225); nothing couples two batches, so independent chains share the chip.  HIP multiplexes the
+        lanes' streams onto GPU_MAX_HW_QUEUES hardware queues: on the default 4, three lanes gave x1.7 step-tokens/s and four fell
+        BELOW one lane (x0.8) once the process had created more streams (a trainer's) -- two lanes on one queue run one after
+        the other.  On 8 queues (run_model.py / bench.py / this package set GPU_MAX_HW_QUEUES=8 before HIP initialises) three
+        lanes give x2.06 and four x2.35 in a process that trained first; six collapse again (profiles/r6_probes.md).
         Same arithmetic, same ids as ``greedy`` batch by batch."""
         dbs = list(dbs)
         n_lane = max(1, min(in_flight, len(dbs)))

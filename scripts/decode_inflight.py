@@ -22,8 +22,9 @@ if n_train:                                            # the bench's situation: 
     torch.cuda.synchronize()
     print("trained %d steps, loss %.3f" % (n_train, tr.last_loss()), flush=True)
 model.eval()
-dbs = [DeviceBatch(store.batch(range(64 * i, 64 * i + 64)), cfg) for i in range(4)]
-for n in (1, 2, 3, 4):
+NB = int(os.environ.get("N_BATCH", "4"))                # batches per group (256 synthetic commits: reused modulo 4)
+dbs = [DeviceBatch(store.batch(range(64 * (i % 4), 64 * (i % 4) + 64)), cfg) for i in range(NB)]
+for n in [int(x) for x in os.environ.get("N_LANES", "1,2,3,4").split(",")]:
     s = Searcher(model)
     for _ in range(2):
         s.greedy_many(dbs, in_flight=n)
@@ -33,5 +34,5 @@ for n in (1, 2, 3, 4):
         s.greedy_many(dbs, in_flight=n)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print("in flight %d: %.2f ms for 4 batches of 64 x 29 steps = %.4f ms per batch-step, %.0f step-tokens/s" %
-          (n, dt * 1e3, dt * 1e3 / (4 * 29), 4 * 64 * 29 / dt), flush=True)
+    print("in flight %d: %.2f ms for %d batches of 64 x 29 steps = %.4f ms per batch-step, %.0f step-tokens/s" %
+          (n, dt * 1e3, NB, dt * 1e3 / (NB * 29), NB * 64 * 29 / dt), flush=True)

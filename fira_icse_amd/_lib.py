@@ -110,7 +110,9 @@ SIGNATURES = {
     "fira_train_step_rows": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, C.POINTER(AdamOpts), _P]),
     "fira_adam_rows_sync": (_I, [_P, _DP, _P, C.POINTER(AdamOpts), _P]),
     "fira_adam_rows_catchup": (_I, [_P, _DP, _P, C.POINTER(AdamOpts), _P, _I, _P, _I]),
-    "fira_adam_rows_step": (_I, [_P, _DP, _P, _P, C.POINTER(AdamOpts), _P, _P]),
+    "fira_adam_rows_step": (_I, [_P, _DP, _P, _P, C.POINTER(AdamOpts), _P, _P, _P, _I]),
+    "fira_train_step_begin_rows": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P, C.POINTER(AdamOpts), _P]),
+    "fira_train_step_end_rows": (_I, [_P, _P, C.POINTER(AdamOpts), _P, _P, _P]),
     "fira_train_step_begin": (_I, [_P, _DP, _BP, _P, _P, _P, _Z, _OP, _P, _P, _P]),
     "fira_train_step_end": (_I, [_P, _P, C.POINTER(AdamOpts), _P, _P]),
     "fira_f32_to_bf16": (_I, [_P, _L, _P, _P]),

@@ -563,17 +563,17 @@ __global__ __launch_bounds__(256) void adam_mb_kernel(int64_t n, float* __restri
 __global__ __launch_bounds__(256) void adam_rows_kernel(AdamRowsTables tb, const float* __restrict__ gbase, float lr,
                                                         float beta1, float beta2, float eps, int step, AdamRowsHist h,
                                                         const int32_t* __restrict__ n0, const float* __restrict__ count,
-                                                        int force, float gz) {
+                                                        int force, float gz, int it_lo, int it_hi) {
     float scale;
     if (count) scale = 1.0f / fmaxf(*count, 1.0f);
     else { const int nt = *n0; scale = 1.0f / (float)(nt > 0 ? nt : 1); }
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4;
-    const int total = tb.rows[0] + tb.rows[1];
+    const int total = it_hi;                              // rows it_lo .. it_hi of the two tables' combined row space
     const float ss = lr / h.bc1[step % ADAM_ROWS_K], b2s = h.bc2s[step % ADAM_ROWS_K];
     // four gradient rows requested per trip (the launch is a stream of 1 KB reads with a wave-uniform skip: one row per trip
     // left it latency-bound at 2.5 TB/s)
-    for (int it0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; it0 < total; it0 += nw * 4) {
+    for (int it0 = it_lo + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; it0 < total; it0 += nw * 4) {
         float4 gq[4];
         size_t oq[4];
 #pragma unroll
@@ -980,14 +980,15 @@ AdamRowsView adam_rows_view(const AdamRowsTables& tb, int table, float lr, float
     return vw;
 }
 int adam_rows_step(hipStream_t s, const AdamRowsTables& tb, const float* g, float lr, float beta1, float beta2, float eps,
-                   int step, const int32_t* n0, const float* count) {
+                   int step, const int32_t* n0, const float* count, int tables) {
     ProfScope prof(s, PROF_ADAM, 0.0);
     FIRA_REQUIRE(step >= 1 && tb.last && (n0 || count), "adam_rows_step: bad argument");
-    const int total = tb.rows[0] + tb.rows[1];
+    const int it_lo = (tables & 1) ? 0 : tb.rows[0], it_hi = (tables & 2) ? tb.rows[0] + tb.rows[1] : tb.rows[0];
+    const int total = it_hi - it_lo;
     if (total <= 0) return 0;
     const int grid = std::min(cdiv(total, 16), 256 * 8);
     hipLaunchKernelGGL(adam_rows_kernel, dim3(grid), dim3(256), 0, s, tb, g, lr, beta1, beta2, eps, step,
-                       adam_rows_hist(beta1, beta2, step), n0, count, step % ADAM_ROWS_K == 0 ? 1 : 0, 0.0f);
+                       adam_rows_hist(beta1, beta2, step), n0, count, step % ADAM_ROWS_K == 0 ? 1 : 0, 0.0f, it_lo, it_hi);
     FIRA_CHECK_LAUNCH("adam_rows_step");
     return 0;
 }

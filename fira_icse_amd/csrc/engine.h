@@ -307,7 +307,7 @@ struct AdamRowsLists { int n_lists; int end[4]; int table[4]; const int32_t* ids
 // the step `step` on every row whose gradient row is not zero (every row when step % K == 0); g: the flat gradient buffer;
 // normaliser 1 / max(*count, 1) if count else 1 / max(*n0, 1)
 int adam_rows_step(hipStream_t s, const AdamRowsTables& tb, const float* g, float lr, float beta1, float beta2, float eps,
-                   int step, const int32_t* n0, const float* count);
+                   int step, const int32_t* n0, const float* count, int tables = 3);    // tables: bit t = table t takes part
 // rows brought up to step `to` by zero-gradient updates: the listed ids (ls) or, ls == nullptr, every row
 int adam_rows_catchup(hipStream_t s, const AdamRowsTables& tb, const AdamRowsLists* ls, float lr, float beta1, float beta2,
                       float eps, int to);

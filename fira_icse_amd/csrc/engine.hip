@@ -764,6 +764,7 @@ struct Ctx {
     // current.  The rows this batch gathers are brought up to step - 1 ahead of the forward pass; the update itself runs on
     // the rows whose gradient row is not zero.
     int32_t* row_step = nullptr;
+    fira_adam_opts rows_ad{};        // lr / beta / eps / step / moments the lazy reads use (a COPY: a begun data-parallel step outlives the call)
     // data-parallel form of the same (fira_train_step_begin / _end, round 6): the gradients of [0, split) are all-reduced by the
     // caller between the two calls -- Adam of [0, split) waits for ev_early (the caller's event behind that collective) instead of
     // the local weight-gradient mark, scales by the all-reduced token count `count` (a device float), and [split, live) is the
@@ -883,7 +884,7 @@ static inline bool fold_one_launch() {
 static int adam_rows_prefetch(Ctx& c, hipStream_t st) {
     const fira_batch& bt = *c.bt;
     const Plan& p = *c.pl;
-    const fira_adam_opts& ad = *c.adam;
+    const fira_adam_opts& ad = c.rows_ad;
     AdamRowsLists ls{};
     auto add = [&](const int32_t* ids, int n, int table) {
         if (!ids || n <= 0) return;
@@ -892,7 +893,7 @@ static int adam_rows_prefetch(Ctx& c, hipStream_t st) {
         ls.end[k] = (k ? ls.end[k - 1] : 0) + n;
     };
     add(bt.tar, p.B * p.T, 0);
-    return adam_rows_catchup(st, adam_rows_tables(*c.L, c.Pw, ad, c.row_step), &ls, ad.lr, ad.beta1, ad.beta2, ad.eps,
+    return adam_rows_catchup(st, adam_rows_tables(*c.L, const_cast<float*>(c.P), ad, c.row_step), &ls, ad.lr, ad.beta1, ad.beta2, ad.eps,
                              ad.step - 1);
 }
 
@@ -1005,9 +1006,9 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
     // (row-sparse Adam: a word row the last steps did not touch is read with the zero-gradient updates it still owes applied in
     //  registers -- adam_rows.h; the view is empty otherwise)
     AdamRowsView vw_emb;
-    if (c.row_step && c.adam)
-        vw_emb = adam_rows_view(adam_rows_tables(L, c.Pw, *c.adam, c.row_step), 1, c.adam->lr, c.adam->beta1, c.adam->beta2,
-                                c.adam->eps, c.adam->step - 1);
+    if (c.row_step)
+        vw_emb = adam_rows_view(adam_rows_tables(L, nullptr, c.rows_ad, c.row_step), 1, c.rows_ad.lr, c.rows_ad.beta1, c.rows_ad.beta2,
+                                c.rows_ad.eps, c.rows_ad.step - 1);
     TRY(node_features(s, Nc, bt.node_rows, p.N, p.L, p.S, bt.sou, bt.sub_token, bt.ast_change, c.P + L.emb, c.P + L.ast_emb,
                       p.pos_code, p.X[0], p.code_slot, p.enc[0].Xc, &vw_emb));
     // value projection of the 4-row mark table for all layers at once: vtab_all [4, nl*256]
@@ -1087,12 +1088,12 @@ static int decoder_forward(Ctx& c) {
     const int D = FIRA_D, H = L.d.n_head, Sm = p.L + p.S;
     if (c.row_bt) {
         AdamRowsView vw;                          // (see encoder_forward: the target-word table under a row-sparse Adam)
-        if (c.row_step && c.adam)
-            vw = adam_rows_view(adam_rows_tables(L, c.Pw, *c.adam, c.row_step), 0, c.adam->lr, c.adam->beta1, c.adam->beta2,
-                                c.adam->eps, c.adam->step - 1);
+        if (c.row_step)
+            vw = adam_rows_view(adam_rows_tables(L, nullptr, c.rows_ad, c.row_step), 0, c.rows_ad.lr, c.rows_ad.beta1, c.rows_ad.beta2,
+                                c.rows_ad.eps, c.rows_ad.step - 1);
         TRY(embed_rows_fwd(c.s, c.Td, p.T, c.row_bt, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, &vw));
     } else {
-        if (c.row_step && c.adam) TRY(adam_rows_prefetch(c, c.s));      // dense target rows: the batch's rows brought up to date first
+        if (c.row_step) TRY(adam_rows_prefetch(c, c.s));      // dense target rows: the batch's rows brought up to date first
         TRY(embed_gather_fwd(c.s, p.B, p.T, c.bt->tar, c.P + L.dec_emb, p.pos_tar, p.x0, p.T, 0));
     }
     ProfDecoderTag prof_tag;                   // the M = B*30 products below are reported as their own class
@@ -1672,8 +1673,14 @@ static int backward_encoder(Ctx& c, BwdMid& mid) {
             // data parallel: the bucket's all-reduce (enqueued by the caller between the two calls) has passed ev_early; the
             // normaliser is the all-reduced token count
             if (c.ev_early) TRY(main_wait(s, c.ev_early, __LINE__));
-            if (c.count) TRY(adam_step(s, L.split, c.Pw, G, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.count, 1));
-            else TRY(adam_step_mb(s, L.split, c.Pw, G, nullptr, ad.m, ad.v, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+            // (row-sparse tables, data parallel: decoder.embedding -- the head of this slice -- by the rows of the ALL-REDUCED
+            //  gradient that are not zero: the union of the ranks' touched rows, the same on every rank)
+            const int64_t a0 = c.row_step ? L.dec_emb + (int64_t)L.d.vocab * D : 0;
+            if (c.count) TRY(adam_step(s, L.split - a0, c.Pw + a0, G + a0, ad.m + a0, ad.v + a0, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.count, 1));
+            else TRY(adam_step_mb(s, L.split - a0, c.Pw + a0, G + a0, nullptr, ad.m + a0, ad.v + a0, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step, c.n_tok, nullptr));
+            if (c.row_step)
+                TRY(adam_rows_step(s, adam_rows_tables(L, c.Pw, ad, c.row_step), G, ad.lr, ad.beta1, ad.beta2, ad.eps, ad.step,
+                                   c.count ? nullptr : c.n_tok, c.count, 1));
         } else {
         if (ev_groupA) TRY(main_wait(s, ev_groupA, __LINE__));
         // (row-sparse tables: decoder.embedding is the head of [0, split) -- layout.cpp -- and is left to the rows launch below)
@@ -1849,7 +1856,11 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
     c.Pw = params_w;
     const bool zero_g = opts && opts->zero_grads;
     if (!side_on() && zero_g) TRY(zero(c.s, grads, (size_t)L->live * sizeof(float)));
-    if (adam && row_step && L->d.d_model == FIRA_D) c.row_step = row_step;      // (encoder_forward brings the batch's rows up to date)
+    if (adam && row_step && L->d.d_model == FIRA_D) {        // (the forward gathers read lagging rows lazily: adam_rows_load)
+        c.row_step = row_step;
+        c.rows_ad = *adam;
+    }
+    if (begin_only) c.adam = nullptr;        // (fira_train_step_begin_rows: the optimizer's values serve the lazy reads only)
     TRY(encoder_forward(c, true));
     if (side_on()) {
         // the buffers the backward pass accumulates into are cleared on the auxiliary stream beside the forward pass (they
@@ -1950,6 +1961,28 @@ int fira_train_step_begin(void* stream, const fira_dims* d, const fira_batch* ba
                       nullptr, true);
 }
 
+// (v10) the data-parallel step with the row-sparse update of the word tables: _begin_rows takes the optimizer's values for the
+// lazy reads of its forward pass (nothing is updated there), _end_rows updates decoder.embedding by rows inside the library;
+// encoder.embedding is the caller's (fira_adam_rows_step with tables = 2 behind the late bucket's all-reduce)
+static int32_t* g_end_row_step = nullptr;
+int fira_train_step_begin_rows(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                               void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                               int32_t* n_tok, void* mid_event, const fira_adam_opts* adam, int32_t* row_step) {
+    FIRA_REQUIRE(mid_event, "fira_train_step_begin_rows: mid_event missing (the caller's collective waits for it)");
+    FIRA_REQUIRE(adam && adam->m && adam->v && adam->step >= 1 && row_step, "fira_train_step_begin_rows: bad Adam arguments");
+    FIRA_REQUIRE(opts && opts->zero_grads, "fira_train_step_begin_rows: needs opts.zero_grads");
+    // (adam only parameterises the lazy reads; train_call(begin_only) returns before any update)
+    return train_call(stream, d, batch, params, grads, workspace, workspace_bytes, opts, loss_sum, n_tok, mid_event, nullptr,
+                      adam, true, row_step);
+}
+int fira_train_step_end_rows(void* stream, float* params, const fira_adam_opts* adam, void* early_event, const float* count,
+                             int32_t* row_step) {
+    FIRA_REQUIRE(adam && row_step, "fira_train_step_end_rows: bad argument");
+    g_end_row_step = row_step;
+    const int rc = fira_train_step_end(stream, params, adam, early_event, count);
+    g_end_row_step = nullptr;
+    return rc;
+}
 int fira_train_step_end(void* stream, float* params, const fira_adam_opts* adam, void* early_event, const float* count) {
     PendingStep& ps = g_pending;
     FIRA_REQUIRE(ps.active, "fira_train_step_end: no step begun on this thread (fira_train_step_begin)");
@@ -1964,6 +1997,7 @@ int fira_train_step_end(void* stream, float* params, const fira_adam_opts* adam,
     Ctx& c = ps.ctx;
     c.adam = adam;
     c.Pw = params;
+    c.row_step = g_end_row_step;             // (fira_train_step_end_rows; nullptr: every row of decoder.embedding, as before)
     c.adam_a_only = true;
     c.ev_early = (hipEvent_t)early_event;
     c.count = count;
@@ -1992,13 +2026,14 @@ int fira_train_step_rows(void* stream, const fira_dims* d, const fira_batch* bat
 }
 // op-level pieces of the same (tests/test_adam_rows_gpu.py compares them with fira_adam_step_mb bit for bit)
 int fira_adam_rows_step(void* stream, const fira_dims* d, float* params, const float* grads, const fira_adam_opts* adam,
-                        int32_t* row_step, const int32_t* n_tok) {
+                        int32_t* row_step, const int32_t* n_tok, const float* count, int tables) {
     const Layout* L = get_layout(d);
     if (!L) return 1;
-    FIRA_REQUIRE(params && grads && adam && adam->m && adam->v && row_step && n_tok && adam->step >= 1, "fira_adam_rows_step: bad argument");
+    FIRA_REQUIRE(params && grads && adam && adam->m && adam->v && row_step && (n_tok || count) && adam->step >= 1 && tables >= 1 &&
+                     tables <= 3, "fira_adam_rows_step: bad argument");
     FIRA_REQUIRE(L->d.d_model == FIRA_D, "fira_adam_rows_step: model width must be %d", FIRA_D);
     return adam_rows_step((hipStream_t)stream, adam_rows_tables(*L, params, *adam, row_step), grads, adam->lr, adam->beta1,
-                          adam->beta2, adam->eps, adam->step, n_tok, nullptr);
+                          adam->beta2, adam->eps, adam->step, count ? nullptr : n_tok, count, tables);
 }
 int fira_adam_rows_catchup(void* stream, const fira_dims* d, float* params, const fira_adam_opts* adam, int32_t* row_step,
                            int table, const int32_t* ids, int n_ids) {

@@ -526,12 +526,13 @@ class TransModel(nn.Module):
         return self.loss_sum, self.n_tok
 
     def train_step_begin(self, db: DeviceBatch, mid_event, dropout: Optional[float] = None,
-                         gcn_dropout: Optional[float] = None):
+                         gcn_dropout: Optional[float] = None, rows=None):
         """First half of a data-parallel step (fira_train_step_begin): forward + the backward pass of the head and the decoder;
         ``mid_event`` fires when the gradients of ``[0, split)`` are final.  The step stays pending until
         :meth:`train_step_end`; ``db`` must stay alive until then."""
         lib = _lib.lib()
-        self.sync_params()
+        if rows is None:
+            self.sync_params()
         db.wait_ready()
         p = (self.cfg.dropout_rate if self.training else 0.0) if dropout is None else dropout
         pg = (0.2 if self.training else 0.0) if gcn_dropout is None else gcn_dropout
@@ -540,6 +541,17 @@ class TransModel(nn.Module):
                               1 if self.compact_dec else 0, 1)
         ws = self.workspace(db.B, 1)
         self._pending_db = db
+        if rows is not None:
+            # row-sparse Adam of the word tables (fira_train_step_begin_rows): rows = (m, v, lr, step, beta1, beta2, eps, row_step)
+            # -- the optimizer's values parameterise the forward pass's lazy reads of lagging rows; nothing is updated here
+            m_, v_, lr, step, b1, b2, eps, row_step = rows
+            adam = _lib.AdamOpts(lr, b1, b2, eps, int(step), _lib.ptr(m_), _lib.ptr(v_))
+            _lib.check(lib.fira_train_step_begin_rows(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
+                                                      _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
+                                                      C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok),
+                                                      self._event_handle(mid_event), C.byref(adam), _lib.ptr(row_step)),
+                       "fira_train_step_begin_rows")
+            return self.loss_sum, self.n_tok
         _lib.check(lib.fira_train_step_begin(_lib.cur_stream(), C.byref(self.dims), C.byref(db.struct),
                                              _lib.ptr(self.flat.data), _lib.ptr(self.gbuf), _lib.ptr(ws), ws.numel(),
                                              C.byref(opts), _lib.ptr(self.loss_sum), _lib.ptr(self.n_tok),
@@ -547,13 +559,18 @@ class TransModel(nn.Module):
         return self.loss_sum, self.n_tok
 
     def train_step_end(self, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, early_event=None, count=None,
-                       beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+                       beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, row_step=None):
         """Second half (fira_train_step_end): the encoder's backward pass; Adam of ``[0, split)`` once the current stream has
         passed ``early_event`` (the caller's event behind the all-reduce of that slice), scaled by ``1 / count`` (a device
         float, the all-reduced token count).  ``[split, live)`` is left to the caller (its bucket is reduced afterwards)."""
         adam = _lib.AdamOpts(lr, beta1, beta2, eps, int(step), _lib.ptr(m), _lib.ptr(v))
-        _lib.check(_lib.lib().fira_train_step_end(_lib.cur_stream(), _lib.ptr(self.flat.data), C.byref(adam),
-                                                  self._event_handle(early_event), _lib.ptr(count)), "fira_train_step_end")
+        if row_step is not None:
+            _lib.check(_lib.lib().fira_train_step_end_rows(_lib.cur_stream(), _lib.ptr(self.flat.data), C.byref(adam),
+                                                           self._event_handle(early_event), _lib.ptr(count), _lib.ptr(row_step)),
+                       "fira_train_step_end_rows")
+        else:
+            _lib.check(_lib.lib().fira_train_step_end(_lib.cur_stream(), _lib.ptr(self.flat.data), C.byref(adam),
+                                                      self._event_handle(early_event), _lib.ptr(count)), "fira_train_step_end")
         self._pending_db = None
 
     def _dtype_code(self) -> int:

@@ -54,8 +54,8 @@ class Trainer:
         self.row_step = None
         self._rows_dirty = False
         self._rows_hyper = None
-        if self.fused_step and os.environ.get("FIRA_ADAM_ROWS", "1") != "0" and _lib.has_symbol("fira_train_step_rows") \
-                and model.cfg.embedding_dim == 256:
+        if (self.fused_step or self.fused_dp) and os.environ.get("FIRA_ADAM_ROWS", "1") != "0" \
+                and _lib.has_symbol("fira_train_step_end_rows") and model.cfg.embedding_dim == 256:
             model.sync_params()                                  # (an earlier trainer of this model may still owe rows)
             self.row_step = torch.zeros(2 * model.cfg.vocab_size, dtype=torch.int32, device=model.gbuf.device)
             model._rows_sync = self.sync
@@ -88,17 +88,17 @@ class Trainer:
             self.mid_event.record()
             loss_sum, n_tok = m.loss_sum, m.n_tok
         elif self.fused_step and self.reducer is None and self.zero is None:
-            hyper = (self.lr, self.betas[0], self.betas[1], self.eps)
-            if self._rows_hyper != hyper:                        # lazily applied updates use the step's own lr / beta / eps
-                self.sync()
-                self._rows_hyper = hyper
+            self._rows_check_hyper()
             self.t += 1
             m.train_step(db, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps, row_step=self.row_step)
             self._rows_dirty = self.row_step is not None
             return
         elif dp and self.fused_dp and self.zero is None:
             fused_dp = True
-            loss_sum, n_tok = m.train_step_begin(db, self.mid_event)
+            self._rows_check_hyper()
+            rows = None if self.row_step is None else \
+                (self.m, self.v, self.lr, self.t + 1, self.betas[0], self.betas[1], self.eps, self.row_step)
+            loss_sum, n_tok = m.train_step_begin(db, self.mid_event, rows=rows)
         else:
             loss_sum, n_tok = m.train_fwd_bwd(db, zero_grad=True, mid_event=self.mid_event)
         b1, b2 = self.betas
@@ -116,15 +116,15 @@ class Trainer:
             if fused_dp:
                 # encoder backward; Adam of [0, split) inside the library as soon as the caller's stream has passed the
                 # encoder's chain and `ev`, beside the last weight gradients; the join
-                m.train_step_end(self.m, self.v, self.lr, self.t, early_event=ev, count=count, beta1=b1, beta2=b2, eps=self.eps)
+                m.train_step_end(self.m, self.v, self.lr, self.t, early_event=ev, count=count, beta1=b1, beta2=b2, eps=self.eps,
+                                 row_step=self.row_step)
             else:
                 red.wait_early()
-                ops.adam_step_count(m.flat.data[:split], m.gbuf[:split], self.m[:split], self.v[:split], self.lr, self.t, count,
-                                    b1, b2, self.eps)
+                self._adam_slice(0, split, count, table=0)
             red.start_late(m.gbuf)
             red.wait_late(m.gbuf)
-            ops.adam_step_count(m.flat.data[split:live], m.gbuf[split:live], self.m[split:live], self.v[split:live], self.lr,
-                                self.t, count, b1, b2, self.eps)
+            self._adam_slice(split, live, count, table=1)
+            self._rows_dirty = self.row_step is not None
             return
         self.t += 1
         # [live, total) holds the tensors no kernel touches (encoder.lstm, combination_list1, gate_fc): their gradient is
@@ -162,6 +162,29 @@ class Trainer:
                                         self.t, self.stats[1:2], b1, b2, self.eps)
                 z.all_gather(b, m.flat.data)
         main.wait_stream(zs)                                   # the next forward pass reads every parameter
+
+    def _rows_check_hyper(self):
+        hyper = (self.lr, self.betas[0], self.betas[1], self.eps)
+        if self._rows_hyper != hyper:                            # lazily applied updates use the step's own lr / beta / eps
+            self.sync()
+            self._rows_hyper = hyper
+
+    def _adam_slice(self, lo: int, hi: int, count, table: int):
+        """Adam on ``[lo, hi)`` of the flat buffers, scaled by ``1 / count`` (data-parallel step).  On the row-sparse path the
+        vocabulary-sized table at the head of the slice (``table`` 0: decoder.embedding at 0, 1: encoder.embedding at
+        ``split``) is updated on the rows of the all-reduced gradient that are not zero (fira_adam_rows_step)."""
+        m = self.model
+        b1, b2 = self.betas
+        if self.row_step is not None:
+            import ctypes as C
+            self._rows_check_hyper()
+            adam = _lib.AdamOpts(self.lr, b1, b2, self.eps, int(self.t), _lib.ptr(self.m), _lib.ptr(self.v))
+            _lib.check(_lib.lib().fira_adam_rows_step(_lib.cur_stream(), C.byref(m.dims), _lib.ptr(m.flat.data), _lib.ptr(m.gbuf),
+                                                      C.byref(adam), _lib.ptr(self.row_step), None, _lib.ptr(count), 1 << table),
+                       "fira_adam_rows_step")
+            lo += m.cfg.vocab_size * 256
+        ops.adam_step_count(m.flat.data[lo:hi], m.gbuf[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.t, count, b1, b2,
+                            self.eps)
 
     def sync(self):
         """Apply the embedding-row updates the row-sparse path still owes (fira_adam_rows_sync): afterwards ``model.flat``,

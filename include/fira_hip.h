@@ -521,7 +521,7 @@ int fira_train_step_end(void* stream, float* params, const fira_adam_opts* adam,
  * at most 31 steps.  Results are those of fira_train_step bit for bit ONCE fira_adam_rows_sync has run: call it (same adam
  * values, step = the last completed step) before anything else reads the tables or the moments -- checkpoint, dev pass,
  * search, another optimizer -- and before changing lr / beta / eps.  adam->step must advance by one per call.  Needs
- * opts->zero_grads = 1.  Single-device training only (a data-parallel step keeps fira_train_step_begin / _end).             */
+ * opts->zero_grads = 1.  (Data parallel: fira_train_step_begin_rows / _end_rows below.)                                      */
 int fira_train_step_rows(void* stream, const fira_dims* d, const fira_batch* batch, float* params, float* grads,
                          void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
                          int32_t* n_tok, const fira_adam_opts* adam, int32_t* row_step);
@@ -529,12 +529,23 @@ int fira_adam_rows_sync(void* stream, const fira_dims* d, float* params, const f
 /* The two pieces fira_train_step_rows is made of, as op-level entries (params / grads / m / v: the flat buffers of geometry d):
  * fira_adam_rows_catchup  rows ids[0 .. n_ids) of table `table` (0 decoder.embedding, 1 encoder.embedding; duplicates and
  *                         out-of-range ids allowed) brought up to step adam->step by zero-gradient updates;
- * fira_adam_rows_step     step adam->step on every row of the two tables whose gradient row is not all zero (every row when
- *                         step % 32 == 0), normaliser 1 / max(*n_tok, 1) as fira_adam_step_mb.                              */
+ * fira_adam_rows_step     step adam->step on every row of the selected tables whose gradient row is not all zero (every row
+ *                         when step % 32 == 0), normaliser 1 / max(*n_tok, 1) as fira_adam_step_mb or 1 / max(*count, 1).   */
 int fira_adam_rows_catchup(void* stream, const fira_dims* d, float* params, const fira_adam_opts* adam, int32_t* row_step,
                            int table, const int32_t* ids, int n_ids);
 int fira_adam_rows_step(void* stream, const fira_dims* d, float* params, const float* grads, const fira_adam_opts* adam,
-                        int32_t* row_step, const int32_t* n_tok);
+                        int32_t* row_step, const int32_t* n_tok, const float* count /* NULL, or the normaliser 1 / max(*count, 1)
+                        of fira_adam_step_count */, int tables /* bit t: table t takes part; 3 = both */);
+/* The data-parallel step (fira_train_step_begin / _end) with the same update.  The union of the ranks' touched rows is what
+ * the ALL-REDUCED gradient shows as non-zero rows, the same on every rank, so the replicas (tables, moments, row_step) stay
+ * identical.  _begin_rows takes the optimizer's values for the lazy reads of its forward pass (nothing is updated there);
+ * _end_rows updates [0, split) as fira_train_step_end does, decoder.embedding by rows; encoder.embedding is the caller's:
+ * fira_adam_rows_step(tables = 2, count) + fira_adam_step_count on the rest of [split, live) behind the late bucket.          */
+int fira_train_step_begin_rows(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
+                               void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
+                               int32_t* n_tok, void* mid_event, const fira_adam_opts* adam, int32_t* row_step);
+int fira_train_step_end_rows(void* stream, float* params, const fira_adam_opts* adam, void* early_event, const float* count,
+                             int32_t* row_step);
 
 /* (v8) bf16 wire format of a gradient bucket (BASELINE configs[2]: 55.6 MB instead of 111.2 MB per step on xGMI):
  * out[i] = bf16(in[i]) (round to nearest even) / out[i] = float(in[i]).  n % 4 == 0, 16-byte aligned buffers. */

@@ -87,7 +87,7 @@ def test_rows_update_equals_dense_update_bit_for_bit(touch_frac):
                 _lib.check(lib.fira_adam_rows_catchup(s, C.byref(dims), _lib.ptr(pr), C.byref(ad), _lib.ptr(last), t, _lib.ptr(ids),
                                                       ids.numel()))
         ad = opts(step, mr, vr)
-        _lib.check(lib.fira_adam_rows_step(s, C.byref(dims), _lib.ptr(pr), _lib.ptr(g), C.byref(ad), _lib.ptr(last), _lib.ptr(n_tok)))
+        _lib.check(lib.fira_adam_rows_step(s, C.byref(dims), _lib.ptr(pr), _lib.ptr(g), C.byref(ad), _lib.ptr(last), _lib.ptr(n_tok), None, 3))
         for t, (a, b) in enumerate(tabs):                        # the touched rows are current after the step
             rows = touched[t].long()
             nz = (g[a:b].view(V, 256)[rows] != 0).any(1)
@@ -125,7 +125,7 @@ def test_rows_update_leaves_untouched_rows_alone_between_syncs():
     p0, m0 = p.clone(), m.clone()
     ad = _lib.AdamOpts(1e-3, 0.9, 0.999, 1e-8, 5, _lib.ptr(m), _lib.ptr(v))
     _lib.check(lib.fira_adam_rows_step(_lib.cur_stream(), C.byref(model.dims), _lib.ptr(p), _lib.ptr(g), C.byref(ad), _lib.ptr(last),
-                                       _lib.ptr(n_tok)))
+                                       _lib.ptr(n_tok), None, 3))
     changed = (p != p0).view(-1)
     rows = torch.nonzero(changed[a:b].view(V, 256).any(1)).flatten().tolist()
     assert rows == [7, 9000]

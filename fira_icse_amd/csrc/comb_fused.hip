@@ -335,6 +335,98 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
     }
 }
 
+// ---- (round 6) out = X W^T + bias for N = nb x 256 output columns on the same machinery --------------------------------------
+// The cross-attention K|V projection of all layers (gnn_transformer.py:139-141 on the encoder's memory rows: [n_mem, 256] x
+// [nl * 512, 256]^T, 6.8 GFLOP at batch 32) ran on the auxiliary stream as one fp32 MFMA launch per layer (19 us each at 0.34 of
+// the fp32 peak) and the decoder's first cross attention stood waiting for the first pair (13 us at batch 32, 39 us at batch 64,
+// 41-45 us in bf16 mode at batch 64: profiles/r6_waitprobe.txt).  Here a workgroup stages its 16-row tiles of X ONCE as bf16
+// planes in LDS and multiplies them with every 256-column block of the weight in turn (cx_product: pre-split weight planes in
+// fragment order streamed from L2, six term products per k step; NP = 1: the bf16 mode's one plane).  Bound by the weight stream:
+// every workgroup reads nb x 384 KB of planes from L2 (one 16-row tile per CU at batch 32).
+struct LinearX3Args {
+    int n_rows;
+    const float* X;          // [n, ldx] fp32 rows
+    int ldx;
+    const uint16_t* Wx;      // nb matrices' planes (3 * 65536 bf16 each, gcn_split_planes of W[256 j .. 256 j + 255][256])
+    int nb;
+    const float* bias;       // [nb * 256] or nullptr
+    float* out;              // [n, ldo]
+    int ldo;
+};
+template <int NP>
+__global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kernel(const LinearX3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+    char* const sm_p = reinterpret_cast<char*>(cf_lds);                    // three bf16 planes [32][256] (48 KB)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wg = (blockIdx.x & 7) * (CF_GRID / 8) + (blockIdx.x >> 3);
+    const int n_tiles = (a.n_rows + CF_TILE - 1) / CF_TILE;
+    const int tq = n_tiles / CF_GRID, tr = n_tiles % CF_GRID;
+    const int t_beg = wg * tq + min(wg, tr), t_cnt = tq + (wg < tr ? 1 : 0);
+    if (t_cnt == 0) return;
+    const int col = wave * 16 + l15;
+    const unsigned xlane = gx_wlane(wave, lane);
+    const int a_q = gx_frag_base(l15, kq);
+    constexpr size_t WX = 3 * (size_t)FIRA_D * FIRA_D;
+    const rsrc_t rO = buf_rsrc(a.out, (unsigned)((size_t)a.n_rows * a.ldo * 4));
+    for (int pass = 0; pass < t_cnt; pass += CF_TMAX) {
+        const int nt = min(CF_TMAX, t_cnt - pass);
+        const int row0 = (t_beg + pass) * CF_TILE;
+        const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
+        uint4 bx3[3];
+        cx_first<NP>(a.Wx, xlane, bx3);                  // (block 0's first k step: in flight under the row loads)
+        asm volatile("" ::: "memory");
+        {
+            f32x4v x[CF_RPW];
+#pragma unroll
+            for (int i = 0; i < CF_RPW; ++i) {
+                const int row = row0 + wave * CF_RPW + i;
+                x[i] = *reinterpret_cast<const f32x4v*>(a.X + (size_t)min(row, a.n_rows - 1) * a.ldx + lane * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < CF_RPW; ++i) {
+                const int row = row0 + wave * CF_RPW + i;
+                gx_store_row4<NP>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+        __syncthreads();
+        for (int blk = 0; blk < a.nb; ++blk) {
+            cf_acc acc[CF_TMAX];
+#pragma unroll
+            for (int tt = 0; tt < CF_TMAX; ++tt) acc[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+            const float bias = a.bias ? a.bias[blk * FIRA_D + col] : 0.f;
+            cx_product<CF_TMAX, NP>(sm_p, CX_PLANE, a_q, a.Wx + blk * WX, xlane, nt, bx3, acc,
+                                    blk + 1 < a.nb ? a.Wx + (blk + 1) * WX : nullptr);
+#pragma unroll
+            for (int tt = 0; tt < CF_TMAX; ++tt) {
+                if (tt < nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = row0 + tt * CF_TILE + 4 * kq + r;
+                        const unsigned o = row < row_end ? ((unsigned)row * (unsigned)a.ldo + (unsigned)(blk * FIRA_D + col)) * 4u : FIRA_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tt][r] + bias), rO, o, 0, 0);
+                    }
+                }
+            }
+        }
+        if (pass + CF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
+    }
+}
+// one_plane: the engine's bf16 mode (operands rounded to bf16 once); else three terms per operand (fp32-accurate)
+int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx, int nb, const float* bias, float* out, int ldo,
+              bool one_plane) {
+    if (M <= 0 || nb <= 0) return 0;
+    FIRA_REQUIRE(X && Wx && out && ldx % 4 == 0 && (uintptr_t)X % 16 == 0, "linear_x3: bad argument");
+    FIRA_REQUIRE((size_t)M * ldo * 4 < (1ull << 31), "linear_x3: %d x %d floats exceed the 2 GiB the kernel addresses", M, ldo);
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * (double)nb * FIRA_D * FIRA_D, 4.0 * ((double)M * FIRA_D + (double)M * nb * FIRA_D) + 6.0 * nb * FIRA_D * FIRA_D);
+    LinearX3Args a{M, X, ldx, Wx, nb, bias, out, ldo};
+    const size_t lds = 3 * CX_PLANE + 256;
+    if (one_plane) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(CF_GRID), dim3(CF_WAVES * 64), lds, s, a);
+    else hipLaunchKernelGGL(linear_x3_kernel<3>, dim3(CF_GRID), dim3(CF_WAVES * 64), lds, s, a);
+    FIRA_CHECK_LAUNCH("linear_x3");
+    return 0;
+}
+
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,
@@ -675,6 +767,12 @@ int transpose256_table(hipStream_t s, const TransposeTable& tab) {
 }  // namespace fira
 
 extern "C" {
+int fira_linear_x3(void* stream, int M, int N, const float* x, int ldx, const uint16_t* w_planes, const float* bias, float* out,
+                   int ldo, int dtype) {
+    FIRA_REQUIRE(x && w_planes && out && M > 0 && N > 0 && N % FIRA_D == 0 && ldo >= N, "fira_linear_x3: bad argument");
+    FIRA_REQUIRE(dtype == FIRA_F32X3 || dtype == FIRA_BF16X1, "fira_linear_x3: dtype must be FIRA_F32X3 or FIRA_BF16X1");
+    return fira::linear_x3((hipStream_t)stream, M, x, ldx, w_planes, N / FIRA_D, bias, out, ldo, dtype == FIRA_BF16X1);
+}
 int fira_combination_block_bwd(void* stream, int n_rows, float* dG, const int32_t* rows, const float* sum, const float* stats,
                                const float* gamma, const float* Wo, const float* Wqk, const float* qk, const float* vtab, int ldv,
                                const int32_t* mark, float* dYc, float* dqk, float* dgamma, float* dbeta, float* dvtab, int lddv,

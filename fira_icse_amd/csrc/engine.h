@@ -110,6 +110,10 @@ int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[
 // residual and LayerNorm of gnn_transformer.py:176-205 on the code rows.  WqT / WkT / WoT: the three weights K-MAJOR
 // ([256 in][256 out], i.e. transposed nn.Linear weights: transpose256_table).  Stores q|k [n,512] and c [n,256] (what the
 // backward pass reads), the pre-norm rows `sum` [n,256], (mean, rstd) `stats` [n,2], and the output rows at y[y_rows[r]].
+// out [M, ldo] = X [M, 256] W^T + bias for N = nb * 256 columns; Wx: the planes of W's nb [256, 256] row blocks (gcn_split_planes);
+// three bf16 terms per operand (fp32-accurate) or, one_plane, the bf16 mode's single rounding (comb_fused.hip: linear_x3_kernel)
+int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx, int nb, const float* bias, float* out, int ldo,
+              bool one_plane);
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,

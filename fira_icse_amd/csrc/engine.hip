@@ -76,6 +76,7 @@ struct Plan {
     float *W21t;                    // the folded weights transposed = k-major for U W21^T: what the fused GCN forward streams
     uint16_t *W21x = nullptr, *W21tx = nullptr;   // (round 6) three bf16 planes of W21 / W21^T per layer, fragment order (gcn_fused.hip: X3)
     uint16_t *WcX = nullptr, *WcTX = nullptr;     // the same of the Combination weights Wq | Wk | Wo per layer, as stored / transposed
+    uint16_t* WkvX = nullptr;                     // ... and of the stacked cross-attention K|V weight: nl * 2 row blocks of [256, 256]
     uint16_t *xh_planes = nullptr;                // planes of the head's input rows (head_x3.hip)
     float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
@@ -135,6 +136,7 @@ struct Plan {
         W21tx = a.get<uint16_t>((size_t)nl * 3 * D * D);
         WcX = a.get<uint16_t>((size_t)nl * 9 * D * D);
         WcTX = a.get<uint16_t>((size_t)nl * 9 * D * D);
+        WkvX = a.get<uint16_t>((size_t)nl * 6 * D * D);
         xh_planes = a.get<uint16_t>(head_logits_x3_scratch_elems(TB));
         WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
@@ -868,6 +870,12 @@ static inline bool comb_x3_on(int nl) {
     static const bool off16 = [] { const char* e = getenv("FIRA_X1_BF16"); return e && e[0] == '0'; }();
     return !off && (g_dtype == 0 || !off16) && comb_fused_on() && nl <= 8;
 }
+// the training step's K|V projection of the memory rows as linear_x3 (three-term planes in fp32 mode, one plane in bf16 mode)
+// instead of one fp32 / bf16 GEMM launch per layer; FIRA_KV_X3=0: those launches (A/B switch)
+static inline bool kv_x3_on(int nl) {
+    static const bool off = [] { const char* e = getenv("FIRA_KV_X3"); return e && e[0] == '0'; }();
+    return !off && nl * 2 <= 24;
+}
 static inline bool gcn_x3_on(int nl) {
     static const bool off = [] { const char* e = getenv("FIRA_GCN_X3"); return e && e[0] == '0'; }();
     // (bf16 mode runs the one-plane form of the same kernels; FIRA_X1_BF16=0 = its round-5 kernels, A/B switch)
@@ -1061,8 +1069,22 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // layer on the side stream under it; decoder_forward / head_forward wait for the mark they need.
         TRY(aux_fork(s));
         hipStream_t ss = side().aux;
+        const bool kvx = c.G && kv_x3_on(p.nl);         // (the training step only: the search keeps the fp32 chains of its reference lines)
+        if (kvx) {
+            // (round 6) two launches, one per mark: layers 0-1, then the rest; the planes of the stacked weight first
+            const float* src[24];
+            uint16_t* dst[24];
+            for (int j = 0; j < p.nl * 2; ++j) { src[j] = c.P + L.wkv_all + (size_t)j * D * D; dst[j] = p.WkvX + (size_t)j * 3 * D * D; }
+            TRY(gcn_split_planes(ss, p.nl * 2, src, dst));
+        }
         for (int l = 0; l < p.nl; ++l) {
             const size_t o = (size_t)l * 2 * D;
+            if (kvx) {
+                const int l1 = l == 0 ? std::min(2, p.nl) : p.nl;            // layers l .. l1 in this launch
+                if (l == 0 || l == std::min(2, p.nl))
+                    TRY(linear_x3(ss, Mc, p.mem_c, D, p.WkvX + (size_t)l * 2 * 3 * D * D, (l1 - l) * 2, c.P + L.bkv_all + o, p.kv_all + o,
+                                  p.kvp, g_dtype == 1));
+            } else
             TRY(gemm_any(ss, 0, 1, Mc, 2 * D, D, p.mem_c, D, c.P + L.wkv_all + o * D, D, p.kv_all + o, p.kvp, c.P + L.bkv_all + o, 0,
                          0, nullptr));
             // two marks (behind layers 1 and the last one) instead of one per layer: every wait is a barrier packet in the
@@ -1964,7 +1986,7 @@ int fira_train_step_begin(void* stream, const fira_dims* d, const fira_batch* ba
 // (v10) the data-parallel step with the row-sparse update of the word tables: _begin_rows takes the optimizer's values for the
 // lazy reads of its forward pass (nothing is updated there), _end_rows updates decoder.embedding by rows inside the library;
 // encoder.embedding is the caller's (fira_adam_rows_step with tables = 2 behind the late bucket's all-reduce)
-static int32_t* g_end_row_step = nullptr;
+static thread_local int32_t* g_end_row_step = nullptr;
 int fira_train_step_begin_rows(void* stream, const fira_dims* d, const fira_batch* batch, const float* params, float* grads,
                                void* workspace, size_t workspace_bytes, const fira_train_opts* opts, float* loss_sum,
                                int32_t* n_tok, void* mid_event, const fira_adam_opts* adam, int32_t* row_step) {

@@ -213,6 +213,19 @@ def gcn_weight_planes(B):
     return planes
 
 
+def linear_x3(x, W, bias=None, dtype=2, ldo=None):
+    """fira_linear_x3: out = x W^T + bias, x [M, 256], W [N, 256] with N a multiple of 256, on the bf16 matrix cores -- dtype 2:
+    three bf16 terms per operand (fp32-accurate), 3: one plane (the bf16 mode's rounding).  Returns out [M, N] (row pitch ldo)."""
+    x = _f32(x)
+    M, N = x.shape[0], W.shape[0]
+    planes = gcn_weight_planes(W)
+    ldo = N if ldo is None else ldo
+    out = torch.zeros((M, ldo), dtype=torch.float32, device=x.device)
+    check(_lib.lib().fira_linear_x3(cur_stream(), M, N, ptr(x), x.stride(0), ptr(planes), ptr(None if bias is None else _f32(bias)),
+                                    ptr(out), ldo, dtype), "fira_linear_x3")
+    return out[:, :N]
+
+
 def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0, want_rowsum=True):
     """fira_gcn_layer_fwd: (sum, y, stats, rowsum) of one folded GCN layer on the CSR adjacency (global column ids);
     W21t = W21^T contiguous.  dtype 2 / 3 (FIRA_F32X3 / FIRA_BF16X1): the planes of W21 are formed here."""

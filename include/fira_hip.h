@@ -225,6 +225,12 @@ int fira_gcn_layer_bwd(void* stream, int n_rows, const int32_t* rowptr, const in
  * The result differs from the FIRA_F32 launch by fp32 rounding noise only (the dropped lo.lo, lo.mid, mid.lo terms are
  * below 2^-24 of a product).                                                                                           */
 int fira_gcn_weight_planes(void* stream, int n_mats, const float* B, uint16_t* planes);
+/* (v10) out [M, ldo] = x [M, 256] W^T + bias for N = a multiple of 256 output columns, W [N, 256] row-major given as the planes of
+ * its N / 256 row blocks (fira_gcn_weight_planes(N / 256, W, planes)): the nn.Linear of the cross-attention K|V projection of all
+ * layers on the encoder's memory rows (gnn_transformer.py:139-141; what fira_train_step runs on its auxiliary stream).
+ * dtype FIRA_F32X3: three bf16 terms per operand (fp32-accurate); FIRA_BF16X1: both operands rounded to bf16 once.            */
+int fira_linear_x3(void* stream, int M, int N, const float* x, int ldx, const uint16_t* w_planes, const float* bias, float* out,
+                   int ldo, int dtype);
 /* The same for fira_combination_block_{fwd,bwd} with dtype FIRA_F32X3: the forward launch takes, in its WqT argument, the planes
  * of the THREE stacked matrices Wq | Wk | Wo as nn.Linear stores them ([out][in]; WkT / WoT are then ignored, pass WqT again);
  * the backward launch takes, in its Wo argument, the planes of Wq^T | Wk^T | Wo^T (Wqk is then ignored).                      */

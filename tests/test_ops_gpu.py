@@ -1040,6 +1040,32 @@ def test_head_logits_three_term_product(R, V):
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,ldo", [(4331, 3072, 3136), (8104, 1024, 1024), (17, 256, 320), (600, 512, 512)])
+def test_linear_three_term_product(M, N, ldo):
+    """fira_linear_x3 (comb_fused.hip: linear_x3_kernel) -- the training step's cross-attention K|V projection of all layers on the
+    memory rows (gnn_transformer.py:139-141): against the fp64 product at the tolerance of the fp32 product (dtype 2: three bf16
+    terms) and against the fp64 product of the bf16-rounded operands (dtype 3: one plane); ragged last tile, fewer tiles than
+    workgroups, two tiles per workgroup, a padded output pitch (the engine's K|V rows) whose padding stays untouched."""
+    from fira_icse_amd import ops
+    x = randn(M, 256, seed=1)
+    W, b = randn(N, 256, seed=2, scale=0.06), randn(N, seed=3, scale=0.1)
+    ref = x.double() @ W.double().t() + b.double()
+    got = ops.linear_x3(x, W, b, dtype=2, ldo=ldo)
+    f32 = ops.gemm(x, W, bias=b)
+    e3, e32 = rel_err(got, ref), rel_err(f32, ref)
+    assert e3 < 1e-6, (e3, e32)
+    assert e3 < 3 * e32 + 1e-7, (e3, e32)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    if ldo > N:
+        assert not got.untyped_storage() is None and float(got.as_strided((M, ldo - N), (ldo, 1), N).abs().max()) == 0.0
+    xb, Wb = x.bfloat16().double(), W.bfloat16().double()
+    ref1 = xb @ Wb.t() + b.double()
+    got1 = ops.linear_x3(x, W, b, dtype=3, ldo=ldo)
+    assert rel_err(got1, ref1) < 2e-6, rel_err(got1, ref1)
+    got0 = ops.linear_x3(x, W, None, dtype=2)
+    assert rel_err(got0, x.double() @ W.double().t()) < 1e-6
+
+
 @pytest.mark.parametrize("dtype", [2, 3])
 def test_gcn_layer_batch64_sized(dtype):
     """The fused GCN launch at batch 64's size (19 500 rows = 4.8 tiles per workgroup: two passes, the second for one tile; hub rows of

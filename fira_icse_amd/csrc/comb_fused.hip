@@ -338,8 +338,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
 // ---- (round 6) out = X W^T + bias for N = nb x 256 output columns on the same machinery --------------------------------------
 // The cross-attention K|V projection of all layers (gnn_transformer.py:139-141 on the encoder's memory rows: [n_mem, 256] x
 // [nl * 512, 256]^T, 6.8 GFLOP at batch 32) ran on the auxiliary stream as one fp32 MFMA launch per layer (19 us each at 0.34 of
-// the fp32 peak) and the decoder's first cross attention stood waiting for the first pair (13 us at batch 32, 39 us at batch 64,
-// 41-45 us in bf16 mode at batch 64: profiles/r6_waitprobe.txt).  Here a workgroup stages its 16-row tiles of X ONCE as bf16
+// the fp32 peak), beside the decoder's forward chain.  Here a workgroup stages its 16-row tiles of X ONCE as bf16
 // planes in LDS and multiplies them with every 256-column block of the weight in turn (cx_product: pre-split weight planes in
 // fragment order streamed from L2, six term products per k step; NP = 1: the bf16 mode's one plane).  Bound by the weight stream:
 // every workgroup reads nb x 384 KB of planes from L2 (one 16-row tile per CU at batch 32).

@@ -358,9 +358,10 @@ __global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kernel(const LinearX3
     char* const sm_p = reinterpret_cast<char*>(cf_lds);                    // three bf16 planes [32][256] (48 KB)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
-    const int wg = (blockIdx.x & 7) * (CF_GRID / 8) + (blockIdx.x >> 3);
+    const int grid = gridDim.x;                          // a multiple of 8 (the launch: >= two tiles per workgroup where there are enough)
+    const int wg = (blockIdx.x & 7) * (grid / 8) + (blockIdx.x >> 3);
     const int n_tiles = (a.n_rows + CF_TILE - 1) / CF_TILE;
-    const int tq = n_tiles / CF_GRID, tr = n_tiles % CF_GRID;
+    const int tq = n_tiles / grid, tr = n_tiles % grid;
     const int t_beg = wg * tq + min(wg, tr), t_cnt = tq + (wg < tr ? 1 : 0);
     if (t_cnt == 0) return;
     const int col = wave * 16 + l15;
@@ -411,6 +412,120 @@ __global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kernel(const LinearX3
         if (pass + CF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
     }
 }
+// Workgroups of a linear_x3 launch: every workgroup streams ALL of the weight's planes from L2 (384 KB per 256 x 256 block and
+// pass), so a pass should carry its two tiles and the launch should not be wider than it must: with one 16-row tile per CU
+// (batch 32: 271 tiles on 256 workgroups) a d-memory pair moved 256 x 1.5 MB through L2 and was no faster than the fp32 GEMM it
+// replaced; on 136 workgroups of two tiles it is (+1.6 % of the step), and at batch 64 (507 tiles) 128 workgroups of four tiles
+// beat 256 of two (+1.1 % against +-0; profiles/r6_probes.md).  The launches run beside the decoder's chain: the CUs they
+// leave alone are not idle.  FIRA_LINX3_MAX_WGS (default 136).
+static int linear_x3_grid(int M) {
+    static const int cap = [] { const char* e = getenv("FIRA_LINX3_MAX_WGS"); const int v = e ? atoi(e) : 136; return std::max(8, std::min(CF_GRID, v / 8 * 8)); }();
+    const int n_tiles = cdiv(M, CF_TILE);
+    const int g = (cdiv(n_tiles, CF_TMAX) + 7) / 8 * 8;
+    return std::max(8, std::min(cap, g));
+}
+// The data-gradient shape of the same: out [M, 256] (+)= A [M, nkb * 256] B, B given as the planes of its nkb TRANSPOSED
+// [256, 256] row blocks (Bt_kb[n][k] = B[256 kb + k][n]: for a weight stored [N, 256] with out = dY W, the k-major copy of its
+// kb-th row block).  The d-memory products of the decoder's backward pass (d memory += dK|dV Wkv, K = 1024 per layer pair; three
+// fp32 MFMA launches of 40-70 us beside the decoder's backward chain: skipping them -- a timing probe -- was worth +3.0 % of the
+// step at batch 32, +2.8 % at batch 64, profiles/r6_probes.md).  One accumulator per tile over all K blocks; the panel is
+// re-staged per block with the next block's rows requested under the product.
+struct LinearX3KArgs {
+    int n_rows;
+    const float* A;          // [n, lda] fp32 rows, nkb * 256 columns used
+    int lda;
+    const uint16_t* Wx;      // planes of the nkb transposed blocks
+    int nkb;
+    float* out;              // [n, ldo], 256 columns
+    int ldo;
+    int accum;
+};
+template <int NP>
+__global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kacc_kernel(const LinearX3KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+    char* const sm_p = reinterpret_cast<char*>(cf_lds);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int grid = gridDim.x;                          // a multiple of 8 (the launch: >= two tiles per workgroup where there are enough)
+    const int wg = (blockIdx.x & 7) * (grid / 8) + (blockIdx.x >> 3);
+    const int n_tiles = (a.n_rows + CF_TILE - 1) / CF_TILE;
+    const int tq = n_tiles / grid, tr = n_tiles % grid;
+    const int t_beg = wg * tq + min(wg, tr), t_cnt = tq + (wg < tr ? 1 : 0);
+    if (t_cnt == 0) return;
+    const int col = wave * 16 + l15;
+    const unsigned xlane = gx_wlane(wave, lane);
+    const int a_q = gx_frag_base(l15, kq);
+    constexpr size_t WX = 3 * (size_t)FIRA_D * FIRA_D;
+    const rsrc_t rO = buf_rsrc(a.out, (unsigned)((size_t)a.n_rows * a.ldo * 4));
+    for (int pass = 0; pass < t_cnt; pass += CF_TMAX) {
+        const int nt = min(CF_TMAX, t_cnt - pass);
+        const int row0 = (t_beg + pass) * CF_TILE;
+        const int row_end = min(a.n_rows, row0 + nt * CF_TILE);
+        uint4 bx3[3];
+        cx_first<NP>(a.Wx, xlane, bx3);
+        asm volatile("" ::: "memory");
+        const float* arow[CF_RPW];
+        f32x4v x[CF_RPW];
+#pragma unroll
+        for (int i = 0; i < CF_RPW; ++i) {
+            arow[i] = a.A + (size_t)min(row0 + wave * CF_RPW + i, a.n_rows - 1) * a.lda + lane * 4;
+            x[i] = *reinterpret_cast<const f32x4v*>(arow[i]);
+        }
+        float old[CF_TMAX][4];                            // the rows the product is added to: requested early
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + tt * CF_TILE + 4 * kq + r;
+                const unsigned o = (a.accum && tt < nt && row < row_end) ? ((unsigned)row * (unsigned)a.ldo + (unsigned)col) * 4u : FIRA_OOB;
+                old[tt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rO, o, 0, 0));      // (out of range: 0)
+            }
+        cf_acc acc[CF_TMAX];
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) acc[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < a.nkb; ++kb) {
+#pragma unroll
+            for (int i = 0; i < CF_RPW; ++i) {
+                const int row = row0 + wave * CF_RPW + i;
+                gx_store_row4<NP>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f});
+            }
+            __syncthreads();
+            if (kb + 1 < a.nkb) {                        // the next block's rows: in flight under this block's product
+#pragma unroll
+                for (int i = 0; i < CF_RPW; ++i) x[i] = *reinterpret_cast<const f32x4v*>(arow[i] + (kb + 1) * FIRA_D);
+            }
+            cx_product<CF_TMAX, NP>(sm_p, CX_PLANE, a_q, a.Wx + kb * WX, xlane, nt, bx3, acc,
+                                    kb + 1 < a.nkb ? a.Wx + (kb + 1) * WX : nullptr);
+            __syncthreads();                             // every wave has read its fragments: the panel can be overwritten
+        }
+#pragma unroll
+        for (int tt = 0; tt < CF_TMAX; ++tt) {
+            if (tt < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + tt * CF_TILE + 4 * kq + r;
+                    const unsigned o = row < row_end ? ((unsigned)row * (unsigned)a.ldo + (unsigned)col) * 4u : FIRA_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[tt][r] + old[tt][r]), rO, o, 0, 0);
+                }
+            }
+        }
+    }
+}
+int linear_x3_kacc(hipStream_t s, int M, const float* A, int lda, const uint16_t* Wx, int nkb, float* out, int ldo, bool accum,
+                   bool one_plane) {
+    if (M <= 0 || nkb <= 0) return 0;
+    FIRA_REQUIRE(A && Wx && out && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && lda >= nkb * FIRA_D, "linear_x3_kacc: bad argument");
+    FIRA_REQUIRE((size_t)M * ldo * 4 < (1ull << 31), "linear_x3_kacc: %d x %d floats exceed the 2 GiB the kernel addresses", M, ldo);
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * (double)nkb * FIRA_D * FIRA_D, 4.0 * ((double)M * nkb * FIRA_D + 2.0 * M * FIRA_D) + 6.0 * nkb * FIRA_D * FIRA_D);
+    LinearX3KArgs a{M, A, lda, Wx, nkb, out, ldo, accum ? 1 : 0};
+    const size_t lds = 3 * CX_PLANE + 256;
+    const int grid = linear_x3_grid(M);
+    if (one_plane) hipLaunchKernelGGL(linear_x3_kacc_kernel<1>, dim3(grid), dim3(CF_WAVES * 64), lds, s, a);
+    else hipLaunchKernelGGL(linear_x3_kacc_kernel<3>, dim3(grid), dim3(CF_WAVES * 64), lds, s, a);
+    FIRA_CHECK_LAUNCH("linear_x3_kacc");
+    return 0;
+}
+
 // one_plane: the engine's bf16 mode (operands rounded to bf16 once); else three terms per operand (fp32-accurate)
 int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx, int nb, const float* bias, float* out, int ldo,
               bool one_plane) {
@@ -420,8 +535,9 @@ int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx,
     ProfScope prof(s, PROF_GEMM, 2.0 * M * (double)nb * FIRA_D * FIRA_D, 4.0 * ((double)M * FIRA_D + (double)M * nb * FIRA_D) + 6.0 * nb * FIRA_D * FIRA_D);
     LinearX3Args a{M, X, ldx, Wx, nb, bias, out, ldo};
     const size_t lds = 3 * CX_PLANE + 256;
-    if (one_plane) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(CF_GRID), dim3(CF_WAVES * 64), lds, s, a);
-    else hipLaunchKernelGGL(linear_x3_kernel<3>, dim3(CF_GRID), dim3(CF_WAVES * 64), lds, s, a);
+    const int grid = linear_x3_grid(M);
+    if (one_plane) hipLaunchKernelGGL(linear_x3_kernel<1>, dim3(grid), dim3(CF_WAVES * 64), lds, s, a);
+    else hipLaunchKernelGGL(linear_x3_kernel<3>, dim3(grid), dim3(CF_WAVES * 64), lds, s, a);
     FIRA_CHECK_LAUNCH("linear_x3");
     return 0;
 }
@@ -766,6 +882,13 @@ int transpose256_table(hipStream_t s, const TransposeTable& tab) {
 }  // namespace fira
 
 extern "C" {
+int fira_linear_dgrad_x3(void* stream, int M, int K, const float* dy, int lddy, const uint16_t* wt_planes, float* dx, int lddx,
+                         int accumulate, int dtype) {
+    FIRA_REQUIRE(dy && wt_planes && dx && M > 0 && K > 0 && K % FIRA_D == 0 && lddx >= FIRA_D, "fira_linear_dgrad_x3: bad argument");
+    FIRA_REQUIRE(dtype == FIRA_F32X3 || dtype == FIRA_BF16X1, "fira_linear_dgrad_x3: dtype must be FIRA_F32X3 or FIRA_BF16X1");
+    return fira::linear_x3_kacc((hipStream_t)stream, M, dy, lddy, wt_planes, K / FIRA_D, dx, lddx, accumulate != 0,
+                                dtype == FIRA_BF16X1);
+}
 int fira_linear_x3(void* stream, int M, int N, const float* x, int ldx, const uint16_t* w_planes, const float* bias, float* out,
                    int ldo, int dtype) {
     FIRA_REQUIRE(x && w_planes && out && M > 0 && N > 0 && N % FIRA_D == 0 && ldo >= N, "fira_linear_x3: bad argument");

@@ -114,6 +114,9 @@ int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[
 // three bf16 terms per operand (fp32-accurate) or, one_plane, the bf16 mode's single rounding (comb_fused.hip: linear_x3_kernel)
 int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx, int nb, const float* bias, float* out, int ldo,
               bool one_plane);
+// out [M, 256] (+)= A [M, nkb * 256] B; Wx: the planes of B's nkb TRANSPOSED [256, 256] row blocks (transpose256_table + gcn_split_planes)
+int linear_x3_kacc(hipStream_t s, int M, const float* A, int lda, const uint16_t* Wx, int nkb, float* out, int ldo, bool accum,
+                   bool one_plane);
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,
                    const float* bqk, const float* bo, const float* vtab, int ldv, const int32_t* mark, float* qk, float* c,
                    const float* gamma, const float* beta, float* sum, float* y, const int32_t* y_rows, float* stats,

@@ -77,6 +77,8 @@ struct Plan {
     uint16_t *W21x = nullptr, *W21tx = nullptr;   // (round 6) three bf16 planes of W21 / W21^T per layer, fragment order (gcn_fused.hip: X3)
     uint16_t *WcX = nullptr, *WcTX = nullptr;     // the same of the Combination weights Wq | Wk | Wo per layer, as stored / transposed
     uint16_t* WkvX = nullptr;                     // ... and of the stacked cross-attention K|V weight: nl * 2 row blocks of [256, 256]
+    float* WkvT = nullptr;                        // k-major copies of those blocks and their planes (the d-memory products: linear_x3_kacc)
+    uint16_t* WkvTX = nullptr;
     uint16_t *xh_planes = nullptr;                // planes of the head's input rows (head_x3.hip)
     float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
@@ -137,6 +139,8 @@ struct Plan {
         WcX = a.get<uint16_t>((size_t)nl * 9 * D * D);
         WcTX = a.get<uint16_t>((size_t)nl * 9 * D * D);
         WkvX = a.get<uint16_t>((size_t)nl * 6 * D * D);
+        WkvT = a.f((size_t)nl * 2 * D * D);
+        WkvTX = a.get<uint16_t>((size_t)nl * 6 * D * D);
         xh_planes = a.get<uint16_t>(head_logits_x3_scratch_elems(TB));
         WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
@@ -765,6 +769,7 @@ struct Ctx {
     // adam_rows_kernel): row_step [2 * vocab] = the step up to which each row of decoder.embedding / encoder.embedding is
     // current.  The rows this batch gathers are brought up to step - 1 ahead of the forward pass; the update itself runs on
     // the rows whose gradient row is not zero.
+    bool kv_planes = false;          // (round 6) WkvTX holds this step's planes: the d-memory products run as linear_x3_kacc
     int32_t* row_step = nullptr;
     fira_adam_opts rows_ad{};        // lr / beta / eps / step / moments the lazy reads use (a COPY: a begun data-parallel step outlives the call)
     // data-parallel form of the same (fira_train_step_begin / _end, round 6): the gradients of [0, split) are all-reduced by the
@@ -1095,6 +1100,19 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
         // (LinearSource: output rows straight to their dense [B,370] slots through the row map of the GEMM epilogue)
         TRY(gemm_any(ss, 0, 1, Mc, D, D, p.mem_c, D, c.P + L.ws, D, p.src, D, nullptr, 0, 0, nullptr, bt.mem_dst));
         TRY(side_mark(&c.ev_src));
+        if (kvx && p.nl * 2 <= 24) {
+            // the transposed blocks' planes for the backward pass's d-memory products: behind everything the forward pass waits for
+            TransposeTable tt;
+            const float* src[24];
+            uint16_t* dst[24];
+            for (int j = 0; j < p.nl * 2; ++j) {
+                tt.src[tt.n] = c.P + L.wkv_all + (size_t)j * D * D; tt.dst[tt.n++] = p.WkvT + (size_t)j * D * D;
+                src[j] = p.WkvT + (size_t)j * D * D; dst[j] = p.WkvTX + (size_t)j * 3 * D * D;
+            }
+            TRY(transpose256_table(ss, tt));
+            TRY(gcn_split_planes(ss, p.nl * 2, src, dst));
+            c.kv_planes = true;
+        }
         c.deferred = true;
         return 0;
     }
@@ -1388,7 +1406,11 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
             } else
             TRY(aux_fork_all());
             prof_decoder_tag(-1);               // a memory-row product: not one of the decoder's M = B*30 ones
-            const int rc_kv = linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_all + o, p.kvp, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
+            // (round 6) FIRA_DMEM_X3=0: the fp32 / bf16 GEMM launch instead of linear_x3_kacc (A/B switch)
+            static const bool dmem_x3_off = [] { const char* e = getenv("FIRA_DMEM_X3"); return e && e[0] == '0'; }();
+            const int rc_kv = (c.kv_planes && !dmem_x3_off)
+                    ? linear_x3_kacc(ss, Mc, p.dkv_all + o, p.kvp, p.WkvTX + (size_t)l * 2 * 3 * D * D, nlay * 2, p.dmem_c, D, true, g_dtype == 1)
+                    : linear_dgrad(ss, Mc, nlay * 2 * D, D, p.dkv_all + o, p.kvp, c.P + L.wkv_all + o * D, p.dmem_c, D, true);
             prof_decoder_tag(+1);
             return rc_kv;
         };

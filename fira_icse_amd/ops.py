@@ -226,6 +226,20 @@ def linear_x3(x, W, bias=None, dtype=2, ldo=None):
     return out[:, :N]
 
 
+def linear_dgrad_x3(dy, W, dx=None, dtype=2):
+    """fira_linear_dgrad_x3: dx (+)= dy W for W [K, 256] (K a multiple of 256), dy [M, K]; dx None: a fresh result."""
+    assert dy.is_cuda and dy.dtype == torch.float32 and dy.stride(1) == 1          # (a column slice of wider rows is fine)
+    M, K = dy.shape
+    Wt = _f32(W).view(K // 256, 256, 256).transpose(1, 2).contiguous()
+    planes = gcn_weight_planes(Wt)
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty((M, 256), dtype=torch.float32, device=dy.device)
+    check(_lib.lib().fira_linear_dgrad_x3(cur_stream(), M, K, ptr(dy), dy.stride(0), ptr(planes), ptr(dx), dx.stride(0), 1 if acc else 0,
+                                          dtype), "fira_linear_dgrad_x3")
+    return dx
+
+
 def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0, want_rowsum=True):
     """fira_gcn_layer_fwd: (sum, y, stats, rowsum) of one folded GCN layer on the CSR adjacency (global column ids);
     W21t = W21^T contiguous.  dtype 2 / 3 (FIRA_F32X3 / FIRA_BF16X1): the planes of W21 are formed here."""

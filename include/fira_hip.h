@@ -231,6 +231,11 @@ int fira_gcn_weight_planes(void* stream, int n_mats, const float* B, uint16_t* p
  * dtype FIRA_F32X3: three bf16 terms per operand (fp32-accurate); FIRA_BF16X1: both operands rounded to bf16 once.            */
 int fira_linear_x3(void* stream, int M, int N, const float* x, int ldx, const uint16_t* w_planes, const float* bias, float* out,
                    int ldo, int dtype);
+/* ... and its data gradient: dx [M, lddx >= 256] (+)= dy [M, K] W for W [K, 256] row-major with K a multiple of 256 (the d-memory
+ * products of the decoder's backward pass, K = 1024 per layer pair).  wt_planes: the planes of the TRANSPOSED [256, 256] row
+ * blocks of W (block kb transposed, then fira_gcn_weight_planes), K / 256 of them.                                           */
+int fira_linear_dgrad_x3(void* stream, int M, int K, const float* dy, int lddy, const uint16_t* wt_planes, float* dx, int lddx,
+                         int accumulate, int dtype);
 /* The same for fira_combination_block_{fwd,bwd} with dtype FIRA_F32X3: the forward launch takes, in its WqT argument, the planes
  * of the THREE stacked matrices Wq | Wk | Wo as nn.Linear stores them ([out][in]; WkT / WoT are then ignored, pass WqT again);
  * the backward launch takes, in its Wo argument, the planes of Wq^T | Wk^T | Wo^T (Wqk is then ignored).                      */

@@ -1066,6 +1066,32 @@ def test_linear_three_term_product(M, N, ldo):
     assert rel_err(got0, x.double() @ W.double().t()) < 1e-6
 
 
+@pytest.mark.parametrize("M,K,pitch", [(4331, 1024, 3136), (8104, 512, 512), (17, 256, 256), (700, 2048, 2048)])
+def test_linear_dgrad_three_term_product(M, K, pitch):
+    """fira_linear_dgrad_x3 (comb_fused.hip: linear_x3_kacc_kernel) -- the d-memory products of the decoder's backward pass
+    (d memory += dK|dV Wkv, gnn_transformer.py:139-141 backward): a column slice of padded rows as dy, accumulation into dx,
+    against fp64 at the fp32 product's tolerance (dtype 2) and against the bf16-rounded operands (dtype 3)."""
+    from fira_icse_amd import ops
+    full = randn(M, pitch, seed=4)
+    dy = full[:, :K]
+    W = randn(K, 256, seed=5, scale=0.06)
+    base = randn(M, 256, seed=6)
+    ref = base.double() + dy.double() @ W.double()
+    dx = base.clone()
+    ops.linear_dgrad_x3(dy, W, dx, dtype=2)
+    f32 = base.clone()
+    ops.gemm(dy.contiguous(), W, transB=False, out=f32, accumulate=True)
+    e3, e32 = rel_err(dx, ref), rel_err(f32, ref)
+    assert e3 < 1e-6, (e3, e32)
+    assert e3 < 3 * e32 + 1e-7, (e3, e32)
+    fresh = ops.linear_dgrad_x3(dy, W, None, dtype=2)
+    assert rel_err(fresh, dy.double() @ W.double()) < 1e-6
+    ref1 = base.double() + dy.bfloat16().double() @ W.bfloat16().double()
+    dx1 = base.clone()
+    ops.linear_dgrad_x3(dy, W, dx1, dtype=3)
+    assert rel_err(dx1, ref1) < 2e-6, rel_err(dx1, ref1)
+
+
 @pytest.mark.parametrize("dtype", [2, 3])
 def test_gcn_layer_batch64_sized(dtype):
     """The fused GCN launch at batch 64's size (19 500 rows = 4.8 tiles per workgroup: two passes, the second for one tile; hub rows of

@@ -70,6 +70,8 @@ SIGNATURES = {
     "fira_gcn_weight_planes": (_I, [_P, _I, _P, _P]),
     "fira_linear_x3": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I]),
     "fira_linear_dgrad_x3": (_I, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _I]),
+    "fira_dgrad_x3_splitk_planes_bytes": (_Z, [_I]),
+    "fira_dgrad_x3_splitk": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I]),
     "fira_head_logits_x3_scratch_bytes": (_Z, [_I]),
     "fira_head_logits_x3": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _P]),
     "fira_combination_block_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32, _U32, _I]),

@@ -526,6 +526,129 @@ int linear_x3_kacc(hipStream_t s, int M, const float* A, int lda, const uint16_t
     return 0;
 }
 
+// ---- the generator projection's data gradient: d dec [R, 256] += dlogits [R, V] Wout [V, 256] -----------------------------
+// (Model.py:54 backward.)  The head's largest product after the weight gradient: 6.7 GFLOP at batch 32 as one fp32 MFMA launch
+// of 58 us on the auxiliary stream beside the copy head's backward kernel (skipping it -- a timing probe -- was worth +1.6 % of
+// the step).  The reduction runs over the VOCABULARY, which is the contiguous dimension of dlogits and the row dimension of
+// Wout: split_planes_t writes the planes of Wout's transposed 256-row blocks (Bt_kb[n][k] = Wout[256 kb + k][n], rows past V zero)
+// once per step, and the product is the K-accumulating kernel above with the K blocks split over workgroups: workgroup = (pair of
+// 16-row tiles, chunk of K blocks), partial sums added with float atomics (13 chunks at batch 32).
+__global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ W, int V, uint16_t* __restrict__ planes, int np) {
+    const int kb = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;        // j < 8192: n = j % 256 (coalesced reads), unit c = j / 256
+    const int n = j & 255, c = j >> 8;
+    float u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int v = kb * FIRA_D + c * 8 + i;
+        u[i] = v < V ? W[(size_t)v * FIRA_D + n] : 0.f;
+    }
+    const int unit = ((n >> 4) * 8 + (c >> 2)) * 64 + (c & 3) * 16 + (n & 15);
+    uint16_t* dst = planes + (size_t)kb * 3 * FIRA_D * FIRA_D + (size_t)unit * 8;
+    for (int pl = 0; pl < np; ++pl) {
+        const uint32_t p0 = gx_pack(u[0], u[1]), p1 = gx_pack(u[2], u[3]), p2 = gx_pack(u[4], u[5]), p3 = gx_pack(u[6], u[7]);
+        *reinterpret_cast<uint4*>(dst + (size_t)pl * FIRA_D * FIRA_D) = uint4{p0, p1, p2, p3};
+        if (pl + 1 < np) {
+            u[0] = gx_rest_lo(u[0], p0); u[1] = gx_rest_hi(u[1], p0); u[2] = gx_rest_lo(u[2], p1); u[3] = gx_rest_hi(u[3], p1);
+            u[4] = gx_rest_lo(u[4], p2); u[5] = gx_rest_hi(u[5], p2); u[6] = gx_rest_lo(u[6], p3); u[7] = gx_rest_hi(u[7], p3);
+        }
+    }
+}
+// planes [ceil(V / 256)][3][65536] bf16 of the transposed row blocks of W [V, 256]; one_plane: only plane 0 is written
+int split_planes_t(hipStream_t s, const float* W, int V, uint16_t* planes, bool one_plane) {
+    if (V <= 0) return 0;
+    hipLaunchKernelGGL(split_planes_t_kernel, dim3(32, cdiv(V, FIRA_D)), dim3(256), 0, s, W, V, planes, one_plane ? 1 : 3);
+    FIRA_CHECK_LAUNCH("split_planes_t");
+    return 0;
+}
+struct DgradSplitKArgs {
+    int n_rows;
+    const float* A;          // [n, lda] fp32 rows, K valid columns
+    int lda, K;
+    const uint16_t* Wx;      // planes of the ceil(K / 256) transposed blocks
+    int nkb, kb_chunk, n_pairs;
+    float* out;              // [n, ldo], 256 columns: += by float atomics
+    int ldo;
+};
+template <int NP>
+__global__ __launch_bounds__(CF_WAVES * 64) void dgrad_x3_splitk_kernel(const DgradSplitKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float cf_lds[];
+    char* const sm_p = reinterpret_cast<char*>(cf_lds);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int pi = blockIdx.x % a.n_pairs, ci = blockIdx.x / a.n_pairs;
+    const int row0 = pi * CF_ROWS;
+    const int row_end = min(a.n_rows, row0 + CF_ROWS);
+    const int nt = (row_end - row0 + CF_TILE - 1) / CF_TILE;
+    const int kb0 = ci * a.kb_chunk, kb1 = min(a.nkb, kb0 + a.kb_chunk);
+    if (kb0 >= kb1) return;
+    const int col = wave * 16 + l15;
+    const unsigned xlane = gx_wlane(wave, lane);
+    const int a_q = gx_frag_base(l15, kq);
+    constexpr size_t WX = 3 * (size_t)FIRA_D * FIRA_D;
+    uint4 bx3[3];
+    cx_first<NP>(a.Wx + kb0 * WX, xlane, bx3);
+    asm volatile("" ::: "memory");
+    const float* arow[CF_RPW];
+    bool live[CF_RPW];
+    f32x4v x[CF_RPW];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < CF_RPW; ++i) {
+            const int k = kb * FIRA_D + lane * 4;
+            // (the last block is ragged: columns past K are padding of the row pitch, never multiplied)
+            if (k + 3 < a.K) x[i] = *reinterpret_cast<const f32x4v*>(arow[i] + k);
+            else x[i] = f32x4v{k < a.K ? arow[i][k] : 0.f, k + 1 < a.K ? arow[i][k + 1] : 0.f, k + 2 < a.K ? arow[i][k + 2] : 0.f, 0.f};
+            if (!live[i]) x[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < CF_RPW; ++i) {
+        const int row = row0 + wave * CF_RPW + i;
+        live[i] = row < row_end;
+        arow[i] = a.A + (size_t)min(row, a.n_rows - 1) * a.lda;
+    }
+    fetch(kb0);
+    cf_acc acc[CF_TMAX];
+#pragma unroll
+    for (int tt = 0; tt < CF_TMAX; ++tt) acc[tt] = cf_acc{0.f, 0.f, 0.f, 0.f};
+    for (int kb = kb0; kb < kb1; ++kb) {
+#pragma unroll
+        for (int i = 0; i < CF_RPW; ++i) gx_store_row4<NP>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, x[i]);
+        __syncthreads();
+        if (kb + 1 < kb1) fetch(kb + 1);                 // in flight under this block's product
+        cx_product<CF_TMAX, NP>(sm_p, CX_PLANE, a_q, a.Wx + kb * WX, xlane, nt, bx3, acc, kb + 1 < kb1 ? a.Wx + (kb + 1) * WX : nullptr);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tt = 0; tt < CF_TMAX; ++tt) {
+        if (tt < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + tt * CF_TILE + 4 * kq + r;
+                if (row < row_end) unsafeAtomicAdd(a.out + (size_t)row * a.ldo + col, acc[tt][r]);
+            }
+        }
+    }
+}
+// out [M, ldo >= 256] += A [M, K] W for W [K, 256] given as split_planes_t(W, K); K any size (A's row pitch lda >= K, lda % 4 == 0)
+int dgrad_x3_splitk(hipStream_t s, int M, int K, const float* A, int lda, const uint16_t* Wx, float* out, int ldo, bool one_plane) {
+    if (M <= 0 || K <= 0) return 0;
+    FIRA_REQUIRE(A && Wx && out && lda % 4 == 0 && (uintptr_t)A % 16 == 0 && lda >= K && ldo >= FIRA_D, "dgrad_x3_splitk: bad argument");
+    ProfScope prof(s, PROF_GEMM, 2.0 * M * (double)K * FIRA_D, 4.0 * ((double)M * K + 2.0 * M * FIRA_D) + 6.0 * (double)K * FIRA_D);
+    DgradSplitKArgs a{};
+    a.n_rows = M; a.A = A; a.lda = lda; a.K = K; a.Wx = Wx; a.nkb = cdiv(K, FIRA_D); a.out = out; a.ldo = ldo;
+    a.n_pairs = cdiv(M, CF_ROWS);
+    // K blocks per workgroup: about 256 workgroups in all, at least four blocks each (a workgroup streams 384 KB of planes per block)
+    const int chunks = std::max(1, std::min(cdiv(a.nkb, 4), cdiv(CF_GRID, a.n_pairs)));
+    a.kb_chunk = cdiv(a.nkb, chunks);
+    const int grid = a.n_pairs * cdiv(a.nkb, a.kb_chunk);
+    const size_t lds = 3 * CX_PLANE + 256;
+    if (one_plane) hipLaunchKernelGGL(dgrad_x3_splitk_kernel<1>, dim3(grid), dim3(CF_WAVES * 64), lds, s, a);
+    else hipLaunchKernelGGL(dgrad_x3_splitk_kernel<3>, dim3(grid), dim3(CF_WAVES * 64), lds, s, a);
+    FIRA_CHECK_LAUNCH("dgrad_x3_splitk");
+    return 0;
+}
+
 // one_plane: the engine's bf16 mode (operands rounded to bf16 once); else three terms per operand (fp32-accurate)
 int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx, int nb, const float* bias, float* out, int ldo,
               bool one_plane) {
@@ -888,6 +1011,15 @@ int fira_linear_dgrad_x3(void* stream, int M, int K, const float* dy, int lddy, 
     FIRA_REQUIRE(dtype == FIRA_F32X3 || dtype == FIRA_BF16X1, "fira_linear_dgrad_x3: dtype must be FIRA_F32X3 or FIRA_BF16X1");
     return fira::linear_x3_kacc((hipStream_t)stream, M, dy, lddy, wt_planes, K / FIRA_D, dx, lddx, accumulate != 0,
                                 dtype == FIRA_BF16X1);
+}
+size_t fira_dgrad_x3_splitk_planes_bytes(int K) { return (size_t)((K + FIRA_D - 1) / FIRA_D) * 3 * FIRA_D * FIRA_D * sizeof(uint16_t); }
+int fira_dgrad_x3_splitk(void* stream, int M, int K, const float* dy, int lddy, const float* W, uint16_t* planes_ws, float* dx,
+                         int lddx, int dtype) {
+    FIRA_REQUIRE(dy && W && planes_ws && dx && M > 0 && K > 0, "fira_dgrad_x3_splitk: bad argument");
+    FIRA_REQUIRE(dtype == FIRA_F32X3 || dtype == FIRA_BF16X1, "fira_dgrad_x3_splitk: dtype must be FIRA_F32X3 or FIRA_BF16X1");
+    const bool one = dtype == FIRA_BF16X1;
+    const int rc = fira::split_planes_t((hipStream_t)stream, W, K, planes_ws, one);
+    return rc ? rc : fira::dgrad_x3_splitk((hipStream_t)stream, M, K, dy, lddy, planes_ws, dx, lddx, one);
 }
 int fira_linear_x3(void* stream, int M, int N, const float* x, int ldx, const uint16_t* w_planes, const float* bias, float* out,
                    int ldo, int dtype) {

@@ -115,6 +115,10 @@ int transpose256(hipStream_t s, int nl, const float* W, float* Wt);       // Wt[
 int linear_x3(hipStream_t s, int M, const float* X, int ldx, const uint16_t* Wx, int nb, const float* bias, float* out, int ldo,
               bool one_plane);
 // out [M, 256] (+)= A [M, nkb * 256] B; Wx: the planes of B's nkb TRANSPOSED [256, 256] row blocks (transpose256_table + gcn_split_planes)
+// the generator projection's data gradient: out [M, ldo] += A [M, K] W (float atomics over chunks of K), W [K, 256] as the planes
+// split_planes_t writes (ceil(K / 256) transposed row blocks, 3 * 65536 bf16 each)
+int split_planes_t(hipStream_t s, const float* W, int V, uint16_t* planes, bool one_plane);
+int dgrad_x3_splitk(hipStream_t s, int M, int K, const float* A, int lda, const uint16_t* Wx, float* out, int ldo, bool one_plane);
 int linear_x3_kacc(hipStream_t s, int M, const float* A, int lda, const uint16_t* Wx, int nkb, float* out, int ldo, bool accum,
                    bool one_plane);
 int comb_fused_fwd(hipStream_t s, int n_rows, const float* Xc, const float* WqT, const float* WkT, const float* WoT,

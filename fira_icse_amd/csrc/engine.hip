@@ -79,6 +79,7 @@ struct Plan {
     uint16_t* WkvX = nullptr;                     // ... and of the stacked cross-attention K|V weight: nl * 2 row blocks of [256, 256]
     float* WkvT = nullptr;                        // k-major copies of those blocks and their planes (the d-memory products: linear_x3_kacc)
     uint16_t* WkvTX = nullptr;
+    uint16_t* WoutTX = nullptr;                   // planes of the generator projection's transposed 256-row blocks (its data gradient)
     uint16_t *xh_planes = nullptr;                // planes of the head's input rows (head_x3.hip)
     float *WcT;                     // per layer Wq^T | Wk^T | Wo^T of the Combination block, k-major (comb_fused.hip)
     float *dW21, *dc21;             // their gradients (training), one contiguous block zeroed per step
@@ -141,6 +142,7 @@ struct Plan {
         WkvX = a.get<uint16_t>((size_t)nl * 6 * D * D);
         WkvT = a.f((size_t)nl * 2 * D * D);
         WkvTX = a.get<uint16_t>((size_t)nl * 6 * D * D);
+        WoutTX = a.get<uint16_t>((size_t)cdiv(V, D) * 3 * D * D);
         xh_planes = a.get<uint16_t>(head_logits_x3_scratch_elems(TB));
         WcT = a.f((size_t)nl * 3 * D * D);
         H = a.f((size_t)NB * D);
@@ -769,6 +771,7 @@ struct Ctx {
     // adam_rows_kernel): row_step [2 * vocab] = the step up to which each row of decoder.embedding / encoder.embedding is
     // current.  The rows this batch gathers are brought up to step - 1 ahead of the forward pass; the update itself runs on
     // the rows whose gradient row is not zero.
+    bool wout_planes = false;        // (round 6) WoutTX holds this step's planes: the vocabulary data gradient runs as dgrad_x3_splitk
     bool kv_planes = false;          // (round 6) WkvTX holds this step's planes: the d-memory products run as linear_x3_kacc
     int32_t* row_step = nullptr;
     fira_adam_opts rows_ad{};        // lr / beta / eps / step / moments the lazy reads use (a COPY: a begun data-parallel step outlives the call)
@@ -1113,6 +1116,15 @@ static int encoder_forward(Ctx& c, bool defer_memory_proj) {
             TRY(gcn_split_planes(ss, p.nl * 2, src, dst));
             c.kv_planes = true;
         }
+        // ... and, in bf16 mode, the plane of the generator projection's transposed row blocks (one 38 MB pass under the decoder's
+        // forward chain) for its data gradient as dgrad_x3_splitk: +1.0 % at batch 64.  (fp32 mode keeps the fp32 MFMA launch: the
+        // three-plane form streams 680 MB of planes through L2 per launch at batch 32 and LOST 0.9 % -- profiles/r6_probes.md;
+        // FIRA_VOCAB_DGRAD_X3=1 forces it, =0 switches it off in both modes.)
+        static const int vd_mode = [] { const char* e = getenv("FIRA_VOCAB_DGRAD_X3"); return e ? atoi(e) : -1; }();
+        if (c.G && (vd_mode == 1 || (vd_mode == -1 && g_dtype == 1))) {
+            TRY(split_planes_t(ss, c.P + L.wout, p.V, p.WoutTX, g_dtype == 1));
+            c.wout_planes = true;
+        }
         c.deferred = true;
         return 0;
     }
@@ -1316,6 +1328,8 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
     if (R > 0) {
         if (so) TRY(aux_fork(s));
         // ddec_rows = dlogits W_out, split over the vocabulary axis
+        if (c.wout_planes) TRY(dgrad_x3_splitk(ss, R, p.V, p.logits, p.ldl, p.WoutTX, p.ddec_c, D, g_dtype == 1));
+        else
         TRY(gemm_any(ss, 0, 0, R, D, p.V, p.logits, p.ldl, c.P + L.wout, D, p.ddec_c, D, nullptr, FIRA_GEMM_ACCUM, 0,
                         nullptr));
         if (so) TRY(side_mark(&ev_dfc));

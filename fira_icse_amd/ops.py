@@ -240,6 +240,16 @@ def linear_dgrad_x3(dy, W, dx=None, dtype=2):
     return dx
 
 
+def dgrad_x3_splitk(dy, W, dx, dtype=2):
+    """fira_dgrad_x3_splitk: dx += dy W, dy [M, K] (row pitch a multiple of 4 floats), W [K, 256], K any size."""
+    assert dy.is_cuda and dy.dtype == torch.float32 and dy.stride(1) == 1
+    M, K = dy.shape
+    ws = torch.empty(_lib.lib().fira_dgrad_x3_splitk_planes_bytes(K), dtype=torch.uint8, device=dy.device)
+    check(_lib.lib().fira_dgrad_x3_splitk(cur_stream(), M, K, ptr(dy), dy.stride(0), ptr(_f32(W)), ptr(ws), ptr(dx), dx.stride(0),
+                                          dtype), "fira_dgrad_x3_splitk")
+    return dx
+
+
 def gcn_layer_fwd(rowptr, col, val, X, W21t, bias, c21, gamma, beta, dropout=0.0, seed=0, site=0, dtype=0, want_rowsum=True):
     """fira_gcn_layer_fwd: (sum, y, stats, rowsum) of one folded GCN layer on the CSR adjacency (global column ids);
     W21t = W21^T contiguous.  dtype 2 / 3 (FIRA_F32X3 / FIRA_BF16X1): the planes of W21 are formed here."""

@@ -236,6 +236,14 @@ int fira_linear_x3(void* stream, int M, int N, const float* x, int ldx, const ui
  * blocks of W (block kb transposed, then fira_gcn_weight_planes), K / 256 of them.                                           */
 int fira_linear_dgrad_x3(void* stream, int M, int K, const float* dy, int lddy, const uint16_t* wt_planes, float* dx, int lddx,
                          int accumulate, int dtype);
+/* (v10) The generator projection's data gradient (Model.py:54 backward): dx [M, lddx >= 256] += dy [M, K] W for W [K, 256], K ANY
+ * size (the vocabulary; dy's row pitch lddy >= K, a multiple of 4 floats; columns past K are never read as operands).  The
+ * reduction is split over workgroups and summed with float atomics: dx must hold what the product is added to (zeros for the
+ * plain product).  planes_ws: fira_dgrad_x3_splitk_planes_bytes(K) bytes of scratch (the planes of W's transposed row blocks,
+ * written by the call).  dtype FIRA_F32X3 | FIRA_BF16X1.                                                                     */
+size_t fira_dgrad_x3_splitk_planes_bytes(int K);
+int fira_dgrad_x3_splitk(void* stream, int M, int K, const float* dy, int lddy, const float* W, uint16_t* planes_ws, float* dx,
+                         int lddx, int dtype);
 /* The same for fira_combination_block_{fwd,bwd} with dtype FIRA_F32X3: the forward launch takes, in its WqT argument, the planes
  * of the THREE stacked matrices Wq | Wk | Wo as nn.Linear stores them ([out][in]; WkT / WoT are then ignored, pass WqT again);
  * the backward launch takes, in its Wo argument, the planes of Wq^T | Wk^T | Wo^T (Wqk is then ignored).                      */

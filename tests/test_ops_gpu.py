@@ -1092,6 +1092,31 @@ def test_linear_dgrad_three_term_product(M, K, pitch):
     assert rel_err(dx1, ref1) < 2e-6, rel_err(dx1, ref1)
 
 
+@pytest.mark.parametrize("M,K", [(530, 24650), (1130, 24650), (37, 4099), (16, 250), (2049, 1000)])
+def test_vocabulary_dgrad_three_term_split_k(M, K):
+    """fira_dgrad_x3_splitk (comb_fused.hip: dgrad_x3_splitk_kernel): the generator projection's data gradient d dec += dlogits Wout
+    (Model.py:54 backward) -- the reduction over the vocabulary split over workgroups, float atomics; ragged last K block (24650 =
+    96 x 256 + 74; K not a multiple of 4 either), padded row pitch with GARBAGE in the padding, ragged row tiles; against fp64 at
+    the fp32 product's tolerance (dtype 2) and against the bf16-rounded operands (dtype 3)."""
+    from fira_icse_amd import ops
+    pitch = (K + 63) // 64 * 64
+    full = torch.full((M, pitch), float("nan"), device="cuda")
+    full[:, :K] = randn(M, K, seed=7, scale=0.05)
+    dy = full[:, :K]
+    W = randn(K, 256, seed=8, scale=0.06)
+    base = randn(M, 256, seed=9)
+    ref = base.double() + dy.double() @ W.double()
+    dx = ops.dgrad_x3_splitk(dy, W, base.clone(), dtype=2)
+    f32 = base.clone()
+    ops.gemm(dy.contiguous(), W, transB=False, out=f32, accumulate=True)
+    e3, e32 = rel_err(dx, ref), rel_err(f32, ref)
+    assert e3 < 1e-6, (e3, e32)
+    assert e3 < 3 * e32 + 2e-7, (e3, e32)
+    ref1 = base.double() + dy.bfloat16().double() @ W.bfloat16().double()
+    dx1 = ops.dgrad_x3_splitk(dy, W, base.clone(), dtype=3)
+    assert rel_err(dx1, ref1) < 2e-6, rel_err(dx1, ref1)
+
+
 @pytest.mark.parametrize("dtype", [2, 3])
 def test_gcn_layer_batch64_sized(dtype):
     """The fused GCN launch at batch 64's size (19 500 rows = 4.8 tiles per workgroup: two passes, the second for one tile; hub rows of

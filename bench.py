@@ -474,8 +474,8 @@ def gemm_objects(prof, dtype, prof_steps, traffic, dec_rows=None):
     g_s = max(gemm["ms"], 1e-9) * 1e-3
     total_ms = sum(v["ms"] for v in prof.values()) or 1.0
     peak_tf = BF16_MFMA_PEAK_TF if dtype == "bf16" else FP32_MFMA_PEAK_TF
-    kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16)" if dtype == "bf16" else \
-        "gemm_f32_kernel / gemm_tile32_kernel (v_mfma_f32_32x32x2_f32) + wgrad_panel_kernel (weight gradients) and head_logits_x3_kernel (generator projection): fp32-accurate three-term bf16 split on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16; algorithmic fp32 FLOP priced against the fp32 MFMA peak"
+    kern = "gemm_bf16_k256_kernel / gemm_bf16_small_kernel / gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16) + the one-plane linear_x3 / dgrad_x3_splitk / wgrad_panel kernels (v_mfma_f32_16x16x32_bf16)" if dtype == "bf16" else \
+        "gemm_f32_kernel / gemm_tile32_kernel (v_mfma_f32_32x32x2_f32) + wgrad_panel_kernel (weight gradients), head_logits_x3_kernel (generator projection), linear_x3_kernel / linear_x3_kacc_kernel (cross-attention K|V projection of the memory rows and its data gradient): fp32-accurate three-term bf16 split on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16; algorithmic fp32 FLOP priced against the fp32 MFMA peak"
     roofline = {"bound": "mfma", "kernel": kern, "achieved": gemm["work"] / g_s / 1e12, "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": gemm["work"] / g_s / 1e12 / peak_tf,
                 "traffic": traffic.get("gemm", {}).get("hbm_bytes_per_launch"),

@@ -771,6 +771,7 @@ struct Ctx {
     // adam_rows_kernel): row_step [2 * vocab] = the step up to which each row of decoder.embedding / encoder.embedding is
     // current.  The rows this batch gathers are brought up to step - 1 ahead of the forward pass; the update itself runs on
     // the rows whose gradient row is not zero.
+    bool dp_begin = false;           // fira_train_step_begin(_rows): the first half of a data-parallel step (see backward_decoder: dec_every)
     bool wout_planes = false;        // (round 6) WoutTX holds this step's planes: the vocabulary data gradient runs as dgrad_x3_splitk
     bool kv_planes = false;          // (round 6) WkvTX holds this step's planes: the d-memory products run as linear_x3_kacc
     int32_t* row_step = nullptr;
@@ -1382,7 +1383,18 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
     // neutral (profiles/r5_probes.md).  fp32, single device (data-parallel runs hand the bucket over at the mid event);
     // FIRA_DEC_WGRAD_EVERY=0: one launch behind the loop.
     static const int dec_every_env = [] { const char* e = getenv("FIRA_DEC_WGRAD_EVERY"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 0; }();
-    const int dec_every = (mid_event || g_dtype != 0 || dec_every_env == 0 || p.nl % dec_every_env != 0) ? 0 : dec_every_env;
+    // Round 6 re-measured both exclusions.  (1) A mid event (data-parallel steps) used to force the single launch; with the panel
+    // kernels that launch is the SLOW form (FIRA_DEC_WGRAD_EVERY=0 on one device: -11 % at batch 32, -17 % at batch 64), and the
+    // two-call step on one device (scripts/probes/dp1_probe.py) goes 2.716 -> 2.444 ms at batch 32, 4.214 -> 3.546 ms at batch 64
+    // with the launches of three layers.  Every gradient of [0, split) is still final when the mid event fires
+    // (scripts/probes/mid_event_probe.py: a stream waiting for the event snapshots the slice -- no element changes afterwards).
+    // Taken by fira_train_step_begin / _begin_rows (Ctx::dp_begin); fira_train_fwd_bwd with a mid event -- the ZeRO-1 and
+    // the unfused trainers -- keeps the single launch (FIRA_DEC_WGRAD_DP=1 extends it to them, =0 switches it off).
+    // (2) bf16 mode: +0.8 % at batch 64 with the launches of three layers (23 513 -> 23 691, same-box triple); FIRA_DEC_WGRAD_BF16=0.
+    static const int dec_dp = [] { const char* e = getenv("FIRA_DEC_WGRAD_DP"); return e ? atoi(e) : -1; }();
+    static const bool dec_bf16_off = [] { const char* e = getenv("FIRA_DEC_WGRAD_BF16"); return e && e[0] == '0'; }();
+    const bool mid_single = mid_event && (dec_dp == 0 || (dec_dp == -1 && !c.dp_begin));
+    const int dec_every = (mid_single || (g_dtype != 0 && dec_bf16_off) || dec_every_env == 0 || p.nl % dec_every_env != 0) ? 0 : dec_every_env;
     {
     ProfScope prof_region(s, PROF_DEC_REGION, 0.0);      // wall time of the decoder's backward layers (see decoder_forward)
     TRY(lanes_fork(c));                        // (lane 1 starts behind the head's backward kernels)
@@ -1918,6 +1930,7 @@ static int train_call(void* stream, const fira_dims* d, const fira_batch* batch,
         c.row_step = row_step;
         c.rows_ad = *adam;
     }
+    c.dp_begin = begin_only;
     if (begin_only) c.adam = nullptr;        // (fira_train_step_begin_rows: the optimizer's values serve the lazy reads only)
     TRY(encoder_forward(c, true));
     if (side_on()) {

@@ -253,16 +253,28 @@ def spmm_standalone(cfg, store):
             Z = ops.csr_spmm(rp, c, v, Xs[i], graph_rows=N, variant=0, out=Ys[i], dtype=dt, auto=True)
             lin = ops.gemm(Z, W21, bias=b2)
             ops.add_layernorm_fwd(lin, Xs[i], gamma, beta, dropout=0.2, seed=1, site=3)
+        def unfused_bwd():                            # the engine's backward on a dense batch (gcn_fused_on() false)
+            i = k[0] % 3
+            k[0] += 1
+            ds, dxd, _, _ = ops.add_layernorm_bwd(Ys[i], summ, stats, gamma, dropout=0.2, seed=1, site=3, want_dx_drop=True)
+            V = ops.csr_spmm(rp, c, v, dxd, graph_rows=N, variant=0, dtype=dt, auto=True)
+            ops.gemm(V, W21, transB=False, out=ds, accumulate=True, dtype="bf16" if dt else "f32")
+            ops.gemm(V, Xs[i], transA=True, transB=False, out=dW, accumulate=True)
         try:
             t_u = time_gpu(unfused, iters=9, warmup=3)
+            t_ub = time_gpu(unfused_bwd, iters=9, warmup=3)
         except Exception as ex:                       # noqa: BLE001 -- the comparison leg must not take the object down
-            t_u = float("nan")
+            t_u = t_ub = float("nan")
             g5["unfused_error_%s" % name] = str(ex)[:120]
-        g5[name] = {"fwd_us": t_f * 1e6, "bwd_us": t_b * 1e6, "unfused_fwd_us": t_u * 1e6,
+        g5[name] = {"fwd_us": t_f * 1e6, "bwd_us": t_b * 1e6, "unfused_fwd_us": t_u * 1e6, "unfused_bwd_us": t_ub * 1e6,
+                    "routed_frac_hbm_fwd": layer_bytes_fwd / t_u / 1e9 / HBM_PEAK_GBS,
+                    "routed_frac_hbm_bwd": layer_bytes_bwd / t_ub / 1e9 / HBM_PEAK_GBS,
                     "frac_hbm_fwd": layer_bytes_fwd / t_f / 1e9 / HBM_PEAK_GBS, "frac_hbm_bwd": layer_bytes_bwd / t_b / 1e9 / HBM_PEAK_GBS,
                     "frac_mfma_fwd": 2.0 * n * 256 * 256 / t_f / 1e12 / (FP32_MFMA_PEAK_TF if dt == 0 else BF16_MFMA_PEAK_TF)}
     g5["note"] = ("one GCN layer on config 5 (116 entries per row: the fused kernel's gather is its tail path throughout); "
-                  "bwd = LayerNorm backward + fused V = A dY, dX += V W21 + the weight gradient V^T X")
+                  "bwd = LayerNorm backward + fused V = A dY, dX += V W21 + the weight gradient V^T X; unfused_* = the launches "
+                  "the ENGINE issues on a batch this dense (aggregation kernel of the density crossover + product + row kernel), "
+                  "routed_frac_* = the layer's algorithmic bytes over those times")
     out["gcn_cfg5"] = g5
     return out
 
@@ -667,6 +679,10 @@ def compact_line(line, detail_path):
     put("gcn_cfg5_f32_bwd_us", line, "gcn_cfg5", "f32", "bwd_us")
     put("gcn_cfg5_bf16_fwd_us", line, "gcn_cfg5", "bf16", "fwd_us")
     put("gcn_cfg5_bf16_bwd_us", line, "gcn_cfg5", "bf16", "bwd_us")
+    put("gcn_cfg5_f32_routed_fwd_us", line, "gcn_cfg5", "f32", "unfused_fwd_us")
+    put("gcn_cfg5_f32_routed_bwd_us", line, "gcn_cfg5", "f32", "unfused_bwd_us")
+    put("gcn_cfg5_bf16_routed_fwd_us", line, "gcn_cfg5", "bf16", "unfused_fwd_us")
+    put("gcn_cfg5_bf16_routed_bwd_us", line, "gcn_cfg5", "bf16", "unfused_bwd_us")
     put("host_inclusive_commits_per_s", line, "host_inclusive", "commits_per_s")
     for leg in ("b64", "b170"):
         for dt in ("f32", "bf16"):

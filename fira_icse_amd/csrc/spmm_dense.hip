@@ -6,8 +6,8 @@
 //
 // The input stays the engine's block-diagonal CSR (no dense adjacency in HBM): a workgroup owns R consecutive rows of
 // ONE graph and all 256 feature columns, and
-//   1. densifies its R x N slice of A_hat into LDS (zero fill, then one LDS store per CSR entry; the slice's entries are
-//      one contiguous range of col/val, read with coalesced loads; k-contiguous rows = MFMA A-operand layout);
+//   1. densifies its R x N slice of A_hat into LDS (zero fill, then one LDS store per CSR entry; a wave owns consecutive rows
+//      and requests all their entries in one round trip -- densify_rows; k-contiguous rows = MFMA A-operand layout);
 //   2. walks the graph's N feature rows in chunks: every wavefront owns 64 output columns, so each H element is fetched
 //      ONCE per workgroup, straight into registers in MFMA B-fragment layout (lane = column, registers = k: dword loads
 //      whose 32-lane halves cover whole 128-byte row segments), one chunk ahead of the MFMAs; A fragments come from LDS
@@ -44,44 +44,77 @@ __device__ __forceinline__ void store_elem(char* p, float v, uint16_t) {
 }
 
 // R x KP slice of the adjacency (rows r0.. of the graph whose first node is row0) -> LDS tile, element type T.
-// The slice's CSR entries are ONE contiguous range of col / val: the workgroup's threads stride over it with DN_U entries
-// each in flight per pass (a row-by-row walk is a chain of three dependent global round trips per row: 70 us per
-// workgroup at any density).  The row of an entry comes from the LDS copy of the slice's row offsets: a thread's entries
-// ascend, so its row pointer only moves forward.
-constexpr int DN_U = 8;
+// A wave owns R / (NT / 64) consecutive rows of the slice and requests ALL their entries before it uses any: DN_SLOTS slots of
+// 64 entries per row, every lane of every slot a buffer load (lanes without an entry carry the descriptor's out-of-range
+// offset: no request, no branch), one round trip for the slice.  A slot is then one row's entries in lane order, so the row is
+// known (no search) and the neighbour's column is the adjacent lane's (wave_shl / wave_shr DPP).  Fast path of a slot -- no
+// entry has an equal successor (one compare + ballot) -- every entry stores its value; otherwise the LAST entry of a run of
+// equal columns (sorted rows) stores the run's sum, the earlier ones walked back in global memory.  Rows longer than the
+// slots finish in a tail loop.  (Round 5's form -- threads striding over the whole slice, eight entries in flight, the row
+// found by walking the LDS copy of the row offsets, the predecessor's column by a dependent load -- cost 35 us of the bf16
+// launch's 82 on config 5; a per-entry search over the wave's 16 row boundaries, 16.5 us per 128-row slice: this form is
+// bound by its ~1 000 instructions per wave.)
+constexpr int DN_SLOTS = 3;
 template <typename T, int R, int NT>
 __device__ __forceinline__ void densify_rows(char* tile, int* sm_rp, int pitch, int graph_rows, int row0, int r0,
                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                              const float* __restrict__ val) {
+    constexpr int RW = R / (NT / 64);                                // rows of a wave
+    static_assert(R % (NT / 64) == 0 && NT > R, "densify_rows: rows per wave");
     const int nr = min(R, graph_rows - r0);                          // rows of this slice
     if ((int)threadIdx.x <= nr) sm_rp[threadIdx.x] = rowptr[row0 + r0 + threadIdx.x];
     const int n16 = R * pitch / 16;
     for (int i = threadIdx.x; i < n16; i += NT) reinterpret_cast<uint4*>(tile)[i] = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
-    const int beg = sm_rp[0], end = sm_rp[nr];
-    int lo = 0;                                                      // sm_rp[lo] <= e < sm_rp[lo + 1] for the current entry
-    for (int base = beg + threadIdx.x; base < end; base += NT * DN_U) {
-        int c[DN_U], cn[DN_U];
-        float v[DN_U];
+    const int lane = threadIdx.x & 63, w0 = (threadIdx.x >> 6) * RW;
+    const rsrc_t rC = buf_rsrc(col, 0x7fffffffu), rV = buf_rsrc(val, 0x7fffffffu);
+    int pc[RW][DN_SLOTS];
+    float pv[RW][DN_SLOTS];
 #pragma unroll
-        for (int u = 0; u < DN_U; ++u) {                             // everything requested before anything is used
-            const int e = base + u * NT;
-            const bool in = e < end;
-            c[u] = in ? col[e] : -1;
-            cn[u] = (in && e + 1 < end) ? col[e + 1] : -1;
-            v[u] = in ? val[e] : 0.f;
+    for (int rr = 0; rr < RW; ++rr) {                                // (rows past the slice: rb == re, no lane has an entry)
+        const int rb = sm_rp[min(w0 + rr, nr)], re = sm_rp[min(w0 + rr + 1, nr)];
+#pragma unroll
+        for (int sl = 0; sl < DN_SLOTS; ++sl) {
+            const int e = rb + sl * 64 + lane;
+            const unsigned off = e < re ? (unsigned)e * 4u : FIRA_OOB;
+            pc[rr][sl] = (int)__builtin_amdgcn_raw_buffer_load_b32(rC, off, 0, 0);     // (no arithmetic on it here: that would wait)
+            pv[rr][sl] = buf_load_f32(rV, off);
         }
+    }
 #pragma unroll
-        for (int u = 0; u < DN_U; ++u) {
-            const int e = base + u * NT;
-            if (e >= end) break;
-            while (sm_rp[lo + 1] <= e) ++lo;
-            const int cl = c[u] - row0;
-            // the LAST entry of a run of equal columns (sorted rows) stores the run's sum
-            if ((e + 1 < sm_rp[lo + 1] && cn[u] == c[u]) || (unsigned)cl >= (unsigned)graph_rows) continue;
-            float sum = v[u];
-            for (int k = e - 1; k >= sm_rp[lo] && col[k] == c[u]; --k) sum += val[k];
-            store_elem(tile + (size_t)lo * pitch + (size_t)cl * sizeof(T), sum, T());
+    for (int rr = 0; rr < RW; ++rr) {
+        if (w0 + rr >= nr) break;                                    // (wave-uniform)
+        const int rb = sm_rp[w0 + rr], re = sm_rp[w0 + rr + 1];
+        char* rowp = tile + (size_t)(w0 + rr) * pitch;
+#pragma unroll
+        for (int sl = 0; sl < DN_SLOTS; ++sl) {
+            if (rb + sl * 64 >= re) break;                           // (wave-uniform)
+            const int c = pc[rr][sl] - row0;
+            const int nx0 = sl + 1 < DN_SLOTS ? __builtin_amdgcn_readlane(pc[rr][sl + 1 < DN_SLOTS ? sl + 1 : sl], 0) - row0 : -2;
+            int cn = __builtin_amdgcn_update_dpp(nx0, c, 0x130, 0xf, 0xf, false);          // wave_shl:1: lane i <- lane i + 1
+            const int e = rb + sl * 64 + lane;
+            const bool more = sl + 1 == DN_SLOTS && rb + DN_SLOTS * 64 < re;               // (wave-uniform)
+            if (__ballot(e + 1 < re && cn == c) == 0ull && !more) {
+                if (e < re && (unsigned)c < (unsigned)graph_rows) store_elem(rowp + (size_t)c * sizeof(T), pv[rr][sl], T());
+                continue;
+            }
+            const int pv0 = sl > 0 ? __builtin_amdgcn_readlane(pc[rr][sl > 0 ? sl - 1 : 0], 63) - row0 : -2;
+            const int cp = __builtin_amdgcn_update_dpp(pv0, c, 0x138, 0xf, 0xf, false);    // wave_shr:1: lane i <- lane i - 1
+            if (more && lane == 63) cn = col[e + 1] - row0;
+            if (e >= re || (e + 1 < re && cn == c) || (unsigned)c >= (unsigned)graph_rows) continue;
+            float sum = pv[rr][sl];
+            if (e > rb && cp == c)
+                for (int k = e - 1; k >= rb && col[k] - row0 == c; --k) sum += val[k];
+            store_elem(rowp + (size_t)c * sizeof(T), sum, T());
+        }
+        for (int base = rb + DN_SLOTS * 64; base < re; base += 64) {  // rows longer than the slots (rare)
+            const int e = base + lane;
+            const int c = e < re ? col[e] - row0 : -1;
+            const int cn = e + 1 < re ? col[e + 1] - row0 : -2;
+            if (e >= re || cn == c || (unsigned)c >= (unsigned)graph_rows) continue;
+            float sum = val[e];
+            for (int k = e - 1; k >= rb && col[k] - row0 == c; --k) sum += val[k];
+            store_elem(rowp + (size_t)c * sizeof(T), sum, T());
         }
     }
     __syncthreads();

@@ -244,7 +244,7 @@ def spmm_standalone(cfg, store):
             k[0] += 1
             ds, dxd, _, _ = ops.add_layernorm_bwd(Ys[i], summ, stats, gamma, dropout=0.2, seed=1, site=3, want_dx_drop=True)
             V = ops.gcn_layer_bwd(rp, c, v, dxd, W21, ds, dtype=dt)
-            ops.gemm(V, Xs[i], transA=True, transB=False, out=dW, accumulate=True)
+            ops.gemm_wgrad_panel(V, Xs[i], dW, dtype=dt)       # the engine's weight-gradient kernel
         t_b = time_gpu(bwd, iters=9, warmup=3)
 
         def unfused():
@@ -259,7 +259,7 @@ def spmm_standalone(cfg, store):
             ds, dxd, _, _ = ops.add_layernorm_bwd(Ys[i], summ, stats, gamma, dropout=0.2, seed=1, site=3, want_dx_drop=True)
             V = ops.csr_spmm(rp, c, v, dxd, graph_rows=N, variant=0, dtype=dt, auto=True)
             ops.gemm(V, W21, transB=False, out=ds, accumulate=True, dtype="bf16" if dt else "f32")
-            ops.gemm(V, Xs[i], transA=True, transB=False, out=dW, accumulate=True)
+            ops.gemm_wgrad_panel(V, Xs[i], dW, dtype=dt)       # the engine's weight-gradient kernel
         try:
             t_u = time_gpu(unfused, iters=9, warmup=3)
             t_ub = time_gpu(unfused_bwd, iters=9, warmup=3)

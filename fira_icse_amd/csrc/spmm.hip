@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void spmm_rowwave_kernel(int n_rows, const int
 // per round trip, whichever row they belong to (the set bits of one ballot word, in lane order; a lane group's index is the
 // accumulator).  Entries beyond the last one of a trip carry the out-of-range offset of the buffer descriptor: no request.
 // Rows with more than 16 entries finish as the kernel above does.  4x fewer waves, 4-5 trips per four rows instead of 12.
+constexpr int SB_U = 8;          // neighbour rows per round trip (16: 14.4 against 13.4 us on batch 64's compact rows)
 template <bool ACCUM>
 __global__ __launch_bounds__(256) void spmm_rowbatch_kernel(int n_rows, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
@@ -130,12 +131,12 @@ __global__ __launch_bounds__(256) void spmm_rowbatch_kernel(int n_rows, const in
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4s{0.f, 0.f, 0.f, 0.f};
     unsigned long long m = __ballot(ge < my_cnt);
-    while (m) {                                           // wave-uniform: the listed entries of the four rows, eight per trip
-        f32x4s g[8];
-        float w[8];
-        int own[8];
+    while (m) {                                           // wave-uniform: the listed entries of the four rows, SB_U per trip
+        f32x4s g[SB_U];
+        float w[SB_U];
+        int own[SB_U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < SB_U; ++u) {
             const bool ok = m != 0ull;
             const int src = ok ? (int)__builtin_ctzll(m) : 0;
             if (ok) m &= m - 1;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void spmm_rowbatch_kernel(int n_rows, const in
                                                                                     (unsigned)cj * (unsigned)ldx * 4u, 0));
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < SB_U; ++u) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (own[u] == i) {                        // wave-uniform

@@ -470,6 +470,8 @@ class TransModel(nn.Module):
             if n == 0:
                 _lib.check(1, "fira_workspace_bytes")
             self._ws[key] = torch.empty(n, dtype=torch.uint8, device=self.device_)
+            if os.environ.get("FIRA_WS_POISON"):     # debug: every float of a fresh workspace is NaN -- a kernel that reads
+                self._ws[key].fill_(0xFF)            # scratch it never wrote (or wrote on another stream) shows up at once
         return self._ws[key]
 
     def train_fwd_bwd(self, db: DeviceBatch, zero_grad: bool = True, dropout: Optional[float] = None,

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                 else *reinterpret_cast<f32x4v*>(&sm_u[r_off[i]]) = xv;
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 2. q and k: two products over the same panel
         cf_acc aq[CF_TMAX], ak[CF_TMAX];
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
         cf_product<BF, CF_TMAX>(sm_u, a_off, a.WqT, wlane, nt, bx, aq, a.WkT);
         cf_product<BF, CF_TMAX>(sm_u, a_off, a.WkT, wlane, nt, bx, ak, a.WoT);       // (Wo's first chunk: in flight under the gate)
         }
-        __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
+        lds_barrier();                                    // every wave has read its last A fragment: the panel can be overwritten
         // ------------------------------------------------------------ 3. the gate, element by element in the accumulator layout
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 4. the output projection
         cf_acc ao[CF_TMAX];
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
             yr[i] = a.y_rows ? a.y_rows[row] : row;
         }
         asm volatile("" ::: "memory");
-        __syncthreads();
+        lds_barrier();   
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) {
             if (tt < nt) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                 for (int r = 0; r < 4; ++r) sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = ao[tt][r];
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 5. whole rows: bias, dropout, residual, LayerNorm
         if (rbase < row_end) {
 #pragma unroll
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_fwd_kernel(const Com
                 }
             }
         }
-        if (pass + CF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
+        if (pass + CF_TMAX < t_cnt) lds_barrier();         // the next pass overwrites the panel
     }
 }
 
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kernel(const LinearX3
                 gx_store_row4<NP>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f});
             }
         }
-        __syncthreads();
+        lds_barrier();   
         for (int blk = 0; blk < a.nb; ++blk) {
             cf_acc acc[CF_TMAX];
 #pragma unroll
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kernel(const LinearX3
                 }
             }
         }
-        if (pass + CF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
+        if (pass + CF_TMAX < t_cnt) lds_barrier();         // the next pass overwrites the panel
     }
 }
 // Workgroups of a linear_x3 launch: every workgroup streams ALL of the weight's planes from L2 (384 KB per 256 x 256 block and
@@ -489,14 +489,14 @@ __global__ __launch_bounds__(CF_WAVES * 64) void linear_x3_kacc_kernel(const Lin
                 const int row = row0 + wave * CF_RPW + i;
                 gx_store_row4<NP>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, row < row_end ? x[i] : f32x4v{0.f, 0.f, 0.f, 0.f});
             }
-            __syncthreads();
+            lds_barrier();   
             if (kb + 1 < a.nkb) {                        // the next block's rows: in flight under this block's product
 #pragma unroll
                 for (int i = 0; i < CF_RPW; ++i) x[i] = *reinterpret_cast<const f32x4v*>(arow[i] + (kb + 1) * FIRA_D);
             }
             cx_product<CF_TMAX, NP>(sm_p, CX_PLANE, a_q, a.Wx + kb * WX, xlane, nt, bx3, acc,
                                     kb + 1 < a.nkb ? a.Wx + (kb + 1) * WX : nullptr);
-            __syncthreads();                             // every wave has read its fragments: the panel can be overwritten
+            lds_barrier();                                // every wave has read its fragments: the panel can be overwritten
         }
 #pragma unroll
         for (int tt = 0; tt < CF_TMAX; ++tt) {
@@ -614,10 +614,10 @@ __global__ __launch_bounds__(CF_WAVES * 64) void dgrad_x3_splitk_kernel(const Dg
     for (int kb = kb0; kb < kb1; ++kb) {
 #pragma unroll
         for (int i = 0; i < CF_RPW; ++i) gx_store_row4<NP>(sm_p, CX_PLANE, wave * CF_RPW + i, lane, x[i]);
-        __syncthreads();
+        lds_barrier();   
         if (kb + 1 < kb1) fetch(kb + 1);                 // in flight under this block's product
         cx_product<CF_TMAX, NP>(sm_p, CX_PLANE, a_q, a.Wx + kb * WX, xlane, nt, bx3, acc, kb + 1 < kb1 ? a.Wx + (kb + 1) * WX : nullptr);
-        __syncthreads();
+        lds_barrier();   
     }
 #pragma unroll
     for (int tt = 0; tt < CF_TMAX; ++tt) {
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                 if (live) *reinterpret_cast<f32x4v*>(a.dYc + (size_t)(rbase + i) * FIRA_D + lane * 4) = o4;
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 2. dc = dYc Wo; the saved q | k of this lane's elements on the way
         float qs[CB_TMAX][4], ks[CB_TMAX][4];
         auto load_qk = [&]() {
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         else
         cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wo, wlane, nt, bx, ac, a.Wqk);    // (Wq's first chunk: in flight under the gate's arithmetic)
         if constexpr (BF) load_qk();
-        __syncthreads();                                                // the panel's A fragments are consumed
+        lds_barrier();                                                   // the panel's A fragments are consumed
         // ------------------------------------------------------------ 3. gate backward in the accumulator layout
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) {
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 4. dX = dq Wq + dk Wk
         cf_acc ax[CB_TMAX];
 #pragma unroll
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
         cf_product<BF, CB_TMAX>(sm_u, a_off, a.Wqk, wlane, nt, bx, ax, a.Wqk + (size_t)FIRA_D * FIRA_D);
         cf_product<BF, CB_TMAX>(sm_w, a_off, a.Wqk + (size_t)FIRA_D * FIRA_D, wlane, nt, bx, ax);
         }
-        __syncthreads();
+        lds_barrier();   
 #pragma unroll
         for (int tt = 0; tt < CB_TMAX; ++tt) {
             if (tt < nt) {
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
                 for (int r = 0; r < 4; ++r) sm_u[d_off[r] + tt * (CF_TILE * FIRA_D)] = ax[tt][r];
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 5. rows: dG = ds + dX
 #pragma unroll
         for (int i = 0; i < CB_RPW; ++i) {
@@ -926,11 +926,11 @@ __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const Com
             const f32x4v x = *reinterpret_cast<const f32x4v*>(&sm_u[r_off[i]]);
             *reinterpret_cast<f32x4v*>(a.dG + (size_t)nr[i] * FIRA_D + lane * 4) = ds[i] + x;
         }
-        __syncthreads();                                                // the next pass (or the reduction below) reuses the panels
+        lds_barrier();                                                   // the next pass (or the reduction below) reuses the panels
     }
     // ---------------------------------------------------------------- the workgroup's partial rows (every workgroup writes: the
     // reducer sums CF_GRID of them)
-    __syncthreads();
+    lds_barrier();   
     if (t < 2 * FIRA_D) {
         float acc = 0.f;
 #pragma unroll

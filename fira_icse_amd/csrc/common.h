@@ -130,4 +130,10 @@ __device__ __forceinline__ void gate_elem(float q, float k, float v, float& g0, 
     g1 = a >= b ? small : big;
 }
 
+// Workgroup barrier for LDS traffic only.  __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: it also waits for
+// every outstanding GLOBAL load of the wave, i.e. for the weight fragments / next rows a kernel requests ahead of a barrier
+// precisely so that they arrive under the phase behind it.  Only valid where no thread reads global memory that another
+// thread of the workgroup wrote before the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 }  // namespace fira

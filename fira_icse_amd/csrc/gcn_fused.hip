@@ -240,7 +240,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
             b[0][s2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rW, wlane, s2 * FIRA_D * 4, 0));
         }
         asm volatile("" ::: "memory");
-        __syncthreads();
+        lds_barrier();   
 
         // ------------------------------------------------------------ 2. product: panel [16 nt, 256] x Wk, 16 columns per wave
         f32x4acc acc[GF_TMAX];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                 asm volatile("" ::: "memory");
             }
         }
-        __syncthreads();                                 // every wave has read its last A fragment: the panel can be overwritten
+        lds_barrier();                                    // every wave has read its last A fragment: the panel can be overwritten
         // accumulator register r of tile tt: row 16 tt + 4 kq + r, column 16 wave + l15
 #pragma unroll
         for (int tt = 0; tt < GF_TMAX; ++tt) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                 for (int r = 0; r < 4; ++r) sm_u[d_off[r] + tt * (GF_TILE * FIRA_D)] = acc[tt][r];
             }
         }
-        __syncthreads();
+        lds_barrier();   
 
         // ------------------------------------------------------------ 3. whole rows
         const int rbase = row0 + wave * GF_RPW;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(GF_WAVES * 64) void gcn_fused_kernel(const GcnFused
                 }
             }
         }
-        if (pass + GF_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the panel
+        if (pass + GF_TMAX < t_cnt) lds_barrier();         // the next pass overwrites the panel
     }
 }
 

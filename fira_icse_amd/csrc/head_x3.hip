@@ -162,7 +162,7 @@ __global__ __launch_bounds__(HX_WAVES * 64) void head_logits_x3_kernel(int R, in
                 for (int i = 0; i < 8; ++i) gx_store_row4(hx_lds, HX_PLANE, wave * 8 + i, lane, w[i]);
             }
         }
-        __syncthreads();
+        lds_barrier();   
         // ------------------------------------------------------------ 2. chunks of 32 target-row blocks: up to four per wave
         for (int mb0 = 0; mb0 < n_mb; mb0 += HX_NB * HX_WAVES) {
             // this wave's blocks mb0 + wave + 8 j, j < cnt (wave-uniform)
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(HX_WAVES * 64) void head_logits_x3_kernel(int R, in
                 default: break;
             }
         }
-        if (pass + HX_TMAX < t_cnt) __syncthreads();      // the next pass overwrites the planes
+        if (pass + HX_TMAX < t_cnt) lds_barrier();         // the next pass overwrites the planes
     }
 }
 

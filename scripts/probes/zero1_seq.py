@@ -30,3 +30,17 @@ if __name__ == "__main__":
     rows.sort(reverse=True)
     for dn, xn, n in rows[:6]:
         print("%-55s diff %.3e  norm %.3e" % (n, dn, xn))
+    # WHERE the worst tensors differ: count and index pattern of the elements that are off
+    views = model.named_views()
+    for dn, xn, n in rows[:3]:
+        t = views[n]
+        o = (t.data_ptr() - base) // 4
+        x, y = a["m"][o:o + t.numel()].view(t.shape), b["m"][o:o + t.numel()].view(t.shape)
+        d = (x - y).abs()
+        bad = d > 1e-3 * x.abs().max()
+        print(n, tuple(t.shape), "elements off by > 1e-3 of max:", int(bad.sum()), "of", t.numel(), " max |diff| %.3e  max |m| %.3e" % (float(d.max()), float(x.abs().max())))
+        if bad.any():
+            r, c = bad.nonzero(as_tuple=True)
+            print("   rows", sorted(set(r.tolist()))[:24], "... cols", sorted(set(c.tolist()))[:24])
+        rel = d.sum(1) / x.abs().sum(1).clamp_min(1e-30)
+        print("   per-row relative L1 diff: min %.2e  median %.2e  max %.2e" % (float(rel.min()), float(rel.median()), float(rel.max())))

@@ -375,6 +375,42 @@ def test_block_dense_spmm_sums_repeated_columns():
         assert rel_err(Y, ref) < 1e-6, variant
 
 
+def test_block_dense_spmm_long_rows_with_runs_across_slot_boundaries():
+    """densify_rows requests a row's entries in slots of 64 (three per row, then a tail loop): rows of ~330 entries whose runs
+    of equal columns straddle entry 63|64, 127|128, 191|192 (the last slot's successor comes from memory) and sit in the tail."""
+    from fira_icse_amd import ops
+    N, B = 512, 2
+    rng = np.random.default_rng(11)
+    rowptr, col, val = [0], [], []
+    dense = np.zeros((B, N, N), dtype=np.float64)
+    for g in range(B):
+        for r in range(N):
+            n = 40 if r % 3 == 0 else 330                                  # short rows between the long ones
+            cs = sorted(rng.choice(N, size=n, replace=False).tolist())
+            for pos in (62, 63, 126, 127, 190, 191, 192, 255, 256, 300):   # duplicate the entry AT pos: a run across pos | pos + 1
+                if pos < len(cs):
+                    cs.insert(pos + 1, cs[pos])
+            if r % 5 == 0 and len(cs) > 66:
+                cs[61:66] = [cs[61]] * 5                                   # a run of five over the first slot boundary
+                cs.sort()
+            for c in cs:
+                v = float(np.float32(rng.uniform(0.1, 1.0)))
+                dense[g, r, c] += v
+                col.append(g * N + c); val.append(v)
+            rowptr.append(len(col))
+    t = lambda a, dt: torch.tensor(np.array(a, dtype=dt), device=DEV)
+    X = randn(B * N, 256, seed=4)
+    dn = torch.tensor(dense, device=DEV)
+    ref = torch.bmm(dn, X.view(B, N, 256).double()).view(B * N, 256)
+    Y = ops.csr_spmm(t(rowptr, np.int32), t(col, np.int32), t(val, np.float32), X, graph_rows=N, variant=3)
+    assert rel_err(Y, ref) < 1e-6
+    Yb = ops.csr_spmm(t(rowptr, np.int32), t(col, np.int32), t(val, np.float32), X, graph_rows=N, variant=4)
+    # the tile holds the bf16 rounding of the fp32 SUM of a run (summed last-to-first in fp32)
+    ref_b = torch.bmm(dn.float().bfloat16().double(), X.bfloat16().view(B, N, 256).double()).view(B * N, 256)
+    assert rel_err(Yb, ref_b) < 2e-4                                       # (a run's fp32 sum order may round the bf16 differently)
+    assert rel_err(Yb, ref) < 6e-3
+
+
 # ------------------------------------------------------------------------------------------------ row ops
 def test_embed_gather_and_scatter():
     from fira_icse_amd import ops

@@ -1388,12 +1388,15 @@ static int backward_decoder(Ctx& c, int R, const int32_t* rows, hipEvent_t mid_e
     // two-call step on one device (scripts/probes/dp1_probe.py) goes 2.716 -> 2.444 ms at batch 32, 4.214 -> 3.546 ms at batch 64
     // with the launches of three layers.  Every gradient of [0, split) is still final when the mid event fires
     // (scripts/probes/mid_event_probe.py: a stream waiting for the event snapshots the slice -- no element changes afterwards).
-    // Taken by fira_train_step_begin / _begin_rows (Ctx::dp_begin); fira_train_fwd_bwd with a mid event -- the ZeRO-1 and
-    // the unfused trainers -- keeps the single launch (FIRA_DEC_WGRAD_DP=1 extends it to them, =0 switches it off).
+    // Taken by every caller with a mid event: fira_train_step_begin / _begin_rows and fira_train_fwd_bwd (the ZeRO-1 and the
+    // unfused trainers; FIRA_DEC_WGRAD_DP=0 = the single launch under a mid event, A/B switch).  (The ZeRO-1 test that kept the
+    // second group on the single launch for a while was a ReLU tie of the golden batch, not this schedule: one hidden unit of
+    // decoder layer 3 has a pre-activation of +-1e-9 in step 1 and two SINGLE-process runs disagree on its mask as often --
+    // scripts/probes/nondet_probe.py, profiles/r6_probes.md.)
     // (2) bf16 mode: +0.8 % at batch 64 with the launches of three layers (23 513 -> 23 691, same-box triple); FIRA_DEC_WGRAD_BF16=0.
     static const int dec_dp = [] { const char* e = getenv("FIRA_DEC_WGRAD_DP"); return e ? atoi(e) : -1; }();
     static const bool dec_bf16_off = [] { const char* e = getenv("FIRA_DEC_WGRAD_BF16"); return e && e[0] == '0'; }();
-    const bool mid_single = mid_event && (dec_dp == 0 || (dec_dp == -1 && !c.dp_begin));
+    const bool mid_single = mid_event && dec_dp == 0;
     const int dec_every = (mid_single || (g_dtype != 0 && dec_bf16_off) || dec_every_env == 0 || p.nl % dec_every_env != 0) ? 0 : dec_every_env;
     {
     ProfScope prof_region(s, PROF_DEC_REGION, 0.0);      // wall time of the decoder's backward layers (see decoder_forward)

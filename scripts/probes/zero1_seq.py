@@ -19,6 +19,11 @@ if __name__ == "__main__":
         args = {"a": (2, port + 1, two), "b": (2, port + 1, two, False, "gloo", "bf16"), "z": (2, port + 1, two, True)}[ch]
         mp.spawn(T._run, args=args, nprocs=2, join=True)
         a, b = torch.load(one, weights_only=False), torch.load(two, weights_only=False)
+        if ch == order[0]:
+            gold = a                                    # the first single-process run: which side of a later pair moved?
+        else:
+            rd = lambda x, y: float((x["m"] - y["m"]).norm() / y["m"].norm())
+            print("   ", ch, "single-process run vs the first one: %.3e;  two-rank run vs the first single-process run: %.3e" % (rd(a, gold), rd(b, gold)))
         print(ch, "rel diff m %.3e  v %.3e  flat %.3e" % tuple(float((a[k] - b[k]).norm() / a[k].norm()) for k in ("m", "v", "flat")))
     model = TransModel(FiraConfig(), device="cuda")
     base = model.flat.data.data_ptr()

@@ -38,6 +38,7 @@ def _run(rank, world, port, out, zero1=False, backend="gloo", wire="f32"):
     if world > 1 and not zero1:
         assert trainer.fused_dp                         # (round 6) fira_train_step_begin / _end with the collectives in between
     losses = []
+    m_first = None
     for step in range(3):
         # the last global batch holds ONE commit: with two ranks, rank 1's shard is empty (DataParallel.scatter chunking)
         # and it must still join the collectives and apply the same Adam update (deadlock / divergence)
@@ -45,10 +46,12 @@ def _run(rank, world, port, out, zero1=False, backend="gloo", wire="f32"):
         mine = shard_indices(gidx, rank, world)
         trainer.step(DeviceBatch(store.batch(mine), cfg) if mine else None)
         losses.append(trainer.last_loss())
+        if step == 0 and (zero1 or world == 1):
+            m_first = trainer.state_dict()["m"].cpu()           # (collective with zero1) first moment after the FIRST update
     torch.cuda.synchronize()
     opt = trainer.state_dict()                              # collective with zero1 (shards gathered onto every rank)
     if rank == 0:
-        torch.save({"flat": model.flat.data.cpu(), "losses": losses, "m": opt["m"].cpu(), "v": opt["v"].cpu()}, out)
+        torch.save({"flat": model.flat.data.cpu(), "losses": losses, "m": opt["m"].cpu(), "v": opt["v"].cpu(), "m_first": m_first}, out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -104,9 +107,23 @@ def test_two_rank_zero1_equals_single_process(tmp_path):
     diff = (a["flat"] - b["flat"]).abs()
     assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
     assert float(diff.mean()) < 1e-3 * cfg.lr
-    for k in ("m", "v"):                                     # moments: same accumulation up to the reduction order
-        d = (a[k] - b[k]).norm() / a[k].norm()
-        assert float(d) < 1e-4, (k, float(d))
+    _check_moments(a, b)
+
+
+def _check_moments(a, b):
+    """Moments: the same accumulation up to the reduction order.  The first update is compared tightly (the forward pass of
+    step 0 is bit-identical between the runs).  From the second step on the runs' parameters differ by the rounding noise
+    of the float atomics, and on this batch one hidden unit of decoder layer 3 (feed_forward fc1, unit 693) sits at a ReLU tie in
+    step 1: its pre-activation is +-1e-9, so either run may take either side -- the loss does not see it (relu(h) ~ 0 both ways),
+    but the mask does: row 693 of that weight's gradient changes wholesale and everything below it by ~5e-4
+    (scripts/probes/nondet_probe.py finds the same two outcomes between two SINGLE-process runs; profiles/r6_probes.md).  A flip
+    moves |dm| / |m| to 9.5e-4, so the three-step moments get 3e-3; v (squares: the small gradients hardly count) stays tight."""
+    d1 = (a["m_first"] - b["m_first"]).norm() / a["m_first"].norm()
+    assert float(d1) < 1e-5, float(d1)
+    dm = (a["m"] - b["m"]).norm() / a["m"].norm()
+    assert float(dm) < 3e-3, float(dm)
+    dv = (a["v"] - b["v"]).norm() / a["v"].norm()
+    assert float(dv) < 1e-4, float(dv)
 
 
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2,
@@ -131,9 +148,12 @@ def test_two_ranks_over_rccl_equal_single_process(tmp_path, zero1):
     diff = (a["flat"] - b["flat"]).abs()
     assert float((diff > 0.05 * cfg.lr).float().mean()) < 2e-4, float(diff.max())
     assert float(diff.mean()) < 1e-3 * cfg.lr
-    for k in ("m", "v"):
-        d = (a[k] - b[k]).norm() / a[k].norm()
-        assert float(d) < 1e-4, (k, float(d))
+    if zero1:
+        _check_moments(a, b)
+    else:
+        for k, tol in (("m", 3e-3), ("v", 1e-4)):          # (m: see _check_moments -- a ReLU tie in step 1)
+            d = (a[k] - b[k]).norm() / a[k].norm()
+            assert float(d) < tol, (k, float(d))
 
 
 @needs_two_gpus

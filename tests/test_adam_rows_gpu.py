@@ -177,7 +177,12 @@ def test_rows_trainer_equals_dense_trainer():
         if k < 3:
             a, b, b2 = a[:live], b[:live], b2[:live]
         noise = dist(b2, b)
-        assert dist(a, b) < 6 * noise + 1e-6, (name, dist(a, b), noise)
+        # (floors: two runs of the SAME trainer can also differ by a ReLU tie taken the other way -- a pre-activation of +-1e-9
+        #  whose mask flips with the atomics' rounding noise: the loss does not move, one row of a weight gradient does; seen as
+        #  |dv| / |v| = 7e-5 against a quiet pair's 8e-6, |dm| / |m| up to 1e-3: scripts/probes/nondet_probe.py.  A row the
+        #  sparse update left behind is caught by the table check below, which such a flip does not reach.)
+        floor = {"params": 1e-4, "m": 1e-2, "v": 1e-3}.get(name, 1e-4)
+        assert dist(a, b) < 6 * noise + floor, (name, dist(a, b), noise)
     # a row left behind would differ by whole updates: every row of the tables moved as the dense update moves it
     for k in (3, 4):
         a, b, b2 = (out[r][k] for r in ("rows", "dense", "dense2"))

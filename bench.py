@@ -183,6 +183,15 @@ def spmm_standalone(cfg, store):
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
                                "buffer_sets": n_sets, "rotated_bytes": tot,
                                "note": "computed-node rows only (what encoder_forward launches), batch 64, stand-alone"}
+    # what the CUs actually pull: every listed neighbour row is 1 KiB through the L2 -> CU path even when it hits (a row is
+    # gathered ~3.4 times), plus the stored rows.  The chip's L2s deliver ~8.4 TB/s to 256 CUs (13.6 B / clk / CU, measured on
+    # config 5: profiles/r6_probes.md) -- the bound this launch sits on, whatever its HBM fraction says.
+    for key in ("spmm_b64", "spmm_b64_compact"):
+        o = out[key]
+        moved = 8 * o["nnz"] + o["nnz"] * 1024 + o["rows"] * 1024
+        o["cu_side_bytes"] = moved
+        o["cu_side_GBs"] = moved / (o["avg_launch_us"] * 1e-6) / 1e9
+        o["cu_side_frac_of_8400GBs"] = o["cu_side_GBs"] / 8400.0
     # BASELINE config 5: 128 graphs x 512 nodes x 4 edge types x 8192 edges
     B, N = 128, 512
     rp, c, v = (torch.from_numpy(x).cuda() for x in graphs.dense_stress_batch(B, N))
@@ -673,6 +682,7 @@ def compact_line(line, detail_path):
     put("spmm_b64_frac", line, "spmm_b64", "frac")
     put("spmm_b64_us", line, "spmm_b64", "avg_launch_us")
     put("spmm_b64_compact_frac", line, "spmm_b64_compact", "frac")
+    put("spmm_b64_compact_cu_side_GBs", line, "spmm_b64_compact", "cu_side_GBs")
     put("spmm_cfg5_frac_f32", line, "spmm_cfg5", "frac")
     put("spmm_cfg5_frac_bf16", line, "spmm_cfg5", "frac_bf16")
     put("gcn_cfg5_f32_fwd_us", line, "gcn_cfg5", "f32", "fwd_us")

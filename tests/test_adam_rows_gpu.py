@@ -180,12 +180,16 @@ def test_rows_trainer_equals_dense_trainer():
         # (floors: two runs of the SAME trainer can also differ by a ReLU tie taken the other way -- a pre-activation of +-1e-9
         #  whose mask flips with the atomics' rounding noise: the loss does not move, one row of a weight gradient does; seen as
         #  |dv| / |v| = 7e-5 against a quiet pair's 8e-6, |dm| / |m| up to 1e-3: scripts/probes/nondet_probe.py.  A row the
-        #  sparse update left behind is caught by the table check below, which such a flip does not reach.)
+        #  sparse update left behind is caught by the table check below and, bit for bit, by the torch.equal tests above.)
         floor = {"params": 1e-4, "m": 1e-2, "v": 1e-3}.get(name, 1e-4)
         assert dist(a, b) < 6 * noise + floor, (name, dist(a, b), noise)
-    # a row left behind would differ by whole updates: every row of the tables moved as the dense update moves it
+    # a row left behind would differ by whole updates, step after step: every row of the tables moved as the dense update moves
+    # it.  (Floor: a ReLU tie taken the other way changes gradients everywhere, embedding rows included, and Adam turns that into
+    # differences of a fraction of lr per element -- 6.3e-5 seen once in the full suite against a quiet pair's 3e-7; a row the
+    # sparse update forgot lags by ~lr per step it was owed.  The bit-for-bit guarantees are the torch.equal tests above, which
+    # feed both kernels the same gradients.)
     for k in (3, 4):
         a, b, b2 = (out[r][k] for r in ("rows", "dense", "dense2"))
         worst = ((a - b).abs().amax(1) / (b2 - b).abs().amax(1).clamp_min(1e-7)).max()
-        assert float((a - b).abs().max()) < 6 * float((b2 - b).abs().max()) + 1e-7, (k, float(worst))
+        assert float((a - b).abs().max()) < 6 * float((b2 - b).abs().max()) + 2 * cfg.lr, (k, float(worst))
     assert np.allclose(out["rows"][5], out["dense"][5], rtol=5e-3), (out["rows"][5], out["dense"][5])

@@ -742,8 +742,16 @@ struct CombFusedBwdArgs {
 
 constexpr size_t CBX_PLANE = (size_t)CB_ROWS * 512;       // backward: bytes of one bf16 plane of a 16-row panel
 constexpr size_t CB_LDS_X3 = 100 * 1024;                  // two panels of three planes (48 KB) + marks + the column sums (48 KB)
-template <bool BF, int NP = 0>
+constexpr size_t CB_LDS_X3_2 = 2 * 3 * (size_t)2 * CF_TILE * 512 + 256 + 48 * 1024 + 1024;   // the same at two tiles per pass (145 KB)
+// TM (round 6, late): tiles per pass.  Every pass streams the three products' weight planes (1.15 MB in fp32 mode) through the
+// CU, so a workgroup with two tiles (batch 64: 429 tiles of code rows on 256 workgroups) pays for them twice at one tile per pass
+// and once at two: +0.7 % fp32 / +1.3 % bf16 at batch 64.  At batch 32 (229 tiles: nobody has two) the two-tile form LOSES 0.8 %
+// (the three-term form spills 18 registers, 145 KB of LDS): TM = 2 only when some workgroup has more than one tile, plane forms
+// only (the fp32-panel forms spill 35-56 registers at two tiles).
+template <bool BF, int NP = 0, int TM = 1>
 __global__ __launch_bounds__(CF_WAVES * 64) void comb_fused_bwd_kernel(const CombFusedBwdArgs a) {
+    constexpr int CB_TMAX = TM, CB_ROWS = CF_TILE * TM, CB_RPW = CB_ROWS / CF_WAVES;      // (shadow the one-tile constants above)
+    constexpr size_t CBX_PLANE = (size_t)CB_ROWS * 512;
     constexpr bool X3 = NP > 0;
     constexpr int NPX = X3 ? NP : 3;
     extern __shared__ __attribute__((aligned(16))) float cf_lds[];
@@ -970,11 +978,23 @@ int comb_fused_bwd(hipStream_t s, int n_rows, float* dG, const int32_t* rows, co
             e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3_2);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)comb_fused_bwd_kernel<false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_X3_2);
         return e == hipSuccess ? 0 : set_err("comb_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }();
     if (attr) return attr;
     if (WTx) {                           // bf16 planes (WTx: planes of Wq^T | Wk^T | Wo^T): three terms in fp32 mode, one in bf16 mode
         a.Wo = reinterpret_cast<const float*>(WTx);
+        // FIRA_COMB_BWD_TILES=1|2 forces the tiles per pass (A/B switch); default: two once some workgroup has more than one tile
+        static const int tm_env = [] { const char* e = getenv("FIRA_COMB_BWD_TILES"); return e ? atoi(e) : 0; }();
+        const int n_tiles = (n_rows + CF_TILE - 1) / CF_TILE;
+        const bool two = tm_env == 2 || (tm_env != 1 && n_tiles > CF_GRID);
+        if (two) {
+            if (bf16) hipLaunchKernelGGL((comb_fused_bwd_kernel<false, 1, 2>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3_2, s, a);
+            else hipLaunchKernelGGL((comb_fused_bwd_kernel<false, 3, 2>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3_2, s, a);
+        } else
         if (bf16) hipLaunchKernelGGL((comb_fused_bwd_kernel<false, 1>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3, s, a);
         else hipLaunchKernelGGL((comb_fused_bwd_kernel<false, 3>), dim3(CF_GRID), dim3(CF_WAVES * 64), CB_LDS_X3, s, a);
     } else

@@ -53,7 +53,8 @@ __device__ __forceinline__ void store_elem(char* p, float v, uint16_t) {
 // slots finish in a tail loop.  (Round 5's form -- threads striding over the whole slice, eight entries in flight, the row
 // found by walking the LDS copy of the row offsets, the predecessor's column by a dependent load -- cost 35 us of the bf16
 // launch's 82 on config 5; a per-entry search over the wave's 16 row boundaries, 16.5 us per 128-row slice: this form is
-// bound by its ~1 000 instructions per wave.)
+// bound by its ~1 000 instructions per wave.)  Entry offsets travel as 31-bit byte offsets of a buffer descriptor: fewer than
+// 2^29 entries per launch (a block-diagonal batch of <= 512-node graphs holds at most 512 per row: a million rows).
 constexpr int DN_SLOTS = 3;
 template <typename T, int R, int NT>
 __device__ __forceinline__ void densify_rows(char* tile, int* sm_rp, int pitch, int graph_rows, int row0, int r0,
